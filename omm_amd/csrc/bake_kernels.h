@@ -1,0 +1,55 @@
+// bake_kernels.h -- host-callable launch wrappers of the HIP kernels (bake_kernels.hip, tail_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bake_types.h"
+
+namespace ommx {
+
+// classification of one level group (items listed in itemIds, all at `level`)
+void launch_classify(const ClassifyParams& P, const ItemArrays& A, const uint32_t* itemIds, uint32_t numItems, uint32_t level, hipStream_t stream);
+// XXH64(seed 42) of the 3-state byte stream of each listed item -> digests[item]
+void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
+                   uint64_t* digests, hipStream_t stream);
+// summed-area table of (alpha > cutoff)
+void launch_sat_build(const void* texels, int fp32, uint32_t* sat, int w, int h, float cutoff, hipStream_t stream);
+void launch_gather_omms(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* order, const uint32_t* dstOfs, const uint32_t* sizes,
+                        uint32_t numOmms, uint8_t* arrayData, hipStream_t stream);
+void launch_write_indices(const int32_t* triToItem, const uint32_t* rep, const int32_t* itemValue, uint32_t numTris, int32_t unresolved,
+                          int32_t* out, hipStream_t stream);
+
+// ---- device tail (tail_kernels.hip) ----
+struct TailInputs {
+    uint32_t numItems, numTris;
+    const float*    uv;         // 6 per item
+    const uint8_t*  level;      // per item
+    const uint32_t* stateMask;  // per item
+    const uint32_t* knownCount; // per item or null
+    uint64_t*       digests;    // per item: filled for non-uniform items by launch_digest; uniform ones are filled here
+    const uint64_t* uniformDigest; // [13][4] table: XXH64 of 4^level bytes of value s (s = 0,1,3)
+    const int32_t*  triToItem;  // per triangle, -1 = unresolved
+    int      format;            // global format (bits per micro-triangle)
+    int      disableSpecial, disableDedup;
+    float    rejectionThreshold;
+    int32_t  unresolved;
+};
+struct TailOutputs {            // device buffers owned by the caller
+    int32_t*  special;          // per item: 0 = none, else special index
+    uint32_t* rep;              // per item: first item with the same digest
+    uint32_t* order;            // [numOmms] item of descriptor j
+    uint32_t* dstOfs;           // [numOmms] byte offset in arrayData
+    uint32_t* sizes;            // [numOmms]
+    int32_t*  itemValue;        // per item: special index or descriptor slot
+    int32_t*  indexBuffer;      // per triangle
+    uint32_t* arrayHist;        // [13]
+    uint32_t* indexHist;        // [13]
+};
+struct TailCounts { uint32_t numOmms; uint64_t arrayDataSize; };
+
+// scratch handling: call with scratch == nullptr to get the size
+size_t tail_scratch_bytes(uint32_t numItems, uint32_t numTris);
+// runs the device tail up to (and including) offsets; returns counts (synchronises the stream once)
+hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch, size_t scratchBytes, TailCounts* counts, hipStream_t stream);
+void launch_write_descs(const uint32_t* order, const uint32_t* dstOfs, const uint8_t* level, int format, uint32_t numOmms, void* descArray, hipStream_t stream);
+
+} // namespace ommx

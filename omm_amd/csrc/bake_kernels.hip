@@ -1,0 +1,350 @@
+// bake_kernels.hip -- HIP kernels of the MI355X opacity-micromap baker (gfx950, wave64).
+//
+//   classify_tiles      coarse (SAT) + fine (level-line) classification of micro-triangles,
+//                       LDS work queue between the two passes, 2-/1-bit packed output
+//   digest_items        XXH64(seed 42) of the 3-state byte stream of each non-uniform work item
+//   sat_* / tail_*      summed-area-table build, dedup/sort/pack helpers
+//
+// No MFMA anywhere: this is a sampling / reduction path (fp32 VALU + sqrt/div + texel gathers).
+// Compile with -ffp-contract=off (see classify_device.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bake_types.h"
+#include "classify_device.h"
+#include "bake_kernels.h"
+
+namespace ommx {
+
+// ------------------------------------------------------------------------------------------------
+// Classification.
+//
+// One workgroup (256 threads = 4 waves) owns a tile of TILE consecutive micro-triangles of the
+// level's item list: a slice of one item when 4^level >= TILE, or TILE / 4^level whole items
+// otherwise.  Three phases, all state kept in LDS:
+//   1. every lane: bird-curve micro-triangle -> SAT test (4 reads).  Unresolved ones are appended to
+//      an LDS queue by wave-ballot compaction, so that
+//   2. the expensive level-line pass runs on densely packed lanes instead of a few divergent ones,
+//   3. states are packed LSB-first into 32-bit words and stored coalesced; the tile's state mask
+//      (which states occur) is OR-reduced for the uniform-OMM ("special index") detection.
+// ------------------------------------------------------------------------------------------------
+constexpr int TILE = 1024;
+constexpr int BLOCK = 256;
+
+template <bool FP32>
+__global__ __launch_bounds__(BLOCK) void classify_tiles(ClassifyParams P, ItemArrays A, const uint32_t* __restrict__ itemIds,
+                                                        uint32_t numItems, uint32_t level)
+{
+    __shared__ uint8_t  s_state[TILE];
+    __shared__ uint16_t s_queue[TILE];
+    __shared__ uint32_t s_qcount;
+    __shared__ uint32_t s_mask, s_known;
+
+    const uint32_t M = 1u << (2 * level);
+    const uint32_t tid = threadIdx.x;
+    const bool sliced = M >= (uint32_t)TILE;               // tile is a slice of one item
+    const uint32_t tilesPerItem = sliced ? M / TILE : 1u;
+    const uint32_t itemsPerTile = sliced ? 1u : TILE / M;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t firstItem = sliced ? tile / tilesPerItem : tile * itemsPerTile;
+    const uint32_t base = sliced ? (tile % tilesPerItem) * TILE : 0u; // first micro-triangle of the slice
+    uint32_t itemsHere = numItems - firstItem;
+    if (itemsHere > itemsPerTile) itemsHere = itemsPerTile;
+    const uint32_t count = sliced ? (uint32_t)TILE : itemsHere * M;   // micro-triangles in this tile
+
+    if (tid == 0) { s_qcount = 0; s_mask = 0; s_known = 0; }
+    __syncthreads();
+
+    // ---- phase 1: coarse ----
+    const bool coarse = P.useCoarse != 0;
+    for (uint32_t i = tid; i < ((count + 63u) & ~63u); i += BLOCK) {
+        bool unresolved = false;
+        if (i < count) {
+            const uint32_t it = sliced ? firstItem : firstItem + (i >> (2 * level));
+            const uint32_t u = sliced ? base + i : (i & (M - 1u));
+            int st = -1;
+            if (coarse) {
+                const uint32_t item = itemIds[it];
+                const MicroTri t = micro_triangle(A.uv + 6ull * item, u, level);
+                st = coarse_state(P, t);
+            }
+            // the reference's fine pass re-classifies everything still "UnknownOpaque" (bake_cpu_impl.cpp:861)
+            unresolved = (st < 0) || (st == 3) || !P.filterLinear;
+            s_state[i] = (uint8_t)(st < 0 ? 3 : st);
+        }
+        const unsigned long long vote = __ballot(unresolved);
+        if (vote) {
+            const uint32_t lane = tid & 63u;
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&s_qcount, (uint32_t)__popcll(vote));
+            wbase = __shfl(wbase, 0);
+            if (unresolved) s_queue[wbase + __popcll(vote & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: fine, dense over the queue ----
+    const uint32_t qn = s_qcount;
+    for (uint32_t q = tid; q < qn; q += BLOCK) {
+        const uint32_t i = s_queue[q];
+        const uint32_t it = sliced ? firstItem : firstItem + (i >> (2 * level));
+        const uint32_t u = sliced ? base + i : (i & (M - 1u));
+        const uint32_t item = itemIds[it];
+        const MicroTri t = micro_triangle(A.uv + 6ull * item, u, level);
+        s_state[i] = (uint8_t)fine_state<FP32>(P, t, A.degenerate[item] != 0);
+    }
+    __syncthreads();
+
+    // ---- phase 3: pack + per-item summary ----
+    const uint32_t bits = (uint32_t)P.format;          // 1 or 2 bits per micro-triangle
+    const uint32_t perWord = 32u / bits;               // micro-triangles per 32-bit word
+    if (M >= perWord) {
+        const uint32_t words = count / perWord;
+        uint32_t localMask = 0, localKnown = 0;
+        for (uint32_t w = tid; w < words; w += BLOCK) {
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < perWord; ++k) {
+                const uint32_t s = s_state[w * perWord + k];
+                v |= s << (k * bits);
+                localMask |= 1u << s;
+                localKnown += s < 2u;
+            }
+            const uint32_t i0 = w * perWord;
+            const uint32_t it = sliced ? firstItem : firstItem + (i0 >> (2 * level));
+            const uint32_t u0 = sliced ? base + i0 : (i0 & (M - 1u));
+            const uint32_t item = itemIds[it];
+            *(uint32_t*)(A.states + A.stateOfs[item] + (size_t)(u0 / perWord) * 4u) = v;
+            if (!sliced) { // several words of one item sit in neighbouring lanes: fold them without atomics when the item is one word
+                if (M == perWord) { A.stateMask[item] = localMask; if (P.wantKnownCount) A.knownCount[item] = localKnown; localMask = 0; localKnown = 0; }
+                else { atomicOr(&A.stateMask[item], localMask); if (P.wantKnownCount) atomicAdd(&A.knownCount[item], localKnown); localMask = 0; localKnown = 0; }
+            }
+        }
+        if (sliced) {
+            if (localMask) atomicOr(&s_mask, localMask);
+            if (P.wantKnownCount && localKnown) atomicAdd(&s_known, localKnown);
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t item = itemIds[firstItem];
+                atomicOr(&A.stateMask[item], s_mask);
+                if (P.wantKnownCount) atomicAdd(&A.knownCount[item], s_known);
+            }
+        }
+    } else {
+        // items smaller than one word (level 0/1, and level 2 in 2-state): one lane per item, byte stores
+        for (uint32_t k = tid; k < itemsHere; k += BLOCK) {
+            const uint32_t item = itemIds[firstItem + k];
+            uint32_t v = 0, mask = 0, known = 0;
+            for (uint32_t j = 0; j < M; ++j) {
+                const uint32_t s = s_state[k * M + j];
+                v |= s << (j * bits);
+                mask |= 1u << s;
+                known += s < 2u;
+            }
+            uint32_t nbytes = (M * bits) >> 3; if (nbytes < 1u) nbytes = 1u;
+            uint8_t* dst = A.states + A.stateOfs[item];
+            for (uint32_t bI = 0; bI < nbytes; ++bI) dst[bI] = (uint8_t)(v >> (8u * bI));
+            A.stateMask[item] = mask;
+            if (P.wantKnownCount) A.knownCount[item] = known;
+        }
+    }
+}
+
+void launch_classify(const ClassifyParams& P, const ItemArrays& A, const uint32_t* itemIds, uint32_t numItems, uint32_t level, hipStream_t stream)
+{
+    if (numItems == 0) return;
+    const uint64_t M = 1ull << (2 * level);
+    const uint64_t tiles = M >= (uint64_t)TILE ? (uint64_t)numItems * (M / TILE) : ((uint64_t)numItems * M + TILE - 1) / TILE;
+    // blockIdx.x is 32-bit; split very large level groups
+    const uint64_t maxTiles = 0x7FFFFFFFull / 1;
+    (void)maxTiles;
+    if (P.texIsFp32) hipLaunchKernelGGL(classify_tiles<true>, dim3((uint32_t)tiles), dim3(BLOCK), 0, stream, P, A, itemIds, numItems, level);
+    else             hipLaunchKernelGGL(classify_tiles<false>, dim3((uint32_t)tiles), dim3(BLOCK), 0, stream, P, A, itemIds, numItems, level);
+}
+
+// ------------------------------------------------------------------------------------------------
+// XXH64 (seed 42) over the item's 3-state byte stream: one byte per micro-triangle, UT folded into
+// UO (bake_cpu_impl.cpp:374-377,1038-1040).  The bytes are never materialised: each lane expands
+// its 8-byte lane of every 32-byte stripe from the packed states on the fly.
+//
+// XXH64 keeps four independent accumulators, each a strictly sequential chain over the stripes, so
+// the parallelism is (items) x (4 accumulators): a wave carries 16 items, lane = (item, accumulator).
+// ------------------------------------------------------------------------------------------------
+constexpr uint64_t XP1 = 0x9E3779B185EBCA87ULL, XP2 = 0xC2B2AE3D27D4EB4FULL, XP3 = 0x165667B19E3779F9ULL,
+                   XP4 = 0x85EBCA77C2B2AE63ULL, XP5 = 0x27D4EB2F165667C5ULL;
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ uint64_t xxh_round(uint64_t acc, uint64_t in) { acc += in * XP2; acc = rotl64(acc, 31); return acc * XP1; }
+__device__ __forceinline__ uint64_t xxh_merge(uint64_t h, uint64_t v) { h ^= xxh_round(0, v); return h * XP1 + XP4; }
+__device__ __forceinline__ uint64_t xxh_avalanche(uint64_t h) { h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32; return h; }
+
+// 8 consecutive micro-triangle states -> 8 bytes (little endian), UT(2) -> UO(3)
+__device__ __forceinline__ uint64_t expand8(uint32_t packed, uint32_t bits)
+{
+    uint64_t out = 0;
+    if (bits == 2) {
+        #pragma unroll
+        for (int k = 0; k < 8; ++k) { uint32_t s = (packed >> (2 * k)) & 3u; s = (s == 2u) ? 3u : s; out |= (uint64_t)s << (8 * k); }
+    } else {
+        #pragma unroll
+        for (int k = 0; k < 8; ++k) { const uint32_t s = (packed >> k) & 1u; out |= (uint64_t)s << (8 * k); }
+    }
+    return out;
+}
+
+__device__ __forceinline__ uint32_t state_at(const uint8_t* p, uint32_t u, uint32_t bits)
+{
+    if (bits == 2) { uint32_t s = (p[u >> 2] >> ((u & 3u) << 1)) & 3u; return s == 2u ? 3u : s; }
+    return (p[u >> 3] >> (u & 7u)) & 1u;
+}
+
+__global__ __launch_bounds__(256) void digest_items(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs,
+                                                    const uint32_t* __restrict__ itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
+                                                    uint64_t* __restrict__ digests)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t it = gid >> 2, acc = gid & 3u;
+    const bool live = it < numItems;
+    const uint32_t item = live ? itemIds[it] : 0u;
+    const uint8_t* p = states + (live ? stateOfs[item] : 0ull);
+    const uint32_t M = 1u << (2 * level);     // stream length in bytes
+    const uint64_t seed = 42;
+    uint64_t h;
+    if (M >= 32u) {
+        uint64_t v = acc == 0 ? seed + XP1 + XP2 : (acc == 1 ? seed + XP2 : (acc == 2 ? seed : seed - XP1));
+        const uint32_t stripes = M >> 5;
+        if (live) {
+            if (bits == 2) {
+                // stripe s = micro-triangles [32s, 32s+32) = packed bytes [8s, 8s+8); this lane takes bytes [8s+2acc, +2)
+                const uint16_t* q = (const uint16_t*)p + acc;
+                for (uint32_t s = 0; s < stripes; ++s) v = xxh_round(v, expand8((uint32_t)q[4 * s], 2));
+            } else {
+                const uint8_t* q = p + acc; // packed bytes [4s, 4s+4), one byte per accumulator lane
+                for (uint32_t s = 0; s < stripes; ++s) v = xxh_round(v, expand8((uint32_t)q[4 * s], 1));
+            }
+        }
+        // combine the four accumulators of this item (lanes 4k..4k+3)
+        const uint32_t lane = threadIdx.x & 63u, l0 = lane & ~3u;
+        const uint64_t v1 = __shfl(v, l0), v2 = __shfl(v, l0 + 1), v3 = __shfl(v, l0 + 2), v4 = __shfl(v, l0 + 3);
+        h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        h = xxh_merge(h, v1); h = xxh_merge(h, v2); h = xxh_merge(h, v3); h = xxh_merge(h, v4);
+        h += (uint64_t)M; // M is a multiple of 32: no tail
+    } else {
+        h = seed + XP5 + (uint64_t)M;
+        if (live) {
+            uint32_t u = 0;
+            for (; u + 8 <= M; u += 8) {
+                uint64_t w = 0;
+                for (uint32_t k = 0; k < 8; ++k) w |= (uint64_t)state_at(p, u + k, bits) << (8 * k);
+                h ^= xxh_round(0, w); h = rotl64(h, 27) * XP1 + XP4;
+            }
+            if (u + 4 <= M) {
+                uint32_t w = 0;
+                for (uint32_t k = 0; k < 4; ++k) w |= state_at(p, u + k, bits) << (8 * k);
+                h ^= (uint64_t)w * XP1; h = rotl64(h, 23) * XP2 + XP3; u += 4;
+            }
+            for (; u < M; ++u) { h ^= (uint64_t)state_at(p, u, bits) * XP5; h = rotl64(h, 11) * XP1; }
+        }
+    }
+    h = xxh_avalanche(h);
+    if (live && acc == 0) digests[item] = h;
+}
+
+void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
+                   uint64_t* digests, hipStream_t stream)
+{
+    if (numItems == 0) return;
+    const uint32_t threads = numItems * 4u;
+    hipLaunchKernelGGL(digest_items, dim3((threads + 255u) / 256u), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Summed-area table of (alpha > cutoff) (texture_impl.cpp:191-220): indicator + row scan, then a
+// column scan.  uint32 sums are exact, so any summation order gives the reference's table.
+// ------------------------------------------------------------------------------------------------
+template <bool FP32>
+__global__ __launch_bounds__(256) void sat_rows(const void* __restrict__ texels, uint32_t* __restrict__ sat, int w, int h, float cutoff)
+{
+    // one wave per row, 64-texel chunks with a carried running sum
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= h) return;
+    uint32_t carry = 0;
+    for (int x0 = 0; x0 < w; x0 += 64) {
+        const int x = x0 + lane;
+        uint32_t v = 0;
+        if (x < w) {
+            const size_t idx = (size_t)x + (size_t)row * (size_t)w;
+            const float a = FP32 ? ((const float*)texels)[idx] : (float)((const uint8_t*)texels)[idx] * (1.f / 255.f);
+            v = a > cutoff ? 1u : 0u;
+        }
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t n = __shfl_up(v, d); if (lane >= d) v += n; }
+        v += carry;
+        if (x < w) sat[(size_t)x + (size_t)row * (size_t)w] = v;
+        carry = __shfl(v, 63);
+    }
+}
+
+__global__ __launch_bounds__(256) void sat_cols(uint32_t* __restrict__ sat, int w, int h)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= w) return;
+    uint32_t run = 0;
+    for (int y = 0; y < h; ++y) { const size_t i = (size_t)x + (size_t)y * (size_t)w; run += sat[i]; sat[i] = run; }
+}
+
+void launch_sat_build(const void* texels, int fp32, uint32_t* sat, int w, int h, float cutoff, hipStream_t stream)
+{
+    if (fp32) hipLaunchKernelGGL(sat_rows<true>, dim3((h + 3) / 4), dim3(256), 0, stream, texels, sat, w, h, cutoff);
+    else      hipLaunchKernelGGL(sat_rows<false>, dim3((h + 3) / 4), dim3(256), 0, stream, texels, sat, w, h, cutoff);
+    hipLaunchKernelGGL(sat_cols, dim3((w + 255) / 256), dim3(256), 0, stream, sat, w, h);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tail: gather the surviving OMMs into the final arrayData order, write descriptors and the index buffer.
+// ------------------------------------------------------------------------------------------------
+// one workgroup per emitted OMM: 16-byte vector copy of its packed states (sizes are powers of two)
+__global__ __launch_bounds__(256) void tail_gather_omms(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs,
+                                                        const uint32_t* __restrict__ order, const uint32_t* __restrict__ dstOfs,
+                                                        const uint32_t* __restrict__ sizes, uint32_t numOmms, uint8_t* __restrict__ arrayData)
+{
+    for (uint32_t j = blockIdx.x; j < numOmms; j += gridDim.x) {
+        const uint32_t item = order[j];
+        const uint8_t* src = states + stateOfs[item];
+        uint8_t* dst = arrayData + dstOfs[j];
+        const uint32_t n = sizes[j];
+        if (n >= 16u) {
+            const uint4* s4 = (const uint4*)src; uint4* d4 = (uint4*)dst;
+            for (uint32_t k = threadIdx.x; k < n / 16u; k += blockDim.x) d4[k] = s4[k];
+        } else {
+            if (threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
+        }
+    }
+}
+
+void launch_gather_omms(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* order, const uint32_t* dstOfs, const uint32_t* sizes,
+                        uint32_t numOmms, uint8_t* arrayData, hipStream_t stream)
+{
+    if (numOmms == 0) return;
+    const uint32_t grid = numOmms < 65536u * 4u ? numOmms : 65536u * 4u;
+    hipLaunchKernelGGL(tail_gather_omms, dim3(grid), dim3(256), 0, stream, states, stateOfs, order, dstOfs, sizes, numOmms, arrayData);
+}
+
+// index buffer: triangle -> unique work item -> dedup representative -> special index or descriptor slot
+// (bake_cpu_impl.cpp:1856-1870)
+__global__ __launch_bounds__(256) void tail_write_indices(const int32_t* __restrict__ triToItem, const uint32_t* __restrict__ rep,
+                                                          const int32_t* __restrict__ itemValue, uint32_t numTris, int32_t unresolved,
+                                                          int32_t* __restrict__ out)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= numTris) return;
+    const int32_t it = triToItem[t];
+    out[t] = it < 0 ? unresolved : itemValue[rep[it]];
+}
+
+void launch_write_indices(const int32_t* triToItem, const uint32_t* rep, const int32_t* itemValue, uint32_t numTris, int32_t unresolved,
+                          int32_t* out, hipStream_t stream)
+{
+    if (numTris == 0) return;
+    hipLaunchKernelGGL(tail_write_indices, dim3((numTris + 255u) / 256u), dim3(256), 0, stream, triToItem, rep, itemValue, numTris, unresolved, out);
+}
+
+} // namespace ommx

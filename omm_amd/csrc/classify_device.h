@@ -1,0 +1,422 @@
+// classify_device.h -- per-micro-triangle classification for gfx950, bit-exact with the
+// reference CPU baker.
+//
+// Every expression keeps the reference's fp32 association order; this translation unit is
+// compiled with -ffp-contract=off (no v_fma contraction), IEEE-correct division/sqrt (hipcc's
+// default -fhip-fp32-correctly-rounded-divide-sqrt) and fp32 denormals on (gfx950 default), so
+// the VALU results equal what the reference's -msse4.1 build computes on x86.
+// Citations are relative to /root/reference/libraries/omm-lib/src/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "bake_types.h"
+
+namespace ommx {
+
+struct V2 { float x, y; };
+__device__ __forceinline__ V2 mk2(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
+
+// x86 cvttss2si: NaN / out-of-range -> INT_MIN ("integer indefinite"); v_cvt_i32_f32 saturates instead.
+__device__ __forceinline__ int cvt_trunc_x86(float f)
+{
+    return (f >= -2147483648.f && f < 2147483648.f) ? (int)f : (int)0x80000000;
+}
+__device__ __forceinline__ float std_min(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }
+__device__ __forceinline__ float vlen(float x, float y) { return __builtin_sqrtf(x * x + y * y); }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (hi < v ? hi : v); }
+
+// UV-space micro-triangle with the cached edge vectors of util/geometry.h:59-75.
+struct MicroTri {
+    V2 p0, p1, p2;
+    V2 p0p2, p1p0, p2p1;
+    V2 lo, hi; // aabb_s, aabb_e
+};
+
+__device__ __forceinline__ void finish_tri(MicroTri& t)
+{
+    t.p0p2 = mk2(t.p0.x - t.p2.x, t.p0.y - t.p2.y);
+    t.p1p0 = mk2(t.p1.x - t.p0.x, t.p1.y - t.p0.y);
+    t.p2p1 = mk2(t.p2.x - t.p1.x, t.p2.y - t.p1.y);
+    t.lo = mk2(std_min(std_min(t.p0.x, t.p1.x), t.p2.x), std_min(std_min(t.p0.y, t.p1.y), t.p2.y));
+    t.hi = mk2(std_max(std_max(t.p0.x, t.p1.x), t.p2.x), std_max(std_max(t.p0.y, t.p1.y), t.p2.y));
+}
+
+// ---- bird curve: micro-triangle index -> barycentrics (util/bird.h:34-118) ----
+__device__ __forceinline__ uint32_t even_bits(uint32_t x)
+{
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0f0f0f0fu;
+    x = (x | (x >> 4)) & 0x00ff00ffu;
+    x = (x | (x >> 8)) & 0x0000ffffu;
+    return x;
+}
+__device__ __forceinline__ uint32_t prefix_xor(uint32_t x)
+{
+    x ^= x >> 1; x ^= x >> 2; x ^= x >> 4; x ^= x >> 8;
+    return x;
+}
+
+// util/geometry.h:241-248 with bc = (1-u-v, u, v)
+__device__ __forceinline__ V2 bary_point(const float* __restrict__ tri, float u, float v)
+{
+    const float bx = 1.f - u - v;
+    return mk2(tri[0] * bx + tri[2] * u + tri[4] * v, tri[1] * bx + tri[3] * u + tri[5] * v);
+}
+
+// util/bird.h:170-182
+__device__ __forceinline__ MicroTri micro_triangle(const float* __restrict__ tri, uint32_t index, uint32_t level)
+{
+    MicroTri t;
+    if (level == 0) {
+        t.p0 = bary_point(tri, 0.f, 0.f); t.p1 = bary_point(tri, 1.f, 0.f); t.p2 = bary_point(tri, 0.f, 1.f);
+    } else {
+        const uint32_t b0 = even_bits(index), b1 = even_bits(index >> 1);
+        const uint32_t fx = prefix_xor(b0), fy = prefix_xor(b0 & ~b1);
+        const uint32_t tt = fy ^ b1;
+        uint32_t iu = (fx & ~tt) | (b0 & ~tt) | (~b0 & ~fx & tt);
+        uint32_t iv = fy ^ b0;
+        uint32_t iw = (~fx & ~tt) | (b0 & ~tt) | (~b0 & fx & tt);
+        const uint32_t mask = (1u << level) - 1u;
+        iu &= mask; iv &= mask; iw &= mask;
+        const bool upright = ((iu ^ iv ^ iw) & 1u) != 0;
+        if (!upright) { iu += 1; iv += 1; }
+        const float ls = __uint_as_float((127u - level) << 23);
+        float du = 1.f * ls, dv = 1.f * ls;
+        const float u = (float)iu * ls, v = (float)iv * ls;
+        if (!upright) { du = -du; dv = -dv; }
+        t.p0 = bary_point(tri, u, v); t.p1 = bary_point(tri, u + du, v); t.p2 = bary_point(tri, u, v + dv);
+    }
+    finish_tri(t);
+    return t;
+}
+
+// ---- texture addressing (util/texture.h:34-91) ----
+__device__ __forceinline__ int tex_coord(int mode, int pow2, int x, int size, int sizeLog2)
+{
+    switch (mode) {
+    case 0: // Wrap
+        return pow2 ? (int)((uint32_t)x & (uint32_t)(size - 1)) : (int)((uint32_t)x % (uint32_t)size);
+    case 1: // Mirror
+        if (pow2) {
+            const int xa = (x < 0 ? -x : x) - (x < 0 ? 1 : 0);
+            const int flipped = (xa >> sizeLog2) & 1;
+            const int w = (int)((uint32_t)xa & (uint32_t)(size - 1));
+            return flipped ? size - w - 1 : w;
+        } else {
+            const int xa = cvt_trunc_x86(__builtin_fabsf((float)x + 0.5f));
+            const uint32_t flipped = ((uint32_t)(xa / size)) % 2u;
+            const int w = (int)((uint32_t)xa % (uint32_t)size);
+            return flipped ? size - w - 1 : w;
+        }
+    case 2: // Clamp
+        return clampi(x, 0, size - 1);
+    case 3: // Border
+        return (x >= size || x < 0) ? kTexCoordBorder : x;
+    case 4: // MirrorOnce
+        return clampi(cvt_trunc_x86(__builtin_fabsf((float)x + 0.5f)), 0, size - 1);
+    default:
+        return 0x7FFFFFFF;
+    }
+}
+
+// texture_impl.h:178-202
+template <bool FP32>
+__device__ __forceinline__ float load_texel(const DevMip& m, int x, int y)
+{
+    const size_t idx = (size_t)x + (size_t)y * (size_t)m.w;
+    if (FP32) return ((const float*)m.texels)[idx];
+    return (float)((const uint8_t*)m.texels)[idx] * (1.f / 255.f);
+}
+
+template <bool FP32>
+__device__ __forceinline__ float load_texel_border(const DevMip& m, int x, int y, float borderAlpha)
+{
+    return (x == kTexCoordBorder || y == kTexCoordBorder) ? borderAlpha : load_texel<FP32>(m, x, y);
+}
+
+// texture_impl.cpp:261-278 (centre vote).  Border texels take borderAlpha (the reference reads out of
+// bounds there -- documented fence).
+template <bool FP32>
+__device__ __forceinline__ float bilinear(const ClassifyParams& P, const DevMip& m, V2 p)
+{
+    const float px = p.x * m.fw - 0.5f, py = p.y * m.fh - 0.5f;
+    const float fx = __builtin_floorf(px), fy = __builtin_floorf(py);
+    const int ix = cvt_trunc_x86(fx), iy = cvt_trunc_x86(fy);
+    const int x0 = tex_coord(P.addrMode, m.pow2, ix, m.w, m.log2w), y0 = tex_coord(P.addrMode, m.pow2, iy, m.h, m.log2h);
+    const int x1 = tex_coord(P.addrMode, m.pow2, ix + 1, m.w, m.log2w), y1 = tex_coord(P.addrMode, m.pow2, iy + 1, m.h, m.log2h);
+    const float a = load_texel_border<FP32>(m, x0, y0, P.borderAlpha);
+    const float b = load_texel_border<FP32>(m, x0, y1, P.borderAlpha);
+    const float c = load_texel_border<FP32>(m, x1, y0, P.borderAlpha);
+    const float d = load_texel_border<FP32>(m, x1, y1, P.borderAlpha);
+    const float wx = px - fx, wy = py - fy;
+    const float ac = a * (1.f - wx) + c * wx;
+    const float bd = b * (1.f - wx) + d * wx;
+    return ac * (1.f - wy) + bd * wy;
+}
+
+// ---- coverage -> state (bake_kernels_cpu.h:25-61) ----
+__device__ __forceinline__ int state_from_coverage(const ClassifyParams& P, uint32_t above, uint32_t below)
+{
+    if (above != 0 && below != 0) {
+        if (P.format == 2) {
+            if (P.promotion == 1) return 3;
+            if (P.promotion == 2) return 2;
+            return above >= below ? (P.stateGT | 2) : (P.stateLE | 2);
+        }
+        if (P.promotion == 1) return 1;
+        if (P.promotion == 2) return 0;
+        return above >= below ? P.stateGT : P.stateLE;
+    }
+    return above == 0 ? P.stateLE : P.stateGT;
+}
+__device__ __forceinline__ bool state_is_unknown(int s) { return s >= 2; }
+
+// ---- geometry predicates ----
+// util/geometry.h:101-114
+__device__ __forceinline__ bool point_in_triangle(const MicroTri& t, float px, float py)
+{
+    const float s = t.p0p2.x * (py - t.p2.y) - t.p0p2.y * (px - t.p2.x);
+    const float tt = t.p1p0.x * (py - t.p0.y) - t.p1p0.y * (px - t.p0.x);
+    if (((s < 0) != (tt < 0)) && s != 0 && tt != 0) return false;
+    const float d = t.p2p1.x * (py - t.p1.y) - t.p2p1.y * (px - t.p1.x);
+    return d == 0 || ((d < 0) == (s + tt <= 0));
+}
+
+__device__ __forceinline__ bool near_zero(float v, float eps) { return v < eps && v > -eps; }
+__device__ __forceinline__ bool in_unit_square(float x, float y) { return x >= 0.f && x <= 1.f && y >= 0.f && y <= 1.f; }
+
+// bake_kernels_cpu.h:144-238 -- does segment (a0,a1) cross the level curve
+// h.x + h.y*x + h.z*y + h.w*x*y = 0 inside the unit texel?
+__device__ __forceinline__ bool edge_crosses_level_curve(V2 a0, V2 a1, float ha, float hb, float hc, float hd)
+{
+    if (a0.x > a1.x) { V2 t = a0; a0 = a1; a1 = t; }
+    const float len = vlen(a1.x - a0.x, a1.y - a0.y);
+#define ON_EDGE(X, Y) near_zero(vlen((X) - a0.x, (Y) - a0.y) + vlen((X) - a1.x, (Y) - a1.y) - len, 1e-5f)
+    const float kd = a1.x - a0.x;
+    if (near_zero(kd, 1e-6f)) {
+        const float x = a0.x;
+        const float c0 = hd * x + hc;
+        const float c1 = ha + hb * x;
+        if (near_zero(c0, 1e-6f)) return false;
+        const float y = -c1 / c0;
+        return in_unit_square(x, y) && ON_EDGE(x, y);
+    }
+    const float k = (a1.y - a0.y) / kd;
+    const float m = a1.y - a1.x * k;
+    const float c0 = hd * k;
+    const float c1 = hc * k + hd * m + hb;
+    const float c2 = ha + hc * m;
+    if (near_zero(c0, 1e-6f)) {
+        if (near_zero(c1, 1e-6f)) return false;
+        const float x = -c2 / c1;
+        const float y = k * x + m;
+        return in_unit_square(x, y) && ON_EDGE(x, y);
+    }
+    const float inner = c1 * c1 - 4 * c0 * c2;
+    if (inner > 0.f) {
+        const float root = __builtin_sqrtf(inner);
+        const float x0 = 0.5f * (-c1 + root) / c0;
+        const float x1 = 0.5f * (-c1 - root) / c0;
+        const float y0 = k * x0 + m, y1 = k * x1 + m;
+        const bool i0 = in_unit_square(x0, y0) && ON_EDGE(x0, y0);
+        const bool i1 = in_unit_square(x1, y1) && ON_EDGE(x1, y1);
+        return i0 || i1;
+    }
+    return false;
+#undef ON_EDGE
+}
+
+// bake_kernels_cpu.h:241-399 : one texel of the bilinear footprint grid.  Adds to (above, below).
+template <bool FP32, bool DEGENERATE>
+__device__ __forceinline__ void level_line_texel(const ClassifyParams& P, const DevMip& m, const MicroTri& t, int px, int py,
+                                                 uint32_t& above, uint32_t& below)
+{
+    const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
+    const int x0 = tex_coord(P.addrMode, P.pow2Dispatch, px, m.w, m.log2w), y0 = tex_coord(P.addrMode, P.pow2Dispatch, py, m.h, m.log2h);
+    const int x1 = tex_coord(P.addrMode, P.pow2Dispatch, px + 1, m.w, m.log2w), y1 = tex_coord(P.addrMode, P.pow2Dispatch, py + 1, m.h, m.log2h);
+    float gx, gy, gz, gw; // 00, 01, 11, 10
+    if (P.addrMode == 3) {
+        gx = load_texel_border<FP32>(m, x0, y0, P.borderAlpha); gy = load_texel_border<FP32>(m, x0, y1, P.borderAlpha);
+        gz = load_texel_border<FP32>(m, x1, y1, P.borderAlpha); gw = load_texel_border<FP32>(m, x1, y0, P.borderAlpha);
+    } else {
+        gx = load_texel<FP32>(m, x0, y0); gy = load_texel<FP32>(m, x0, y1);
+        gz = load_texel<FP32>(m, x1, y1); gw = load_texel<FP32>(m, x1, y0);
+    }
+    if (!DEGENERATE) {
+        const float ipx = pfx * m.rw, ipy = pfy * m.rh;
+        const bool o0 = P.cutoff < gx, o1 = P.cutoff < gy, o2 = P.cutoff < gz, o3 = P.cutoff < gw;
+        const bool in0 = point_in_triangle(t, ipx, ipy);
+        const bool in1 = point_in_triangle(t, ipx + 0.0f, ipy + m.rh);
+        const bool in2 = point_in_triangle(t, ipx + m.rw, ipy + m.rh);
+        const bool in3 = point_in_triangle(t, ipx + m.rw, ipy + 0.0f);
+        const bool isO = (in0 && o0) || (in1 && o1) || (in2 && o2) || (in3 && o3);
+        const bool isT = (in0 && !o0) || (in1 && !o1) || (in2 && !o2) || (in3 && !o3);
+        if (isO) above += 1;
+        if (isT) below += 1;
+        if (isO && isT) return;
+    }
+    const float a = gx;
+    const float b = gw - gx;
+    const float c = gy - gx;
+    const float d = gx + gz - gy - gw;
+    if (near_zero(b, 1e-6f) && near_zero(c, 1e-6f) && near_zero(d, 1e-6f)) {
+        if (P.cutoff < a) above += 1; else below += 1;
+        return;
+    }
+    const float ha = a - P.cutoff;
+    if (DEGENERATE) {
+        const V2 q0 = mk2(m.fw * t.lo.x - pfx, m.fh * t.lo.y - pfy);
+        const V2 q1 = mk2(m.fw * t.hi.x - pfx, m.fh * t.hi.y - pfy);
+        if (edge_crosses_level_curve(q0, q1, ha, b, c, d)) { above += 1; below += 1; }
+        return;
+    }
+    const V2 q0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy);
+    const V2 q1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy);
+    const V2 q2 = mk2(m.fw * t.p2.x - pfx, m.fh * t.p2.y - pfy);
+    if (edge_crosses_level_curve(q0, q1, ha, b, c, d) || edge_crosses_level_curve(q1, q2, ha, b, c, d) ||
+        edge_crosses_level_curve(q2, q0, ha, b, c, d)) {
+        above += 1; below += 1;
+    }
+}
+
+// bake_cpu_impl.cpp:994-1009
+template <bool FP32>
+__device__ __forceinline__ void nearest_texel(const ClassifyParams& P, const DevMip& m, int px, int py, uint32_t& above, uint32_t& below)
+{
+    const int cx = tex_coord(P.addrMode, P.pow2Dispatch, px, m.w, m.log2w), cy = tex_coord(P.addrMode, P.pow2Dispatch, py, m.h, m.log2h);
+    const bool border = P.addrMode == 3 && (cx == kTexCoordBorder || cy == kTexCoordBorder);
+    const float alpha = border ? P.borderAlpha : load_texel<FP32>(m, cx, cy);
+    if (P.cutoff < alpha) above++; else below++;
+}
+
+// ---- conservative rasterisation of one micro-triangle (util/cpu_raster.h:20-52,117-124,277-383) ----
+struct EdgeEq { float nx, ny, c, bias; };
+__device__ __forceinline__ EdgeEq edge_eq(V2 p, V2 q)
+{
+    EdgeEq e;
+    e.nx = q.y - p.y; e.ny = p.x - q.x;
+    e.c = -(e.nx * p.x + e.ny * p.y);
+    e.bias = 0.f; // unused; the conservative offsets are re-added in reference order below
+    return e;
+}
+__device__ __forceinline__ float eval_cons(const EdgeEq& e, float sx, float sy)
+{
+    const float ev = (e.nx * sx + e.ny * sy) + e.c;
+    const float bx = e.nx > 0 ? 0.f : e.nx;
+    const float by = e.ny > 0 ? 0.f : e.ny;
+    return ev + bx * 1.f + by * 1.f;
+}
+
+// KIND: 0 = level-line (linear filter), 1 = nearest vote
+template <bool FP32, int KIND>
+__device__ __forceinline__ void raster_micro_triangle(const ClassifyParams& P, const DevMip& m, const MicroTri& t, float off,
+                                                      uint32_t& above, uint32_t& below)
+{
+    // util/geometry.h:49-55 : winding from the fp64 cross product of fp32 edge vectors
+    const double ax = (double)(t.p2.x - t.p0.x), ay = (double)(t.p2.y - t.p0.y);
+    const double bx = (double)(t.p1.x - t.p0.x), by = (double)(t.p1.y - t.p0.y);
+    const bool ccw = (ax * by - bx * ay) < 0;
+    V2 a = mk2(t.p0.x * m.fw + off, t.p0.y * m.fh + off);
+    const V2 b = mk2(t.p1.x * m.fw + off, t.p1.y * m.fh + off);
+    V2 c = mk2(t.p2.x * m.fw + off, t.p2.y * m.fh + off);
+    if (!ccw) { V2 s = a; a = c; c = s; }
+    const float lox = std_min(std_min(a.x, b.x), c.x), loy = std_min(std_min(a.y, b.y), c.y);
+    const float hix = std_max(std_max(a.x, b.x), c.x), hiy = std_max(std_max(a.y, b.y), c.y);
+    const int minx = cvt_trunc_x86(__builtin_floorf(lox)), miny = cvt_trunc_x86(__builtin_floorf(loy));
+    const int maxx = cvt_trunc_x86(__builtin_ceilf(hix)), maxy = cvt_trunc_x86(__builtin_ceilf(hiy));
+    const EdgeEq e0 = edge_eq(a, b), e1 = edge_eq(b, c), e2 = edge_eq(c, a);
+    for (int y = miny; y < maxy; ++y) {
+        bool wasInside = false;
+        for (int x = minx; x < maxx; ++x) {
+            const float sx = (float)x, sy = (float)y;
+            const bool inside = eval_cons(e0, sx, sy) < 0.f && eval_cons(e1, sx, sy) < 0.f && eval_cons(e2, sx, sy) < 0.f;
+            if (inside) {
+                if (KIND == 0) level_line_texel<FP32, false>(P, m, t, x, y, above, below);
+                else nearest_texel<FP32>(P, m, x, y, above, below);
+                wasInside = true;
+            } else if (wasInside) break;
+        }
+    }
+}
+
+// conservative line walk for degenerate work items (util/cpu_raster.h:486-555)
+template <bool FP32>
+__device__ __forceinline__ void raster_micro_segment(const ClassifyParams& P, const DevMip& m, const MicroTri& t,
+                                                     uint32_t& above, uint32_t& below)
+{
+    V2 p0 = mk2(t.lo.x * m.fw + -0.5f, t.lo.y * m.fh + -0.5f);
+    V2 p1 = mk2(t.hi.x * m.fw + -0.5f, t.hi.y * m.fh + -0.5f);
+    if (p0.x > p1.x) { V2 s = p0; p0 = p1; p1 = s; }
+    const float dx = p1.x - p0.x, dy = p1.y - p0.y;
+    int x = cvt_trunc_x86(__builtin_floorf(p0.x));
+    int y = cvt_trunc_x86(__builtin_floorf(p0.y));
+    const int stepX = dx > 0 ? 1 : (dx < 0 ? -1 : 0);
+    const int stepY = dy > 0 ? 1 : (dy < 0 ? -1 : 0);
+    const float inf = __builtin_inff();
+    const float tDeltaX = stepX != 0 ? 1.f / __builtin_fabsf(dx) : inf;
+    const float tDeltaY = stepY != 0 ? 1.f / __builtin_fabsf(dy) : inf;
+    float tMaxX = inf, tMaxY = inf;
+    if (stepX != 0) tMaxX = (((float)x + (stepX > 0 ? 1.f : 0.f)) - p0.x) / dx;
+    if (stepY != 0) tMaxY = (((float)y + (stepY > 0 ? 1.f : 0.f)) - p0.y) / dy;
+    if (stepX == 0 && stepY == 0) { level_line_texel<FP32, true>(P, m, t, x, y, above, below); return; }
+    const int yMin = cvt_trunc_x86(std_min(__builtin_floorf(p0.y), __builtin_floorf(p1.y)));
+    const int yMax = cvt_trunc_x86(std_max(__builtin_ceilf(p0.y), __builtin_ceilf(p1.y)));
+    const int xMin = cvt_trunc_x86(std_min(__builtin_floorf(p0.x), __builtin_floorf(p1.x)));
+    const int xMax = cvt_trunc_x86(std_max(__builtin_ceilf(p0.x), __builtin_ceilf(p1.x)));
+    while (x >= xMin && x <= xMax && y >= yMin && y <= yMax) {
+        level_line_texel<FP32, true>(P, m, t, x, y, above, below);
+        if (tMaxX < tMaxY) { x += stepX; tMaxX += tDeltaX; }
+        else { y += stepY; tMaxY += tDeltaY; }
+    }
+}
+
+// ---- coarse pass: summed-area-table test of one micro-triangle (bake_cpu_impl.cpp:749-801) ----
+// returns -1 when the micro-triangle stays unresolved
+__device__ __forceinline__ int coarse_state(const ClassifyParams& P, const MicroTri& t)
+{
+    const DevMip& m = P.mips[0];
+    if (cvt_trunc_x86(t.lo.x) != cvt_trunc_x86(t.hi.x) || cvt_trunc_x86(t.lo.y) != cvt_trunc_x86(t.hi.y)) return -1;
+    const float fsx = t.lo.x * m.fw - 0.5f, fsy = t.lo.y * m.fh - 0.5f;
+    const float fex = t.hi.x * m.fw - 0.5f, fey = t.hi.y * m.fh - 0.5f;
+    const int sx = tex_coord(P.addrMode, P.pow2Dispatch, cvt_trunc_x86(__builtin_floorf(fsx)), m.w, m.log2w);
+    const int sy = tex_coord(P.addrMode, P.pow2Dispatch, cvt_trunc_x86(__builtin_floorf(fsy)), m.h, m.log2h);
+    const int ex = tex_coord(P.addrMode, P.pow2Dispatch, cvt_trunc_x86(__builtin_floorf(fex)) + 1, m.w, m.log2w);
+    const int ey = tex_coord(P.addrMode, P.pow2Dispatch, cvt_trunc_x86(__builtin_floorf(fey)) + 1, m.h, m.log2h);
+    if (ex < sx || ey < sy) return -1;
+    if (!(sx >= 0 && sy >= 0 && sx < m.w && sy < m.h)) return -1;
+    if (!(ex >= 0 && ey >= 0 && ex < m.w && ey < m.h)) return -1;
+    const uint32_t area = (uint32_t)((ex - sx + 1) * (ey - sy + 1));
+    // texture_impl.h:110-125
+    const uint32_t* sat = m.sat;
+    const size_t W = (size_t)m.w;
+    const uint32_t A = (sx > 0 && sy > 0) ? sat[(size_t)(sx - 1) + (size_t)(sy - 1) * W] : 0u;
+    const uint32_t B = sy > 0 ? sat[(size_t)ex + (size_t)(sy - 1) * W] : 0u;
+    const uint32_t C = sx > 0 ? sat[(size_t)(sx - 1) + (size_t)ey * W] : 0u;
+    const uint32_t D = sat[(size_t)ex + (size_t)ey * W];
+    const uint32_t sa = D + A - B - C;
+    if (sa == 0) return P.stateLE;
+    if (sa == area) return P.stateGT;
+    return -1;
+}
+
+// ---- fine pass for one micro-triangle (bake_cpu_impl.cpp:859-914 linear, :983-1022 nearest) ----
+template <bool FP32>
+__device__ __forceinline__ int fine_state(const ClassifyParams& P, const MicroTri& t, bool degenerate)
+{
+    uint32_t above = 0, below = 0;
+    for (int mip = 0; mip < P.mipCount; ++mip) {
+        const DevMip& m = P.mips[mip];
+        if (P.filterLinear) {
+            if (P.cutoff < bilinear<FP32>(P, m, t.p0)) above++; else below++;
+            if (!degenerate) raster_micro_triangle<FP32, 0>(P, m, t, -0.5f, above, below);
+            else raster_micro_segment<FP32>(P, m, t, above, below);
+        } else {
+            raster_micro_triangle<FP32, 1>(P, m, t, 0.f, above, below);
+        }
+        if (state_is_unknown(state_from_coverage(P, above, below))) break;
+    }
+    return state_from_coverage(P, above, below);
+}
+
+} // namespace ommx

@@ -1,0 +1,242 @@
+// tail_kernels.hip -- device restatement of the reference's serial tail
+// (bake_cpu_impl.cpp:1432-1472 promote, :1031-1066 exact dedup, :1690-1705 histograms,
+//  :1707-1754 spatial sort, :1756-1920 serialize) with parallel primitives.
+//
+// The reference's sequential "first occurrence wins" semantics are kept by construction:
+//   * exact dedup     = stable radix sort of (digest, item) + segment heads  -> rep[item] = lowest item with that digest
+//   * spatial order   = stable radix sort ascending of (key, item), read back to front
+//                       == std::sort(std::greater<pair<key,item>>)
+// rocPRIM/hipCUB radix sort and scan are the only library calls.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+#include "bake_types.h"
+#include "bake_kernels.h"
+
+namespace ommx {
+
+__device__ __forceinline__ int cvt_trunc_x86_t(float f) { return (f >= -2147483648.f && f < 2147483648.f) ? (int)f : (int)0x80000000; }
+__device__ __forceinline__ int clampi_t(int v, int lo, int hi) { return v < lo ? lo : (hi < v ? hi : v); }
+__device__ __forceinline__ uint32_t spread16(uint32_t x)
+{
+    x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu; x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+// promote (bake_cpu_impl.cpp:1432-1472) + digest of uniform items from the table
+__global__ __launch_bounds__(256) void tail_summarize(TailInputs in, int32_t* __restrict__ special, uint64_t* __restrict__ digestKeys,
+                                                      uint32_t* __restrict__ itemIdx)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= in.numItems) return;
+    const uint32_t mask = in.stateMask[i];
+    const uint32_t level = in.level[i];
+    bool allEqual = (mask & (mask - 1u)) == 0u;
+    int common = 31 - __clz((int)mask);
+    if (allEqual && in.uniformDigest) {
+        const int s3 = common == 2 ? 3 : common;
+        in.digests[i] = in.uniformDigest[level * 4u + (uint32_t)s3];
+    }
+    if (!allEqual && in.rejectionThreshold > 0.f) {
+        const float frac = (float)in.knownCount[i] / (float)(1u << (2u * level));
+        if (frac < in.rejectionThreshold) { allEqual = true; common = 2; }
+    }
+    special[i] = (allEqual && !in.disableSpecial) ? (-(int32_t)common - 1) : 0;
+    digestKeys[i] = in.digests[i];
+    itemIdx[i] = i;
+}
+
+__global__ __launch_bounds__(256) void tail_iota(uint32_t* __restrict__ v, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+
+// segment heads of the digest-sorted list -> position of the head (for the running-max scan)
+__global__ __launch_bounds__(256) void tail_head_pos(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ headPos)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    headPos[p] = (p == 0 || keys[p] != keys[p - 1]) ? p : 0u;
+}
+
+__global__ __launch_bounds__(256) void tail_assign_rep(const uint32_t* __restrict__ sortedItems, const uint32_t* __restrict__ headPos, uint32_t n,
+                                                       uint32_t* __restrict__ rep)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    rep[sortedItems[p]] = sortedItems[headPos[p]];
+}
+
+// spatial sort key (bake_cpu_impl.cpp:1722-1748); non-emitted items sort to the far end
+__global__ __launch_bounds__(256) void tail_sort_keys(TailInputs in, const int32_t* __restrict__ special, const uint32_t* __restrict__ rep,
+                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ emittedFlag)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= in.numItems) return;
+    const bool emitted = rep[i] == i && special[i] == 0;
+    uint64_t key = ~0ull;
+    if (emitted) {
+        const float* p = in.uv + 6ull * i;
+        const float cx = (p[0] + p[2] + p[4]) / 3.f, cy = (p[1] + p[3] + p[5]) / 3.f;
+        const int qx = cvt_trunc_x86_t(8192.f * cx), qy = cvt_trunc_x86_t(8192.f * cy);
+        // GetTexCoord<MirrorOnce, non-pow2> on an 8192^2 grid (util/texture.h:84-87)
+        const int mx = clampi_t(cvt_trunc_x86_t(__builtin_fabsf((float)qx + 0.5f)), 0, 8191);
+        const int my = clampi_t(cvt_trunc_x86_t(__builtin_fabsf((float)qy + 0.5f)), 0, 8191);
+        key = ((uint64_t)in.level[i] << 60) | (uint64_t)(spread16((uint32_t)mx) | (spread16((uint32_t)my) << 1));
+    }
+    keys[i] = key;
+    emittedFlag[i] = emitted ? 1u : 0u;
+}
+
+// descriptor order = emitted items of the ascending sort, back to front; sizes for the offset scan
+__global__ __launch_bounds__(256) void tail_order_sizes(const uint32_t* __restrict__ sortedItems, const uint32_t* __restrict__ numEmitted,
+                                                        const uint8_t* __restrict__ level, int bits, uint32_t* __restrict__ order,
+                                                        uint64_t* __restrict__ sizes64, uint32_t* __restrict__ sizes, uint32_t* __restrict__ arrayHist)
+{
+    const uint32_t E = *numEmitted;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= E) return;
+    const uint32_t item = sortedItems[E - 1u - j];
+    order[j] = item;
+    const uint32_t lvl = level[item];
+    uint32_t n = ((1u << (2u * lvl)) * (uint32_t)bits) >> 3; if (n < 1u) n = 1u;
+    sizes[j] = n; sizes64[j] = n;
+    atomicAdd(&arrayHist[lvl], 1u);
+}
+
+__global__ __launch_bounds__(256) void tail_item_values(const uint32_t* __restrict__ order, const uint32_t* __restrict__ numEmitted,
+                                                        const uint64_t* __restrict__ ofs64, uint32_t* __restrict__ dstOfs,
+                                                        const int32_t* __restrict__ special, uint32_t numItems, int32_t* __restrict__ itemValue)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t E = *numEmitted;
+    if (i < numItems && special[i] != 0) itemValue[i] = special[i];
+    if (i < E) { itemValue[order[i]] = (int32_t)i; dstOfs[i] = (uint32_t)ofs64[i]; }
+}
+
+// index buffer + index histogram (bake_cpu_impl.cpp:1697-1702,1856-1870)
+__global__ __launch_bounds__(256) void tail_indices(TailInputs in, const uint32_t* __restrict__ rep, const int32_t* __restrict__ itemValue,
+                                                    int32_t* __restrict__ out, uint32_t* __restrict__ indexHist)
+{
+    __shared__ uint32_t h[kNumLevels];
+    if (threadIdx.x < kNumLevels) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < in.numTris) {
+        const int32_t it = in.triToItem[t];
+        int32_t v = in.unresolved;
+        if (it >= 0) {
+            const uint32_t r = rep[it];
+            v = itemValue[r];
+            if (v >= 0) atomicAdd(&h[in.level[r]], 1u);
+        }
+        out[t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumLevels && h[threadIdx.x]) atomicAdd(&indexHist[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void tail_descs(const uint32_t* __restrict__ order, const uint32_t* __restrict__ dstOfs, const uint8_t* __restrict__ level,
+                                                  int format, uint32_t numOmms, uint2* __restrict__ descs)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= numOmms) return;
+    // ommCpuOpacityMicromapDesc { u32 offset; u16 subdivisionLevel; u16 format; }
+    descs[j] = make_uint2(dstOfs[j], (uint32_t)level[order[j]] | ((uint32_t)format << 16));
+}
+
+void launch_write_descs(const uint32_t* order, const uint32_t* dstOfs, const uint8_t* level, int format, uint32_t numOmms, void* descArray, hipStream_t stream)
+{
+    if (numOmms == 0) return;
+    hipLaunchKernelGGL(tail_descs, dim3((numOmms + 255u) / 256u), dim3(256), 0, stream, order, dstOfs, level, format, numOmms, (uint2*)descArray);
+}
+
+// ---- scratch layout ----
+struct Scratch {
+    uint64_t *keysA, *keysB, *sizes64, *ofs64;
+    uint32_t *valsA, *valsB, *headPos, *headScan, *emitted, *numEmitted;
+    uint64_t* total;
+    void* cub; size_t cubBytes;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static size_t cub_bytes(uint32_t n)
+{
+    size_t a = 0, b = 0, c = 0, d = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+    hipcub::DeviceScan::InclusiveScan(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, hipcub::Max(), (int)n);
+    hipcub::DeviceScan::ExclusiveSum(nullptr, c, (uint64_t*)nullptr, (uint64_t*)nullptr, (int)n);
+    hipcub::DeviceReduce::Sum(nullptr, d, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+    size_t m = a; if (b > m) m = b; if (c > m) m = c; if (d > m) m = d;
+    return align_up(m, 256) + 256;
+}
+
+static Scratch carve(void* base, uint32_t n)
+{
+    Scratch s; uint8_t* p = (uint8_t*)base;
+    const size_t n64 = align_up((size_t)n * 8, 256), n32 = align_up((size_t)n * 4, 256);
+    s.keysA = (uint64_t*)p; p += n64; s.keysB = (uint64_t*)p; p += n64; s.sizes64 = (uint64_t*)p; p += n64; s.ofs64 = (uint64_t*)p; p += n64;
+    s.valsA = (uint32_t*)p; p += n32; s.valsB = (uint32_t*)p; p += n32; s.headPos = (uint32_t*)p; p += n32; s.headScan = (uint32_t*)p; p += n32;
+    s.emitted = (uint32_t*)p; p += n32;
+    s.numEmitted = (uint32_t*)p; p += 256; s.total = (uint64_t*)p; p += 256;
+    s.cub = p; s.cubBytes = cub_bytes(n);
+    return s;
+}
+
+size_t tail_scratch_bytes(uint32_t numItems, uint32_t numTris)
+{
+    (void)numTris;
+    const uint32_t n = numItems ? numItems : 1;
+    return 4 * align_up((size_t)n * 8, 256) + 5 * align_up((size_t)n * 4, 256) + 512 + cub_bytes(n);
+}
+
+#define TAIL_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch, size_t scratchBytes, TailCounts* counts, hipStream_t stream)
+{
+    const uint32_t n = in.numItems;
+    counts->numOmms = 0; counts->arrayDataSize = 0;
+    TAIL_CHECK(hipMemsetAsync(out.arrayHist, 0, sizeof(uint32_t) * kNumLevels, stream));
+    TAIL_CHECK(hipMemsetAsync(out.indexHist, 0, sizeof(uint32_t) * kNumLevels, stream));
+    if (n != 0) {
+        if (scratchBytes < tail_scratch_bytes(n, in.numTris)) return hipErrorInvalidValue;
+        Scratch s = carve(scratch, n);
+        const dim3 grid((n + 255u) / 256u), block(256);
+        hipLaunchKernelGGL(tail_summarize, grid, block, 0, stream, in, out.special, s.keysA, s.valsA);
+        if (in.disableDedup) {
+            hipLaunchKernelGGL(tail_iota, grid, block, 0, stream, out.rep, n);
+        } else {
+            size_t tb = s.cubBytes;
+            TAIL_CHECK(hipcub::DeviceRadixSort::SortPairs(s.cub, tb, s.keysA, s.keysB, s.valsA, s.valsB, (int)n, 0, 64, stream));
+            hipLaunchKernelGGL(tail_head_pos, grid, block, 0, stream, s.keysB, n, s.headPos);
+            tb = s.cubBytes;
+            TAIL_CHECK(hipcub::DeviceScan::InclusiveScan(s.cub, tb, s.headPos, s.headScan, hipcub::Max(), (int)n, stream));
+            hipLaunchKernelGGL(tail_assign_rep, grid, block, 0, stream, s.valsB, s.headScan, n, out.rep);
+        }
+        hipLaunchKernelGGL(tail_sort_keys, grid, block, 0, stream, in, out.special, out.rep, s.keysA, s.emitted);
+        hipLaunchKernelGGL(tail_iota, grid, block, 0, stream, s.valsA, n);
+        size_t tb = s.cubBytes;
+        TAIL_CHECK(hipcub::DeviceReduce::Sum(s.cub, tb, s.emitted, s.numEmitted, (int)n, stream));
+        tb = s.cubBytes;
+        TAIL_CHECK(hipcub::DeviceRadixSort::SortPairs(s.cub, tb, s.keysA, s.keysB, s.valsA, s.valsB, (int)n, 0, 64, stream));
+        TAIL_CHECK(hipMemsetAsync(s.sizes64, 0, (size_t)n * 8, stream));
+        hipLaunchKernelGGL(tail_order_sizes, grid, block, 0, stream, s.valsB, s.numEmitted, in.level, in.format, out.order, s.sizes64, out.sizes, out.arrayHist);
+        tb = s.cubBytes;
+        TAIL_CHECK(hipcub::DeviceScan::ExclusiveSum(s.cub, tb, s.sizes64, s.ofs64, (int)n, stream));
+        hipLaunchKernelGGL(tail_item_values, grid, block, 0, stream, out.order, s.numEmitted, s.ofs64, out.dstOfs, out.special, n, out.itemValue);
+        // total = ofs[n-1] + sizes[n-1] (entries past numEmitted are zero-sized)
+        uint32_t E = 0; uint64_t lastOfs = 0, lastSize = 0;
+        TAIL_CHECK(hipMemcpyAsync(&E, s.numEmitted, 4, hipMemcpyDeviceToHost, stream));
+        TAIL_CHECK(hipMemcpyAsync(&lastOfs, s.ofs64 + (n - 1), 8, hipMemcpyDeviceToHost, stream));
+        TAIL_CHECK(hipMemcpyAsync(&lastSize, s.sizes64 + (n - 1), 8, hipMemcpyDeviceToHost, stream));
+        TAIL_CHECK(hipStreamSynchronize(stream));
+        counts->numOmms = E; counts->arrayDataSize = lastOfs + lastSize;
+    }
+    if (in.numTris != 0)
+        hipLaunchKernelGGL(tail_indices, dim3((in.numTris + 255u) / 256u), dim3(256), 0, stream, in, out.rep, out.itemValue, out.indexBuffer, out.indexHist);
+    return hipGetLastError();
+}
+
+} // namespace ommx

