@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- micro-triangles classified per second by ommCpuBake() on MI355X.
+
+A "step" is one complete bake (the whole hot path: work-item setup, SAT coarse pass, level-line fine pass, special-index
+promotion, XXH64 dedup, spatial sort, pack, index buffer) of BASELINE.json's metric configuration:
+    1 M random-UV triangles, 4096^2 foliage-style UNORM8 alpha (texture alphaCutoff = 0.5 => SAT on),
+    subdivision level 8, 4-state, Wrap / Linear, ForceOpaque promotion                       (configs[2] / [3])
+Prints ONE JSON line (rank 0).  `value` = micro-triangles of all unique work items / wall time of the step.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ommtest as ot  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+class BakeTimings(C.Structure):
+    _fields_ = [("hostSetupMs", C.c_float), ("uploadMs", C.c_float), ("classifyMs", C.c_float), ("digestMs", C.c_float),
+                ("tailMs", C.c_float), ("gatherMs", C.c_float), ("downloadMs", C.c_float), ("totalMs", C.c_float),
+                ("microTriangles", C.c_uint64), ("uniqueItems", C.c_uint32), ("classifyLaunches", C.c_uint32),
+                ("stateBytes", C.c_uint64)]
+
+
+def make_workload(args):
+    """Seeded synthetic inputs (identical on every rank and for the CPU baseline)."""
+    tex = ot.foliage_texture(args.seed, args.tex, args.tex, feature=args.feature)
+    uv, ix = ot.random_triangles(args.seed + 1, args.tris, args.extent_texels / args.tex)
+    return tex, uv, ix
+
+
+def bake_desc(tex_handle, uv, ix, args, lo, hi):
+    return ot.make_desc(tex_handle, uv[3 * lo:3 * hi], ix[:3 * (hi - lo)], args.level, addr=ot.WRAP, filt=ot.LINEAR,
+                        promo=ot.PROMO_FORCE_OPAQUE, fmt=ot.FMT_4STATE, flags=ot.FLAG_THREADS)
+
+
+def cpu_baseline(args, tex, uv, ix):
+    """The oracle (bit-exact restatement of the reference CPU baker, OpenMP over work items like the reference) timed on a
+    bounded sample of the same triangle stream: the reference needs 2 * 4^N bytes per work item (131 GB at full size)."""
+    import multiprocessing
+    cores = multiprocessing.cpu_count()
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    orc = ot.Lib("oracle")
+    b = orc.create_baker()
+    t = orc.create_texture(b, [tex], alpha_cutoff=0.5)
+    k = min(args.cpu_sample, args.tris)
+    d = bake_desc(t, uv, ix, args, 0, k)
+    t0 = time.time()
+    res = orc.bake(b, d, want_stats=False)
+    dt = time.time() - t0
+    orc.destroy_texture(b, t)
+    orc.destroy_baker(b)
+    mt = k * 4 ** args.level
+    return {"value": mt / dt, "unit": "micro-triangles/s", "cores": cores, "kind": "port",
+            "sample": "first %d triangles of the same seeded stream (%.3g micro-triangles), SAT on, %.1f s" % (k, mt, dt)}, res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tris", type=int, default=1000000)
+    ap.add_argument("--level", type=int, default=8)
+    ap.add_argument("--tex", type=int, default=4096)
+    ap.add_argument("--feature", type=int, default=64, help="foliage blob size in texels")
+    ap.add_argument("--extent-texels", type=float, default=8.0, help="triangle size in texels")
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="triangles baked by the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl")
+
+    tex, uv, ix = make_workload(args)
+    # strong scaling: the fixed triangle stream is split into contiguous per-rank ranges
+    lo, hi = args.tris * rank // world, args.tris * (rank + 1) // world
+
+    prod = ot.Lib("product")
+    prod.dll.ommxGetLastBakeTimings.argtypes = [C.c_void_p, C.POINTER(BakeTimings)]
+    baker = prod.create_baker()
+    th = prod.create_texture(baker, [tex], alpha_cutoff=0.5)
+    desc = bake_desc(th, uv, ix, args, lo, hi)
+
+    def step():
+        r, out = prod.bake_raw(baker, desc)
+        assert r == ot.SUCCESS, "ommCpuBake failed: %d" % r
+        return out
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    last = None
+    for _ in range(args.warmup):
+        if last is not None:
+            prod.fn("ommCpuDestroyBakeResult")(last)
+        last = step()
+    sync()
+    t0 = time.perf_counter()
+    tms = []
+    for _ in range(args.steps):
+        if last is not None:
+            prod.fn("ommCpuDestroyBakeResult")(last)
+        last = step()
+        tm = BakeTimings()
+        prod.dll.ommxGetLastBakeTimings(baker, C.byref(tm))
+        tms.append(tm)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        mt = torch.tensor([float(tms[-1].microTriangles)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(mt, op=dist.ReduceOp.SUM)
+        micro_tris = float(mt.item())
+    else:
+        micro_tris = float(tms[-1].microTriangles)
+
+    pd = C.POINTER(ot.BakeResultDesc)()
+    prod.fn("ommCpuGetBakeResultDesc")(last, C.byref(pd))
+    rd = pd.contents
+    result_info = {"arrayDataBytes": int(rd.arrayDataSize), "descs": int(rd.descArrayCount), "triangles": int(rd.indexCount)}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        avg = lambda f: float(np.mean([getattr(t, f) for t in tms]))
+        classify_ms = avg("classifyMs")
+        launches = max(1, tms[-1].classifyLaunches)
+        # algorithmic bytes of the classification launch (DESIGN.md "Roofline"): 0.25 B written per 4-state micro-triangle,
+        # 24 B of UV read per work item, one pass over the texture and its summed-area table
+        alg_bytes = 0.25 * tms[-1].microTriangles + 24.0 * tms[-1].uniqueItems + args.tex * args.tex * (1 + 4)
+        achieved = alg_bytes / (classify_ms * 1e-3) / 1e9 if classify_ms > 0 else 0.0
+        line = {
+            "metric": "micro-triangles classified/sec (whole node)", "value": micro_tris / (elapsed / args.steps),
+            "unit": "micro-triangles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d random-UV triangles (%.1f texels), %dx%d foliage-style UNORM8 alpha + SAT, subdiv level %d, 4-state, Wrap/Linear"
+                                   % (args.tris, args.extent_texels, args.tex, args.tex, args.level),
+                       "entry": "ommCpuBake (host pointers in/out)", "sharding": "contiguous triangle ranges per rank" if world > 1 else "none",
+                       "result": result_info},
+            "bake_wall_time_ms": ms_per_step,
+            "phases_ms": {k: avg(k) for k in ("hostSetupMs", "uploadMs", "classifyMs", "digestMs", "tailMs", "gatherMs", "downloadMs", "totalMs")},
+            "roofline": {"bound": "hbm", "kernel": "classify_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": classify_ms / launches,
+                         "note": "classification is fp32-VALU/sqrt/div bound, not HBM bound (SURVEY.md section 8d)"},
+        }
+        if args.cpu_sample > 0 and world == 1:
+            cb, cpu_res = cpu_baseline(args, tex, uv, ix)
+            line["cpu_baseline"] = cb
+            line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"]
+        print(json.dumps(line))
+    prod.fn("ommCpuDestroyBakeResult")(last)
+    prod.destroy_texture(baker, th)
+    prod.destroy_baker(baker)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,31 @@
+/*
+ * omm_mi355x_ext.h -- MI355X-specific additions to the C ABI (not part of the reference SDK).
+ *
+ * The reference exposes no timing or device-resident interface: its baker is a host library
+ * (libraries/omm-lib/include/omm.h:568-594).  These entry points exist so a harness can (a) read HIP-event
+ * timings of the kernels a bake launched on the library's own stream and (b) run a bake whose inputs and
+ * outputs stay in HBM.  They use only plain C types.
+ */
+#ifndef OMM_MI355X_EXT_H
+#define OMM_MI355X_EXT_H
+#include "omm_mi355x.h"
+
+/* HIP-event timings of the most recent successful bake on this baker (milliseconds). */
+typedef struct ommxBakeTimings {
+    float    hostSetupMs;      /* work-item setup on the host (0 when the device setup path ran) */
+    float    uploadMs;         /* host -> device copies of the work-item tables */
+    float    classifyMs;       /* all classify_tiles launches (coarse SAT pass + fine level-line pass) */
+    float    digestMs;         /* XXH64 digests */
+    float    tailMs;           /* promote / dedup / sort / offsets / index buffer */
+    float    gatherMs;         /* gather of surviving OMM blocks + descriptors */
+    float    downloadMs;       /* device -> host copy of the result arrays */
+    float    totalMs;          /* wall clock of the whole call */
+    uint64_t microTriangles;   /* sum of 4^level over unique work items */
+    uint32_t uniqueItems;
+    uint32_t classifyLaunches;
+    uint64_t stateBytes;       /* packed state bytes written by classification */
+} ommxBakeTimings;
+
+OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings* out);
+
+#endif

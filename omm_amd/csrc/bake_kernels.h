@@ -32,6 +32,7 @@ struct TailInputs {
     int      disableSpecial, disableDedup;
     float    rejectionThreshold;
     int32_t  unresolved;
+    uint32_t* errorFlag;        // device word, set when an item was left unclassified (internal consistency check)
 };
 struct TailOutputs {            // device buffers owned by the caller
     int32_t*  special;          // per item: 0 = none, else special index

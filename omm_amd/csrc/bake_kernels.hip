@@ -32,7 +32,7 @@ constexpr int BLOCK = 256;
 
 template <bool FP32>
 __global__ __launch_bounds__(BLOCK) void classify_tiles(ClassifyParams P, ItemArrays A, const uint32_t* __restrict__ itemIds,
-                                                        uint32_t numItems, uint32_t level)
+                                                        uint32_t numItems, uint32_t level, uint64_t numTiles)
 {
     __shared__ uint8_t  s_state[TILE];
     __shared__ uint16_t s_queue[TILE];
@@ -44,7 +44,10 @@ __global__ __launch_bounds__(BLOCK) void classify_tiles(ClassifyParams P, ItemAr
     const bool sliced = M >= (uint32_t)TILE;               // tile is a slice of one item
     const uint32_t tilesPerItem = sliced ? M / TILE : 1u;
     const uint32_t itemsPerTile = sliced ? 1u : TILE / M;
-    const uint32_t tile = blockIdx.x;
+    // 2-D grid: the AQL dispatch packet counts work-items per dimension in 32 bits, so x alone tops out at 2^24 tiles
+    const uint64_t tile64 = (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (tile64 >= numTiles) return;
+    const uint32_t tile = (uint32_t)tile64;
     const uint32_t firstItem = sliced ? tile / tilesPerItem : tile * itemsPerTile;
     const uint32_t base = sliced ? (tile % tilesPerItem) * TILE : 0u; // first micro-triangle of the slice
     uint32_t itemsHere = numItems - firstItem;
@@ -153,11 +156,11 @@ void launch_classify(const ClassifyParams& P, const ItemArrays& A, const uint32_
     if (numItems == 0) return;
     const uint64_t M = 1ull << (2 * level);
     const uint64_t tiles = M >= (uint64_t)TILE ? (uint64_t)numItems * (M / TILE) : ((uint64_t)numItems * M + TILE - 1) / TILE;
-    // blockIdx.x is 32-bit; split very large level groups
-    const uint64_t maxTiles = 0x7FFFFFFFull / 1;
-    (void)maxTiles;
-    if (P.texIsFp32) hipLaunchKernelGGL(classify_tiles<true>, dim3((uint32_t)tiles), dim3(BLOCK), 0, stream, P, A, itemIds, numItems, level);
-    else             hipLaunchKernelGGL(classify_tiles<false>, dim3((uint32_t)tiles), dim3(BLOCK), 0, stream, P, A, itemIds, numItems, level);
+    if (tiles > 0xFFFFFFFFull) return; // cannot happen: the packed states of such a level group would not fit in HBM
+    const uint32_t gx = tiles < (1u << 20) ? (uint32_t)tiles : (1u << 20);
+    const uint32_t gy = (uint32_t)((tiles + gx - 1) / gx);
+    if (P.texIsFp32) hipLaunchKernelGGL(classify_tiles<true>, dim3(gx, gy), dim3(BLOCK), 0, stream, P, A, itemIds, numItems, level, tiles);
+    else             hipLaunchKernelGGL(classify_tiles<false>, dim3(gx, gy), dim3(BLOCK), 0, stream, P, A, itemIds, numItems, level, tiles);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@
 // validates, builds the work-item list and drives the HIP kernels.  There is NO CPU classification
 // path here: without a working HIP device every bake returns ommResult_FAILURE with a Fatal log line.
 #include "../../include/omm_mi355x.h"
+#include "../../include/omm_mi355x_ext.h"
 #include "bake_types.h"
 #include "bake_kernels.h"
 
@@ -12,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <unordered_map>
@@ -81,7 +83,18 @@ inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 struct Baker {
     Allocator mem; Logger log; ommBakerType type;
     DeviceArena arena;
+    std::mutex timingsMu; ommxBakeTimings timings; bool haveTimings = false;
 };
+
+// HIP events on the bake's own stream (torch / the caller never see this stream)
+struct EventTimer {
+    hipStream_t s; hipEvent_t ev[16]; int n = 0;
+    explicit EventTimer(hipStream_t st) : s(st) { for (auto& e : ev) e = nullptr; }
+    ~EventTimer() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+    int mark() { if (n >= 16) return -1; if (hipEventCreate(&ev[n]) != hipSuccess) return -1; (void)hipEventRecord(ev[n], s); return n++; }
+    float ms(int a, int b) const { float v = 0.f; if (a < 0 || b < 0 || hipEventElapsedTime(&v, ev[a], ev[b]) != hipSuccess) return 0.f; return v; }
+};
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct TexMip { int w = 0, h = 0; void* texels = nullptr; uint32_t* sat = nullptr; };
 struct Texture {
@@ -261,6 +274,7 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     const Logger& L = baker.log;
     const uint32_t flags = (uint32_t)d.bakeFlags;
     const Texture& tex = *untag<Texture>(d.texture);
+    const double t0 = now_ms();
 
     // ---- scope fences (documented in DESIGN.md) ----
     if ((flags & ((1u << 4) | (1u << 10))) != 0)
@@ -330,6 +344,7 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
         }
     }
 
+    const double tSetup = now_ms();
     // ---- device layout ----
     const int bits = (int)d.format;
     std::vector<uint64_t> stateOfs(U ? U : 1);
@@ -347,7 +362,7 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     const size_t perItem32 = pad256((size_t)(U ? U : 1) * 4), perItem64 = pad256((size_t)(U ? U : 1) * 8);
     size_t need = pad256((size_t)(U ? U : 1) * 24) /*uv*/ + 2 * pad256(U ? U : 1) /*level,degenerate*/ + perItem64 /*stateOfs*/ + perItem32 /*itemIds*/
                 + pad256((size_t)(triCount ? triCount : 1) * 4) * 2 /*triToItem, indexBuffer*/ + perItem32 * 8 /*mask, known, special, rep, order, dstOfs, sizes, itemValue*/
-                + perItem64 /*digests*/ + 1024 /*histograms*/ + pad256(scratchBytes) + pad256(stateBytes) + 4096;
+                + perItem64 /*digests*/ + 2048 /*histograms, error flag*/ + pad256(scratchBytes) + pad256(stateBytes) + 4096;
 
     std::unique_lock<std::mutex> lock(baker.arena.mu, std::try_to_lock);
     DeviceArena local; DeviceArena* arena = lock.owns_lock() ? &baker.arena : &local; // concurrent bakes on one baker get a private arena
@@ -367,9 +382,12 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     uint32_t* dSizes = arena->take<uint32_t>(U ? U : 1); int32_t* dItemValue = arena->take<int32_t>(U ? U : 1);
     uint64_t* dDigests = arena->take<uint64_t>(U ? U : 1);
     uint32_t* dArrayHist = arena->take<uint32_t>(kNumLevels); uint32_t* dIndexHist = arena->take<uint32_t>(kNumLevels);
+    uint32_t* dErr = arena->take<uint32_t>(1);
     uint8_t* dScratch = arena->take<uint8_t>(scratchBytes);
     uint8_t* dStates = arena->take<uint8_t>(stateBytes ? stateBytes : 1);
 
+    EventTimer et(stream);
+    const int e0 = et.mark();
     bool ok = true;
     if (U) {
         ok &= HIP_OK(hipMemcpyAsync(dUv, itemUv.data(), (size_t)U * 24, hipMemcpyHostToDevice, stream));
@@ -402,27 +420,31 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     P.cutoff = d.alphaCutoff; P.borderAlpha = d.runtimeSamplerDesc.borderAlpha;
     P.wantKnownCount = d.rejectionThreshold > 0.f;
 
+    const int e1 = et.mark();
     ItemArrays A; A.uv = dUv; A.degenerate = dDegen; A.stateOfs = dStateOfs; A.states = dStates; A.stateMask = dMask; A.knownCount = dKnown;
     for (int l = 0; l < kNumLevels; ++l)
         launch_classify(P, A, dItemIds + levelStart[l], levelCount[l], (uint32_t)l, stream);
+    const int e2 = et.mark();
     // ---- CalcDigest (bake_cpu_impl.cpp:1038-1040) ----
     if (!(flags & (1u << 3)))
         for (int l = 0; l < kNumLevels; ++l)
             launch_digest(dStates, dStateOfs, dItemIds + levelStart[l], levelCount[l], (uint32_t)l, (uint32_t)bits, dDigests, stream);
     if (!HIP_OK(hipGetLastError())) return L.failure("[Failure] - kernel launch failed");
 
+    const int e3 = et.mark();
     // ---- promote / dedup / sort / offsets on the device ----
     TailInputs ti; memset(&ti, 0, sizeof ti);
     ti.numItems = U; ti.numTris = triCount; ti.uv = dUv; ti.level = dLevel; ti.stateMask = dMask; ti.knownCount = dKnown; ti.digests = dDigests;
     ti.uniformDigest = nullptr; ti.triToItem = dTriToItem; ti.format = bits;
     ti.disableSpecial = (flags & (1u << 1)) != 0; ti.disableDedup = (flags & (1u << 3)) != 0;
-    ti.rejectionThreshold = d.rejectionThreshold; ti.unresolved = (int32_t)d.unresolvedTriState;
+    ti.rejectionThreshold = d.rejectionThreshold; ti.unresolved = (int32_t)d.unresolvedTriState; ti.errorFlag = dErr;
     TailOutputs to; memset(&to, 0, sizeof to);
     to.special = dSpecial; to.rep = dRep; to.order = dOrder; to.dstOfs = dDstOfs; to.sizes = dSizes; to.itemValue = dItemValue;
     to.indexBuffer = dIndex; to.arrayHist = dArrayHist; to.indexHist = dIndexHist;
     TailCounts counts;
     if (!HIP_OK(run_tail(ti, to, dScratch, scratchBytes, &counts, stream))) return L.failure("[Failure] - device tail failed");
     if (counts.arrayDataSize > 0xFFFFFFFFull) return ommResult_FAILURE; // bake_cpu_impl.cpp:1774-1775
+    const int e4 = et.mark();
 
     // ---- Serialize (bake_cpu_impl.cpp:1756-1920): gather on device, copy out through the user's allocator ----
     BakeResult* res = baker.mem.make<BakeResult>();
@@ -432,6 +454,7 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     uint32_t hostHist[2 * kNumLevels];
     ok = true;
     uint8_t* dArray = nullptr; ommCpuOpacityMicromapDesc* dDescs = nullptr;
+    int e5 = e4;
     if (E) {
         res->arrayData = baker.mem.allocate((size_t)counts.arrayDataSize, 64);
         res->descs = (ommCpuOpacityMicromapDesc*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, 16);
@@ -440,6 +463,7 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
         if (ok) {
             launch_gather_omms(dStates, dStateOfs, dOrder, dDstOfs, dSizes, E, dArray, stream);
             launch_write_descs(dOrder, dDstOfs, dLevel, bits, E, dDescs, stream);
+            e5 = et.mark();
             ok &= HIP_OK(hipMemcpyAsync(res->arrayData, dArray, (size_t)counts.arrayDataSize, hipMemcpyDeviceToHost, stream));
             ok &= HIP_OK(hipMemcpyAsync(res->descs, dDescs, sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, hipMemcpyDeviceToHost, stream));
         }
@@ -449,6 +473,7 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     if (ok && triCount) ok &= HIP_OK(hipMemcpyAsync(res->index, dIndex, (size_t)triCount * 4, hipMemcpyDeviceToHost, stream));
     if (ok) ok &= HIP_OK(hipMemcpyAsync(hostHist, dArrayHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
     if (ok) ok &= HIP_OK(hipMemcpyAsync(hostHist + kNumLevels, dIndexHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
+    const int e6 = et.mark();
     if (ok) ok &= HIP_OK(hipStreamSynchronize(stream));
     if (dArray) (void)hipFree(dArray);
     if (dDescs) (void)hipFree(dDescs);
@@ -473,6 +498,15 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     res->desc.descArrayHistogram = res->arrayHist; res->desc.descArrayHistogramCount = nAH;
     res->desc.indexBuffer = res->index; res->desc.indexCount = triCount; res->desc.indexFormat = ifmt;
     res->desc.indexHistogram = res->indexHist; res->desc.indexHistogramCount = nIH;
+    {
+        ommxBakeTimings tm; memset(&tm, 0, sizeof tm);
+        tm.hostSetupMs = (float)(tSetup - t0); tm.uploadMs = et.ms(e0, e1); tm.classifyMs = et.ms(e1, e2); tm.digestMs = et.ms(e2, e3);
+        tm.tailMs = et.ms(e3, e4); tm.gatherMs = et.ms(e4, e5); tm.downloadMs = et.ms(e5, e6); tm.totalMs = (float)(now_ms() - t0);
+        for (uint32_t i = 0; i < U; ++i) tm.microTriangles += (uint64_t)1 << (2 * itemLevel[i]);
+        tm.uniqueItems = U; tm.stateBytes = stateBytes;
+        for (int l = 0; l < kNumLevels; ++l) tm.classifyLaunches += levelCount[l] != 0;
+        std::lock_guard<std::mutex> g(baker.timingsMu); baker.timings = tm; baker.haveTimings = true;
+    }
     *out = (ommCpuBakeResult)res;
     return ommResult_SUCCESS;
 }
@@ -660,5 +694,15 @@ OMM_MI355X_API ommResult ommDebugGetStats(ommBaker baker, const ommCpuBakeResult
         st.totalUnknownTransparent += (uint64_t)refs[i] * c[2]; st.totalUnknownOpaque += (uint64_t)refs[i] * c[3];
     }
     *out = st;
+    return ommResult_SUCCESS;
+}
+
+OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings* out)
+{
+    if (baker == 0 || out == nullptr || tag_of(baker) != kCpuBaker) return ommResult_INVALID_ARGUMENT;
+    Baker* b = untag<Baker>(baker);
+    std::lock_guard<std::mutex> g(b->timingsMu);
+    if (!b->haveTimings) return ommResult_FAILURE;
+    *out = b->timings;
     return ommResult_SUCCESS;
 }

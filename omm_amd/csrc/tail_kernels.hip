@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void tail_summarize(TailInputs in, int32_t* __
     if (i >= in.numItems) return;
     const uint32_t mask = in.stateMask[i];
     const uint32_t level = in.level[i];
+    if (mask == 0u || mask > 15u) atomicOr(in.errorFlag, 1u); // every work item must have been classified
     bool allEqual = (mask & (mask - 1u)) == 0u;
     int common = 31 - __clz((int)mask);
     if (allEqual && in.uniformDigest) {
@@ -200,6 +201,7 @@ hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch,
     counts->numOmms = 0; counts->arrayDataSize = 0;
     TAIL_CHECK(hipMemsetAsync(out.arrayHist, 0, sizeof(uint32_t) * kNumLevels, stream));
     TAIL_CHECK(hipMemsetAsync(out.indexHist, 0, sizeof(uint32_t) * kNumLevels, stream));
+    TAIL_CHECK(hipMemsetAsync(in.errorFlag, 0, sizeof(uint32_t), stream));
     if (n != 0) {
         if (scratchBytes < tail_scratch_bytes(n, in.numTris)) return hipErrorInvalidValue;
         Scratch s = carve(scratch, n);
@@ -227,12 +229,14 @@ hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch,
         TAIL_CHECK(hipcub::DeviceScan::ExclusiveSum(s.cub, tb, s.sizes64, s.ofs64, (int)n, stream));
         hipLaunchKernelGGL(tail_item_values, grid, block, 0, stream, out.order, s.numEmitted, s.ofs64, out.dstOfs, out.special, n, out.itemValue);
         // total = ofs[n-1] + sizes[n-1] (entries past numEmitted are zero-sized)
-        uint32_t E = 0; uint64_t lastOfs = 0, lastSize = 0;
+        uint32_t E = 0, err = 0; uint64_t lastOfs = 0, lastSize = 0;
+        TAIL_CHECK(hipMemcpyAsync(&err, in.errorFlag, 4, hipMemcpyDeviceToHost, stream));
         TAIL_CHECK(hipMemcpyAsync(&E, s.numEmitted, 4, hipMemcpyDeviceToHost, stream));
         TAIL_CHECK(hipMemcpyAsync(&lastOfs, s.ofs64 + (n - 1), 8, hipMemcpyDeviceToHost, stream));
         TAIL_CHECK(hipMemcpyAsync(&lastSize, s.sizes64 + (n - 1), 8, hipMemcpyDeviceToHost, stream));
         TAIL_CHECK(hipStreamSynchronize(stream));
         counts->numOmms = E; counts->arrayDataSize = lastOfs + lastSize;
+        if (err) return hipErrorAssert;
     }
     if (in.numTris != 0)
         hipLaunchKernelGGL(tail_indices, dim3((in.numTris + 255u) / 256u), dim3(256), 0, stream, in, out.rep, out.itemValue, out.indexBuffer, out.indexHist);

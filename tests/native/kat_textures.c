@@ -135,3 +135,45 @@ void kat_fill_u8(int kind, float param, int w, int h, uint8_t* out)
             out[i + (long)j * w] = v;
         }
 }
+
+/* ---- seeded synthetic workload textures (bench.py / scale tests; not reference KATs) ---- */
+static uint32_t wl_hash(uint32_t x)
+{
+    x = (x ^ (x >> 16)) * 0x7feb352du;
+    x = (x ^ (x >> 15)) * 0x846ca68bu;
+    return x ^ (x >> 16);
+}
+static float wl_lattice(uint32_t ix, uint32_t iy, uint32_t seed)
+{
+    return (float)(wl_hash(ix * 73856093u ^ iy * 19349663u ^ seed) >> 8) * (1.0f / 16777216.0f);
+}
+/* multi-octave value noise in [0,1] */
+static float wl_noise(int x, int y, uint32_t seed, int octaves, int baseCell)
+{
+    float sum = 0.f, amp = 1.f, tot = 0.f;
+    for (int o = 0; o < octaves; ++o) {
+        int cell = baseCell >> o; if (cell < 1) cell = 1;
+        const uint32_t gx = (uint32_t)(x / cell), gy = (uint32_t)(y / cell);
+        const float fx = ((float)(x % cell) + 0.5f) / (float)cell, fy = ((float)(y % cell) + 0.5f) / (float)cell;
+        const float sx = fx * fx * (3.f - 2.f * fx), sy = fy * fy * (3.f - 2.f * fy);
+        const uint32_t s = seed * 83492791u + (uint32_t)o * 2654435761u;
+        const float a = wl_lattice(gx, gy, s), b = wl_lattice(gx + 1, gy, s), c = wl_lattice(gx, gy + 1, s), d = wl_lattice(gx + 1, gy + 1, s);
+        const float v = (a * (1.f - sx) + b * sx) * (1.f - sy) + (c * (1.f - sx) + d * sx) * sy;
+        sum += amp * v; tot += amp; amp *= 0.5f;
+    }
+    return sum / tot;
+}
+void wl_noise_f32(uint32_t seed, int w, int h, int octaves, int baseCell, float* out)
+{
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) out[x + (long)y * w] = wl_noise(x, y, seed, octaves, baseCell);
+}
+/* "foliage-style" mask: thresholded low-frequency blobs with a soft edge a few texels wide */
+void wl_foliage_u8(uint32_t seed, int w, int h, int feature, uint8_t* out)
+{
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            float a = (wl_noise(x, y, seed, 3, feature) - 0.5f) * 24.0f + 0.5f;
+            a = a < 0.f ? 0.f : (a > 1.f ? 1.f : a);
+            out[x + (long)y * w] = (uint8_t)(a * 255.0f + 0.5f);
+        }
+}

@@ -148,6 +148,8 @@ def kat_lib():
         _KAT = C.CDLL(out)
         _KAT.kat_fill_f32.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
         _KAT.kat_fill_u8.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
+        _KAT.wl_noise_f32.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _KAT.wl_foliage_u8.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
     return _KAT
 
 
@@ -374,31 +376,14 @@ def random_triangles(seed, n, extent, lo=0.0, hi=1.0):
 
 
 def value_noise(seed, w, h, octaves=4, base_cell=64):
-    """Multi-octave value noise on an integer-hash lattice -> float32 (h, w) in [0,1]."""
-    out = np.zeros((h, w), np.float32)
-    amp, tot = 1.0, 0.0
-    ys, xs = np.mgrid[0:h, 0:w]
-    for o in range(octaves):
-        cell = max(base_cell >> o, 1)
-        gx, gy = xs // cell, ys // cell
-        fx = ((xs % cell).astype(np.float32) + 0.5) / cell
-        fy = ((ys % cell).astype(np.float32) + 0.5) / cell
-        sx = fx * fx * (3 - 2 * fx)
-        sy = fy * fy * (3 - 2 * fy)
-
-        def lat(ix, iy):
-            k = (ix.astype(np.uint64) * np.uint64(73856093)) ^ (iy.astype(np.uint64) * np.uint64(19349663)) ^ np.uint64(seed * 83492791 + o * 2654435761)
-            return (hash_u32(k & np.uint64(0xFFFFFFFF)) >> np.uint32(8)).astype(np.float32) / np.float32(16777216.0)
-
-        v = (lat(gx, gy) * (1 - sx) + lat(gx + 1, gy) * sx) * (1 - sy) + (lat(gx, gy + 1) * (1 - sx) + lat(gx + 1, gy + 1) * sx) * sy
-        out += np.float32(amp) * v.astype(np.float32)
-        tot += amp
-        amp *= 0.5
-    return (out / np.float32(tot)).astype(np.float32)
+    """Multi-octave value noise on an integer-hash lattice -> float32 (h, w) in [0,1] (tests/native/kat_textures.c)."""
+    out = np.empty((h, w), np.float32)
+    kat_lib().wl_noise_f32(seed, w, h, octaves, base_cell, out.ctypes.data)
+    return out
 
 
 def foliage_texture(seed, w, h, feature=64):
-    """'Foliage-style' alpha: thresholded low-frequency noise blobs with a soft (blurred) edge -> uint8 (h, w)."""
-    n = value_noise(seed, w, h, octaves=3, base_cell=feature)
-    a = np.clip((n - np.float32(0.5)) * np.float32(24.0) + np.float32(0.5), 0, 1)
-    return (a * 255.0 + 0.5).astype(np.uint8)
+    """'Foliage-style' alpha: thresholded low-frequency noise blobs with a soft edge -> uint8 (h, w)."""
+    out = np.empty((h, w), np.uint8)
+    kat_lib().wl_foliage_u8(seed, w, h, feature, out.ctypes.data)
+    return out

@@ -261,3 +261,43 @@ def test_properties_at_scale(product):
     assert s1 == s3
     product.destroy_texture(b, t)
     product.destroy_baker(b)
+
+
+def omm_of_triangle(res, t, level_bytes):
+    """special index (negative) or the packed block of triangle t"""
+    v = int(res.index[t])
+    if v < 0:
+        return v
+    off = int(res.descs[v][0])
+    return bytes(res.array_data[off:off + level_bytes])
+
+
+def test_full_size_bake_matches_oracle_on_a_subset(product, oracle):
+    """BASELINE metric configuration at full size (1 M triangles, 4K foliage alpha, level 8, 4-state: 6.5e10 micro-triangles,
+    more than 2^32 GPU threads).  Baking is per-triangle independent, so every triangle's OMM in the full bake must equal the
+    OMM the oracle computes for it in a small bake of the first triangles."""
+    n, k = 1000000, 1500
+    tex = ot.foliage_texture(1234, 4096, 4096, feature=64)
+    uv, ix = ot.random_triangles(1235, n, 8.0 / 4096)
+    b = product.create_baker()
+    t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+    full = product.bake(b, ot.make_desc(t, uv, ix, 8, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE), want_stats=False)
+    product.destroy_texture(b, t)
+    product.destroy_baker(b)
+    assert full.index.size == n and len(full.descs) > n // 50, "suspiciously few OMMs: %d" % len(full.descs)
+    assert full.array_data.size == len(full.descs) * 16384
+    ob = oracle.create_baker()
+    otx = oracle.create_texture(ob, [tex], alpha_cutoff=0.5)
+    small = oracle.bake(ob, ot.make_desc(otx, uv[:3 * k], ix[:3 * k], 8, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE), want_stats=False)
+    oracle.destroy_texture(ob, otx)
+    oracle.destroy_baker(ob)
+    for tri in list(range(k)):
+        assert omm_of_triangle(full, tri, 16384) == omm_of_triangle(small, tri, 16384), tri
+    # the last triangles too (highest work-item ids = highest grid coordinates): compare against a product bake of just them
+    b = product.create_baker()
+    t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+    tail = product.bake(b, ot.make_desc(t, uv[3 * (n - k):], ix[:3 * k], 8, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE), want_stats=False)
+    product.destroy_texture(b, t)
+    product.destroy_baker(b)
+    for j in range(k):
+        assert omm_of_triangle(full, n - k + j, 16384) == omm_of_triangle(tail, j, 16384), j
