@@ -26,7 +26,7 @@ def main(path):
     print("| kernel | calls | total ms | avg us | % of GPU time |")
     print("|---|---|---|---|---|")
     for k, (calls, total, pct) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        print("| `%s` | %d | %.3f | %.1f | %.2f |" % (k, calls, total / 1e6, total / calls / 1e3, pct))
+        print("| `%s` | %d | %.3f | %.1f | %.2f |" % (k, calls, total / 1e3, total / calls, pct))
 
 
 if __name__ == "__main__":
