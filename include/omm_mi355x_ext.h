@@ -14,7 +14,7 @@
 typedef struct ommxBakeTimings {
     float    hostSetupMs;      /* work-item setup on the host (0 when the device setup path ran) */
     float    uploadMs;         /* host -> device copies of the work-item tables */
-    float    classifyMs;       /* all classify_tiles launches (coarse SAT pass + fine level-line pass) */
+    float    classifyMs;       /* all classify_tiles launches (hierarchical + per-micro-triangle SAT pass, fine level-line pass) */
     float    digestMs;         /* XXH64 digests */
     float    tailMs;           /* promote / dedup / sort / offsets / index buffer */
     float    gatherMs;         /* gather of surviving OMM blocks + descriptors */
@@ -24,6 +24,8 @@ typedef struct ommxBakeTimings {
     uint32_t uniqueItems;
     uint32_t classifyLaunches;
     uint64_t stateBytes;       /* packed state bytes written by classification */
+    float    triageMs;         /* level-0 hierarchical query per item + compaction of the active items */
+    uint32_t activeItems;      /* items that needed per-micro-triangle classification */
 } ommxBakeTimings;
 
 OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings* out);

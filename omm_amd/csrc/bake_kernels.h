@@ -8,13 +8,16 @@ namespace ommx {
 
 // classification of one level group (items listed in itemIds, all at `level`)
 void launch_classify(const ClassifyParams& P, const ItemArrays& A, const uint32_t* itemIds, uint32_t numItems, uint32_t level, hipStream_t stream);
+// level-0 hierarchical query per work item: uniform items get stateMask = 1 << state and active = 0
+void launch_triage(const ClassifyParams& P, const float* uv, uint32_t numItems, uint32_t* stateMask, uint8_t* active, hipStream_t stream);
 // XXH64(seed 42) of the 3-state byte stream of each listed item -> digests[item]
 void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
                    uint64_t* digests, hipStream_t stream);
 // summed-area table of (alpha > cutoff)
 void launch_sat_build(const void* texels, int fp32, uint32_t* sat, int w, int h, float cutoff, hipStream_t stream);
-void launch_gather_omms(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* order, const uint32_t* dstOfs, const uint32_t* sizes,
-                        uint32_t numOmms, uint8_t* arrayData, hipStream_t stream);
+// active[item] == 0: the item has no stored states (settled by triage); its block is the constant pattern of its single state
+void launch_gather_omms(const uint8_t* states, const uint64_t* stateOfs, const uint8_t* active, const uint32_t* stateMask, const uint8_t* level, int bits,
+                        const uint32_t* order, const uint32_t* dstOfs, const uint32_t* sizes, uint32_t numOmms, uint8_t* arrayData, hipStream_t stream);
 void launch_write_indices(const int32_t* triToItem, const uint32_t* rep, const int32_t* itemValue, uint32_t numTris, int32_t unresolved,
                           int32_t* out, hipStream_t stream);
 
@@ -47,6 +50,10 @@ struct TailOutputs {            // device buffers owned by the caller
 };
 struct TailCounts { uint32_t numOmms; uint64_t arrayDataSize; };
 
+// compaction of the active (non-uniform) items into per-level lists + their packed-state slots; synchronises the stream once
+hipError_t run_prep(const uint32_t* itemIds, const uint8_t* active, const uint8_t* level, int bits, uint32_t n, const uint32_t* levelStart,
+                    uint32_t* activeIds, uint64_t* stateOfs, void* scratch, size_t scratchBytes, uint32_t* activeLevelStart,
+                    uint64_t* totalStateBytes, hipStream_t stream);
 // scratch handling: call with scratch == nullptr to get the size
 size_t tail_scratch_bytes(uint32_t numItems, uint32_t numTris);
 // runs the device tail up to (and including) offsets; returns counts (synchronises the stream once)

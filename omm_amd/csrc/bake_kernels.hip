@@ -18,17 +18,55 @@ namespace ommx {
 // ------------------------------------------------------------------------------------------------
 // Classification.
 //
-// One workgroup (256 threads = 4 waves) owns a tile of TILE consecutive micro-triangles of the
-// level's item list: a slice of one item when 4^level >= TILE, or TILE / 4^level whole items
-// otherwise.  Three phases, all state kept in LDS:
-//   1. every lane: bird-curve micro-triangle -> SAT test (4 reads).  Unresolved ones are appended to
-//      an LDS queue by wave-ballot compaction, so that
-//   2. the expensive level-line pass runs on densely packed lanes instead of a few divergent ones,
-//   3. states are packed LSB-first into 32-bit words and stored coalesced; the tile's state mask
-//      (which states occur) is OR-reduced for the uniform-OMM ("special index") detection.
+// The reference classifies every micro-triangle on its own (4^N SAT tests + level-line passes per work item).  The
+// bird curve is hierarchical -- micro-triangle i of level N lies inside micro-triangle i >> 2(N-k) of level k -- so a
+// whole sub-triangle can be settled with ONE summed-area-table query when its texel footprint is uniformly <= / >
+// cutoff (region_state() in classify_device.h proves the result equals the per-micro-triangle coarse pass):
+//
+//   triage_items      one lane per work item: the whole triangle (level-0 sub-triangle).  Uniform items need no
+//                     per-micro-triangle work and no state storage at all.
+//   classify_tiles    one workgroup (256 threads = 4 waves) per tile of TILE = 1024 consecutive micro-triangles of
+//                     an ACTIVE (non-uniform) item:
+//        0. tile-level query (level N-5), then one query per 64-micro-triangle group (level N-3): a wave whose group is
+//           settled skips phase 1 for it entirely (a wave = exactly one group)
+//        1. remaining lanes: bird-curve micro-triangle -> coarse SAT test; unresolved ones are appended to an LDS
+//           queue by wave-ballot compaction, so that
+//        2. the expensive level-line pass runs on densely packed lanes,
+//        3. states are packed LSB-first into 32-bit words (coalesced stores) and the tile's state mask is OR-reduced
+//           for the uniform-OMM ("special index") detection.
 // ------------------------------------------------------------------------------------------------
 constexpr int TILE = 1024;
 constexpr int BLOCK = 256;
+constexpr int GROUP = 64;
+
+__device__ __forceinline__ float item_max_abs(const float* __restrict__ uv)
+{
+    float m = __builtin_fabsf(uv[0]);
+    #pragma unroll
+    for (int k = 1; k < 6; ++k) { const float a = __builtin_fabsf(uv[k]); m = a > m ? a : m; }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void triage_items(ClassifyParams P, const float* __restrict__ uv, uint32_t numItems,
+                                                    uint32_t* __restrict__ stateMask, uint8_t* __restrict__ active)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numItems) return;
+    int st = -1;
+    if (P.useCoarse) {
+        const float* t = uv + 6ull * i;
+        const MicroTri whole = micro_triangle(t, 0u, 0u);
+        st = region_state(P, whole, item_max_abs(t));
+    }
+    stateMask[i] = st >= 0 ? (1u << st) : 0u;
+    active[i] = st >= 0 ? 0 : 1;
+}
+
+void launch_triage(const ClassifyParams& P, const float* uv, uint32_t numItems, uint32_t* stateMask, uint8_t* active, hipStream_t stream)
+{
+    if (numItems == 0) return;
+    hipLaunchKernelGGL(triage_items, dim3((numItems + 255u) / 256u), dim3(256), 0, stream, P, uv, numItems, stateMask, active);
+}
 
 template <bool FP32>
 __global__ __launch_bounds__(BLOCK) void classify_tiles(ClassifyParams P, ItemArrays A, const uint32_t* __restrict__ itemIds,
@@ -36,6 +74,8 @@ __global__ __launch_bounds__(BLOCK) void classify_tiles(ClassifyParams P, ItemAr
 {
     __shared__ uint8_t  s_state[TILE];
     __shared__ uint16_t s_queue[TILE];
+    __shared__ int      s_group[TILE / GROUP];
+    __shared__ int      s_tile;
     __shared__ uint32_t s_qcount;
     __shared__ uint32_t s_mask, s_known;
 
@@ -53,53 +93,92 @@ __global__ __launch_bounds__(BLOCK) void classify_tiles(ClassifyParams P, ItemAr
     uint32_t itemsHere = numItems - firstItem;
     if (itemsHere > itemsPerTile) itemsHere = itemsPerTile;
     const uint32_t count = sliced ? (uint32_t)TILE : itemsHere * M;   // micro-triangles in this tile
-
-    if (tid == 0) { s_qcount = 0; s_mask = 0; s_known = 0; }
-    __syncthreads();
-
-    // ---- phase 1: coarse ----
     const bool coarse = P.useCoarse != 0;
-    for (uint32_t i = tid; i < ((count + 63u) & ~63u); i += BLOCK) {
-        bool unresolved = false;
-        if (i < count) {
+
+    // ---- phase 0: hierarchical queries ----
+    if (tid == 0) {
+        s_qcount = 0; s_mask = 0; s_known = 0;
+        int ts = -1;
+        if (coarse && sliced && level >= 5) { // the tile is the level-(N-5) sub-triangle number base/1024
+            const float* uvp = A.uv + 6ull * itemIds[firstItem];
+            ts = region_state(P, micro_triangle(uvp, base >> 10, level - 5), item_max_abs(uvp));
+        }
+        s_tile = ts;
+    }
+    __syncthreads();
+    const int tileState = s_tile;
+    if (tileState < 0) {
+        if (tid < (uint32_t)(TILE / GROUP)) {
+            int gs = -1;
+            const uint32_t i0 = tid * GROUP;
+            if (coarse && level >= 3 && i0 < count) { // 64 consecutive micro-triangles = one level-(N-3) sub-triangle
+                const uint32_t it = sliced ? firstItem : firstItem + (i0 >> (2 * level));
+                const uint32_t u0 = sliced ? base + i0 : (i0 & (M - 1u));
+                const float* uvp = A.uv + 6ull * itemIds[it];
+                gs = region_state(P, micro_triangle(uvp, u0 >> 6, level - 3), item_max_abs(uvp));
+            }
+            s_group[tid] = gs;
+        }
+        __syncthreads();
+
+        // ---- phase 1: per-micro-triangle coarse test in the unsettled groups ----
+        for (uint32_t i = tid; i < ((count + 63u) & ~63u); i += BLOCK) {
+            const int gs = s_group[i >> 6];      // wave-uniform: a wave is exactly one group
+            if (gs >= 0) { if (i < count) s_state[i] = (uint8_t)gs; continue; }
+            bool unresolved = false;
+            if (i < count) {
+                const uint32_t it = sliced ? firstItem : firstItem + (i >> (2 * level));
+                const uint32_t u = sliced ? base + i : (i & (M - 1u));
+                int st = -1;
+                if (coarse) {
+                    const uint32_t item = itemIds[it];
+                    const MicroTri t = micro_triangle(A.uv + 6ull * item, u, level);
+                    st = coarse_state(P, t);
+                }
+                // the reference's fine pass re-classifies everything still "UnknownOpaque" (bake_cpu_impl.cpp:861)
+                unresolved = (st < 0) || (st == 3) || !P.filterLinear;
+                s_state[i] = (uint8_t)(st < 0 ? 3 : st);
+            }
+            const unsigned long long vote = __ballot(unresolved);
+            if (vote) {
+                const uint32_t lane = tid & 63u;
+                uint32_t wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&s_qcount, (uint32_t)__popcll(vote));
+                wbase = __shfl(wbase, 0);
+                if (unresolved) s_queue[wbase + __popcll(vote & ((1ull << lane) - 1ull))] = (uint16_t)i;
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: fine, dense over the queue ----
+        const uint32_t qn = s_qcount;
+        for (uint32_t q = tid; q < qn; q += BLOCK) {
+            const uint32_t i = s_queue[q];
             const uint32_t it = sliced ? firstItem : firstItem + (i >> (2 * level));
             const uint32_t u = sliced ? base + i : (i & (M - 1u));
-            int st = -1;
-            if (coarse) {
-                const uint32_t item = itemIds[it];
-                const MicroTri t = micro_triangle(A.uv + 6ull * item, u, level);
-                st = coarse_state(P, t);
-            }
-            // the reference's fine pass re-classifies everything still "UnknownOpaque" (bake_cpu_impl.cpp:861)
-            unresolved = (st < 0) || (st == 3) || !P.filterLinear;
-            s_state[i] = (uint8_t)(st < 0 ? 3 : st);
+            const uint32_t item = itemIds[it];
+            const MicroTri t = micro_triangle(A.uv + 6ull * item, u, level);
+            s_state[i] = (uint8_t)fine_state<FP32>(P, t, A.degenerate[item] != 0);
         }
-        const unsigned long long vote = __ballot(unresolved);
-        if (vote) {
-            const uint32_t lane = tid & 63u;
-            uint32_t wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&s_qcount, (uint32_t)__popcll(vote));
-            wbase = __shfl(wbase, 0);
-            if (unresolved) s_queue[wbase + __popcll(vote & ((1ull << lane) - 1ull))] = (uint16_t)i;
-        }
+        __syncthreads();
     }
-    __syncthreads();
-
-    // ---- phase 2: fine, dense over the queue ----
-    const uint32_t qn = s_qcount;
-    for (uint32_t q = tid; q < qn; q += BLOCK) {
-        const uint32_t i = s_queue[q];
-        const uint32_t it = sliced ? firstItem : firstItem + (i >> (2 * level));
-        const uint32_t u = sliced ? base + i : (i & (M - 1u));
-        const uint32_t item = itemIds[it];
-        const MicroTri t = micro_triangle(A.uv + 6ull * item, u, level);
-        s_state[i] = (uint8_t)fine_state<FP32>(P, t, A.degenerate[item] != 0);
-    }
-    __syncthreads();
 
     // ---- phase 3: pack + per-item summary ----
     const uint32_t bits = (uint32_t)P.format;          // 1 or 2 bits per micro-triangle
     const uint32_t perWord = 32u / bits;               // micro-triangles per 32-bit word
+    if (tileState >= 0) {
+        // whole tile settled by one query (only happens for sliced tiles): constant words
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < perWord; ++k) v |= (uint32_t)tileState << (k * bits);
+        const uint32_t item = itemIds[firstItem];
+        uint32_t* dst = (uint32_t*)(A.states + A.stateOfs[item]) + base / perWord;
+        for (uint32_t w = tid; w < (uint32_t)TILE / perWord; w += BLOCK) dst[w] = v;
+        if (tid == 0) {
+            atomicOr(&A.stateMask[item], 1u << tileState);
+            if (P.wantKnownCount && tileState < 2) atomicAdd(&A.knownCount[item], (uint32_t)TILE);
+        }
+        return;
+    }
     if (M >= perWord) {
         const uint32_t words = count / perWord;
         uint32_t localMask = 0, localKnown = 0;
@@ -304,16 +383,27 @@ void launch_sat_build(const void* texels, int fp32, uint32_t* sat, int w, int h,
 // ------------------------------------------------------------------------------------------------
 // Tail: gather the surviving OMMs into the final arrayData order, write descriptors and the index buffer.
 // ------------------------------------------------------------------------------------------------
-// one workgroup per emitted OMM: 16-byte vector copy of its packed states (sizes are powers of two)
+// one workgroup per emitted OMM: 16-byte vector copy of its packed states (sizes are powers of two); OMMs of items that
+// were settled by triage (only emitted when special indices are disabled) are written as their constant pattern
 __global__ __launch_bounds__(256) void tail_gather_omms(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs,
+                                                        const uint8_t* __restrict__ active, const uint32_t* __restrict__ stateMask,
+                                                        const uint8_t* __restrict__ level, int bits,
                                                         const uint32_t* __restrict__ order, const uint32_t* __restrict__ dstOfs,
                                                         const uint32_t* __restrict__ sizes, uint32_t numOmms, uint8_t* __restrict__ arrayData)
 {
     for (uint32_t j = blockIdx.x; j < numOmms; j += gridDim.x) {
         const uint32_t item = order[j];
-        const uint8_t* src = states + stateOfs[item];
         uint8_t* dst = arrayData + dstOfs[j];
         const uint32_t n = sizes[j];
+        if (!active[item]) {
+            const uint32_t st = (uint32_t)(31 - __clz((int)stateMask[item]));
+            uint32_t usedBits = (1u << (2u * level[item])) * (uint32_t)bits; if (usedBits > 8u) usedBits = 8u;
+            uint32_t pat = 0;
+            for (uint32_t b = 0; b < usedBits; b += (uint32_t)bits) pat |= st << b;
+            for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) dst[k] = (uint8_t)pat;
+            continue;
+        }
+        const uint8_t* src = states + stateOfs[item];
         if (n >= 16u) {
             const uint4* s4 = (const uint4*)src; uint4* d4 = (uint4*)dst;
             for (uint32_t k = threadIdx.x; k < n / 16u; k += blockDim.x) d4[k] = s4[k];
@@ -323,12 +413,12 @@ __global__ __launch_bounds__(256) void tail_gather_omms(const uint8_t* __restric
     }
 }
 
-void launch_gather_omms(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* order, const uint32_t* dstOfs, const uint32_t* sizes,
-                        uint32_t numOmms, uint8_t* arrayData, hipStream_t stream)
+void launch_gather_omms(const uint8_t* states, const uint64_t* stateOfs, const uint8_t* active, const uint32_t* stateMask, const uint8_t* level, int bits,
+                        const uint32_t* order, const uint32_t* dstOfs, const uint32_t* sizes, uint32_t numOmms, uint8_t* arrayData, hipStream_t stream)
 {
     if (numOmms == 0) return;
     const uint32_t grid = numOmms < 65536u * 4u ? numOmms : 65536u * 4u;
-    hipLaunchKernelGGL(tail_gather_omms, dim3(grid), dim3(256), 0, stream, states, stateOfs, order, dstOfs, sizes, numOmms, arrayData);
+    hipLaunchKernelGGL(tail_gather_omms, dim3(grid), dim3(256), 0, stream, states, stateOfs, active, stateMask, level, bits, order, dstOfs, sizes, numOmms, arrayData);
 }
 
 // index buffer: triangle -> unique work item -> dedup representative -> special index or descriptor slot

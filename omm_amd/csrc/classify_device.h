@@ -326,6 +326,9 @@ __device__ __forceinline__ void raster_micro_triangle(const ClassifyParams& P, c
     const int minx = cvt_trunc_x86(__builtin_floorf(lox)), miny = cvt_trunc_x86(__builtin_floorf(loy));
     const int maxx = cvt_trunc_x86(__builtin_ceilf(hix)), maxy = cvt_trunc_x86(__builtin_ceilf(hiy));
     const EdgeEq e0 = edge_eq(a, b), e1 = edge_eq(b, c), e2 = edge_eq(c, a);
+    // Only the Nearest promotion looks at the counts (bake_kernels_cpu.h:38,49); for the forced promotions the state is
+    // final as soon as both counters are non-zero, so the remaining texels cannot change the result.
+    const bool countsMatter = P.promotion == 0;
     for (int y = miny; y < maxy; ++y) {
         bool wasInside = false;
         for (int x = minx; x < maxx; ++x) {
@@ -334,6 +337,7 @@ __device__ __forceinline__ void raster_micro_triangle(const ClassifyParams& P, c
             if (inside) {
                 if (KIND == 0) level_line_texel<FP32, false>(P, m, t, x, y, above, below);
                 else nearest_texel<FP32>(P, m, x, y, above, below);
+                if (!countsMatter && above != 0 && below != 0) return;
                 wasInside = true;
             } else if (wasInside) break;
         }
@@ -364,8 +368,10 @@ __device__ __forceinline__ void raster_micro_segment(const ClassifyParams& P, co
     const int yMax = cvt_trunc_x86(std_max(__builtin_ceilf(p0.y), __builtin_ceilf(p1.y)));
     const int xMin = cvt_trunc_x86(std_min(__builtin_floorf(p0.x), __builtin_floorf(p1.x)));
     const int xMax = cvt_trunc_x86(std_max(__builtin_ceilf(p0.x), __builtin_ceilf(p1.x)));
+    const bool countsMatter = P.promotion == 0;
     while (x >= xMin && x <= xMax && y >= yMin && y <= yMax) {
         level_line_texel<FP32, true>(P, m, t, x, y, above, below);
+        if (!countsMatter && above != 0 && below != 0) return;
         if (tMaxX < tMaxY) { x += stepX; tMaxX += tDeltaX; }
         else { y += stepY; tMaxY += tDeltaY; }
     }
@@ -398,6 +404,46 @@ __device__ __forceinline__ int coarse_state(const ClassifyParams& P, const Micro
     if (sa == 0) return P.stateLE;
     if (sa == area) return P.stateGT;
     return -1;
+}
+
+// ---- hierarchical shortcut: is a whole bird-curve sub-triangle provably resolved by the coarse pass? ----
+// `sub` is an ancestor (level k <= N) of micro-triangles of one work item; `maxAbs` = largest |coordinate| of the item's
+// vertices.  Returns the state every descendant micro-triangle gets from coarse_state(), or -1 when that cannot be
+// guaranteed.  Argument: every descendant's fp32 vertices lie within 12 ulp(maxAbs) of the
+// ancestor's fp32 AABB, so with the AABB grown by 64 ulp each descendant's (a) UV-tile test, (b) texel rectangle
+// [floor(lo*W-.5), floor(hi*W-.5)+1] -- all operations monotone -- is contained in the ancestor's; if the address mode maps
+// the ancestor's rectangle without a seam and the SAT says the rectangle is uniformly <= / > cutoff, so does it for every
+// sub-rectangle.  States that the reference's fine pass would revisit (value 3, bake_cpu_impl.cpp:861) are not shortcut.
+__device__ __forceinline__ int region_state(const ClassifyParams& P, const MicroTri& sub, float maxAbs)
+{
+    const DevMip& m = P.mips[0];
+    if (!(maxAbs <= 16384.f)) return -1;
+    const float grow = maxAbs * 7.62939453125e-06f + 1e-30f; // 2^-17 * maxAbs  (= 64 ulp)
+    const float lx = sub.lo.x - grow, ly = sub.lo.y - grow, hx = sub.hi.x + grow, hy = sub.hi.y + grow;
+    if (cvt_trunc_x86(lx) != cvt_trunc_x86(hx) || cvt_trunc_x86(ly) != cvt_trunc_x86(hy)) return -1;
+    const int X0 = cvt_trunc_x86(__builtin_floorf(lx * m.fw - 0.5f)), Y0 = cvt_trunc_x86(__builtin_floorf(ly * m.fh - 0.5f));
+    const int X1 = cvt_trunc_x86(__builtin_floorf(hx * m.fw - 0.5f)) + 1, Y1 = cvt_trunc_x86(__builtin_floorf(hy * m.fh - 0.5f)) + 1;
+    if (X1 - X0 >= m.w || Y1 - Y0 >= m.h) return -1;
+    int sx, sy, ex, ey;
+    if (P.addrMode == 0) { // Wrap: any single period is fine as long as the rectangle does not cross the seam
+        sx = tex_coord(0, P.pow2Dispatch, X0, m.w, m.log2w); ex = tex_coord(0, P.pow2Dispatch, X1, m.w, m.log2w);
+        sy = tex_coord(0, P.pow2Dispatch, Y0, m.h, m.log2h); ey = tex_coord(0, P.pow2Dispatch, Y1, m.h, m.log2h);
+        if (ex - sx != X1 - X0 || ey - sy != Y1 - Y0) return -1;
+    } else {               // other modes: only the untouched interior [0,W) x [0,H)
+        if (X0 < 0 || Y0 < 0 || X1 >= m.w || Y1 >= m.h) return -1;
+        sx = X0; sy = Y0; ex = X1; ey = Y1;
+    }
+    const uint32_t area = (uint32_t)((ex - sx + 1) * (ey - sy + 1));
+    const uint32_t* sat = m.sat;
+    const size_t W = (size_t)m.w;
+    const uint32_t A = (sx > 0 && sy > 0) ? sat[(size_t)(sx - 1) + (size_t)(sy - 1) * W] : 0u;
+    const uint32_t B = sy > 0 ? sat[(size_t)ex + (size_t)(sy - 1) * W] : 0u;
+    const uint32_t C = sx > 0 ? sat[(size_t)(sx - 1) + (size_t)ey * W] : 0u;
+    const uint32_t D = sat[(size_t)ex + (size_t)ey * W];
+    const uint32_t sa = D + A - B - C;
+    int st = -1;
+    if (sa == 0) st = P.stateLE; else if (sa == area) st = P.stateGT;
+    return st == 3 ? -1 : st;
 }
 
 // ---- fine pass for one micro-triangle (bake_cpu_impl.cpp:859-914 linear, :983-1022 nearest) ----

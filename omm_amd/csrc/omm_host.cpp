@@ -82,7 +82,8 @@ inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct Baker {
     Allocator mem; Logger log; ommBakerType type;
-    DeviceArena arena;
+    DeviceArena arena;        // per-item tables + scratch
+    DeviceArena statesArena;  // packed states of the active (non-uniform) items; guarded by arena.mu
     std::mutex timingsMu; ommxBakeTimings timings; bool haveTimings = false;
 };
 
@@ -113,6 +114,37 @@ struct BakeResult {
     BakeResult() { memset(&desc, 0, sizeof desc); }
     ~BakeResult() { mem.release(arrayData); mem.release(descs); mem.release(arrayHist); mem.release(indexHist); mem.release(index); }
 };
+
+// ---- XXH64 of a constant byte stream: digests of uniform OMMs (bake_cpu_impl.cpp:1038-1040 applied to 4^level equal bytes) ----
+struct UniformDigests {
+    uint64_t v[kNumLevels * 4];
+    UniformDigests() {
+        const uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+        auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
+        auto round = [&](uint64_t acc, uint64_t in) { acc += in * P2; acc = rotl(acc, 31); return acc * P1; };
+        auto merge = [&](uint64_t h, uint64_t val) { h ^= round(0, val); return h * P1 + P4; };
+        for (int l = 0; l < kNumLevels; ++l)
+            for (int st = 0; st < 4; ++st) {
+                const uint64_t len = (uint64_t)1 << (2 * l), seed = 42;
+                const uint64_t w8 = 0x0101010101010101ULL * (uint64_t)st; const uint32_t w4 = 0x01010101u * (uint32_t)st;
+                uint64_t h, rem = len;
+                if (len >= 32) {
+                    uint64_t a = seed + P1 + P2, b = seed + P2, c = seed, d = seed - P1;
+                    for (uint64_t k = 0; k < len / 32; ++k) { a = round(a, w8); b = round(b, w8); c = round(c, w8); d = round(d, w8); }
+                    h = rotl(a, 1) + rotl(b, 7) + rotl(c, 12) + rotl(d, 18);
+                    h = merge(h, a); h = merge(h, b); h = merge(h, c); h = merge(h, d);
+                    rem = 0; // 4^l is a multiple of 32 from level 3 on
+                } else h = seed + P5;
+                h += len;
+                for (; rem >= 8; rem -= 8) { h ^= round(0, w8); h = rotl(h, 27) * P1 + P4; }
+                if (rem >= 4) { h ^= (uint64_t)w4 * P1; h = rotl(h, 23) * P2 + P3; rem -= 4; }
+                for (; rem > 0; --rem) { h ^= (uint64_t)st * P5; h = rotl(h, 11) * P1; }
+                h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+                v[l * 4 + st] = h;
+            }
+    }
+};
+const UniformDigests& uniform_digests() { static const UniformDigests t; return t; }
 
 // ---- x86 conversion semantics used by the reference's host-side arithmetic ----
 inline int f2i(float f) { return _mm_cvtt_ss2si(_mm_set_ss(f)); }
@@ -347,13 +379,8 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     const double tSetup = now_ms();
     // ---- device layout ----
     const int bits = (int)d.format;
-    std::vector<uint64_t> stateOfs(U ? U : 1);
     std::vector<uint32_t> levelCount(kNumLevels, 0), levelStart(kNumLevels + 1, 0);
-    uint64_t stateBytes = 0;
-    for (uint32_t i = 0; i < U; ++i) {
-        uint64_t n = (((uint64_t)1 << (2 * itemLevel[i])) * (uint64_t)bits) >> 3; if (n < 16) n = 16; // 16-byte slots keep vector copies aligned
-        stateOfs[i] = stateBytes; stateBytes += n; levelCount[itemLevel[i]]++;
-    }
+    for (uint32_t i = 0; i < U; ++i) levelCount[itemLevel[i]]++;
     for (int l = 0; l < kNumLevels; ++l) levelStart[l + 1] = levelStart[l] + levelCount[l];
     std::vector<uint32_t> itemIds(U ? U : 1);
     { std::vector<uint32_t> cur(levelStart.begin(), levelStart.end() - 1); for (uint32_t i = 0; i < U; ++i) itemIds[cur[itemLevel[i]]++] = i; }
@@ -361,11 +388,13 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     const size_t scratchBytes = tail_scratch_bytes(U, triCount);
     const size_t perItem32 = pad256((size_t)(U ? U : 1) * 4), perItem64 = pad256((size_t)(U ? U : 1) * 8);
     size_t need = pad256((size_t)(U ? U : 1) * 24) /*uv*/ + 2 * pad256(U ? U : 1) /*level,degenerate*/ + perItem64 /*stateOfs*/ + perItem32 /*itemIds*/
-                + pad256((size_t)(triCount ? triCount : 1) * 4) * 2 /*triToItem, indexBuffer*/ + perItem32 * 8 /*mask, known, special, rep, order, dstOfs, sizes, itemValue*/
-                + perItem64 /*digests*/ + 2048 /*histograms, error flag*/ + pad256(scratchBytes) + pad256(stateBytes) + 4096;
+                + pad256((size_t)(triCount ? triCount : 1) * 4) * 2 /*triToItem, indexBuffer*/ + perItem32 * 9 /*mask, known, special, rep, order, dstOfs, sizes, itemValue, activeIds*/ + pad256(U ? U : 1) /*active*/
+                + perItem64 /*digests*/ + 2048 /*histograms, error flag*/ + pad256(scratchBytes) + 8192;
 
     std::unique_lock<std::mutex> lock(baker.arena.mu, std::try_to_lock);
-    DeviceArena local; DeviceArena* arena = lock.owns_lock() ? &baker.arena : &local; // concurrent bakes on one baker get a private arena
+    DeviceArena local, localStates; // concurrent bakes on one baker get private arenas
+    DeviceArena* arena = lock.owns_lock() ? &baker.arena : &local;
+    DeviceArena* statesArena = lock.owns_lock() ? &baker.statesArena : &localStates;
     if (!arena->reserve(need)) return L.failure("[Failure] - out of device memory for the bake working set");
 
     hipStream_t stream = nullptr;
@@ -384,7 +413,8 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     uint32_t* dArrayHist = arena->take<uint32_t>(kNumLevels); uint32_t* dIndexHist = arena->take<uint32_t>(kNumLevels);
     uint32_t* dErr = arena->take<uint32_t>(1);
     uint8_t* dScratch = arena->take<uint8_t>(scratchBytes);
-    uint8_t* dStates = arena->take<uint8_t>(stateBytes ? stateBytes : 1);
+    uint32_t* dActiveIds = arena->take<uint32_t>(U ? U : 1); uint8_t* dActive = arena->take<uint8_t>(U ? U : 1);
+    uint64_t* dUniformDigest = arena->take<uint64_t>(kNumLevels * 4);
 
     EventTimer et(stream);
     const int e0 = et.mark();
@@ -393,11 +423,10 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
         ok &= HIP_OK(hipMemcpyAsync(dUv, itemUv.data(), (size_t)U * 24, hipMemcpyHostToDevice, stream));
         ok &= HIP_OK(hipMemcpyAsync(dLevel, itemLevel.data(), U, hipMemcpyHostToDevice, stream));
         ok &= HIP_OK(hipMemcpyAsync(dDegen, itemDegenerate.data(), U, hipMemcpyHostToDevice, stream));
-        ok &= HIP_OK(hipMemcpyAsync(dStateOfs, stateOfs.data(), (size_t)U * 8, hipMemcpyHostToDevice, stream));
         ok &= HIP_OK(hipMemcpyAsync(dItemIds, itemIds.data(), (size_t)U * 4, hipMemcpyHostToDevice, stream));
-        ok &= HIP_OK(hipMemsetAsync(dMask, 0, (size_t)U * 4, stream));
         ok &= HIP_OK(hipMemsetAsync(dKnown, 0, (size_t)U * 4, stream));
     }
+    ok &= HIP_OK(hipMemcpyAsync(dUniformDigest, uniform_digests().v, sizeof(uint64_t) * kNumLevels * 4, hipMemcpyHostToDevice, stream));
     if (triCount) ok &= HIP_OK(hipMemcpyAsync(dTriToItem, triToItem.data(), (size_t)triCount * 4, hipMemcpyHostToDevice, stream));
     if (!ok) return L.failure("[Failure] - host to device transfer failed");
 
@@ -421,21 +450,29 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     P.wantKnownCount = d.rejectionThreshold > 0.f;
 
     const int e1 = et.mark();
+    // level-0 hierarchical query per item, then compaction of the items that still need per-micro-triangle work
+    launch_triage(P, dUv, U, dMask, dActive, stream);
+    uint32_t activeStart[kNumLevels + 1]; uint64_t stateBytes = 0;
+    if (!HIP_OK(run_prep(dItemIds, dActive, dLevel, bits, U, levelStart.data(), dActiveIds, dStateOfs, dScratch, scratchBytes, activeStart, &stateBytes, stream)))
+        return L.failure("[Failure] - device work-list compaction failed");
+    if (!statesArena->reserve(stateBytes ? stateBytes : 256)) return L.failure("[Failure] - out of device memory for the packed micro-triangle states");
+    uint8_t* dStates = statesArena->base;
+    const int e1b = et.mark();
     ItemArrays A; A.uv = dUv; A.degenerate = dDegen; A.stateOfs = dStateOfs; A.states = dStates; A.stateMask = dMask; A.knownCount = dKnown;
     for (int l = 0; l < kNumLevels; ++l)
-        launch_classify(P, A, dItemIds + levelStart[l], levelCount[l], (uint32_t)l, stream);
+        launch_classify(P, A, dActiveIds + activeStart[l], activeStart[l + 1] - activeStart[l], (uint32_t)l, stream);
     const int e2 = et.mark();
-    // ---- CalcDigest (bake_cpu_impl.cpp:1038-1040) ----
+    // ---- CalcDigest (bake_cpu_impl.cpp:1038-1040): active items here, uniform ones from the table in the tail ----
     if (!(flags & (1u << 3)))
         for (int l = 0; l < kNumLevels; ++l)
-            launch_digest(dStates, dStateOfs, dItemIds + levelStart[l], levelCount[l], (uint32_t)l, (uint32_t)bits, dDigests, stream);
+            launch_digest(dStates, dStateOfs, dActiveIds + activeStart[l], activeStart[l + 1] - activeStart[l], (uint32_t)l, (uint32_t)bits, dDigests, stream);
     if (!HIP_OK(hipGetLastError())) return L.failure("[Failure] - kernel launch failed");
 
     const int e3 = et.mark();
     // ---- promote / dedup / sort / offsets on the device ----
     TailInputs ti; memset(&ti, 0, sizeof ti);
     ti.numItems = U; ti.numTris = triCount; ti.uv = dUv; ti.level = dLevel; ti.stateMask = dMask; ti.knownCount = dKnown; ti.digests = dDigests;
-    ti.uniformDigest = nullptr; ti.triToItem = dTriToItem; ti.format = bits;
+    ti.uniformDigest = dUniformDigest; ti.triToItem = dTriToItem; ti.format = bits;
     ti.disableSpecial = (flags & (1u << 1)) != 0; ti.disableDedup = (flags & (1u << 3)) != 0;
     ti.rejectionThreshold = d.rejectionThreshold; ti.unresolved = (int32_t)d.unresolvedTriState; ti.errorFlag = dErr;
     TailOutputs to; memset(&to, 0, sizeof to);
@@ -461,7 +498,7 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
         ok &= res->arrayData && res->descs;
         ok = ok && HIP_OK(hipMalloc((void**)&dArray, (size_t)counts.arrayDataSize)) && HIP_OK(hipMalloc((void**)&dDescs, sizeof(ommCpuOpacityMicromapDesc) * (size_t)E));
         if (ok) {
-            launch_gather_omms(dStates, dStateOfs, dOrder, dDstOfs, dSizes, E, dArray, stream);
+            launch_gather_omms(dStates, dStateOfs, dActive, dMask, dLevel, bits, dOrder, dDstOfs, dSizes, E, dArray, stream);
             launch_write_descs(dOrder, dDstOfs, dLevel, bits, E, dDescs, stream);
             e5 = et.mark();
             ok &= HIP_OK(hipMemcpyAsync(res->arrayData, dArray, (size_t)counts.arrayDataSize, hipMemcpyDeviceToHost, stream));
@@ -500,11 +537,11 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     res->desc.indexHistogram = res->indexHist; res->desc.indexHistogramCount = nIH;
     {
         ommxBakeTimings tm; memset(&tm, 0, sizeof tm);
-        tm.hostSetupMs = (float)(tSetup - t0); tm.uploadMs = et.ms(e0, e1); tm.classifyMs = et.ms(e1, e2); tm.digestMs = et.ms(e2, e3);
+        tm.hostSetupMs = (float)(tSetup - t0); tm.uploadMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.digestMs = et.ms(e2, e3);
         tm.tailMs = et.ms(e3, e4); tm.gatherMs = et.ms(e4, e5); tm.downloadMs = et.ms(e5, e6); tm.totalMs = (float)(now_ms() - t0);
         for (uint32_t i = 0; i < U; ++i) tm.microTriangles += (uint64_t)1 << (2 * itemLevel[i]);
-        tm.uniqueItems = U; tm.stateBytes = stateBytes;
-        for (int l = 0; l < kNumLevels; ++l) tm.classifyLaunches += levelCount[l] != 0;
+        tm.uniqueItems = U; tm.stateBytes = stateBytes; tm.activeItems = activeStart[kNumLevels];
+        for (int l = 0; l < kNumLevels; ++l) tm.classifyLaunches += activeStart[l + 1] != activeStart[l];
         std::lock_guard<std::mutex> g(baker.timingsMu); baker.timings = tm; baker.haveTimings = true;
     }
     *out = (ommCpuBakeResult)res;

@@ -1,0 +1,306 @@
+// setup_kernels.hip -- SetupWorkItems (bake_cpu_impl.cpp:589-660) on the device.
+//
+// The reference walks the triangles serially: fetch UVs, pick the subdivision level, drop invalid (NaN/Inf) triangles,
+// and merge triangles with an identical (UV triangle, level, format) into one work item owned by the FIRST occurrence.
+// Device form: one lane per triangle + a stable radix sort by a 64-bit key hash:
+//   * segment heads of the sorted (hash, triangle) list  = first occurrences (stable => lowest triangle index)
+//   * exclusive scan over "is first occurrence" in triangle order = work-item numbering in the reference's order
+//   * stable sort of the items by level = the per-level launch lists
+// The reference itself keys its map by a 64-bit hash and trusts it; here every merged triangle is additionally compared
+// against its predecessor's full key and a mismatch raises `collision` (the host then redoes the setup serially).
+// The one libm-dependent piece -- log2f in the edge heuristic for degenerate triangles under dynamic subdivision
+// (bake_cpu_impl.cpp:511-528) -- is not evaluated here: such triangles are reported in `pending` for the host.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+#include "bake_types.h"
+#include "bake_kernels.h"
+
+namespace ommx {
+
+#define SETUP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+__device__ __forceinline__ float half_bits_to_float(uint32_t h) // glm::unpackHalf2x16 element (IEEE binary16 incl. denormals)
+{
+    const uint32_t sign = (h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t bits;
+    if (e == 0) {
+        if (m == 0) bits = sign;
+        else { e = 1; while (!(m & 0x400u)) { m <<= 1; e--; } m &= 0x3ffu; bits = sign | ((e + 112u) << 23) | (m << 13); }
+    } else if (e == 31) bits = sign | 0x7f800000u | (m << 13);
+    else bits = sign | ((e + 112u) << 23) | (m << 13);
+    return __uint_as_float(bits);
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t h, uint32_t w)
+{
+    h ^= w; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ULL; h ^= h >> 29;
+    return h;
+}
+
+// x86: uint(float) goes through cvttss2si r64 and keeps the low 32 bits (bake_cpu_impl.cpp:502)
+__device__ __forceinline__ uint32_t cvt_u32_x86(float f)
+{
+    return (f >= -9223372036854775808.f && f < 9223372036854775808.f) ? (uint32_t)(long long)f : 0u;
+}
+
+__global__ __launch_bounds__(256) void setup_fetch(SetupParams S, float* __restrict__ triUv, uint8_t* __restrict__ triLevel,
+                                                   uint8_t* __restrict__ triFlags, uint64_t* __restrict__ hashKeys, uint32_t* __restrict__ triIdx,
+                                                   SetupCounters* __restrict__ counters, uint32_t* __restrict__ pendingList)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S.numTris) return;
+    // ---- FetchUVTriangle (util/geometry.h:191-239) ----
+    uint32_t idx[3];
+    const size_t o = 3ull * t;
+    #pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (S.indexFormat == 2) idx[k] = ((const uint8_t*)S.indices)[o + k];
+        else if (S.indexFormat == 0) idx[k] = ((const uint16_t*)S.indices)[o + k];
+        else idx[k] = ((const uint32_t*)S.indices)[o + k];
+    }
+    float p[6];
+    #pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint8_t* base = (const uint8_t*)S.texCoords + (size_t)S.stride * idx[k];
+        if (S.uvFormat == 2) { // stride is caller-defined: assemble from bytes when it is not 4-aligned
+            if (((uintptr_t)base & 3u) == 0) { p[2 * k] = ((const float*)base)[0]; p[2 * k + 1] = ((const float*)base)[1]; }
+            else { uint32_t a = 0, b = 0; for (int q = 0; q < 4; ++q) { a |= (uint32_t)base[q] << (8 * q); b |= (uint32_t)base[4 + q] << (8 * q); } p[2 * k] = __uint_as_float(a); p[2 * k + 1] = __uint_as_float(b); }
+        } else {
+            uint32_t v = 0; for (int q = 0; q < 4; ++q) v |= (uint32_t)base[q] << (8 * q);
+            if (S.uvFormat == 0) { p[2 * k] = (float)(v & 0xffffu) * 1.5259021896696421759314870504694e-5f; p[2 * k + 1] = (float)(v >> 16) * 1.5259021896696421759314870504694e-5f; }
+            else { p[2 * k] = half_bits_to_float(v & 0xffffu); p[2 * k + 1] = half_bits_to_float(v >> 16); }
+        }
+    }
+    bool invalid = false;
+    #pragma unroll
+    for (int k = 0; k < 6; ++k) invalid |= !(__builtin_fabsf(p[k]) < __builtin_inff()); // NaN or Inf (util/geometry.h:37-42)
+    // util/geometry.h:44-47
+    const float area0 = 0.5f * __builtin_fabsf(p[0] * (p[3] - p[5]) + p[2] * (p[5] - p[1]) + p[4] * (p[1] - p[3]));
+    const bool degenerate = (double)area0 < 1e-9;
+    // ---- GetSubdivisionLevelForPrimitive (bake_cpu_impl.cpp:542-560) ----
+    uint32_t level; bool pending = false;
+    if (S.perTriLevels && S.perTriLevels[t] <= 12) level = S.perTriLevels[t];
+    else if (S.dynScale > 0.f) {
+        if (degenerate || S.edgeHeuristic) { level = 0; pending = !invalid; }
+        else { // ComputeAreaHeuristic (:470-509)
+            const float fw = (float)(uint32_t)S.texW, fh = (float)(uint32_t)S.texH;
+            const float ax = p[0] * fw, ay = p[1] * fh, bx = p[2] * fw, by = p[3] * fh, cx = p[4] * fw, cy = p[5] * fh;
+            const float v0x = cx - ax, v0y = cy - ay, v1x = bx - ax, v1y = by - ay;
+            const float nx = v0y * 0.f - v1y * 0.f, ny = 0.f * v1x - 0.f * v0x, nz = v0x * v1y - v1x * v0y;
+            const float pixelArea = 0.5f * __builtin_sqrtf(nx * nx + ny * ny + nz * nz);
+            uint32_t v = cvt_u32_x86(pixelArea / (S.dynScale * S.dynScale));
+            v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v++;
+            uint32_t r = (v & 0xAAAAAAAAu) != 0;
+            r |= (uint32_t)((v & 0xFFFF0000u) != 0) << 4; r |= (uint32_t)((v & 0xFF00FF00u) != 0) << 3;
+            r |= (uint32_t)((v & 0xF0F0F0F0u) != 0) << 2; r |= (uint32_t)((v & 0xCCCCCCCCu) != 0) << 1;
+            level = r >> 1; if (level > (uint32_t)S.globalLevel) level = (uint32_t)S.globalLevel;
+        }
+    } else level = (uint32_t)S.globalLevel;
+
+    #pragma unroll
+    for (int k = 0; k < 6; ++k) triUv[6ull * t + k] = p[k];
+    triLevel[t] = (uint8_t)level;
+    triFlags[t] = (uint8_t)((invalid ? 1u : 0u) | (degenerate ? 2u : 0u) | (pending ? 4u : 0u));
+    triIdx[t] = t;
+    if (invalid) atomicAdd(&counters->numDisabled, 1u);
+    if (pending) { const uint32_t slot = atomicAdd(&counters->numPending, 1u); pendingList[slot] = t; }
+    uint64_t h;
+    if (invalid || S.disableDedup) h = (invalid ? 0xFFFFFFFF00000000ULL : 0ULL) | t; // unique: never merged
+    else {
+        h = 0x9E3779B97F4A7C15ULL;
+        #pragma unroll
+        for (int k = 0; k < 6; ++k) h = mix64(h, __float_as_uint(p[k] == 0.f ? 0.f : p[k])); // +0 == -0 (std::hash<float>)
+        h = mix64(h, level);
+        h &= 0x7FFFFFFFFFFFFFFFULL; // keep clear of the invalid-triangle key range
+    }
+    hashKeys[t] = h;
+}
+
+// after the host has filled in the levels of the pending triangles: recompute their hash keys
+__global__ __launch_bounds__(256) void setup_rehash_pending(SetupParams S, const float* __restrict__ triUv, const uint8_t* __restrict__ triLevel,
+                                                            const uint32_t* __restrict__ pendingList, uint32_t numPending, uint64_t* __restrict__ hashKeys)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= numPending) return;
+    const uint32_t t = pendingList[k];
+    if (S.disableDedup) return;
+    uint64_t h = 0x9E3779B97F4A7C15ULL;
+    for (int q = 0; q < 6; ++q) { const float f = triUv[6ull * t + q]; h = mix64(h, __float_as_uint(f == 0.f ? 0.f : f)); }
+    h = mix64(h, triLevel[t]);
+    hashKeys[t] = h & 0x7FFFFFFFFFFFFFFFULL;
+}
+
+__global__ __launch_bounds__(256) void setup_heads(const uint64_t* __restrict__ sortedKeys, const uint32_t* __restrict__ sortedTris, uint32_t n,
+                                                   const float* __restrict__ triUv, const uint8_t* __restrict__ triLevel,
+                                                   uint32_t* __restrict__ headPos, SetupCounters* __restrict__ counters)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const bool head = p == 0 || sortedKeys[p] != sortedKeys[p - 1];
+    headPos[p] = head ? p : 0u;
+    if (!head) { // equal hash: the full keys must be equal too, else the hash collided
+        const uint32_t a = sortedTris[p], b = sortedTris[p - 1];
+        bool same = triLevel[a] == triLevel[b];
+        for (int q = 0; q < 6; ++q) { const float x = triUv[6ull * a + q], y = triUv[6ull * b + q]; same &= (x == y); }
+        if (!same) atomicOr(&counters->collision, 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void setup_first_tri(const uint32_t* __restrict__ sortedTris, const uint32_t* __restrict__ headScan, uint32_t n,
+                                                       const uint8_t* __restrict__ triFlags, uint32_t* __restrict__ firstTri, uint32_t* __restrict__ isItem)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t t = sortedTris[p], f = sortedTris[headScan[p]];
+    firstTri[t] = f;
+    isItem[t] = (f == t && !(triFlags[t] & 1u)) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void setup_emit_items(SetupParams S, const float* __restrict__ triUv, const uint8_t* __restrict__ triLevel,
+                                                        const uint8_t* __restrict__ triFlags, const uint32_t* __restrict__ firstTri,
+                                                        const uint32_t* __restrict__ isItem, const uint32_t* __restrict__ itemOfTri,
+                                                        float* __restrict__ itemUv, uint8_t* __restrict__ itemLevel, uint8_t* __restrict__ itemDegenerate,
+                                                        int32_t* __restrict__ triToItem, uint32_t* __restrict__ sortKeys, uint32_t* __restrict__ sortVals,
+                                                        SetupCounters* __restrict__ counters)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S.numTris) return;
+    sortKeys[t] = 15u; sortVals[t] = 0u; // slots past the item count sort to the end
+    if (t == S.numTris - 1) counters->numItems = itemOfTri[t] + isItem[t];
+    triToItem[t] = (triFlags[t] & 1u) ? -1 : (int32_t)itemOfTri[firstTri[t]];
+    __syncthreads();
+    if (!isItem[t]) return;
+    const uint32_t i = itemOfTri[t];
+    #pragma unroll
+    for (int k = 0; k < 6; ++k) itemUv[6ull * i + k] = triUv[6ull * t + k];
+    const uint32_t lvl = triLevel[t];
+    itemLevel[i] = (uint8_t)lvl; itemDegenerate[i] = (triFlags[t] >> 1) & 1u;
+    atomicAdd(&counters->levelCount[lvl], 1u);
+    if (S.wantWorkload) { // ComputeWorkloadSize (bake_cpu_impl.cpp:662-680)
+        const float* p = triUv + 6ull * t;
+        const float lox = (p[2] < p[0] ? p[2] : p[0]), lox2 = (p[4] < lox ? p[4] : lox), loy = (p[3] < p[1] ? p[3] : p[1]), loy2 = (p[5] < loy ? p[5] : loy);
+        const float hix = (p[0] < p[2] ? p[2] : p[0]), hix2 = (hix < p[4] ? p[4] : hix), hiy = (p[1] < p[3] ? p[3] : p[1]), hiy2 = (hiy < p[5] ? p[5] : hiy);
+        const float dx = (hix2 - lox2) * (float)S.texW, dy = (hiy2 - loy2) * (float)S.texH;
+        const int ax = (dx >= -2147483648.f && dx < 2147483648.f) ? (int)dx : (int)0x80000000;
+        const int ay = (dy >= -2147483648.f && dy < 2147483648.f) ? (int)dy : (int)0x80000000;
+        atomicAdd((unsigned long long*)&counters->workload, (unsigned long long)(long long)(int)((uint32_t)ax * (uint32_t)ay));
+    }
+}
+
+// items are numbered in triangle order; their level keys are written in a second pass once the numbering exists
+__global__ __launch_bounds__(256) void setup_level_keys(const uint8_t* __restrict__ itemLevel, const SetupCounters* __restrict__ counters, uint32_t n,
+                                                        uint32_t* __restrict__ sortKeys, uint32_t* __restrict__ sortVals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || i >= counters->numItems) return;
+    sortKeys[i] = itemLevel[i]; sortVals[i] = i;
+}
+
+__global__ void setup_level_starts(SetupCounters* __restrict__ counters)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t run = 0;
+        for (int l = 0; l < kNumLevels; ++l) { counters->levelStart[l] = run; run += counters->levelCount[l]; }
+        counters->levelStart[kNumLevels] = run;
+    }
+}
+
+size_t setup_scratch_bytes(uint32_t numTris)
+{
+    const size_t n = numTris ? numTris : 1;
+    size_t a = 0, b = 0, c = 0, d = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+    (void)hipcub::DeviceScan::InclusiveScan(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, hipcub::Max(), (int)n);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, c, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, d, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+    size_t m = a; if (b > m) m = b; if (c > m) m = c; if (d > m) m = d;
+    const size_t p256 = 256;
+    auto pad = [&](size_t v) { return (v + p256 - 1) / p256 * p256; };
+    //           triUv        keys x2          tri/sorted idx x2  headPos,headScan,firstTri,isItem,itemOfTri  level,flags      pending
+    return pad(n * 24) + 2 * pad(n * 8) + 2 * pad(n * 4) + 5 * pad(n * 4) + 2 * pad(n) + pad(n * 4) + 2 * pad(n * 4) + pad(m) + 1024;
+}
+
+// phase A: fetch + levels + hash keys.  The caller then looks at counters->numPending (after its sync) and, if non-zero,
+// fixes those levels and calls setup_rehash().  phase B: dedup + item emission + level grouping.
+struct SetupScratch {
+    float* triUv; uint64_t *keysA, *keysB; uint32_t *trisA, *trisB, *headPos, *headScan, *firstTri, *isItem, *itemOfTri, *pending, *lkeysA, *lkeysB;
+    uint8_t *triLevel, *triFlags; void* cub; size_t cubBytes;
+};
+static SetupScratch carve_setup(void* base, size_t bytes, uint32_t numTris)
+{
+    const size_t n = numTris ? numTris : 1;
+    auto pad = [](size_t v) { return (v + 255) / 256 * 256; };
+    SetupScratch s; uint8_t* p = (uint8_t*)base;
+    s.triUv = (float*)p; p += pad(n * 24);
+    s.keysA = (uint64_t*)p; p += pad(n * 8); s.keysB = (uint64_t*)p; p += pad(n * 8);
+    s.trisA = (uint32_t*)p; p += pad(n * 4); s.trisB = (uint32_t*)p; p += pad(n * 4);
+    s.headPos = (uint32_t*)p; p += pad(n * 4); s.headScan = (uint32_t*)p; p += pad(n * 4); s.firstTri = (uint32_t*)p; p += pad(n * 4);
+    s.isItem = (uint32_t*)p; p += pad(n * 4); s.itemOfTri = (uint32_t*)p; p += pad(n * 4);
+    s.triLevel = p; p += pad(n); s.triFlags = p; p += pad(n);
+    s.pending = (uint32_t*)p; p += pad(n * 4);
+    s.lkeysA = (uint32_t*)p; p += pad(n * 4); s.lkeysB = (uint32_t*)p; p += pad(n * 4);
+    s.cub = p; s.cubBytes = bytes - (size_t)(p - (uint8_t*)base);
+    return s;
+}
+
+hipError_t run_setup_fetch(const SetupParams& S, void* scratch, size_t scratchBytes, SetupCounters* counters, hipStream_t stream)
+{
+    SETUP_CHECK(hipMemsetAsync(counters, 0, sizeof(SetupCounters), stream));
+    if (S.numTris == 0) return hipSuccess;
+    if (scratchBytes < setup_scratch_bytes(S.numTris)) return hipErrorInvalidValue;
+    SetupScratch s = carve_setup(scratch, scratchBytes, S.numTris);
+    hipLaunchKernelGGL(setup_fetch, dim3((S.numTris + 255u) / 256u), dim3(256), 0, stream, S, s.triUv, s.triLevel, s.triFlags, s.keysA, s.trisA, counters, s.pending);
+    return hipGetLastError();
+}
+
+// host-computed levels for the pending (degenerate, dynamic) triangles: levels[k] belongs to triangle pendingHost[k]
+hipError_t run_setup_fix_pending(const SetupParams& S, void* scratch, size_t scratchBytes, const uint32_t* pendingTris /*host*/, const uint8_t* levels /*host*/,
+                                 uint32_t numPending, hipStream_t stream)
+{
+    if (numPending == 0) return hipSuccess;
+    SetupScratch s = carve_setup(scratch, scratchBytes, S.numTris);
+    for (uint32_t k = 0; k < numPending; ++k) // rare path (degenerate triangles under dynamic subdivision): a few bytes each
+        SETUP_CHECK(hipMemcpyAsync(s.triLevel + pendingTris[k], levels + k, 1, hipMemcpyHostToDevice, stream));
+    SETUP_CHECK(hipMemcpyAsync(s.pending, pendingTris, (size_t)numPending * 4, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(setup_rehash_pending, dim3((numPending + 255u) / 256u), dim3(256), 0, stream, S, s.triUv, s.triLevel, s.pending, numPending, s.keysA);
+    return hipGetLastError();
+}
+
+hipError_t copy_pending_to_host(void* scratch, size_t scratchBytes, uint32_t numTris, uint32_t numPending, uint32_t* pendingTris /*host*/, float* pendingUv /*host, 6 each*/,
+                                hipStream_t stream)
+{
+    SetupScratch s = carve_setup(scratch, scratchBytes, numTris);
+    SETUP_CHECK(hipMemcpyAsync(pendingTris, s.pending, (size_t)numPending * 4, hipMemcpyDeviceToHost, stream));
+    SETUP_CHECK(hipStreamSynchronize(stream));
+    for (uint32_t k = 0; k < numPending; ++k)
+        SETUP_CHECK(hipMemcpyAsync(pendingUv + 6ull * k, s.triUv + 6ull * pendingTris[k], 24, hipMemcpyDeviceToHost, stream));
+    return hipStreamSynchronize(stream);
+}
+
+hipError_t run_setup_items(const SetupParams& S, void* scratch, size_t scratchBytes, SetupCounters* counters, float* itemUv, uint8_t* itemLevel,
+                           uint8_t* itemDegenerate, int32_t* triToItem, uint32_t* itemIds, hipStream_t stream)
+{
+    const uint32_t n = S.numTris;
+    if (n == 0) return hipSuccess;
+    SetupScratch s = carve_setup(scratch, scratchBytes, n);
+    const dim3 grid((n + 255u) / 256u), block(256);
+    size_t tb = s.cubBytes;
+    SETUP_CHECK(hipcub::DeviceRadixSort::SortPairs(s.cub, tb, s.keysA, s.keysB, s.trisA, s.trisB, (int)n, 0, 64, stream));
+    hipLaunchKernelGGL(setup_heads, grid, block, 0, stream, s.keysB, s.trisB, n, s.triUv, s.triLevel, s.headPos, counters);
+    tb = s.cubBytes;
+    SETUP_CHECK(hipcub::DeviceScan::InclusiveScan(s.cub, tb, s.headPos, s.headScan, hipcub::Max(), (int)n, stream));
+    hipLaunchKernelGGL(setup_first_tri, grid, block, 0, stream, s.trisB, s.headScan, n, s.triFlags, s.firstTri, s.isItem);
+    tb = s.cubBytes;
+    SETUP_CHECK(hipcub::DeviceScan::ExclusiveSum(s.cub, tb, s.isItem, s.itemOfTri, (int)n, stream));
+    hipLaunchKernelGGL(setup_emit_items, grid, block, 0, stream, S, s.triUv, s.triLevel, s.triFlags, s.firstTri, s.isItem, s.itemOfTri, itemUv, itemLevel,
+                       itemDegenerate, triToItem, s.lkeysA, s.trisA, counters);
+    hipLaunchKernelGGL(setup_level_keys, grid, block, 0, stream, itemLevel, counters, n, s.lkeysA, s.trisA);
+    tb = s.cubBytes;
+    SETUP_CHECK(hipcub::DeviceRadixSort::SortPairs(s.cub, tb, s.lkeysA, s.lkeysB, s.trisA, itemIds, (int)n, 0, 4, stream));
+    hipLaunchKernelGGL(setup_level_starts, dim3(1), dim3(64), 0, stream, counters);
+    return hipGetLastError();
+}
+
+} // namespace ommx

@@ -15,6 +15,9 @@
 
 namespace ommx {
 
+#define TAIL_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+size_t tail_scratch_bytes(uint32_t numItems, uint32_t numTris);
+
 __device__ __forceinline__ int cvt_trunc_x86_t(float f) { return (f >= -2147483648.f && f < 2147483648.f) ? (int)f : (int)0x80000000; }
 __device__ __forceinline__ int clampi_t(int v, int lo, int hi) { return v < lo ? lo : (hi < v ? hi : v); }
 __device__ __forceinline__ uint32_t spread16(uint32_t x)
@@ -153,6 +156,65 @@ void launch_write_descs(const uint32_t* order, const uint32_t* dstOfs, const uin
     hipLaunchKernelGGL(tail_descs, dim3((numOmms + 255u) / 256u), dim3(256), 0, stream, order, dstOfs, level, format, numOmms, (uint2*)descArray);
 }
 
+// ---- active-item compaction (after triage): per-level lists of the items that need per-micro-triangle work, and their
+//      slots in the packed-state buffer ----
+__global__ __launch_bounds__(256) void prep_flags(const uint32_t* __restrict__ itemIds, const uint8_t* __restrict__ active, const uint8_t* __restrict__ level,
+                                                  int bits, uint32_t n, uint32_t* __restrict__ flags, uint64_t* __restrict__ sizes)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t item = itemIds[p];
+    const uint32_t f = active[item] ? 1u : 0u;
+    uint64_t bytes = (((uint64_t)1 << (2u * level[item])) * (uint64_t)bits) >> 3; if (bytes < 16) bytes = 16; // 16-byte slots keep vector copies aligned
+    flags[p] = f; sizes[p] = f ? bytes : 0ull;
+}
+
+__global__ __launch_bounds__(256) void prep_scatter(const uint32_t* __restrict__ itemIds, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos,
+                                                    const uint64_t* __restrict__ ofs, uint32_t n, uint32_t* __restrict__ activeIds, uint64_t* __restrict__ stateOfs)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n || !flags[p]) return;
+    const uint32_t item = itemIds[p];
+    activeIds[pos[p]] = item; stateOfs[item] = ofs[p];
+}
+
+hipError_t run_prep(const uint32_t* itemIds, const uint8_t* active, const uint8_t* level, int bits, uint32_t n, const uint32_t* levelStart /*host, 14*/,
+                    uint32_t* activeIds, uint64_t* stateOfs, void* scratch, size_t scratchBytes, uint32_t* activeLevelStart /*host, 14*/,
+                    uint64_t* totalStateBytes, hipStream_t stream)
+{
+    for (int l = 0; l <= kNumLevels; ++l) activeLevelStart[l] = 0;
+    *totalStateBytes = 0;
+    if (n == 0) return hipSuccess;
+    if (scratchBytes < tail_scratch_bytes(n, 0)) return hipErrorInvalidValue;
+    uint8_t* p = (uint8_t*)scratch;
+    const size_t n64 = (((size_t)n + 1) * 8 + 255) / 256 * 256, n32 = (((size_t)n + 1) * 4 + 255) / 256 * 256;
+    uint64_t* sizes = (uint64_t*)p; p += n64; uint64_t* ofs = (uint64_t*)p; p += n64;
+    uint32_t* flags = (uint32_t*)p; p += n32; uint32_t* pos = (uint32_t*)p; p += n32;
+    void* cub = p; size_t cubBytes = scratchBytes - (size_t)(p - (uint8_t*)scratch);
+    const dim3 grid((n + 255u) / 256u), block(256);
+    hipLaunchKernelGGL(prep_flags, grid, block, 0, stream, itemIds, active, level, bits, n, flags, sizes);
+    size_t tb = cubBytes;
+    TAIL_CHECK(hipcub::DeviceScan::ExclusiveSum(cub, tb, flags, pos, (int)n, stream));
+    tb = cubBytes;
+    TAIL_CHECK(hipcub::DeviceScan::ExclusiveSum(cub, tb, sizes, ofs, (int)n, stream));
+    hipLaunchKernelGGL(prep_scatter, grid, block, 0, stream, itemIds, flags, pos, ofs, n, activeIds, stateOfs);
+    // level boundaries of the compacted list + total bytes
+    uint32_t lastPos = 0, lastFlag = 0; uint64_t lastOfs = 0, lastSize = 0;
+    uint32_t bounds[kNumLevels + 1];
+    for (int l = 0; l < kNumLevels; ++l)
+        if (levelStart[l] < n) TAIL_CHECK(hipMemcpyAsync(&bounds[l], pos + levelStart[l], 4, hipMemcpyDeviceToHost, stream));
+    TAIL_CHECK(hipMemcpyAsync(&lastPos, pos + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+    TAIL_CHECK(hipMemcpyAsync(&lastFlag, flags + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+    TAIL_CHECK(hipMemcpyAsync(&lastOfs, ofs + (n - 1), 8, hipMemcpyDeviceToHost, stream));
+    TAIL_CHECK(hipMemcpyAsync(&lastSize, sizes + (n - 1), 8, hipMemcpyDeviceToHost, stream));
+    TAIL_CHECK(hipStreamSynchronize(stream));
+    const uint32_t totalActive = lastPos + lastFlag;
+    for (int l = 0; l < kNumLevels; ++l) activeLevelStart[l] = levelStart[l] < n ? bounds[l] : totalActive;
+    activeLevelStart[kNumLevels] = totalActive;
+    *totalStateBytes = lastOfs + lastSize;
+    return hipSuccess;
+}
+
 // ---- scratch layout ----
 struct Scratch {
     uint64_t *keysA, *keysB, *sizes64, *ofs64;
@@ -192,8 +254,6 @@ size_t tail_scratch_bytes(uint32_t numItems, uint32_t numTris)
     const uint32_t n = numItems ? numItems : 1;
     return 4 * align_up((size_t)n * 8, 256) + 5 * align_up((size_t)n * 4, 256) + 512 + cub_bytes(n);
 }
-
-#define TAIL_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
 hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch, size_t scratchBytes, TailCounts* counts, hipStream_t stream)
 {

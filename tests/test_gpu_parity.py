@@ -301,3 +301,23 @@ def test_full_size_bake_matches_oracle_on_a_subset(product, oracle):
     product.destroy_baker(b)
     for j in range(k):
         assert omm_of_triangle(full, n - k + j, 16384) == omm_of_triangle(tail, j, 16384), j
+
+
+@pytest.mark.parametrize("offset", [3.0, -7.0, 255.0, 4097.0, 20000.0, -70000.0])
+@pytest.mark.parametrize("addr", [ot.WRAP, ot.MIRROR])
+def test_large_uv_offsets(product, oracle, offset, addr):
+    """far-away UV periods: fp32 texel resolution degrades (ulp(20000) is a texel at 512^2); the hierarchical shortcut must
+    stay conservative there (region_state grows its boxes by 64 ulp, and gives up beyond |uv| = 16384)"""
+    uv, ix = ot.random_triangles(123, 200, 0.05)
+    uv = (uv + np.float32(offset)).astype(np.float32)
+    both(product, oracle, [noise_u8()], uv, ix, 5, addr=addr, promo=ot.PROMO_FORCE_OPAQUE)
+
+
+def test_hierarchy_levels_all_paths(product, oracle):
+    """big triangles (many tiles per item, most of them uniform) and tiny ones, every level 0..9, SAT on"""
+    tex = ot.foliage_texture(77, 1024, 1024, feature=96)
+    for level in range(0, 10):
+        for extent in (0.02, 0.3):
+            uv, ix = ot.random_triangles(500 + level, 24 if level > 7 else 80, extent)
+            both(product, oracle, [tex], uv, ix, level, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+            both(product, oracle, [tex], uv, ix, level, addr=ot.CLAMP, promo=ot.PROMO_NEAREST, flags=ot.FLAG_THREADS | ot.FLAG_NO_SPECIAL)
