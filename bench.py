@@ -27,7 +27,7 @@ class BakeTimings(C.Structure):
     _fields_ = [("hostSetupMs", C.c_float), ("uploadMs", C.c_float), ("classifyMs", C.c_float), ("digestMs", C.c_float),
                 ("tailMs", C.c_float), ("gatherMs", C.c_float), ("downloadMs", C.c_float), ("totalMs", C.c_float),
                 ("microTriangles", C.c_uint64), ("uniqueItems", C.c_uint32), ("classifyLaunches", C.c_uint32),
-                ("stateBytes", C.c_uint64), ("triageMs", C.c_float), ("activeItems", C.c_uint32)]
+                ("stateBytes", C.c_uint64), ("triageMs", C.c_float), ("activeItems", C.c_uint32), ("setupMs", C.c_float)]
 
 
 def make_workload(args):
@@ -158,7 +158,7 @@ def main():
                        "entry": "ommCpuBake (host pointers in/out)", "sharding": "contiguous triangle ranges per rank" if world > 1 else "none",
                        "result": result_info},
             "bake_wall_time_ms": ms_per_step,
-            "phases_ms": {k: avg(k) for k in ("hostSetupMs", "uploadMs", "triageMs", "classifyMs", "digestMs", "tailMs", "gatherMs", "downloadMs", "totalMs")},
+            "phases_ms": {k: avg(k) for k in ("uploadMs", "setupMs", "triageMs", "classifyMs", "digestMs", "tailMs", "gatherMs", "downloadMs", "totalMs")},
             "roofline": {"bound": "hbm", "kernel": "classify_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": classify_ms / launches,
                          "note": "classification is fp32-VALU/sqrt/div bound, not HBM bound (SURVEY.md section 8d)"},

@@ -26,8 +26,21 @@ typedef struct ommxBakeTimings {
     uint64_t stateBytes;       /* packed state bytes written by classification */
     float    triageMs;         /* level-0 hierarchical query per item + compaction of the active items */
     uint32_t activeItems;      /* items that needed per-micro-triangle classification */
+    float    setupMs;          /* device work-item setup: UV fetch, level selection, first-occurrence dedup, level grouping */
 } ommxBakeTimings;
 
 OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings* out);
+
+/* ---- device-resident bake ----
+ * Same contract as ommCpuBake (include/omm_mi355x.h; reference omm.h:574) except for where the bulk data lives:
+ *   in : desc->texCoords, desc->indexBuffer and desc->subdivisionLevels are DEVICE pointers (HBM of the current HIP device);
+ *        desc->formats must be NULL.  All other fields, validation, result codes and log messages are those of ommCpuBake.
+ *   out: an ommCpuBakeResultDesc whose arrayData, descArray and indexBuffer are DEVICE pointers; the two histograms are
+ *        host arrays.  Buffers stay valid until ommxDestroyDeviceBakeResult.
+ * The call returns when the result is complete (the library synchronises its own stream). */
+typedef struct _ommxDeviceBakeResult* ommxDeviceBakeResult;
+OMM_MI355X_API ommResult ommxBakeDevice(ommBaker baker, const ommCpuBakeInputDesc* deviceDesc, ommxDeviceBakeResult* outResult);
+OMM_MI355X_API ommResult ommxGetDeviceBakeResultDesc(ommxDeviceBakeResult result, const ommCpuBakeResultDesc** desc);
+OMM_MI355X_API ommResult ommxDestroyDeviceBakeResult(ommxDeviceBakeResult result);
 
 #endif

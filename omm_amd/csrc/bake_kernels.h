@@ -6,10 +6,12 @@
 
 namespace ommx {
 
+struct SetupCounters;
+
 // classification of one level group (items listed in itemIds, all at `level`)
 void launch_classify(const ClassifyParams& P, const ItemArrays& A, const uint32_t* itemIds, uint32_t numItems, uint32_t level, hipStream_t stream);
 // level-0 hierarchical query per work item: uniform items get stateMask = 1 << state and active = 0
-void launch_triage(const ClassifyParams& P, const float* uv, uint32_t numItems, uint32_t* stateMask, uint8_t* active, hipStream_t stream);
+void launch_triage(const ClassifyParams& P, const float* uv, const SetupCounters* counters, uint32_t maxItems, uint32_t* stateMask, uint8_t* active, hipStream_t stream);
 // XXH64(seed 42) of the 3-state byte stream of each listed item -> digests[item]
 void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
                    uint64_t* digests, hipStream_t stream);
@@ -20,6 +22,30 @@ void launch_gather_omms(const uint8_t* states, const uint64_t* stateOfs, const u
                         const uint32_t* order, const uint32_t* dstOfs, const uint32_t* sizes, uint32_t numOmms, uint8_t* arrayData, hipStream_t stream);
 void launch_write_indices(const int32_t* triToItem, const uint32_t* rep, const int32_t* itemValue, uint32_t numTris, int32_t unresolved,
                           int32_t* out, hipStream_t stream);
+
+// ---- device work-item setup (setup_kernels.hip) ----
+struct SetupParams {
+    const void* texCoords; uint32_t stride; int uvFormat;     // ommTexCoordFormat, stride in bytes (already defaulted)
+    const void* indices; int indexFormat; uint32_t numTris;   // ommIndexFormat
+    const uint8_t* perTriLevels;                               // or null
+    int globalLevel; float dynScale; int edgeHeuristic;
+    int texW, texH; int disableDedup; int wantWorkload;
+};
+struct SetupCounters {                                         // one device-resident block, read back in a single copy
+    uint32_t numItems, numDisabled, numPending, collision;
+    uint64_t workload;
+    uint32_t levelCount[kNumLevels];
+    uint32_t levelStart[kNumLevels + 1];
+    uint32_t activeStart[kNumLevels + 1];                      // filled by run_prep
+    uint32_t pad_;
+    uint64_t stateBytes;                                       // filled by run_prep
+};
+size_t setup_scratch_bytes(uint32_t numTris);
+hipError_t run_setup_fetch(const SetupParams& S, void* scratch, size_t scratchBytes, SetupCounters* counters, hipStream_t stream);
+hipError_t copy_pending_to_host(void* scratch, size_t scratchBytes, uint32_t numTris, uint32_t numPending, uint32_t* pendingTris, float* pendingUv, hipStream_t stream);
+hipError_t run_setup_fix_pending(const SetupParams& S, void* scratch, size_t scratchBytes, const uint32_t* pendingTris, const uint8_t* levels, uint32_t numPending, hipStream_t stream);
+hipError_t run_setup_items(const SetupParams& S, void* scratch, size_t scratchBytes, SetupCounters* counters, float* itemUv, uint8_t* itemLevel,
+                           uint8_t* itemDegenerate, int32_t* triToItem, uint32_t* itemIds, hipStream_t stream);
 
 // ---- device tail (tail_kernels.hip) ----
 struct TailInputs {
@@ -51,9 +77,10 @@ struct TailOutputs {            // device buffers owned by the caller
 struct TailCounts { uint32_t numOmms; uint64_t arrayDataSize; };
 
 // compaction of the active (non-uniform) items into per-level lists + their packed-state slots; synchronises the stream once
-hipError_t run_prep(const uint32_t* itemIds, const uint8_t* active, const uint8_t* level, int bits, uint32_t n, const uint32_t* levelStart,
-                    uint32_t* activeIds, uint64_t* stateOfs, void* scratch, size_t scratchBytes, uint32_t* activeLevelStart,
-                    uint64_t* totalStateBytes, hipStream_t stream);
+// (item count and level boundaries are read from / written to the device-resident counters block; no synchronisation)
+hipError_t run_prep(const uint32_t* itemIds, const uint8_t* active, const uint8_t* level, int bits, uint32_t maxItems, SetupCounters* counters,
+                    uint32_t* activeIds, uint64_t* stateOfs, void* scratch, size_t scratchBytes, hipStream_t stream);
+void launch_narrow_indices(const int32_t* in, uint32_t n, int bytesPerIndex, void* out, hipStream_t stream);
 // scratch handling: call with scratch == nullptr to get the size
 size_t tail_scratch_bytes(uint32_t numItems, uint32_t numTris);
 // runs the device tail up to (and including) offsets; returns counts (synchronises the stream once)

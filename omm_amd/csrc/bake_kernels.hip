@@ -47,11 +47,11 @@ __device__ __forceinline__ float item_max_abs(const float* __restrict__ uv)
     return m;
 }
 
-__global__ __launch_bounds__(256) void triage_items(ClassifyParams P, const float* __restrict__ uv, uint32_t numItems,
+__global__ __launch_bounds__(256) void triage_items(ClassifyParams P, const float* __restrict__ uv, const SetupCounters* __restrict__ counters,
                                                     uint32_t* __restrict__ stateMask, uint8_t* __restrict__ active)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= numItems) return;
+    if (i >= counters->numItems) return;
     int st = -1;
     if (P.useCoarse) {
         const float* t = uv + 6ull * i;
@@ -62,10 +62,25 @@ __global__ __launch_bounds__(256) void triage_items(ClassifyParams P, const floa
     active[i] = st >= 0 ? 0 : 1;
 }
 
-void launch_triage(const ClassifyParams& P, const float* uv, uint32_t numItems, uint32_t* stateMask, uint8_t* active, hipStream_t stream)
+void launch_triage(const ClassifyParams& P, const float* uv, const SetupCounters* counters, uint32_t maxItems, uint32_t* stateMask, uint8_t* active, hipStream_t stream)
 {
-    if (numItems == 0) return;
-    hipLaunchKernelGGL(triage_items, dim3((numItems + 255u) / 256u), dim3(256), 0, stream, P, uv, numItems, stateMask, active);
+    if (maxItems == 0) return;
+    hipLaunchKernelGGL(triage_items, dim3((maxItems + 255u) / 256u), dim3(256), 0, stream, P, uv, counters, stateMask, active);
+}
+
+// index narrowing (bake_cpu_impl.cpp:1872-1902) for results that stay on the device
+__global__ __launch_bounds__(256) void narrow_indices(const int32_t* __restrict__ in, uint32_t n, int bytesPerIndex, void* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (bytesPerIndex == 1) ((int8_t*)out)[i] = (int8_t)in[i];
+    else if (bytesPerIndex == 2) ((int16_t*)out)[i] = (int16_t)in[i];
+    else ((int32_t*)out)[i] = in[i];
+}
+void launch_narrow_indices(const int32_t* in, uint32_t n, int bytesPerIndex, void* out, hipStream_t stream)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(narrow_indices, dim3((n + 255u) / 256u), dim3(256), 0, stream, in, n, bytesPerIndex, out);
 }
 
 template <bool FP32>

@@ -300,145 +300,120 @@ bool is_pow2(int x) { return x > 0 && !(x & (x - 1)); }
 
 #define HIP_OK(call) ((call) == hipSuccess)
 
-// The bake proper: bake_cpu_impl.cpp:1923-1985 re-organised for the device.
-ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult* out)
+// Device-resident result of a bake (what ommxBakeDevice hands out, and what ommCpuBake copies to the host).
+struct DeviceResult {
+    uint8_t* arrayData = nullptr; uint64_t arrayDataSize = 0;
+    ommCpuOpacityMicromapDesc* descs = nullptr; uint32_t numDescs = 0;
+    void* index = nullptr; uint32_t numTris = 0; ommIndexFormat indexFormat = ommIndexFormat_UINT_32;
+    uint32_t hist[2 * kNumLevels]; int bits = 2;
+    DeviceResult() { memset(hist, 0, sizeof hist); }
+    ~DeviceResult() { if (arrayData) (void)hipFree(arrayData); if (descs) (void)hipFree(descs); if (index) (void)hipFree(index); }
+};
+
+struct DeviceInputs {           // raw triangle data, device resident
+    const void* texCoords; const void* indices; const uint8_t* perTriLevels;
+};
+
+// host form of SetupWorkItems, used when the device setup reports a hash collision (never observed; 2^-64 class event)
+void setup_on_host(const ommCpuBakeInputDesc& d, uint32_t flags, const Texture& tex, std::vector<HostTri>& itemUv, std::vector<uint8_t>& itemLevel,
+                   std::vector<uint8_t>& itemDegenerate, std::vector<int32_t>& triToItem, uint32_t& numDisabled)
+{
+    const uint32_t triCount = d.indexCount / 3u;
+    std::unordered_map<UvKey, uint32_t, UvKeyHash> seen;
+    seen.reserve((size_t)triCount * 2);
+    const bool noDedup = (flags & (1u << 3)) != 0;
+    numDisabled = 0;
+    for (uint32_t i = 0; i < triCount; ++i) {
+        const HostTri t = fetch_triangle(d, i);
+        const int32_t lvl = level_for_primitive(d, flags, i, t, tex.mips[0].w, tex.mips[0].h);
+        if (lvl == 0xE || tri_invalid(t)) { numDisabled++; continue; }
+        UvKey key;
+        for (int k = 0; k < 6; ++k) { const float f = t.p[k] == 0.f ? 0.f : t.p[k]; memcpy(&key.k[k], &f, 4); }
+        key.k[6] = (uint32_t)lvl; key.k[7] = (uint32_t)d.format;
+        auto it = noDedup ? seen.end() : seen.find(key);
+        if (it == seen.end()) {
+            const uint32_t id = (uint32_t)itemUv.size();
+            if (!noDedup) seen.emplace(key, id);
+            itemUv.push_back(t); itemLevel.push_back((uint8_t)lvl); itemDegenerate.push_back(tri_degenerate(t) ? 1 : 0);
+            triToItem[i] = (int32_t)id;
+        } else triToItem[i] = (int32_t)it->second;
+    }
+}
+
+// The bake proper: bake_cpu_impl.cpp:1923-1985 re-organised for the device.  `din` points at device copies of the
+// caller's texCoords / indexBuffer / subdivisionLevels; `hostDesc` (may be null for device-resident callers) is the
+// same desc with host pointers, needed only by the serial fallbacks.
+ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInputs& din, const ommCpuBakeInputDesc* hostDesc,
+                    DeviceArena* arena, DeviceArena* statesArena, hipStream_t stream, EventTimer& et, DeviceResult& R, ommxBakeTimings& tm)
 {
     const Logger& L = baker.log;
     const uint32_t flags = (uint32_t)d.bakeFlags;
     const Texture& tex = *untag<Texture>(d.texture);
-    const double t0 = now_ms();
-
-    // ---- scope fences (documented in DESIGN.md) ----
-    if ((flags & ((1u << 4) | (1u << 10))) != 0)
-        { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - near-duplicate merging (EnableNearDuplicateDetection) is not available in the MI355X baker yet"); return ommResult_NOT_IMPLEMENTED; }
-    if (d.maxArrayDataSize != 0xFFFFFFFFu)
-        { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - maxArrayDataSize budgets are not available in the MI355X baker yet"); return ommResult_NOT_IMPLEMENTED; }
-    if ((flags & ((1u << 7) | (1u << 8) | (1u << 9) | (1u << 11))) != 0)
-        { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - internal bake flags (bits 7-11) are not supported"); return ommResult_NOT_IMPLEMENTED; }
-    const uint32_t triCount = d.indexCount / 3u;
-    if (d.formats) // the reference sizes its arrays from the global format only (bake_cpu_impl.cpp:1763-1772): mixed formats corrupt its heap
-        for (uint32_t i = 0; i < triCount; ++i)
-            if (d.formats[i] != ommFormat_INVALID && d.formats[i] != d.format)
-                return L.failure("[Failure] - per-triangle formats that differ from the global format are not supported");
-
-    // ---- SetupWorkItems (bake_cpu_impl.cpp:589-660), host side ----
-    std::vector<HostTri> itemUv; std::vector<uint8_t> itemLevel, itemDegenerate; std::vector<int32_t> triToItem(triCount ? triCount : 1, -1);
-    {
-        std::unordered_map<UvKey, uint32_t, UvKeyHash> seen;
-        seen.reserve((size_t)triCount * 2);
-        itemUv.reserve(triCount); itemLevel.reserve(triCount); itemDegenerate.reserve(triCount);
-        uint32_t numDisabled = 0;
-        const bool noDedup = (flags & (1u << 3)) != 0;
-        for (uint32_t i = 0; i < triCount; ++i) {
-            const HostTri t = fetch_triangle(d, i);
-            const int32_t lvl = level_for_primitive(d, flags, i, t, tex.mips[0].w, tex.mips[0].h);
-            if (lvl == 0xE || tri_invalid(t)) { numDisabled++; continue; }
-            UvKey key;
-            for (int k = 0; k < 6; ++k) { const float f = t.p[k] == 0.f ? 0.f : t.p[k]; memcpy(&key.k[k], &f, 4); }
-            key.k[6] = (uint32_t)lvl; key.k[7] = (uint32_t)d.format;
-            auto it = noDedup ? seen.end() : seen.find(key);
-            if (it == seen.end()) {
-                if (lvl > kMaxLevel) return L.invalid("[Invalid Argument] - subdivisionLevel for primitive (i) is (d) which exceeds kMaxSubdivLevel(12)");
-                const uint32_t id = (uint32_t)itemUv.size();
-                if (!noDedup) seen.emplace(key, id);
-                itemUv.push_back(t); itemLevel.push_back((uint8_t)lvl); itemDegenerate.push_back(tri_degenerate(t) ? 1 : 0);
-                triToItem[i] = (int32_t)id;
-            } else triToItem[i] = (int32_t)it->second;
-        }
-        if ((flags & (1u << 5)) && numDisabled != 0) {
-            char buf[256];
-            snprintf(buf, sizeof buf, "[Info] - The workload consists of %d unclassifiable triangles, these will be classified as unresolvedTriState = %s.", numDisabled, special_name(d.unresolvedTriState));
-            L.msg(ommMessageSeverity_Info, buf);
-        }
-    }
-    const uint32_t U = (uint32_t)itemUv.size();
-
-    // ---- ValidateWorkloadSize (bake_cpu_impl.cpp:662-713) ----
-    {
-        const bool limit = d.maxWorkloadSize != 0xFFFFFFFFFFFFFFFFull;
-        if ((flags & (1u << 5)) || limit) {
-            const float fw = (float)tex.mips[0].w, fh = (float)tex.mips[0].h;
-            uint64_t workload = 0;
-            for (uint32_t i = 0; i < U; ++i) {
-                const float* p = itemUv[i].p;
-                const float lox = std::min(std::min(p[0], p[2]), p[4]), loy = std::min(std::min(p[1], p[3]), p[5]);
-                const float hix = std::max(std::max(p[0], p[2]), p[4]), hiy = std::max(std::max(p[1], p[3]), p[5]);
-                const int ax = f2i((hix - lox) * fw), ay = f2i((hiy - loy) * fh);
-                workload += (uint64_t)(int64_t)(int32_t)((uint32_t)ax * (uint32_t)ay);
-            }
-            if (limit && workload > d.maxWorkloadSize) return ommResult_WORKLOAD_TOO_BIG;
-            if ((flags & (1u << 5)) && workload > (1ull << 27)) {
-                char buf[256];
-                snprintf(buf, sizeof buf, "[Perf Warning] - The workload consists of %lld work items (number of texels to classify), which corresponds to roughly %lld 1024x1024 textures."
-                         " This is unusually large and may result in long bake times.", (long long)workload, (long long)(workload >> 20));
-                L.msg(ommMessageSeverity_PerfWarning, buf);
-            }
-        }
-    }
-
-    const double tSetup = now_ms();
-    // ---- device layout ----
+    const uint32_t T = d.indexCount / 3u;
     const int bits = (int)d.format;
-    std::vector<uint32_t> levelCount(kNumLevels, 0), levelStart(kNumLevels + 1, 0);
-    for (uint32_t i = 0; i < U; ++i) levelCount[itemLevel[i]]++;
-    for (int l = 0; l < kNumLevels; ++l) levelStart[l + 1] = levelStart[l] + levelCount[l];
-    std::vector<uint32_t> itemIds(U ? U : 1);
-    { std::vector<uint32_t> cur(levelStart.begin(), levelStart.end() - 1); for (uint32_t i = 0; i < U; ++i) itemIds[cur[itemLevel[i]]++] = i; }
+    const uint32_t maxItems = T ? T : 1;
 
-    const size_t scratchBytes = tail_scratch_bytes(U, triCount);
-    const size_t perItem32 = pad256((size_t)(U ? U : 1) * 4), perItem64 = pad256((size_t)(U ? U : 1) * 8);
-    size_t need = pad256((size_t)(U ? U : 1) * 24) /*uv*/ + 2 * pad256(U ? U : 1) /*level,degenerate*/ + perItem64 /*stateOfs*/ + perItem32 /*itemIds*/
-                + pad256((size_t)(triCount ? triCount : 1) * 4) * 2 /*triToItem, indexBuffer*/ + perItem32 * 9 /*mask, known, special, rep, order, dstOfs, sizes, itemValue, activeIds*/ + pad256(U ? U : 1) /*active*/
-                + perItem64 /*digests*/ + 2048 /*histograms, error flag*/ + pad256(scratchBytes) + 8192;
-
-    std::unique_lock<std::mutex> lock(baker.arena.mu, std::try_to_lock);
-    DeviceArena local, localStates; // concurrent bakes on one baker get private arenas
-    DeviceArena* arena = lock.owns_lock() ? &baker.arena : &local;
-    DeviceArena* statesArena = lock.owns_lock() ? &baker.statesArena : &localStates;
+    // ---- device layout (worst case: every triangle is its own work item) ----
+    const size_t setupBytes = setup_scratch_bytes(T), tailBytes = tail_scratch_bytes(maxItems, T);
+    const size_t scratchBytes = setupBytes > tailBytes ? setupBytes : tailBytes;
+    const size_t i32 = pad256((size_t)maxItems * 4), i64 = pad256((size_t)maxItems * 8);
+    const size_t need = pad256((size_t)maxItems * 24) + 3 * pad256(maxItems) + i64 * 2 + i32 * 12 + pad256(sizeof(SetupCounters)) + 4096 + pad256(scratchBytes);
     if (!arena->reserve(need)) return L.failure("[Failure] - out of device memory for the bake working set");
-
-    hipStream_t stream = nullptr;
-    if (!HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking))) return L.failure("[Failure] - no usable HIP device (the MI355X baker has no CPU fallback)");
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{ stream };
-
-    float* dUv = arena->take<float>((size_t)(U ? U : 1) * 6);
-    uint8_t* dLevel = arena->take<uint8_t>(U ? U : 1); uint8_t* dDegen = arena->take<uint8_t>(U ? U : 1);
-    uint64_t* dStateOfs = arena->take<uint64_t>(U ? U : 1); uint32_t* dItemIds = arena->take<uint32_t>(U ? U : 1);
-    int32_t* dTriToItem = arena->take<int32_t>(triCount ? triCount : 1); int32_t* dIndex = arena->take<int32_t>(triCount ? triCount : 1);
-    uint32_t* dMask = arena->take<uint32_t>(U ? U : 1); uint32_t* dKnown = arena->take<uint32_t>(U ? U : 1);
-    int32_t* dSpecial = arena->take<int32_t>(U ? U : 1); uint32_t* dRep = arena->take<uint32_t>(U ? U : 1);
-    uint32_t* dOrder = arena->take<uint32_t>(U ? U : 1); uint32_t* dDstOfs = arena->take<uint32_t>(U ? U : 1);
-    uint32_t* dSizes = arena->take<uint32_t>(U ? U : 1); int32_t* dItemValue = arena->take<int32_t>(U ? U : 1);
-    uint64_t* dDigests = arena->take<uint64_t>(U ? U : 1);
-    uint32_t* dArrayHist = arena->take<uint32_t>(kNumLevels); uint32_t* dIndexHist = arena->take<uint32_t>(kNumLevels);
-    uint32_t* dErr = arena->take<uint32_t>(1);
-    uint8_t* dScratch = arena->take<uint8_t>(scratchBytes);
-    uint32_t* dActiveIds = arena->take<uint32_t>(U ? U : 1); uint8_t* dActive = arena->take<uint8_t>(U ? U : 1);
+    float* dUv = arena->take<float>((size_t)maxItems * 6);
+    uint8_t* dLevel = arena->take<uint8_t>(maxItems); uint8_t* dDegen = arena->take<uint8_t>(maxItems); uint8_t* dActive = arena->take<uint8_t>(maxItems);
+    uint64_t* dStateOfs = arena->take<uint64_t>(maxItems); uint64_t* dDigests = arena->take<uint64_t>(maxItems);
+    uint32_t* dItemIds = arena->take<uint32_t>(maxItems); uint32_t* dActiveIds = arena->take<uint32_t>(maxItems);
+    int32_t* dTriToItem = arena->take<int32_t>(maxItems); int32_t* dIndex = arena->take<int32_t>(maxItems);
+    uint32_t* dMask = arena->take<uint32_t>(maxItems); uint32_t* dKnown = arena->take<uint32_t>(maxItems);
+    int32_t* dSpecial = arena->take<int32_t>(maxItems); uint32_t* dRep = arena->take<uint32_t>(maxItems);
+    uint32_t* dOrder = arena->take<uint32_t>(maxItems); uint32_t* dDstOfs = arena->take<uint32_t>(maxItems);
+    uint32_t* dSizes = arena->take<uint32_t>(maxItems); int32_t* dItemValue = arena->take<int32_t>(maxItems);
+    SetupCounters* dCounters = arena->take<SetupCounters>(1);
     uint64_t* dUniformDigest = arena->take<uint64_t>(kNumLevels * 4);
+    uint32_t* dArrayHist = arena->take<uint32_t>(kNumLevels); uint32_t* dIndexHist = arena->take<uint32_t>(kNumLevels); uint32_t* dErr = arena->take<uint32_t>(1);
+    uint8_t* dScratch = arena->take<uint8_t>(scratchBytes);
 
-    EventTimer et(stream);
+    // ---- SetupWorkItems (bake_cpu_impl.cpp:589-660) on the device ----
     const int e0 = et.mark();
-    bool ok = true;
-    if (U) {
-        ok &= HIP_OK(hipMemcpyAsync(dUv, itemUv.data(), (size_t)U * 24, hipMemcpyHostToDevice, stream));
-        ok &= HIP_OK(hipMemcpyAsync(dLevel, itemLevel.data(), U, hipMemcpyHostToDevice, stream));
-        ok &= HIP_OK(hipMemcpyAsync(dDegen, itemDegenerate.data(), U, hipMemcpyHostToDevice, stream));
-        ok &= HIP_OK(hipMemcpyAsync(dItemIds, itemIds.data(), (size_t)U * 4, hipMemcpyHostToDevice, stream));
-        ok &= HIP_OK(hipMemsetAsync(dKnown, 0, (size_t)U * 4, stream));
+    SetupParams S; memset(&S, 0, sizeof S);
+    S.texCoords = din.texCoords; S.indices = din.indices; S.perTriLevels = din.perTriLevels;
+    S.stride = d.texCoordStrideInBytes ? d.texCoordStrideInBytes : (d.texCoordFormat == ommTexCoordFormat_UV32_FLOAT ? 8u : 4u);
+    S.uvFormat = d.texCoordFormat; S.indexFormat = d.indexFormat; S.numTris = T;
+    S.globalLevel = d.maxSubdivisionLevel; S.dynScale = d.dynamicSubdivisionScale; S.edgeHeuristic = 0;
+    S.texW = tex.mips[0].w; S.texH = tex.mips[0].h; S.disableDedup = (flags & (1u << 3)) != 0;
+    S.wantWorkload = ((flags & (1u << 5)) != 0) || d.maxWorkloadSize != 0xFFFFFFFFFFFFFFFFull;
+    bool ok = HIP_OK(hipMemcpyAsync(dUniformDigest, uniform_digests().v, sizeof(uint64_t) * kNumLevels * 4, hipMemcpyHostToDevice, stream));
+    ok = ok && HIP_OK(hipMemsetAsync(dKnown, 0, (size_t)maxItems * 4, stream));
+    ok = ok && HIP_OK(run_setup_fetch(S, dScratch, scratchBytes, dCounters, stream));
+    if (!ok) return L.failure("[Failure] - no usable HIP device (the MI355X baker has no CPU fallback)");
+    SetupCounters hc; memset(&hc, 0, sizeof hc);
+    if (d.dynamicSubdivisionScale > 0.f && T) { // degenerate triangles under dynamic subdivision need glibc's log2f: host (bake_cpu_impl.cpp:511-528)
+        if (!HIP_OK(hipMemcpyAsync(&hc, dCounters, sizeof hc, hipMemcpyDeviceToHost, stream)) || !HIP_OK(hipStreamSynchronize(stream)))
+            return L.failure("[Failure] - device work-item setup failed");
+        if (hc.numPending) {
+            std::vector<uint32_t> pend(hc.numPending); std::vector<float> puv((size_t)hc.numPending * 6); std::vector<uint8_t> plv(hc.numPending);
+            if (!HIP_OK(copy_pending_to_host(dScratch, scratchBytes, T, hc.numPending, pend.data(), puv.data(), stream))) return L.failure("[Failure] - device work-item setup failed");
+            for (uint32_t k = 0; k < hc.numPending; ++k) {
+                HostTri t; memcpy(t.p, &puv[(size_t)k * 6], 24);
+                ommCpuBakeInputDesc tmp = d; tmp.subdivisionLevels = nullptr; // per-triangle overrides were already honoured on the device
+                plv[k] = (uint8_t)level_for_primitive(tmp, flags, 0, t, S.texW, S.texH);
+            }
+            if (!HIP_OK(run_setup_fix_pending(S, dScratch, scratchBytes, pend.data(), plv.data(), hc.numPending, stream))) return L.failure("[Failure] - device work-item setup failed");
+        }
     }
-    ok &= HIP_OK(hipMemcpyAsync(dUniformDigest, uniform_digests().v, sizeof(uint64_t) * kNumLevels * 4, hipMemcpyHostToDevice, stream));
-    if (triCount) ok &= HIP_OK(hipMemcpyAsync(dTriToItem, triToItem.data(), (size_t)triCount * 4, hipMemcpyHostToDevice, stream));
-    if (!ok) return L.failure("[Failure] - host to device transfer failed");
+    if (!HIP_OK(run_setup_items(S, dScratch, scratchBytes, dCounters, dUv, dLevel, dDegen, dTriToItem, dItemIds, stream)))
+        return L.failure("[Failure] - device work-item setup failed");
+    const int e1 = et.mark();
 
-    // ---- classification: ResampleCoarse + ResampleFine (bake_cpu_impl.cpp:715-1029) ----
+    // ---- classification parameters ----
     ClassifyParams P; memset(&P, 0, sizeof P);
     P.mipCount = (int)tex.mips.size();
     for (int m = 0; m < P.mipCount; ++m) {
-        DevMip& dm = P.mips[m]; const TexMip& tm = tex.mips[m];
-        dm.texels = tm.texels; dm.sat = tm.sat; dm.w = tm.w; dm.h = tm.h;
-        dm.log2w = (int)ctz32((uint32_t)tm.w); dm.log2h = (int)ctz32((uint32_t)tm.h);
-        dm.pow2 = is_pow2(tm.w) && is_pow2(tm.h);
-        dm.fw = (float)tm.w; dm.fh = (float)tm.h; dm.rw = 1.f / (float)tm.w; dm.rh = 1.f / (float)tm.h;
+        DevMip& dm = P.mips[m]; const TexMip& tmip = tex.mips[m];
+        dm.texels = tmip.texels; dm.sat = tmip.sat; dm.w = tmip.w; dm.h = tmip.h;
+        dm.log2w = (int)ctz32((uint32_t)tmip.w); dm.log2h = (int)ctz32((uint32_t)tmip.h);
+        dm.pow2 = is_pow2(tmip.w) && is_pow2(tmip.h);
+        dm.fw = (float)tmip.w; dm.fh = (float)tmip.h; dm.rw = 1.f / (float)tmip.w; dm.rh = 1.f / (float)tmip.h;
     }
     P.pow2Dispatch = P.mips[0].pow2;
     P.texIsFp32 = tex.format == ommCpuTextureFormat_FP32;
@@ -449,29 +424,77 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     P.cutoff = d.alphaCutoff; P.borderAlpha = d.runtimeSamplerDesc.borderAlpha;
     P.wantKnownCount = d.rejectionThreshold > 0.f;
 
-    const int e1 = et.mark();
-    // level-0 hierarchical query per item, then compaction of the items that still need per-micro-triangle work
-    launch_triage(P, dUv, U, dMask, dActive, stream);
-    uint32_t activeStart[kNumLevels + 1]; uint64_t stateBytes = 0;
-    if (!HIP_OK(run_prep(dItemIds, dActive, dLevel, bits, U, levelStart.data(), dActiveIds, dStateOfs, dScratch, scratchBytes, activeStart, &stateBytes, stream)))
+    // ---- level-0 hierarchical query per item + compaction of the items that need per-micro-triangle work; ONE sync ----
+    launch_triage(P, dUv, dCounters, maxItems, dMask, dActive, stream);
+    if (!HIP_OK(run_prep(dItemIds, dActive, dLevel, bits, maxItems, dCounters, dActiveIds, dStateOfs, dScratch, scratchBytes, stream)) ||
+        !HIP_OK(hipMemcpyAsync(&hc, dCounters, sizeof hc, hipMemcpyDeviceToHost, stream)) || !HIP_OK(hipStreamSynchronize(stream)))
         return L.failure("[Failure] - device work-list compaction failed");
-    if (!statesArena->reserve(stateBytes ? stateBytes : 256)) return L.failure("[Failure] - out of device memory for the packed micro-triangle states");
+
+    uint32_t U = hc.numItems;
+    if (hc.collision) { // two different (UV, level) tuples shared a 64-bit hash: redo the setup serially with exact keys
+        if (!hostDesc) return L.failure("[Failure] - work-item hash collision on a device-resident bake (retry through ommCpuBake)");
+        std::vector<HostTri> itemUv; std::vector<uint8_t> itemLevel, itemDegenerate; std::vector<int32_t> triToItem(T ? T : 1, -1);
+        setup_on_host(*hostDesc, flags, tex, itemUv, itemLevel, itemDegenerate, triToItem, hc.numDisabled);
+        U = (uint32_t)itemUv.size();
+        memset(hc.levelCount, 0, sizeof hc.levelCount); hc.workload = 0; hc.numItems = U;
+        for (uint32_t i = 0; i < U; ++i) hc.levelCount[itemLevel[i]]++;
+        hc.levelStart[0] = 0; for (int l = 0; l < kNumLevels; ++l) hc.levelStart[l + 1] = hc.levelStart[l] + hc.levelCount[l];
+        std::vector<uint32_t> itemIds(U ? U : 1);
+        { uint32_t cur[kNumLevels]; memcpy(cur, hc.levelStart, sizeof cur); for (uint32_t i = 0; i < U; ++i) itemIds[cur[itemLevel[i]]++] = i; }
+        const float fw = (float)S.texW, fh = (float)S.texH;
+        for (uint32_t i = 0; i < U; ++i) {
+            const float* p = itemUv[i].p;
+            const float lox = std::min(std::min(p[0], p[2]), p[4]), loy = std::min(std::min(p[1], p[3]), p[5]);
+            const float hix = std::max(std::max(p[0], p[2]), p[4]), hiy = std::max(std::max(p[1], p[3]), p[5]);
+            hc.workload += (uint64_t)(int64_t)(int32_t)((uint32_t)f2i((hix - lox) * fw) * (uint32_t)f2i((hiy - loy) * fh));
+        }
+        ok = HIP_OK(hipMemcpyAsync(dCounters, &hc, sizeof hc, hipMemcpyHostToDevice, stream));
+        if (U) {
+            ok = ok && HIP_OK(hipMemcpyAsync(dUv, itemUv.data(), (size_t)U * 24, hipMemcpyHostToDevice, stream));
+            ok = ok && HIP_OK(hipMemcpyAsync(dLevel, itemLevel.data(), U, hipMemcpyHostToDevice, stream));
+            ok = ok && HIP_OK(hipMemcpyAsync(dDegen, itemDegenerate.data(), U, hipMemcpyHostToDevice, stream));
+            ok = ok && HIP_OK(hipMemcpyAsync(dItemIds, itemIds.data(), (size_t)U * 4, hipMemcpyHostToDevice, stream));
+        }
+        if (T) ok = ok && HIP_OK(hipMemcpyAsync(dTriToItem, triToItem.data(), (size_t)T * 4, hipMemcpyHostToDevice, stream));
+        launch_triage(P, dUv, dCounters, maxItems, dMask, dActive, stream);
+        ok = ok && HIP_OK(run_prep(dItemIds, dActive, dLevel, bits, maxItems, dCounters, dActiveIds, dStateOfs, dScratch, scratchBytes, stream));
+        ok = ok && HIP_OK(hipMemcpyAsync(&hc, dCounters, sizeof hc, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipStreamSynchronize(stream));
+        if (!ok) return L.failure("[Failure] - serial work-item setup failed");
+    }
+    if ((flags & (1u << 5)) && hc.numDisabled != 0) { // bake_cpu_impl.cpp:652-657
+        char buf[256];
+        snprintf(buf, sizeof buf, "[Info] - The workload consists of %d unclassifiable triangles, these will be classified as unresolvedTriState = %s.", hc.numDisabled, special_name(d.unresolvedTriState));
+        L.msg(ommMessageSeverity_Info, buf);
+    }
+    // ---- ValidateWorkloadSize (bake_cpu_impl.cpp:662-713) ----
+    if (S.wantWorkload) {
+        if (d.maxWorkloadSize != 0xFFFFFFFFFFFFFFFFull && hc.workload > d.maxWorkloadSize) return ommResult_WORKLOAD_TOO_BIG;
+        if ((flags & (1u << 5)) && hc.workload > (1ull << 27)) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "[Perf Warning] - The workload consists of %lld work items (number of texels to classify), which corresponds to roughly %lld 1024x1024 textures."
+                     " This is unusually large and may result in long bake times.", (long long)hc.workload, (long long)(hc.workload >> 20));
+            L.msg(ommMessageSeverity_PerfWarning, buf);
+        }
+    }
+    if (!statesArena->reserve(hc.stateBytes ? (size_t)hc.stateBytes : 256)) return L.failure("[Failure] - out of device memory for the packed micro-triangle states");
     uint8_t* dStates = statesArena->base;
     const int e1b = et.mark();
+
+    // ---- ResampleCoarse + ResampleFine (bake_cpu_impl.cpp:715-1029) on the active items ----
     ItemArrays A; A.uv = dUv; A.degenerate = dDegen; A.stateOfs = dStateOfs; A.states = dStates; A.stateMask = dMask; A.knownCount = dKnown;
     for (int l = 0; l < kNumLevels; ++l)
-        launch_classify(P, A, dActiveIds + activeStart[l], activeStart[l + 1] - activeStart[l], (uint32_t)l, stream);
+        launch_classify(P, A, dActiveIds + hc.activeStart[l], hc.activeStart[l + 1] - hc.activeStart[l], (uint32_t)l, stream);
     const int e2 = et.mark();
     // ---- CalcDigest (bake_cpu_impl.cpp:1038-1040): active items here, uniform ones from the table in the tail ----
     if (!(flags & (1u << 3)))
         for (int l = 0; l < kNumLevels; ++l)
-            launch_digest(dStates, dStateOfs, dActiveIds + activeStart[l], activeStart[l + 1] - activeStart[l], (uint32_t)l, (uint32_t)bits, dDigests, stream);
+            launch_digest(dStates, dStateOfs, dActiveIds + hc.activeStart[l], hc.activeStart[l + 1] - hc.activeStart[l], (uint32_t)l, (uint32_t)bits, dDigests, stream);
     if (!HIP_OK(hipGetLastError())) return L.failure("[Failure] - kernel launch failed");
-
     const int e3 = et.mark();
+
     // ---- promote / dedup / sort / offsets on the device ----
     TailInputs ti; memset(&ti, 0, sizeof ti);
-    ti.numItems = U; ti.numTris = triCount; ti.uv = dUv; ti.level = dLevel; ti.stateMask = dMask; ti.knownCount = dKnown; ti.digests = dDigests;
+    ti.numItems = U; ti.numTris = T; ti.uv = dUv; ti.level = dLevel; ti.stateMask = dMask; ti.knownCount = dKnown; ti.digests = dDigests;
     ti.uniformDigest = dUniformDigest; ti.triToItem = dTriToItem; ti.format = bits;
     ti.disableSpecial = (flags & (1u << 1)) != 0; ti.disableDedup = (flags & (1u << 3)) != 0;
     ti.rejectionThreshold = d.rejectionThreshold; ti.unresolved = (int32_t)d.unresolvedTriState; ti.errorFlag = dErr;
@@ -483,37 +506,127 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     if (counts.arrayDataSize > 0xFFFFFFFFull) return ommResult_FAILURE; // bake_cpu_impl.cpp:1774-1775
     const int e4 = et.mark();
 
-    // ---- Serialize (bake_cpu_impl.cpp:1756-1920): gather on device, copy out through the user's allocator ----
+    // ---- Serialize (bake_cpu_impl.cpp:1756-1920): gather the surviving blocks into arrayData order, descriptors, index narrowing ----
+    const uint32_t E = counts.numOmms;
+    R.bits = bits; R.numDescs = E; R.arrayDataSize = E ? counts.arrayDataSize : 0; R.numTris = T;
+    ok = true;
+    if (E) {
+        ok = HIP_OK(hipMalloc((void**)&R.arrayData, (size_t)counts.arrayDataSize)) && HIP_OK(hipMalloc((void**)&R.descs, sizeof(ommCpuOpacityMicromapDesc) * (size_t)E));
+        if (ok) {
+            launch_gather_omms(dStates, dStateOfs, dActive, dMask, dLevel, bits, dOrder, dDstOfs, dSizes, E, R.arrayData, stream);
+            launch_write_descs(dOrder, dDstOfs, dLevel, bits, E, R.descs, stream);
+        }
+    }
+    const bool allow8 = (flags & (1u << 6)) != 0, force32 = (flags & (1u << 2)) != 0;
+    int idxBytes = 4; R.indexFormat = ommIndexFormat_UINT_32;
+    if (allow8 && T <= 127 && !force32) { idxBytes = 1; R.indexFormat = ommIndexFormat_UINT_8; }
+    else if (T <= 32767 && !force32) { idxBytes = 2; R.indexFormat = ommIndexFormat_UINT_16; }
+    ok = ok && HIP_OK(hipMalloc(&R.index, (size_t)(T ? T : 1) * 4)); // the reference narrows in place inside an int32 vector (:1882-1900)
+    if (ok) launch_narrow_indices(dIndex, T, idxBytes, R.index, stream);
+    ok = ok && HIP_OK(hipMemcpyAsync(R.hist, dArrayHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
+    ok = ok && HIP_OK(hipMemcpyAsync(R.hist + kNumLevels, dIndexHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
+    const int e5 = et.mark();
+    ok = ok && HIP_OK(hipStreamSynchronize(stream));
+    if (!ok) return L.failure("[Failure] - could not materialise the bake result on the device");
+
+    tm.uploadMs = 0.f; tm.hostSetupMs = 0.f; tm.setupMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.digestMs = et.ms(e2, e3);
+    tm.tailMs = et.ms(e3, e4); tm.gatherMs = et.ms(e4, e5);
+    tm.uniqueItems = U; tm.activeItems = hc.activeStart[kNumLevels]; tm.stateBytes = hc.stateBytes; tm.microTriangles = 0;
+    for (int l = 0; l < kNumLevels; ++l) { tm.microTriangles += (uint64_t)hc.levelCount[l] << (2 * l); tm.classifyLaunches += hc.activeStart[l + 1] != hc.activeStart[l]; }
+    return ommResult_SUCCESS;
+}
+
+ommResult scope_fences(const Baker& baker, const ommCpuBakeInputDesc& d, bool formatsOnHost)
+{
+    const Logger& L = baker.log;
+    const uint32_t flags = (uint32_t)d.bakeFlags;
+    if ((flags & ((1u << 4) | (1u << 10))) != 0)
+        { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - near-duplicate merging (EnableNearDuplicateDetection) is not available in the MI355X baker yet"); return ommResult_NOT_IMPLEMENTED; }
+    if (d.maxArrayDataSize != 0xFFFFFFFFu)
+        { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - maxArrayDataSize budgets are not available in the MI355X baker yet"); return ommResult_NOT_IMPLEMENTED; }
+    if ((flags & ((1u << 7) | (1u << 8) | (1u << 9) | (1u << 11))) != 0)
+        { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - internal bake flags (bits 7-11) are not supported"); return ommResult_NOT_IMPLEMENTED; }
+    if (d.formats) { // the reference sizes its arrays from the global format only (bake_cpu_impl.cpp:1763-1772): mixed formats corrupt its heap
+        if (!formatsOnHost) return L.failure("[Failure] - per-triangle formats are not supported on the device-resident entry point");
+        for (uint32_t i = 0; i < d.indexCount / 3u; ++i)
+            if (d.formats[i] != ommFormat_INVALID && d.formats[i] != d.format)
+                return L.failure("[Failure] - per-triangle formats that differ from the global format are not supported");
+    }
+    return ommResult_SUCCESS;
+}
+
+struct DeviceBakeResult {
+    Allocator mem; DeviceResult R;
+    ommCpuOpacityMicromapUsageCount arrayHist[2 * kNumLevels], indexHist[2 * kNumLevels];
+    ommCpuBakeResultDesc desc;
+};
+
+struct BakeSession { // arenas + stream for one call
+    std::unique_lock<std::mutex> lock; DeviceArena local, localStates; DeviceArena* arena; DeviceArena* states; hipStream_t stream = nullptr;
+    explicit BakeSession(Baker& b) : lock(b.arena.mu, std::try_to_lock) {
+        arena = lock.owns_lock() ? &b.arena : &local; states = lock.owns_lock() ? &b.statesArena : &localStates; // concurrent bakes get private arenas
+    }
+    ~BakeSession() { if (stream) (void)hipStreamDestroy(stream); }
+    bool open() { return hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess; }
+};
+
+// ommCpuBake: host arrays in, host arrays out
+ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult* out)
+{
+    const Logger& L = baker.log;
+    const double t0 = now_ms();
+    const ommResult fr = scope_fences(baker, d, true);
+    if (fr != ommResult_SUCCESS) return fr;
+    const uint32_t T = d.indexCount / 3u;
+    BakeSession ses(baker);
+    if (!ses.open()) return L.failure("[Failure] - no usable HIP device (the MI355X baker has no CPU fallback)");
+    hipStream_t stream = ses.stream;
+
+    // ---- upload the caller's triangle data (the C ABI gives no vertex count: it is max(index)+1, as serialize_impl.cpp:60-79) ----
+    const size_t idxSize = d.indexFormat == ommIndexFormat_UINT_8 ? 1 : (d.indexFormat == ommIndexFormat_UINT_16 ? 2 : 4);
+    uint32_t maxIndex = 0;
+    if (d.indexFormat == ommIndexFormat_UINT_8) { const uint8_t* p = (const uint8_t*)d.indexBuffer; for (size_t i = 0; i < 3ull * T; ++i) maxIndex = p[i] > maxIndex ? p[i] : maxIndex; }
+    else if (d.indexFormat == ommIndexFormat_UINT_16) { const uint16_t* p = (const uint16_t*)d.indexBuffer; for (size_t i = 0; i < 3ull * T; ++i) maxIndex = p[i] > maxIndex ? p[i] : maxIndex; }
+    else { const uint32_t* p = (const uint32_t*)d.indexBuffer; for (size_t i = 0; i < 3ull * T; ++i) maxIndex = p[i] > maxIndex ? p[i] : maxIndex; }
+    const uint32_t stride = d.texCoordStrideInBytes ? d.texCoordStrideInBytes : (d.texCoordFormat == ommTexCoordFormat_UV32_FLOAT ? 8u : 4u);
+    const size_t elem = d.texCoordFormat == ommTexCoordFormat_UV32_FLOAT ? 8 : 4;
+    const size_t uvBytes = T ? (size_t)stride * maxIndex + elem : 0, idxBytes = idxSize * 3ull * T, lvlBytes = d.subdivisionLevels ? T : 0;
+    uint8_t* dRaw = nullptr;
+    if (!HIP_OK(hipMalloc((void**)&dRaw, pad256(uvBytes) + pad256(idxBytes) + pad256(lvlBytes) + 256))) return L.failure("[Failure] - out of device memory for the triangle data");
+    struct RawGuard { uint8_t* p; ~RawGuard() { (void)hipFree(p); } } rawGuard{ dRaw };
+    EventTimer et(stream);
+    const int u0 = et.mark();
+    DeviceInputs din; din.texCoords = dRaw; din.indices = dRaw + pad256(uvBytes); din.perTriLevels = lvlBytes ? dRaw + pad256(uvBytes) + pad256(idxBytes) : nullptr;
+    bool ok = true;
+    if (uvBytes) ok = ok && HIP_OK(hipMemcpyAsync(dRaw, d.texCoords, uvBytes, hipMemcpyHostToDevice, stream));
+    if (idxBytes) ok = ok && HIP_OK(hipMemcpyAsync(dRaw + pad256(uvBytes), d.indexBuffer, idxBytes, hipMemcpyHostToDevice, stream));
+    if (lvlBytes) ok = ok && HIP_OK(hipMemcpyAsync(dRaw + pad256(uvBytes) + pad256(idxBytes), d.subdivisionLevels, lvlBytes, hipMemcpyHostToDevice, stream));
+    if (!ok) return L.failure("[Failure] - host to device transfer failed");
+    const int u1 = et.mark();
+
+    DeviceResult R; ommxBakeTimings tm; memset(&tm, 0, sizeof tm);
+    const ommResult br = bake_core(baker, d, din, &d, ses.arena, ses.states, stream, et, R, tm);
+    if (br != ommResult_SUCCESS) return br;
+
+    // ---- copy the result out through the user's allocator ----
     BakeResult* res = baker.mem.make<BakeResult>();
     if (!res) return ommResult_FAILURE;
     res->mem = baker.mem;
-    const uint32_t E = counts.numOmms;
-    uint32_t hostHist[2 * kNumLevels];
-    ok = true;
-    uint8_t* dArray = nullptr; ommCpuOpacityMicromapDesc* dDescs = nullptr;
-    int e5 = e4;
+    const int d0 = et.mark();
+    const uint32_t E = R.numDescs;
     if (E) {
-        res->arrayData = baker.mem.allocate((size_t)counts.arrayDataSize, 64);
+        res->arrayData = baker.mem.allocate((size_t)R.arrayDataSize, 64);
         res->descs = (ommCpuOpacityMicromapDesc*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, 16);
-        ok &= res->arrayData && res->descs;
-        ok = ok && HIP_OK(hipMalloc((void**)&dArray, (size_t)counts.arrayDataSize)) && HIP_OK(hipMalloc((void**)&dDescs, sizeof(ommCpuOpacityMicromapDesc) * (size_t)E));
-        if (ok) {
-            launch_gather_omms(dStates, dStateOfs, dActive, dMask, dLevel, bits, dOrder, dDstOfs, dSizes, E, dArray, stream);
-            launch_write_descs(dOrder, dDstOfs, dLevel, bits, E, dDescs, stream);
-            e5 = et.mark();
-            ok &= HIP_OK(hipMemcpyAsync(res->arrayData, dArray, (size_t)counts.arrayDataSize, hipMemcpyDeviceToHost, stream));
-            ok &= HIP_OK(hipMemcpyAsync(res->descs, dDescs, sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, hipMemcpyDeviceToHost, stream));
-        }
+        ok = res->arrayData && res->descs;
+        ok = ok && HIP_OK(hipMemcpyAsync(res->arrayData, R.arrayData, (size_t)R.arrayDataSize, hipMemcpyDeviceToHost, stream));
+        ok = ok && HIP_OK(hipMemcpyAsync(res->descs, R.descs, sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, hipMemcpyDeviceToHost, stream));
     }
-    res->index = (int32_t*)baker.mem.allocate(sizeof(int32_t) * (size_t)(triCount ? triCount : 1), 16);
-    ok &= res->index != nullptr;
-    if (ok && triCount) ok &= HIP_OK(hipMemcpyAsync(res->index, dIndex, (size_t)triCount * 4, hipMemcpyDeviceToHost, stream));
-    if (ok) ok &= HIP_OK(hipMemcpyAsync(hostHist, dArrayHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
-    if (ok) ok &= HIP_OK(hipMemcpyAsync(hostHist + kNumLevels, dIndexHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
-    const int e6 = et.mark();
-    if (ok) ok &= HIP_OK(hipStreamSynchronize(stream));
-    if (dArray) (void)hipFree(dArray);
-    if (dDescs) (void)hipFree(dDescs);
+    res->index = (int32_t*)baker.mem.allocate(sizeof(int32_t) * (size_t)(T ? T : 1), 16);
+    ok = ok && res->index != nullptr;
+    const size_t outIdx = R.indexFormat == ommIndexFormat_UINT_8 ? 1 : (R.indexFormat == ommIndexFormat_UINT_16 ? 2 : 4);
+    if (ok && T) ok = HIP_OK(hipMemcpyAsync(res->index, R.index, outIdx * T, hipMemcpyDeviceToHost, stream));
+    const int d1 = et.mark();
+    ok = ok && HIP_OK(hipStreamSynchronize(stream));
     if (!ok) { baker.mem.destroy(res); return L.failure("[Failure] - device to host transfer of the bake result failed"); }
 
     // histograms: format {2-state, 4-state} x level ascending, non-zero entries only (:1833-1850); one global format here
@@ -521,29 +634,16 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     res->indexHist = (ommCpuOpacityMicromapUsageCount*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapUsageCount) * 2 * kNumLevels, 16);
     uint32_t nAH = 0, nIH = 0;
     for (uint32_t l = 0; l < (uint32_t)kNumLevels; ++l) {
-        if (hostHist[l]) { res->arrayHist[nAH].count = hostHist[l]; res->arrayHist[nAH].subdivisionLevel = (uint16_t)l; res->arrayHist[nAH].format = (uint16_t)bits; nAH++; }
-        if (hostHist[kNumLevels + l]) { res->indexHist[nIH].count = hostHist[kNumLevels + l]; res->indexHist[nIH].subdivisionLevel = (uint16_t)l; res->indexHist[nIH].format = (uint16_t)bits; nIH++; }
+        if (R.hist[l]) { res->arrayHist[nAH].count = R.hist[l]; res->arrayHist[nAH].subdivisionLevel = (uint16_t)l; res->arrayHist[nAH].format = (uint16_t)R.bits; nAH++; }
+        if (R.hist[kNumLevels + l]) { res->indexHist[nIH].count = R.hist[kNumLevels + l]; res->indexHist[nIH].subdivisionLevel = (uint16_t)l; res->indexHist[nIH].format = (uint16_t)R.bits; nIH++; }
     }
-    // index narrowing in place (:1872-1902)
-    ommIndexFormat ifmt = ommIndexFormat_UINT_32;
-    const bool allow8 = (flags & (1u << 6)) != 0, force32 = (flags & (1u << 2)) != 0;
-    if (allow8 && triCount <= 127 && !force32) { int8_t* p8 = (int8_t*)res->index; for (uint32_t i = 0; i < triCount; ++i) { const int32_t v = res->index[i]; p8[i] = (int8_t)v; } ifmt = ommIndexFormat_UINT_8; }
-    else if (triCount <= 32767 && !force32) { int16_t* p16 = (int16_t*)res->index; for (uint32_t i = 0; i < triCount; ++i) { const int32_t v = res->index[i]; p16[i] = (int16_t)v; } ifmt = ommIndexFormat_UINT_16; }
-
-    res->desc.arrayData = E ? res->arrayData : nullptr; res->desc.arrayDataSize = E ? (uint32_t)counts.arrayDataSize : 0;
+    res->desc.arrayData = E ? res->arrayData : nullptr; res->desc.arrayDataSize = E ? (uint32_t)R.arrayDataSize : 0;
     res->desc.descArray = E ? res->descs : nullptr; res->desc.descArrayCount = E;
     res->desc.descArrayHistogram = res->arrayHist; res->desc.descArrayHistogramCount = nAH;
-    res->desc.indexBuffer = res->index; res->desc.indexCount = triCount; res->desc.indexFormat = ifmt;
+    res->desc.indexBuffer = res->index; res->desc.indexCount = T; res->desc.indexFormat = R.indexFormat;
     res->desc.indexHistogram = res->indexHist; res->desc.indexHistogramCount = nIH;
-    {
-        ommxBakeTimings tm; memset(&tm, 0, sizeof tm);
-        tm.hostSetupMs = (float)(tSetup - t0); tm.uploadMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.digestMs = et.ms(e2, e3);
-        tm.tailMs = et.ms(e3, e4); tm.gatherMs = et.ms(e4, e5); tm.downloadMs = et.ms(e5, e6); tm.totalMs = (float)(now_ms() - t0);
-        for (uint32_t i = 0; i < U; ++i) tm.microTriangles += (uint64_t)1 << (2 * itemLevel[i]);
-        tm.uniqueItems = U; tm.stateBytes = stateBytes; tm.activeItems = activeStart[kNumLevels];
-        for (int l = 0; l < kNumLevels; ++l) tm.classifyLaunches += activeStart[l + 1] != activeStart[l];
-        std::lock_guard<std::mutex> g(baker.timingsMu); baker.timings = tm; baker.haveTimings = true;
-    }
+    tm.uploadMs = et.ms(u0, u1); tm.downloadMs = et.ms(d0, d1); tm.totalMs = (float)(now_ms() - t0);
+    { std::lock_guard<std::mutex> g(baker.timingsMu); baker.timings = tm; baker.haveTimings = true; }
     *out = (ommCpuBakeResult)res;
     return ommResult_SUCCESS;
 }
@@ -731,6 +831,64 @@ OMM_MI355X_API ommResult ommDebugGetStats(ommBaker baker, const ommCpuBakeResult
         st.totalUnknownTransparent += (uint64_t)refs[i] * c[2]; st.totalUnknownOpaque += (uint64_t)refs[i] * c[3];
     }
     *out = st;
+    return ommResult_SUCCESS;
+}
+
+OMM_MI355X_API ommResult ommxBakeDevice(ommBaker baker, const ommCpuBakeInputDesc* desc, ommxDeviceBakeResult* outResult)
+{
+    if (baker == 0) return ommResult_INVALID_ARGUMENT;
+    Baker* b = untag<Baker>(baker);
+    if (desc == 0 || outResult == 0) return b->log.invalid("input desc was not set");
+    if (tag_of(baker) != kCpuBaker) return b->log.invalid("Baker was not created as the right type");
+    if (desc->texture == 0) return b->log.invalid("[Invalid Argument] - ommCpuBakeInputDesc has no texture set");
+    if (tag_of(desc->texture) == kTexture &&
+        ((unsigned)desc->runtimeSamplerDesc.addressingMode >= (unsigned)ommTextureAddressMode_MAX_NUM ||
+         (unsigned)desc->runtimeSamplerDesc.filter >= (unsigned)ommTextureFilterMode_MAX_NUM))
+        return ommResult_FAILURE;
+    ommResult r = validate_desc(*b, *desc);
+    if (r != ommResult_SUCCESS) return r;
+    r = scope_fences(*b, *desc, false);
+    if (r != ommResult_SUCCESS) return r;
+    const double t0 = now_ms();
+    BakeSession ses(*b);
+    if (!ses.open()) return b->log.failure("[Failure] - no usable HIP device (the MI355X baker has no CPU fallback)");
+    DeviceBakeResult* res = b->mem.make<DeviceBakeResult>();
+    if (!res) return ommResult_FAILURE;
+    res->mem = b->mem; memset(&res->desc, 0, sizeof res->desc);
+    EventTimer et(ses.stream);
+    ommxBakeTimings tm; memset(&tm, 0, sizeof tm);
+    DeviceInputs din; din.texCoords = desc->texCoords; din.indices = desc->indexBuffer; din.perTriLevels = desc->subdivisionLevels;
+    r = bake_core(*b, *desc, din, nullptr, ses.arena, ses.states, ses.stream, et, res->R, tm);
+    if (r != ommResult_SUCCESS) { b->mem.destroy(res); return r; }
+    uint32_t nAH = 0, nIH = 0;
+    for (uint32_t l = 0; l < (uint32_t)kNumLevels; ++l) {
+        if (res->R.hist[l]) { res->arrayHist[nAH].count = res->R.hist[l]; res->arrayHist[nAH].subdivisionLevel = (uint16_t)l; res->arrayHist[nAH].format = (uint16_t)res->R.bits; nAH++; }
+        if (res->R.hist[kNumLevels + l]) { res->indexHist[nIH].count = res->R.hist[kNumLevels + l]; res->indexHist[nIH].subdivisionLevel = (uint16_t)l; res->indexHist[nIH].format = (uint16_t)res->R.bits; nIH++; }
+    }
+    res->desc.arrayData = res->R.arrayData; res->desc.arrayDataSize = (uint32_t)res->R.arrayDataSize;
+    res->desc.descArray = res->R.descs; res->desc.descArrayCount = res->R.numDescs;
+    res->desc.descArrayHistogram = res->arrayHist; res->desc.descArrayHistogramCount = nAH;
+    res->desc.indexBuffer = res->R.index; res->desc.indexCount = res->R.numTris; res->desc.indexFormat = res->R.indexFormat;
+    res->desc.indexHistogram = res->indexHist; res->desc.indexHistogramCount = nIH;
+    tm.totalMs = (float)(now_ms() - t0);
+    { std::lock_guard<std::mutex> g(b->timingsMu); b->timings = tm; b->haveTimings = true; }
+    *outResult = (ommxDeviceBakeResult)res;
+    return ommResult_SUCCESS;
+}
+
+OMM_MI355X_API ommResult ommxGetDeviceBakeResultDesc(ommxDeviceBakeResult result, const ommCpuBakeResultDesc** desc)
+{
+    if (result == 0 || desc == nullptr) return ommResult_INVALID_ARGUMENT;
+    *desc = &((DeviceBakeResult*)result)->desc;
+    return ommResult_SUCCESS;
+}
+
+OMM_MI355X_API ommResult ommxDestroyDeviceBakeResult(ommxDeviceBakeResult result)
+{
+    if (result == 0) return ommResult_INVALID_ARGUMENT;
+    DeviceBakeResult* r = (DeviceBakeResult*)result;
+    const Allocator mem = r->mem;
+    mem.destroy(r);
     return ommResult_SUCCESS;
 }
 

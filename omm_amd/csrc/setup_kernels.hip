@@ -165,28 +165,37 @@ __global__ __launch_bounds__(256) void setup_emit_items(SetupParams S, const flo
                                                         int32_t* __restrict__ triToItem, uint32_t* __restrict__ sortKeys, uint32_t* __restrict__ sortVals,
                                                         SetupCounters* __restrict__ counters)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= S.numTris) return;
-    sortKeys[t] = 15u; sortVals[t] = 0u; // slots past the item count sort to the end
-    if (t == S.numTris - 1) counters->numItems = itemOfTri[t] + isItem[t];
-    triToItem[t] = (triFlags[t] & 1u) ? -1 : (int32_t)itemOfTri[firstTri[t]];
+    __shared__ uint32_t s_hist[kNumLevels];
+    __shared__ unsigned long long s_work;
+    if (threadIdx.x < kNumLevels) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_work = 0;
     __syncthreads();
-    if (!isItem[t]) return;
-    const uint32_t i = itemOfTri[t];
-    #pragma unroll
-    for (int k = 0; k < 6; ++k) itemUv[6ull * i + k] = triUv[6ull * t + k];
-    const uint32_t lvl = triLevel[t];
-    itemLevel[i] = (uint8_t)lvl; itemDegenerate[i] = (triFlags[t] >> 1) & 1u;
-    atomicAdd(&counters->levelCount[lvl], 1u);
-    if (S.wantWorkload) { // ComputeWorkloadSize (bake_cpu_impl.cpp:662-680)
-        const float* p = triUv + 6ull * t;
-        const float lox = (p[2] < p[0] ? p[2] : p[0]), lox2 = (p[4] < lox ? p[4] : lox), loy = (p[3] < p[1] ? p[3] : p[1]), loy2 = (p[5] < loy ? p[5] : loy);
-        const float hix = (p[0] < p[2] ? p[2] : p[0]), hix2 = (hix < p[4] ? p[4] : hix), hiy = (p[1] < p[3] ? p[3] : p[1]), hiy2 = (hiy < p[5] ? p[5] : hiy);
-        const float dx = (hix2 - lox2) * (float)S.texW, dy = (hiy2 - loy2) * (float)S.texH;
-        const int ax = (dx >= -2147483648.f && dx < 2147483648.f) ? (int)dx : (int)0x80000000;
-        const int ay = (dy >= -2147483648.f && dy < 2147483648.f) ? (int)dy : (int)0x80000000;
-        atomicAdd((unsigned long long*)&counters->workload, (unsigned long long)(long long)(int)((uint32_t)ax * (uint32_t)ay));
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < S.numTris) {
+        sortKeys[t] = 15u; sortVals[t] = 0u; // slots past the item count sort to the end
+        if (t == S.numTris - 1) counters->numItems = itemOfTri[t] + isItem[t];
+        triToItem[t] = (triFlags[t] & 1u) ? -1 : (int32_t)itemOfTri[firstTri[t]];
+        if (isItem[t]) {
+            const uint32_t i = itemOfTri[t];
+            #pragma unroll
+            for (int k = 0; k < 6; ++k) itemUv[6ull * i + k] = triUv[6ull * t + k];
+            const uint32_t lvl = triLevel[t];
+            itemLevel[i] = (uint8_t)lvl; itemDegenerate[i] = (triFlags[t] >> 1) & 1u;
+            atomicAdd(&s_hist[lvl], 1u);
+            if (S.wantWorkload) { // ComputeWorkloadSize (bake_cpu_impl.cpp:662-680)
+                const float* p = triUv + 6ull * t;
+                const float lox = (p[2] < p[0] ? p[2] : p[0]), lox2 = (p[4] < lox ? p[4] : lox), loy = (p[3] < p[1] ? p[3] : p[1]), loy2 = (p[5] < loy ? p[5] : loy);
+                const float hix = (p[0] < p[2] ? p[2] : p[0]), hix2 = (hix < p[4] ? p[4] : hix), hiy = (p[1] < p[3] ? p[3] : p[1]), hiy2 = (hiy < p[5] ? p[5] : hiy);
+                const float dx = (hix2 - lox2) * (float)S.texW, dy = (hiy2 - loy2) * (float)S.texH;
+                const int ax = (dx >= -2147483648.f && dx < 2147483648.f) ? (int)dx : (int)0x80000000;
+                const int ay = (dy >= -2147483648.f && dy < 2147483648.f) ? (int)dy : (int)0x80000000;
+                atomicAdd(&s_work, (unsigned long long)(long long)(int)((uint32_t)ax * (uint32_t)ay));
+            }
+        }
     }
+    __syncthreads();
+    if (threadIdx.x < kNumLevels && s_hist[threadIdx.x]) atomicAdd(&counters->levelCount[threadIdx.x], s_hist[threadIdx.x]);
+    if (threadIdx.x == 0 && s_work) atomicAdd((unsigned long long*)&counters->workload, s_work);
 }
 
 // items are numbered in triangle order; their level keys are written in a second pass once the numbering exists

@@ -159,31 +159,41 @@ void launch_write_descs(const uint32_t* order, const uint32_t* dstOfs, const uin
 // ---- active-item compaction (after triage): per-level lists of the items that need per-micro-triangle work, and their
 //      slots in the packed-state buffer ----
 __global__ __launch_bounds__(256) void prep_flags(const uint32_t* __restrict__ itemIds, const uint8_t* __restrict__ active, const uint8_t* __restrict__ level,
-                                                  int bits, uint32_t n, uint32_t* __restrict__ flags, uint64_t* __restrict__ sizes)
+                                                  int bits, const SetupCounters* __restrict__ counters, uint32_t maxItems,
+                                                  uint32_t* __restrict__ flags, uint64_t* __restrict__ sizes)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const uint32_t item = itemIds[p];
-    const uint32_t f = active[item] ? 1u : 0u;
-    uint64_t bytes = (((uint64_t)1 << (2u * level[item])) * (uint64_t)bits) >> 3; if (bytes < 16) bytes = 16; // 16-byte slots keep vector copies aligned
+    if (p >= maxItems) return;
+    uint32_t f = 0; uint64_t bytes = 0;
+    if (p < counters->numItems) {
+        const uint32_t item = itemIds[p];
+        f = active[item] ? 1u : 0u;
+        bytes = (((uint64_t)1 << (2u * level[item])) * (uint64_t)bits) >> 3; if (bytes < 16) bytes = 16; // 16-byte slots keep vector copies aligned
+    }
     flags[p] = f; sizes[p] = f ? bytes : 0ull;
 }
 
 __global__ __launch_bounds__(256) void prep_scatter(const uint32_t* __restrict__ itemIds, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos,
-                                                    const uint64_t* __restrict__ ofs, uint32_t n, uint32_t* __restrict__ activeIds, uint64_t* __restrict__ stateOfs)
+                                                    const uint64_t* __restrict__ ofs, const uint64_t* __restrict__ sizes, uint32_t maxItems,
+                                                    SetupCounters* __restrict__ counters, uint32_t* __restrict__ activeIds, uint64_t* __restrict__ stateOfs)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= maxItems) return;
+    const uint32_t n = counters->numItems;
+    if (p == 0) { // level boundaries of the compacted list + total bytes
+        const uint32_t total = n ? pos[n - 1] + flags[n - 1] : 0u;
+        for (int l = 0; l <= kNumLevels; ++l) { const uint32_t s = counters->levelStart[l]; counters->activeStart[l] = s < n ? pos[s] : total; }
+        counters->stateBytes = n ? ofs[n - 1] + sizes[n - 1] : 0ull;
+    }
     if (p >= n || !flags[p]) return;
     const uint32_t item = itemIds[p];
     activeIds[pos[p]] = item; stateOfs[item] = ofs[p];
 }
 
-hipError_t run_prep(const uint32_t* itemIds, const uint8_t* active, const uint8_t* level, int bits, uint32_t n, const uint32_t* levelStart /*host, 14*/,
-                    uint32_t* activeIds, uint64_t* stateOfs, void* scratch, size_t scratchBytes, uint32_t* activeLevelStart /*host, 14*/,
-                    uint64_t* totalStateBytes, hipStream_t stream)
+hipError_t run_prep(const uint32_t* itemIds, const uint8_t* active, const uint8_t* level, int bits, uint32_t maxItems, SetupCounters* counters,
+                    uint32_t* activeIds, uint64_t* stateOfs, void* scratch, size_t scratchBytes, hipStream_t stream)
 {
-    for (int l = 0; l <= kNumLevels; ++l) activeLevelStart[l] = 0;
-    *totalStateBytes = 0;
+    const uint32_t n = maxItems;
     if (n == 0) return hipSuccess;
     if (scratchBytes < tail_scratch_bytes(n, 0)) return hipErrorInvalidValue;
     uint8_t* p = (uint8_t*)scratch;
@@ -192,27 +202,13 @@ hipError_t run_prep(const uint32_t* itemIds, const uint8_t* active, const uint8_
     uint32_t* flags = (uint32_t*)p; p += n32; uint32_t* pos = (uint32_t*)p; p += n32;
     void* cub = p; size_t cubBytes = scratchBytes - (size_t)(p - (uint8_t*)scratch);
     const dim3 grid((n + 255u) / 256u), block(256);
-    hipLaunchKernelGGL(prep_flags, grid, block, 0, stream, itemIds, active, level, bits, n, flags, sizes);
+    hipLaunchKernelGGL(prep_flags, grid, block, 0, stream, itemIds, active, level, bits, counters, n, flags, sizes);
     size_t tb = cubBytes;
     TAIL_CHECK(hipcub::DeviceScan::ExclusiveSum(cub, tb, flags, pos, (int)n, stream));
     tb = cubBytes;
     TAIL_CHECK(hipcub::DeviceScan::ExclusiveSum(cub, tb, sizes, ofs, (int)n, stream));
-    hipLaunchKernelGGL(prep_scatter, grid, block, 0, stream, itemIds, flags, pos, ofs, n, activeIds, stateOfs);
-    // level boundaries of the compacted list + total bytes
-    uint32_t lastPos = 0, lastFlag = 0; uint64_t lastOfs = 0, lastSize = 0;
-    uint32_t bounds[kNumLevels + 1];
-    for (int l = 0; l < kNumLevels; ++l)
-        if (levelStart[l] < n) TAIL_CHECK(hipMemcpyAsync(&bounds[l], pos + levelStart[l], 4, hipMemcpyDeviceToHost, stream));
-    TAIL_CHECK(hipMemcpyAsync(&lastPos, pos + (n - 1), 4, hipMemcpyDeviceToHost, stream));
-    TAIL_CHECK(hipMemcpyAsync(&lastFlag, flags + (n - 1), 4, hipMemcpyDeviceToHost, stream));
-    TAIL_CHECK(hipMemcpyAsync(&lastOfs, ofs + (n - 1), 8, hipMemcpyDeviceToHost, stream));
-    TAIL_CHECK(hipMemcpyAsync(&lastSize, sizes + (n - 1), 8, hipMemcpyDeviceToHost, stream));
-    TAIL_CHECK(hipStreamSynchronize(stream));
-    const uint32_t totalActive = lastPos + lastFlag;
-    for (int l = 0; l < kNumLevels; ++l) activeLevelStart[l] = levelStart[l] < n ? bounds[l] : totalActive;
-    activeLevelStart[kNumLevels] = totalActive;
-    *totalStateBytes = lastOfs + lastSize;
-    return hipSuccess;
+    hipLaunchKernelGGL(prep_scatter, grid, block, 0, stream, itemIds, flags, pos, ofs, sizes, n, counters, activeIds, stateOfs);
+    return hipGetLastError();
 }
 
 // ---- scratch layout ----
@@ -228,10 +224,10 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static size_t cub_bytes(uint32_t n)
 {
     size_t a = 0, b = 0, c = 0, d = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
-    hipcub::DeviceScan::InclusiveScan(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, hipcub::Max(), (int)n);
-    hipcub::DeviceScan::ExclusiveSum(nullptr, c, (uint64_t*)nullptr, (uint64_t*)nullptr, (int)n);
-    hipcub::DeviceReduce::Sum(nullptr, d, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+    (void)hipcub::DeviceScan::InclusiveScan(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, hipcub::Max(), (int)n);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, c, (uint64_t*)nullptr, (uint64_t*)nullptr, (int)n);
+    (void)hipcub::DeviceReduce::Sum(nullptr, d, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
     size_t m = a; if (b > m) m = b; if (c > m) m = c; if (d > m) m = d;
     return align_up(m, 256) + 256;
 }
