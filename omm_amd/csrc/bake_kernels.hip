@@ -47,6 +47,12 @@ __device__ __forceinline__ float item_max_abs(const float* __restrict__ uv)
     return m;
 }
 
+__device__ __forceinline__ TexWindow no_window()
+{
+    TexWindow W; W.tex = (lds_float*)0; W.sat = (lds_u32*)0; W.base = nullptr; W.sx = W.sy = 0; W.w = W.h = 0;
+    return W;
+}
+
 __global__ __launch_bounds__(256) void triage_items(ClassifyParams P, const float* __restrict__ uv, const SetupCounters* __restrict__ counters,
                                                     uint32_t* __restrict__ stateMask, uint8_t* __restrict__ active)
 {
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(256) void triage_items(ClassifyParams P, const floa
     if (P.useCoarse) {
         const float* t = uv + 6ull * i;
         const MicroTri whole = micro_triangle(t, 0u, 0u);
-        st = region_state(P, whole, item_max_abs(t));
+        st = region_state(P, whole, item_max_abs(t), no_window());
     }
     stateMask[i] = st >= 0 ? (1u << st) : 0u;
     active[i] = st >= 0 ? 0 : 1;
@@ -83,8 +89,12 @@ void launch_narrow_indices(const int32_t* in, uint32_t n, int bytesPerIndex, voi
     hipLaunchKernelGGL(narrow_indices, dim3((n + 255u) / 256u), dim3(256), 0, stream, in, n, bytesPerIndex, out);
 }
 
-template <bool FP32>
-__global__ __launch_bounds__(BLOCK) void classify_tiles(ClassifyParams P, ItemArrays A, const uint32_t* __restrict__ itemIds,
+constexpr int WIN = 32; // largest LDS texel window edge
+
+// SLICED: 4^level >= TILE, the tile is a slice of ONE work item (block-uniform item data, LDS texel/SAT window).
+// !SLICED: the tile holds TILE / 4^level whole items.
+template <bool FP32, bool SLICED>
+__global__ __launch_bounds__(BLOCK, 4) void classify_tiles(ClassifyParams P, ItemArrays A, const uint32_t* __restrict__ itemIds,
                                                         uint32_t numItems, uint32_t level, uint64_t numTiles)
 {
     __shared__ uint8_t  s_state[TILE];
@@ -93,62 +103,89 @@ __global__ __launch_bounds__(BLOCK) void classify_tiles(ClassifyParams P, ItemAr
     __shared__ int      s_tile;
     __shared__ uint32_t s_qcount;
     __shared__ uint32_t s_mask, s_known;
+    __shared__ float    s_wtex[SLICED ? WIN * WIN : 1];
+    __shared__ uint32_t s_wsat[SLICED ? (WIN + 1) * (WIN + 1) : 1];
 
     const uint32_t M = 1u << (2 * level);
     const uint32_t tid = threadIdx.x;
-    const bool sliced = M >= (uint32_t)TILE;               // tile is a slice of one item
-    const uint32_t tilesPerItem = sliced ? M / TILE : 1u;
-    const uint32_t itemsPerTile = sliced ? 1u : TILE / M;
+    const uint32_t tilesPerItem = SLICED ? M / TILE : 1u;
+    const uint32_t itemsPerTile = SLICED ? 1u : TILE / M;
     // 2-D grid: the AQL dispatch packet counts work-items per dimension in 32 bits, so x alone tops out at 2^24 tiles
     const uint64_t tile64 = (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;
     if (tile64 >= numTiles) return;
     const uint32_t tile = (uint32_t)tile64;
-    const uint32_t firstItem = sliced ? tile / tilesPerItem : tile * itemsPerTile;
-    const uint32_t base = sliced ? (tile % tilesPerItem) * TILE : 0u; // first micro-triangle of the slice
+    const uint32_t firstItem = SLICED ? tile / tilesPerItem : tile * itemsPerTile;
+    const uint32_t base = SLICED ? (tile % tilesPerItem) * TILE : 0u; // first micro-triangle of the slice
     uint32_t itemsHere = numItems - firstItem;
     if (itemsHere > itemsPerTile) itemsHere = itemsPerTile;
-    const uint32_t count = sliced ? (uint32_t)TILE : itemsHere * M;   // micro-triangles in this tile
+    const uint32_t count = SLICED ? (uint32_t)TILE : itemsHere * M;   // micro-triangles in this tile
     const bool coarse = P.useCoarse != 0;
 
-    // ---- phase 0: hierarchical queries ----
-    if (tid == 0) {
-        s_qcount = 0; s_mask = 0; s_known = 0;
-        int ts = -1;
-        if (coarse && sliced && level >= 5) { // the tile is the level-(N-5) sub-triangle number base/1024
-            const float* uvp = A.uv + 6ull * itemIds[firstItem];
-            ts = region_state(P, micro_triangle(uvp, base >> 10, level - 5), item_max_abs(uvp));
+    // block-uniform item data of a sliced tile
+    uint32_t uItem = 0; float uUv[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }; float uMaxAbs = 0.f; bool uDegenerate = false;
+    TexWindow W = no_window();
+    if (tid == 0) { s_qcount = 0; s_mask = 0; s_known = 0; s_tile = -1; }
+    if (SLICED) {
+        uItem = itemIds[firstItem];
+        #pragma unroll
+        for (int k = 0; k < 6; ++k) uUv[k] = A.uv[6ull * uItem + k];
+        uMaxAbs = item_max_abs(uUv);
+        uDegenerate = A.degenerate[uItem] != 0;
+        // ---- LDS window: every texel / SAT entry this tile can touch (footprint of its level-(N-5) sub-triangle) ----
+        const MicroTri sub = micro_triangle(uUv, base >> 10, level - 5);
+        const TexRect r = region_rect(P, sub, uMaxAbs);
+        const int ww = r.ex - r.sx + 1, wh = r.ey - r.sy + 1;
+        if (r.ok && ww <= WIN && wh <= WIN) {
+            const DevMip& m0 = P.mips[0];
+            for (int k = (int)tid; k < ww * wh; k += BLOCK) {
+                const int x = r.sx + k % ww, y = r.sy + k / ww;
+                const size_t idx = (size_t)x + (size_t)y * (size_t)m0.w;
+                s_wtex[k] = FP32 ? ((const float*)m0.texels)[idx] : (float)((const uint8_t*)m0.texels)[idx] * (1.f / 255.f);
+            }
+            if (m0.sat) {
+                for (int k = (int)tid; k < (ww + 1) * (wh + 1); k += BLOCK) {
+                    const int x = r.sx - 1 + k % (ww + 1), y = r.sy - 1 + k / (ww + 1);
+                    s_wsat[k] = (x >= 0 && y >= 0) ? m0.sat[(size_t)x + (size_t)y * (size_t)m0.w] : 0u;
+                }
+            }
+            W.tex = (lds_float*)s_wtex; W.sat = (lds_u32*)s_wsat; W.base = m0.texels; W.sx = r.sx; W.sy = r.sy; W.w = ww; W.h = wh; // (SAT part is only read when coarse is on)
         }
-        s_tile = ts;
-    }
-    __syncthreads();
-    const int tileState = s_tile;
-    if (tileState < 0) {
+        __syncthreads();
+        // ---- phase 0: one query for the whole tile (lane 0 of wave 0) and one per 64-micro-triangle group (wave 1) ----
+        if (coarse) {
+            if (tid == 0) s_tile = region_state(P, sub, uMaxAbs, W);
+            if (tid >= 64 && tid < 64 + TILE / GROUP) {
+                const uint32_t g = tid - 64;
+                s_group[g] = region_state(P, micro_triangle(uUv, (base >> 6) + g, level - 3), uMaxAbs, W);
+            }
+        } else if (tid < (uint32_t)(TILE / GROUP)) s_group[tid] = -1;
+        __syncthreads();
+    } else {
+        __syncthreads();
         if (tid < (uint32_t)(TILE / GROUP)) {
             int gs = -1;
             const uint32_t i0 = tid * GROUP;
-            if (coarse && level >= 3 && i0 < count) { // 64 consecutive micro-triangles = one level-(N-3) sub-triangle
-                const uint32_t it = sliced ? firstItem : firstItem + (i0 >> (2 * level));
-                const uint32_t u0 = sliced ? base + i0 : (i0 & (M - 1u));
-                const float* uvp = A.uv + 6ull * itemIds[it];
-                gs = region_state(P, micro_triangle(uvp, u0 >> 6, level - 3), item_max_abs(uvp));
+            if (coarse && level >= 3 && i0 < count) { // 64 consecutive micro-triangles = one level-(N-3) sub-triangle of one item
+                const float* uvp = A.uv + 6ull * itemIds[firstItem + (i0 >> (2 * level))];
+                gs = region_state(P, micro_triangle(uvp, (i0 & (M - 1u)) >> 6, level - 3), item_max_abs(uvp), W);
             }
             s_group[tid] = gs;
         }
         __syncthreads();
-
+    }
+    const int tileState = s_tile;
+    if (tileState < 0) {
         // ---- phase 1: per-micro-triangle coarse test in the unsettled groups ----
         for (uint32_t i = tid; i < ((count + 63u) & ~63u); i += BLOCK) {
             const int gs = s_group[i >> 6];      // wave-uniform: a wave is exactly one group
             if (gs >= 0) { if (i < count) s_state[i] = (uint8_t)gs; continue; }
             bool unresolved = false;
             if (i < count) {
-                const uint32_t it = sliced ? firstItem : firstItem + (i >> (2 * level));
-                const uint32_t u = sliced ? base + i : (i & (M - 1u));
                 int st = -1;
                 if (coarse) {
-                    const uint32_t item = itemIds[it];
-                    const MicroTri t = micro_triangle(A.uv + 6ull * item, u, level);
-                    st = coarse_state(P, t);
+                    const uint32_t u = SLICED ? base + i : (i & (M - 1u));
+                    const float* uvp = SLICED ? uUv : A.uv + 6ull * itemIds[firstItem + (i >> (2 * level))];
+                    st = coarse_state(P, micro_triangle(uvp, u, level), W);
                 }
                 // the reference's fine pass re-classifies everything still "UnknownOpaque" (bake_cpu_impl.cpp:861)
                 unresolved = (st < 0) || (st == 3) || !P.filterLinear;
@@ -169,11 +206,13 @@ __global__ __launch_bounds__(BLOCK) void classify_tiles(ClassifyParams P, ItemAr
         const uint32_t qn = s_qcount;
         for (uint32_t q = tid; q < qn; q += BLOCK) {
             const uint32_t i = s_queue[q];
-            const uint32_t it = sliced ? firstItem : firstItem + (i >> (2 * level));
-            const uint32_t u = sliced ? base + i : (i & (M - 1u));
-            const uint32_t item = itemIds[it];
-            const MicroTri t = micro_triangle(A.uv + 6ull * item, u, level);
-            s_state[i] = (uint8_t)fine_state<FP32>(P, t, A.degenerate[item] != 0);
+            const uint32_t u = SLICED ? base + i : (i & (M - 1u));
+            if (SLICED) {
+                s_state[i] = (uint8_t)fine_state<FP32>(P, micro_triangle(uUv, u, level), uDegenerate, W);
+            } else {
+                const uint32_t item = itemIds[firstItem + (i >> (2 * level))];
+                s_state[i] = (uint8_t)fine_state<FP32>(P, micro_triangle(A.uv + 6ull * item, u, level), A.degenerate[item] != 0, W);
+            }
         }
         __syncthreads();
     }
@@ -181,49 +220,51 @@ __global__ __launch_bounds__(BLOCK) void classify_tiles(ClassifyParams P, ItemAr
     // ---- phase 3: pack + per-item summary ----
     const uint32_t bits = (uint32_t)P.format;          // 1 or 2 bits per micro-triangle
     const uint32_t perWord = 32u / bits;               // micro-triangles per 32-bit word
-    if (tileState >= 0) {
-        // whole tile settled by one query (only happens for sliced tiles): constant words
-        uint32_t v = 0;
-        for (uint32_t k = 0; k < perWord; ++k) v |= (uint32_t)tileState << (k * bits);
-        const uint32_t item = itemIds[firstItem];
-        uint32_t* dst = (uint32_t*)(A.states + A.stateOfs[item]) + base / perWord;
-        for (uint32_t w = tid; w < (uint32_t)TILE / perWord; w += BLOCK) dst[w] = v;
-        if (tid == 0) {
-            atomicOr(&A.stateMask[item], 1u << tileState);
-            if (P.wantKnownCount && tileState < 2) atomicAdd(&A.knownCount[item], (uint32_t)TILE);
+    if (SLICED) {
+        uint32_t* dst = (uint32_t*)(A.states + A.stateOfs[uItem]) + base / perWord;
+        if (tileState >= 0) { // whole tile settled by one query: constant words
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < perWord; ++k) v |= (uint32_t)tileState << (k * bits);
+            for (uint32_t w = tid; w < (uint32_t)TILE / perWord; w += BLOCK) dst[w] = v;
+            if (tid == 0) {
+                atomicOr(&A.stateMask[uItem], 1u << tileState);
+                if (P.wantKnownCount && tileState < 2) atomicAdd(&A.knownCount[uItem], (uint32_t)TILE);
+            }
+            return;
         }
-        return;
-    }
-    if (M >= perWord) {
-        const uint32_t words = count / perWord;
         uint32_t localMask = 0, localKnown = 0;
-        for (uint32_t w = tid; w < words; w += BLOCK) {
+        for (uint32_t w = tid; w < (uint32_t)TILE / perWord; w += BLOCK) {
             uint32_t v = 0;
             for (uint32_t k = 0; k < perWord; ++k) {
-                const uint32_t s = s_state[w * perWord + k];
-                v |= s << (k * bits);
-                localMask |= 1u << s;
-                localKnown += s < 2u;
+                const uint32_t st = s_state[w * perWord + k];
+                v |= st << (k * bits);
+                localMask |= 1u << st;
+                localKnown += st < 2u;
+            }
+            dst[w] = v;
+        }
+        if (localMask) atomicOr(&s_mask, localMask);
+        if (P.wantKnownCount && localKnown) atomicAdd(&s_known, localKnown);
+        __syncthreads();
+        if (tid == 0) {
+            atomicOr(&A.stateMask[uItem], s_mask);
+            if (P.wantKnownCount) atomicAdd(&A.knownCount[uItem], s_known);
+        }
+    } else if (M >= perWord) {
+        const uint32_t words = count / perWord;
+        for (uint32_t w = tid; w < words; w += BLOCK) {
+            uint32_t v = 0, localMask = 0, localKnown = 0;
+            for (uint32_t k = 0; k < perWord; ++k) {
+                const uint32_t st = s_state[w * perWord + k];
+                v |= st << (k * bits);
+                localMask |= 1u << st;
+                localKnown += st < 2u;
             }
             const uint32_t i0 = w * perWord;
-            const uint32_t it = sliced ? firstItem : firstItem + (i0 >> (2 * level));
-            const uint32_t u0 = sliced ? base + i0 : (i0 & (M - 1u));
-            const uint32_t item = itemIds[it];
-            *(uint32_t*)(A.states + A.stateOfs[item] + (size_t)(u0 / perWord) * 4u) = v;
-            if (!sliced) { // several words of one item sit in neighbouring lanes: fold them without atomics when the item is one word
-                if (M == perWord) { A.stateMask[item] = localMask; if (P.wantKnownCount) A.knownCount[item] = localKnown; localMask = 0; localKnown = 0; }
-                else { atomicOr(&A.stateMask[item], localMask); if (P.wantKnownCount) atomicAdd(&A.knownCount[item], localKnown); localMask = 0; localKnown = 0; }
-            }
-        }
-        if (sliced) {
-            if (localMask) atomicOr(&s_mask, localMask);
-            if (P.wantKnownCount && localKnown) atomicAdd(&s_known, localKnown);
-            __syncthreads();
-            if (tid == 0) {
-                const uint32_t item = itemIds[firstItem];
-                atomicOr(&A.stateMask[item], s_mask);
-                if (P.wantKnownCount) atomicAdd(&A.knownCount[item], s_known);
-            }
+            const uint32_t item = itemIds[firstItem + (i0 >> (2 * level))];
+            *(uint32_t*)(A.states + A.stateOfs[item] + (size_t)((i0 & (M - 1u)) / perWord) * 4u) = v;
+            if (M == perWord) { A.stateMask[item] = localMask; if (P.wantKnownCount) A.knownCount[item] = localKnown; }
+            else { atomicOr(&A.stateMask[item], localMask); if (P.wantKnownCount) atomicAdd(&A.knownCount[item], localKnown); }
         }
     } else {
         // items smaller than one word (level 0/1, and level 2 in 2-state): one lane per item, byte stores
@@ -231,10 +272,10 @@ __global__ __launch_bounds__(BLOCK) void classify_tiles(ClassifyParams P, ItemAr
             const uint32_t item = itemIds[firstItem + k];
             uint32_t v = 0, mask = 0, known = 0;
             for (uint32_t j = 0; j < M; ++j) {
-                const uint32_t s = s_state[k * M + j];
-                v |= s << (j * bits);
-                mask |= 1u << s;
-                known += s < 2u;
+                const uint32_t st = s_state[k * M + j];
+                v |= st << (j * bits);
+                mask |= 1u << st;
+                known += st < 2u;
             }
             uint32_t nbytes = (M * bits) >> 3; if (nbytes < 1u) nbytes = 1u;
             uint8_t* dst = A.states + A.stateOfs[item];
@@ -249,12 +290,19 @@ void launch_classify(const ClassifyParams& P, const ItemArrays& A, const uint32_
 {
     if (numItems == 0) return;
     const uint64_t M = 1ull << (2 * level);
-    const uint64_t tiles = M >= (uint64_t)TILE ? (uint64_t)numItems * (M / TILE) : ((uint64_t)numItems * M + TILE - 1) / TILE;
+    const bool sliced = M >= (uint64_t)TILE;
+    const uint64_t tiles = sliced ? (uint64_t)numItems * (M / TILE) : ((uint64_t)numItems * M + TILE - 1) / TILE;
     if (tiles > 0xFFFFFFFFull) return; // cannot happen: the packed states of such a level group would not fit in HBM
     const uint32_t gx = tiles < (1u << 20) ? (uint32_t)tiles : (1u << 20);
     const uint32_t gy = (uint32_t)((tiles + gx - 1) / gx);
-    if (P.texIsFp32) hipLaunchKernelGGL(classify_tiles<true>, dim3(gx, gy), dim3(BLOCK), 0, stream, P, A, itemIds, numItems, level, tiles);
-    else             hipLaunchKernelGGL(classify_tiles<false>, dim3(gx, gy), dim3(BLOCK), 0, stream, P, A, itemIds, numItems, level, tiles);
+    const dim3 grid(gx, gy), block(BLOCK);
+    if (P.texIsFp32) {
+        if (sliced) hipLaunchKernelGGL((classify_tiles<true, true>), grid, block, 0, stream, P, A, itemIds, numItems, level, tiles);
+        else        hipLaunchKernelGGL((classify_tiles<true, false>), grid, block, 0, stream, P, A, itemIds, numItems, level, tiles);
+    } else {
+        if (sliced) hipLaunchKernelGGL((classify_tiles<false, true>), grid, block, 0, stream, P, A, itemIds, numItems, level, tiles);
+        else        hipLaunchKernelGGL((classify_tiles<false, false>), grid, block, 0, stream, P, A, itemIds, numItems, level, tiles);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

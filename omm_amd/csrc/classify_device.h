@@ -120,35 +120,68 @@ __device__ __forceinline__ int tex_coord(int mode, int pow2, int x, int size, in
     }
 }
 
+// LDS copy of the part of mip 0 (texel values already converted to float exactly as Load() does, and the summed-area
+// table) that a tile of micro-triangles can touch.  Coordinates are ADDRESSED texel coordinates; the window only exists
+// when the address mode maps the tile's footprint without a seam (w == 0 otherwise).  A fetch outside the window falls
+// back to HBM, so the window is a pure cache: it never changes a value.
+typedef __attribute__((address_space(3))) const float    lds_float;
+typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+struct TexWindow {
+    lds_float* tex;        // w * h floats, row-major (LDS)
+    lds_u32*   sat;        // (w + 1) * (h + 1): entry (i, j) = SAT(sx - 1 + i, sy - 1 + j), 0 where the coordinate is -1 (LDS)
+    const void*     base;  // texels of mip 0 (the window belongs to that mip only)
+    int sx, sy, w, h;
+};
+
 // texture_impl.h:178-202
 template <bool FP32>
-__device__ __forceinline__ float load_texel(const DevMip& m, int x, int y)
+__device__ __forceinline__ float load_texel(const DevMip& m, int x, int y, const TexWindow& W)
 {
+    const uint32_t wx = (uint32_t)(x - W.sx), wy = (uint32_t)(y - W.sy);
+    if (wx < (uint32_t)W.w && wy < (uint32_t)W.h && m.texels == W.base) return W.tex[wx + wy * (uint32_t)W.w];
     const size_t idx = (size_t)x + (size_t)y * (size_t)m.w;
     if (FP32) return ((const float*)m.texels)[idx];
     return (float)((const uint8_t*)m.texels)[idx] * (1.f / 255.f);
 }
 
 template <bool FP32>
-__device__ __forceinline__ float load_texel_border(const DevMip& m, int x, int y, float borderAlpha)
+__device__ __forceinline__ float load_texel_border(const DevMip& m, int x, int y, float borderAlpha, const TexWindow& W)
 {
-    return (x == kTexCoordBorder || y == kTexCoordBorder) ? borderAlpha : load_texel<FP32>(m, x, y);
+    return (x == kTexCoordBorder || y == kTexCoordBorder) ? borderAlpha : load_texel<FP32>(m, x, y, W);
+}
+
+// one summed-area-table entry of mip 0 (x, y >= 0)
+__device__ __forceinline__ uint32_t load_sat(const DevMip& m, int x, int y, const TexWindow& W)
+{
+    const uint32_t wx = (uint32_t)(x - W.sx + 1), wy = (uint32_t)(y - W.sy + 1);
+    if (wx <= (uint32_t)W.w && wy <= (uint32_t)W.h && W.w != 0) return W.sat[wx + wy * (uint32_t)(W.w + 1)];
+    return m.sat[(size_t)x + (size_t)y * (size_t)m.w];
+}
+
+// texture_impl.h:110-125
+__device__ __forceinline__ uint32_t sat_sum(const DevMip& m, int sx, int sy, int ex, int ey, const TexWindow& W)
+{
+    const uint32_t A = (sx > 0 && sy > 0) ? load_sat(m, sx - 1, sy - 1, W) : 0u;
+    const uint32_t B = sy > 0 ? load_sat(m, ex, sy - 1, W) : 0u;
+    const uint32_t C = sx > 0 ? load_sat(m, sx - 1, ey, W) : 0u;
+    const uint32_t D = load_sat(m, ex, ey, W);
+    return D + A - B - C;
 }
 
 // texture_impl.cpp:261-278 (centre vote).  Border texels take borderAlpha (the reference reads out of
 // bounds there -- documented fence).
 template <bool FP32>
-__device__ __forceinline__ float bilinear(const ClassifyParams& P, const DevMip& m, V2 p)
+__device__ __forceinline__ float bilinear(const ClassifyParams& P, const DevMip& m, V2 p, const TexWindow& W)
 {
     const float px = p.x * m.fw - 0.5f, py = p.y * m.fh - 0.5f;
     const float fx = __builtin_floorf(px), fy = __builtin_floorf(py);
     const int ix = cvt_trunc_x86(fx), iy = cvt_trunc_x86(fy);
     const int x0 = tex_coord(P.addrMode, m.pow2, ix, m.w, m.log2w), y0 = tex_coord(P.addrMode, m.pow2, iy, m.h, m.log2h);
     const int x1 = tex_coord(P.addrMode, m.pow2, ix + 1, m.w, m.log2w), y1 = tex_coord(P.addrMode, m.pow2, iy + 1, m.h, m.log2h);
-    const float a = load_texel_border<FP32>(m, x0, y0, P.borderAlpha);
-    const float b = load_texel_border<FP32>(m, x0, y1, P.borderAlpha);
-    const float c = load_texel_border<FP32>(m, x1, y0, P.borderAlpha);
-    const float d = load_texel_border<FP32>(m, x1, y1, P.borderAlpha);
+    const float a = load_texel_border<FP32>(m, x0, y0, P.borderAlpha, W);
+    const float b = load_texel_border<FP32>(m, x0, y1, P.borderAlpha, W);
+    const float c = load_texel_border<FP32>(m, x1, y0, P.borderAlpha, W);
+    const float d = load_texel_border<FP32>(m, x1, y1, P.borderAlpha, W);
     const float wx = px - fx, wy = py - fy;
     const float ac = a * (1.f - wx) + c * wx;
     const float bd = b * (1.f - wx) + d * wx;
@@ -230,18 +263,18 @@ __device__ __forceinline__ bool edge_crosses_level_curve(V2 a0, V2 a1, float ha,
 // bake_kernels_cpu.h:241-399 : one texel of the bilinear footprint grid.  Adds to (above, below).
 template <bool FP32, bool DEGENERATE>
 __device__ __forceinline__ void level_line_texel(const ClassifyParams& P, const DevMip& m, const MicroTri& t, int px, int py,
-                                                 uint32_t& above, uint32_t& below)
+                                                 uint32_t& above, uint32_t& below, const TexWindow& W)
 {
     const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
     const int x0 = tex_coord(P.addrMode, P.pow2Dispatch, px, m.w, m.log2w), y0 = tex_coord(P.addrMode, P.pow2Dispatch, py, m.h, m.log2h);
     const int x1 = tex_coord(P.addrMode, P.pow2Dispatch, px + 1, m.w, m.log2w), y1 = tex_coord(P.addrMode, P.pow2Dispatch, py + 1, m.h, m.log2h);
     float gx, gy, gz, gw; // 00, 01, 11, 10
     if (P.addrMode == 3) {
-        gx = load_texel_border<FP32>(m, x0, y0, P.borderAlpha); gy = load_texel_border<FP32>(m, x0, y1, P.borderAlpha);
-        gz = load_texel_border<FP32>(m, x1, y1, P.borderAlpha); gw = load_texel_border<FP32>(m, x1, y0, P.borderAlpha);
+        gx = load_texel_border<FP32>(m, x0, y0, P.borderAlpha, W); gy = load_texel_border<FP32>(m, x0, y1, P.borderAlpha, W);
+        gz = load_texel_border<FP32>(m, x1, y1, P.borderAlpha, W); gw = load_texel_border<FP32>(m, x1, y0, P.borderAlpha, W);
     } else {
-        gx = load_texel<FP32>(m, x0, y0); gy = load_texel<FP32>(m, x0, y1);
-        gz = load_texel<FP32>(m, x1, y1); gw = load_texel<FP32>(m, x1, y0);
+        gx = load_texel<FP32>(m, x0, y0, W); gy = load_texel<FP32>(m, x0, y1, W);
+        gz = load_texel<FP32>(m, x1, y1, W); gw = load_texel<FP32>(m, x1, y0, W);
     }
     if (!DEGENERATE) {
         const float ipx = pfx * m.rw, ipy = pfy * m.rh;
@@ -282,11 +315,11 @@ __device__ __forceinline__ void level_line_texel(const ClassifyParams& P, const 
 
 // bake_cpu_impl.cpp:994-1009
 template <bool FP32>
-__device__ __forceinline__ void nearest_texel(const ClassifyParams& P, const DevMip& m, int px, int py, uint32_t& above, uint32_t& below)
+__device__ __forceinline__ void nearest_texel(const ClassifyParams& P, const DevMip& m, int px, int py, uint32_t& above, uint32_t& below, const TexWindow& W)
 {
     const int cx = tex_coord(P.addrMode, P.pow2Dispatch, px, m.w, m.log2w), cy = tex_coord(P.addrMode, P.pow2Dispatch, py, m.h, m.log2h);
     const bool border = P.addrMode == 3 && (cx == kTexCoordBorder || cy == kTexCoordBorder);
-    const float alpha = border ? P.borderAlpha : load_texel<FP32>(m, cx, cy);
+    const float alpha = border ? P.borderAlpha : load_texel<FP32>(m, cx, cy, W);
     if (P.cutoff < alpha) above++; else below++;
 }
 
@@ -311,7 +344,7 @@ __device__ __forceinline__ float eval_cons(const EdgeEq& e, float sx, float sy)
 // KIND: 0 = level-line (linear filter), 1 = nearest vote
 template <bool FP32, int KIND>
 __device__ __forceinline__ void raster_micro_triangle(const ClassifyParams& P, const DevMip& m, const MicroTri& t, float off,
-                                                      uint32_t& above, uint32_t& below)
+                                                      uint32_t& above, uint32_t& below, const TexWindow& W)
 {
     // util/geometry.h:49-55 : winding from the fp64 cross product of fp32 edge vectors
     const double ax = (double)(t.p2.x - t.p0.x), ay = (double)(t.p2.y - t.p0.y);
@@ -335,8 +368,8 @@ __device__ __forceinline__ void raster_micro_triangle(const ClassifyParams& P, c
             const float sx = (float)x, sy = (float)y;
             const bool inside = eval_cons(e0, sx, sy) < 0.f && eval_cons(e1, sx, sy) < 0.f && eval_cons(e2, sx, sy) < 0.f;
             if (inside) {
-                if (KIND == 0) level_line_texel<FP32, false>(P, m, t, x, y, above, below);
-                else nearest_texel<FP32>(P, m, x, y, above, below);
+                if (KIND == 0) level_line_texel<FP32, false>(P, m, t, x, y, above, below, W);
+                else nearest_texel<FP32>(P, m, x, y, above, below, W);
                 if (!countsMatter && above != 0 && below != 0) return;
                 wasInside = true;
             } else if (wasInside) break;
@@ -347,7 +380,7 @@ __device__ __forceinline__ void raster_micro_triangle(const ClassifyParams& P, c
 // conservative line walk for degenerate work items (util/cpu_raster.h:486-555)
 template <bool FP32>
 __device__ __forceinline__ void raster_micro_segment(const ClassifyParams& P, const DevMip& m, const MicroTri& t,
-                                                     uint32_t& above, uint32_t& below)
+                                                     uint32_t& above, uint32_t& below, const TexWindow& W)
 {
     V2 p0 = mk2(t.lo.x * m.fw + -0.5f, t.lo.y * m.fh + -0.5f);
     V2 p1 = mk2(t.hi.x * m.fw + -0.5f, t.hi.y * m.fh + -0.5f);
@@ -363,14 +396,14 @@ __device__ __forceinline__ void raster_micro_segment(const ClassifyParams& P, co
     float tMaxX = inf, tMaxY = inf;
     if (stepX != 0) tMaxX = (((float)x + (stepX > 0 ? 1.f : 0.f)) - p0.x) / dx;
     if (stepY != 0) tMaxY = (((float)y + (stepY > 0 ? 1.f : 0.f)) - p0.y) / dy;
-    if (stepX == 0 && stepY == 0) { level_line_texel<FP32, true>(P, m, t, x, y, above, below); return; }
+    if (stepX == 0 && stepY == 0) { level_line_texel<FP32, true>(P, m, t, x, y, above, below, W); return; }
     const int yMin = cvt_trunc_x86(std_min(__builtin_floorf(p0.y), __builtin_floorf(p1.y)));
     const int yMax = cvt_trunc_x86(std_max(__builtin_ceilf(p0.y), __builtin_ceilf(p1.y)));
     const int xMin = cvt_trunc_x86(std_min(__builtin_floorf(p0.x), __builtin_floorf(p1.x)));
     const int xMax = cvt_trunc_x86(std_max(__builtin_ceilf(p0.x), __builtin_ceilf(p1.x)));
     const bool countsMatter = P.promotion == 0;
     while (x >= xMin && x <= xMax && y >= yMin && y <= yMax) {
-        level_line_texel<FP32, true>(P, m, t, x, y, above, below);
+        level_line_texel<FP32, true>(P, m, t, x, y, above, below, W);
         if (!countsMatter && above != 0 && below != 0) return;
         if (tMaxX < tMaxY) { x += stepX; tMaxX += tDeltaX; }
         else { y += stepY; tMaxY += tDeltaY; }
@@ -379,7 +412,7 @@ __device__ __forceinline__ void raster_micro_segment(const ClassifyParams& P, co
 
 // ---- coarse pass: summed-area-table test of one micro-triangle (bake_cpu_impl.cpp:749-801) ----
 // returns -1 when the micro-triangle stays unresolved
-__device__ __forceinline__ int coarse_state(const ClassifyParams& P, const MicroTri& t)
+__device__ __forceinline__ int coarse_state(const ClassifyParams& P, const MicroTri& t, const TexWindow& W)
 {
     const DevMip& m = P.mips[0];
     if (cvt_trunc_x86(t.lo.x) != cvt_trunc_x86(t.hi.x) || cvt_trunc_x86(t.lo.y) != cvt_trunc_x86(t.hi.y)) return -1;
@@ -393,14 +426,7 @@ __device__ __forceinline__ int coarse_state(const ClassifyParams& P, const Micro
     if (!(sx >= 0 && sy >= 0 && sx < m.w && sy < m.h)) return -1;
     if (!(ex >= 0 && ey >= 0 && ex < m.w && ey < m.h)) return -1;
     const uint32_t area = (uint32_t)((ex - sx + 1) * (ey - sy + 1));
-    // texture_impl.h:110-125
-    const uint32_t* sat = m.sat;
-    const size_t W = (size_t)m.w;
-    const uint32_t A = (sx > 0 && sy > 0) ? sat[(size_t)(sx - 1) + (size_t)(sy - 1) * W] : 0u;
-    const uint32_t B = sy > 0 ? sat[(size_t)ex + (size_t)(sy - 1) * W] : 0u;
-    const uint32_t C = sx > 0 ? sat[(size_t)(sx - 1) + (size_t)ey * W] : 0u;
-    const uint32_t D = sat[(size_t)ex + (size_t)ey * W];
-    const uint32_t sa = D + A - B - C;
+    const uint32_t sa = sat_sum(m, sx, sy, ex, ey, W);
     if (sa == 0) return P.stateLE;
     if (sa == area) return P.stateGT;
     return -1;
@@ -414,33 +440,39 @@ __device__ __forceinline__ int coarse_state(const ClassifyParams& P, const Micro
 // [floor(lo*W-.5), floor(hi*W-.5)+1] -- all operations monotone -- is contained in the ancestor's; if the address mode maps
 // the ancestor's rectangle without a seam and the SAT says the rectangle is uniformly <= / > cutoff, so does it for every
 // sub-rectangle.  States that the reference's fine pass would revisit (value 3, bake_cpu_impl.cpp:861) are not shortcut.
-__device__ __forceinline__ int region_state(const ClassifyParams& P, const MicroTri& sub, float maxAbs)
+struct TexRect { int sx, sy, ex, ey; bool ok; };
+
+// addressed texel rectangle that contains the coarse-pass rectangle of every descendant of `sub`; ok == false when that
+// cannot be guaranteed (huge coordinates, UV-tile crossing, address-mode seam)
+__device__ __forceinline__ TexRect region_rect(const ClassifyParams& P, const MicroTri& sub, float maxAbs)
 {
     const DevMip& m = P.mips[0];
-    if (!(maxAbs <= 16384.f)) return -1;
+    TexRect r; r.sx = r.sy = r.ex = r.ey = 0; r.ok = false;
+    if (!(maxAbs <= 16384.f)) return r;
     const float grow = maxAbs * 7.62939453125e-06f + 1e-30f; // 2^-17 * maxAbs  (= 64 ulp)
     const float lx = sub.lo.x - grow, ly = sub.lo.y - grow, hx = sub.hi.x + grow, hy = sub.hi.y + grow;
-    if (cvt_trunc_x86(lx) != cvt_trunc_x86(hx) || cvt_trunc_x86(ly) != cvt_trunc_x86(hy)) return -1;
+    if (cvt_trunc_x86(lx) != cvt_trunc_x86(hx) || cvt_trunc_x86(ly) != cvt_trunc_x86(hy)) return r;
     const int X0 = cvt_trunc_x86(__builtin_floorf(lx * m.fw - 0.5f)), Y0 = cvt_trunc_x86(__builtin_floorf(ly * m.fh - 0.5f));
     const int X1 = cvt_trunc_x86(__builtin_floorf(hx * m.fw - 0.5f)) + 1, Y1 = cvt_trunc_x86(__builtin_floorf(hy * m.fh - 0.5f)) + 1;
-    if (X1 - X0 >= m.w || Y1 - Y0 >= m.h) return -1;
-    int sx, sy, ex, ey;
+    if (X1 - X0 >= m.w || Y1 - Y0 >= m.h) return r;
     if (P.addrMode == 0) { // Wrap: any single period is fine as long as the rectangle does not cross the seam
-        sx = tex_coord(0, P.pow2Dispatch, X0, m.w, m.log2w); ex = tex_coord(0, P.pow2Dispatch, X1, m.w, m.log2w);
-        sy = tex_coord(0, P.pow2Dispatch, Y0, m.h, m.log2h); ey = tex_coord(0, P.pow2Dispatch, Y1, m.h, m.log2h);
-        if (ex - sx != X1 - X0 || ey - sy != Y1 - Y0) return -1;
+        r.sx = tex_coord(0, P.pow2Dispatch, X0, m.w, m.log2w); r.ex = tex_coord(0, P.pow2Dispatch, X1, m.w, m.log2w);
+        r.sy = tex_coord(0, P.pow2Dispatch, Y0, m.h, m.log2h); r.ey = tex_coord(0, P.pow2Dispatch, Y1, m.h, m.log2h);
+        if (r.ex - r.sx != X1 - X0 || r.ey - r.sy != Y1 - Y0) return r;
     } else {               // other modes: only the untouched interior [0,W) x [0,H)
-        if (X0 < 0 || Y0 < 0 || X1 >= m.w || Y1 >= m.h) return -1;
-        sx = X0; sy = Y0; ex = X1; ey = Y1;
+        if (X0 < 0 || Y0 < 0 || X1 >= m.w || Y1 >= m.h) return r;
+        r.sx = X0; r.sy = Y0; r.ex = X1; r.ey = Y1;
     }
-    const uint32_t area = (uint32_t)((ex - sx + 1) * (ey - sy + 1));
-    const uint32_t* sat = m.sat;
-    const size_t W = (size_t)m.w;
-    const uint32_t A = (sx > 0 && sy > 0) ? sat[(size_t)(sx - 1) + (size_t)(sy - 1) * W] : 0u;
-    const uint32_t B = sy > 0 ? sat[(size_t)ex + (size_t)(sy - 1) * W] : 0u;
-    const uint32_t C = sx > 0 ? sat[(size_t)(sx - 1) + (size_t)ey * W] : 0u;
-    const uint32_t D = sat[(size_t)ex + (size_t)ey * W];
-    const uint32_t sa = D + A - B - C;
+    r.ok = true;
+    return r;
+}
+
+__device__ __forceinline__ int region_state(const ClassifyParams& P, const MicroTri& sub, float maxAbs, const TexWindow& W)
+{
+    const TexRect r = region_rect(P, sub, maxAbs);
+    if (!r.ok) return -1;
+    const uint32_t area = (uint32_t)((r.ex - r.sx + 1) * (r.ey - r.sy + 1));
+    const uint32_t sa = sat_sum(P.mips[0], r.sx, r.sy, r.ex, r.ey, W);
     int st = -1;
     if (sa == 0) st = P.stateLE; else if (sa == area) st = P.stateGT;
     return st == 3 ? -1 : st;
@@ -448,17 +480,17 @@ __device__ __forceinline__ int region_state(const ClassifyParams& P, const Micro
 
 // ---- fine pass for one micro-triangle (bake_cpu_impl.cpp:859-914 linear, :983-1022 nearest) ----
 template <bool FP32>
-__device__ __forceinline__ int fine_state(const ClassifyParams& P, const MicroTri& t, bool degenerate)
+__device__ __forceinline__ int fine_state(const ClassifyParams& P, const MicroTri& t, bool degenerate, const TexWindow& W)
 {
     uint32_t above = 0, below = 0;
     for (int mip = 0; mip < P.mipCount; ++mip) {
         const DevMip& m = P.mips[mip];
         if (P.filterLinear) {
-            if (P.cutoff < bilinear<FP32>(P, m, t.p0)) above++; else below++;
-            if (!degenerate) raster_micro_triangle<FP32, 0>(P, m, t, -0.5f, above, below);
-            else raster_micro_segment<FP32>(P, m, t, above, below);
+            if (P.cutoff < bilinear<FP32>(P, m, t.p0, W)) above++; else below++;
+            if (!degenerate) raster_micro_triangle<FP32, 0>(P, m, t, -0.5f, above, below, W);
+            else raster_micro_segment<FP32>(P, m, t, above, below, W);
         } else {
-            raster_micro_triangle<FP32, 1>(P, m, t, 0.f, above, below);
+            raster_micro_triangle<FP32, 1>(P, m, t, 0.f, above, below, W);
         }
         if (state_is_unknown(state_from_coverage(P, above, below))) break;
     }

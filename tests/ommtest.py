@@ -309,6 +309,63 @@ class Lib:
         return res
 
 
+class Hip:
+    """Minimal ctypes view of the HIP runtime: device buffers for the device-resident entry point (no torch needed)."""
+
+    def __init__(self):
+        self.rt = C.CDLL("libamdhip64.so")
+        self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.rt.hipFree.argtypes = [C.c_void_p]
+        self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = C.c_void_p()
+        assert self.rt.hipMalloc(C.byref(p), max(arr.nbytes, 16)) == 0
+        assert self.rt.hipMemcpy(p, arr.ctypes.data, arr.nbytes, 1) == 0
+        return p
+
+    def download(self, ptr, nbytes, dtype=np.uint8):
+        out = np.empty(nbytes, np.uint8)
+        if nbytes:
+            assert self.rt.hipMemcpy(out.ctypes.data, ptr, nbytes, 2) == 0
+        return out.view(dtype)
+
+    def free(self, p):
+        self.rt.hipFree(p)
+
+
+def bake_device(lib, hip, baker, desc, uv, ix, levels=None):
+    """ommxBakeDevice (include/omm_mi355x_ext.h): same desc, bulk arrays in HBM; returns a host copy as BakeResult."""
+    lib.dll.ommxBakeDevice.argtypes = [C.c_void_p, C.POINTER(BakeInputDesc), C.POINTER(C.c_void_p)]
+    lib.dll.ommxGetDeviceBakeResultDesc.argtypes = [C.c_void_p, C.POINTER(C.POINTER(BakeResultDesc))]
+    lib.dll.ommxDestroyDeviceBakeResult.argtypes = [C.c_void_p]
+    d_uv, d_ix = hip.upload(uv), hip.upload(ix)
+    d_lv = hip.upload(np.ascontiguousarray(levels, dtype=np.uint8)) if levels is not None else None
+    dd = BakeInputDesc.from_buffer_copy(desc)
+    dd.texCoords, dd.indexBuffer = d_uv, d_ix
+    dd.subdivisionLevels = d_lv
+    out = C.c_void_p()
+    r = lib.dll.ommxBakeDevice(baker, C.byref(dd), C.byref(out))
+    assert r == SUCCESS, r
+    pd = C.POINTER(BakeResultDesc)()
+    assert lib.dll.ommxGetDeviceBakeResultDesc(out, C.byref(pd)) == SUCCESS
+    dev = pd.contents
+    isz = {IDX_U8: 1, IDX_U16: 2, IDX_U32: 4}[dev.indexFormat]
+    host_arrays = [hip.download(dev.arrayData, dev.arrayDataSize), hip.download(dev.descArray, 8 * dev.descArrayCount),
+                   hip.download(dev.indexBuffer, isz * dev.indexCount)]
+    hd = BakeResultDesc.from_buffer_copy(dev)
+    hd.arrayData = host_arrays[0].ctypes.data
+    hd.descArray = C.cast(host_arrays[1].ctypes.data, C.POINTER(MicromapDesc))
+    hd.indexBuffer = host_arrays[2].ctypes.data
+    res = BakeResult(hd)
+    assert lib.dll.ommxDestroyDeviceBakeResult(out) == SUCCESS
+    for p in (d_uv, d_ix, d_lv):
+        if p is not None:
+            hip.free(p)
+    return res
+
+
 def make_desc(tex, tex_coords, indices, level, *, alpha_cutoff=0.5, fmt=FMT_4STATE, addr=CLAMP, filt=LINEAR,
               promo=PROMO_NEAREST, flags=FLAG_THREADS, le=T, gt=O, dyn_scale=0.0, unresolved=SPECIAL_FUO,
               uv_format=UV32_FLOAT, max_workload=0xFFFFFFFFFFFFFFFF, levels=None, border_alpha=0.0,

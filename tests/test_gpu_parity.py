@@ -321,3 +321,29 @@ def test_hierarchy_levels_all_paths(product, oracle):
             uv, ix = ot.random_triangles(500 + level, 24 if level > 7 else 80, extent)
             both(product, oracle, [tex], uv, ix, level, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
             both(product, oracle, [tex], uv, ix, level, addr=ot.CLAMP, promo=ot.PROMO_NEAREST, flags=ot.FLAG_THREADS | ot.FLAG_NO_SPECIAL)
+
+
+def test_device_resident_entry_point(product, oracle):
+    """ommxBakeDevice: inputs and outputs stay in HBM; results must equal ommCpuBake's and the oracle's."""
+    hip = ot.Hip()
+    tex = noise_u8()
+    n = 3000
+    uv, ix = ot.random_triangles(321, n, 0.04)
+    lv = (ot.hash_u32(np.arange(n) + 9) % 8).astype(np.uint8)
+    lv[lv == 7] = 0xF
+    for kwargs, levels in ((dict(addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE), None),
+                           (dict(addr=ot.CLAMP, promo=ot.PROMO_NEAREST, dyn_scale=1.5, flags=ot.FLAG_THREADS | ot.FLAG_FORCE32), lv)):
+        ob = oracle.create_baker()
+        otx = oracle.create_texture(ob, [tex], alpha_cutoff=0.5)
+        ref = oracle.bake(ob, ot.make_desc(otx, uv, ix, 6, levels=levels, **kwargs))
+        oracle.destroy_texture(ob, otx)
+        oracle.destroy_baker(ob)
+        b = product.create_baker()
+        t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+        d = ot.make_desc(t, uv, ix, 6, levels=levels, **kwargs)
+        host = product.bake(b, d)
+        dev = ot.bake_device(product, hip, b, d, uv, ix, levels)
+        product.destroy_texture(b, t)
+        product.destroy_baker(b)
+        assert host.same_as(ref), host.diff(ref)
+        assert dev.same_as(ref), dev.diff(ref)
