@@ -27,7 +27,7 @@ class BakeTimings(C.Structure):
     _fields_ = [("hostSetupMs", C.c_float), ("uploadMs", C.c_float), ("classifyMs", C.c_float), ("digestMs", C.c_float),
                 ("tailMs", C.c_float), ("gatherMs", C.c_float), ("downloadMs", C.c_float), ("totalMs", C.c_float),
                 ("microTriangles", C.c_uint64), ("uniqueItems", C.c_uint32), ("classifyLaunches", C.c_uint32),
-                ("stateBytes", C.c_uint64), ("triageMs", C.c_float), ("activeItems", C.c_uint32), ("setupMs", C.c_float)]
+                ("stateBytes", C.c_uint64), ("triageMs", C.c_float), ("activeItems", C.c_uint32), ("fineMicroTriangles", C.c_uint64), ("setupMs", C.c_float)]
 
 
 def make_workload(args):
@@ -182,7 +182,8 @@ def main():
             "config": {"workload": "%d random-UV triangles (%.1f texels), %dx%d foliage-style UNORM8 alpha + SAT, subdiv level %d, 4-state, Wrap/Linear"
                                    % (args.tris, args.extent_texels, args.tex, args.tex, args.level),
                        "entry": "ommxBakeDevice (ommCpuBake contract, UV/index inputs and result arrays resident in HBM)", "sharding": "contiguous triangle ranges per rank" if world > 1 else "none",
-                       "result": result_info},
+                       "result": result_info, "unique_items": int(tms[-1].uniqueItems), "active_items": int(tms[-1].activeItems),
+                       "fine_micro_triangles": int(tms[-1].fineMicroTriangles)},
             "bake_wall_time_ms": ms_per_step,
             "host_api": None if host_ms is None else {"entry": "ommCpuBake (host arrays in/out, PCIe inclusive)", "ms_per_bake": host_ms,
                                                        "uploadMs": host_tm.uploadMs, "downloadMs": host_tm.downloadMs,

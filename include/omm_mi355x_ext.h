@@ -26,6 +26,7 @@ typedef struct ommxBakeTimings {
     uint64_t stateBytes;       /* packed state bytes written by classification */
     float    triageMs;         /* level-0 hierarchical query per item + compaction of the active items */
     uint32_t activeItems;      /* items that needed per-micro-triangle classification */
+    uint64_t fineMicroTriangles; /* micro-triangles that needed the level-line (fine) pass */
     float    setupMs;          /* device work-item setup: UV fetch, level selection, first-occurrence dedup, level grouping */
 } ommxBakeTimings;
 

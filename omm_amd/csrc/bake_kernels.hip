@@ -204,6 +204,7 @@ __global__ __launch_bounds__(BLOCK, 4) void classify_tiles(ClassifyParams P, Ite
 
         // ---- phase 2: fine, dense over the queue ----
         const uint32_t qn = s_qcount;
+        if (tid == 0 && qn) atomicAdd(A.fineCount, (unsigned long long)qn);
         for (uint32_t q = tid; q < qn; q += BLOCK) {
             const uint32_t i = s_queue[q];
             const uint32_t u = SLICED ? base + i : (i & (M - 1u));

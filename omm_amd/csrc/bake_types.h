@@ -45,6 +45,7 @@ struct ItemArrays {
     uint8_t*        states;    // packed 1-/2-bit states, LSB first (bake_cpu_impl.cpp:1806-1816)
     uint32_t*       stateMask; // OR of (1 << state) over the item's micro-triangles
     uint32_t*       knownCount;// number of T/O micro-triangles (only when wantKnownCount)
+    unsigned long long* fineCount; // statistics: micro-triangles that went through the level-line pass
 };
 
 } // namespace ommx

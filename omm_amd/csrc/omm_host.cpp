@@ -371,6 +371,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     SetupCounters* dCounters = arena->take<SetupCounters>(1);
     uint64_t* dUniformDigest = arena->take<uint64_t>(kNumLevels * 4);
     uint32_t* dArrayHist = arena->take<uint32_t>(kNumLevels); uint32_t* dIndexHist = arena->take<uint32_t>(kNumLevels); uint32_t* dErr = arena->take<uint32_t>(1);
+    unsigned long long* dFine = arena->take<unsigned long long>(1);
     uint8_t* dScratch = arena->take<uint8_t>(scratchBytes);
 
     // ---- SetupWorkItems (bake_cpu_impl.cpp:589-660) on the device ----
@@ -481,7 +482,8 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     const int e1b = et.mark();
 
     // ---- ResampleCoarse + ResampleFine (bake_cpu_impl.cpp:715-1029) on the active items ----
-    ItemArrays A; A.uv = dUv; A.degenerate = dDegen; A.stateOfs = dStateOfs; A.states = dStates; A.stateMask = dMask; A.knownCount = dKnown;
+    ItemArrays A; A.uv = dUv; A.degenerate = dDegen; A.stateOfs = dStateOfs; A.states = dStates; A.stateMask = dMask; A.knownCount = dKnown; A.fineCount = dFine;
+    if (!HIP_OK(hipMemsetAsync(dFine, 0, 8, stream))) return L.failure("[Failure] - device memset failed");
     for (int l = 0; l < kNumLevels; ++l)
         launch_classify(P, A, dActiveIds + hc.activeStart[l], hc.activeStart[l + 1] - hc.activeStart[l], (uint32_t)l, stream);
     const int e2 = et.mark();
@@ -525,13 +527,15 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     if (ok) launch_narrow_indices(dIndex, T, idxBytes, R.index, stream);
     ok = ok && HIP_OK(hipMemcpyAsync(R.hist, dArrayHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
     ok = ok && HIP_OK(hipMemcpyAsync(R.hist + kNumLevels, dIndexHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
+    unsigned long long fineCount = 0;
+    ok = ok && HIP_OK(hipMemcpyAsync(&fineCount, dFine, 8, hipMemcpyDeviceToHost, stream));
     const int e5 = et.mark();
     ok = ok && HIP_OK(hipStreamSynchronize(stream));
     if (!ok) return L.failure("[Failure] - could not materialise the bake result on the device");
 
     tm.uploadMs = 0.f; tm.hostSetupMs = 0.f; tm.setupMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.digestMs = et.ms(e2, e3);
     tm.tailMs = et.ms(e3, e4); tm.gatherMs = et.ms(e4, e5);
-    tm.uniqueItems = U; tm.activeItems = hc.activeStart[kNumLevels]; tm.stateBytes = hc.stateBytes; tm.microTriangles = 0;
+    tm.fineMicroTriangles = fineCount; tm.uniqueItems = U; tm.activeItems = hc.activeStart[kNumLevels]; tm.stateBytes = hc.stateBytes; tm.microTriangles = 0;
     for (int l = 0; l < kNumLevels; ++l) { tm.microTriangles += (uint64_t)hc.levelCount[l] << (2 * l); tm.classifyLaunches += hc.activeStart[l + 1] != hc.activeStart[l]; }
     return ommResult_SUCCESS;
 }
