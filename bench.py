@@ -17,6 +17,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ommtest as ot  # noqa: E402
 
@@ -89,8 +90,9 @@ def main():
         dist.init_process_group("nccl")
 
     tex, uv, ix = make_workload(args)
-    # strong scaling: the fixed triangle stream is split into contiguous per-rank ranges
-    lo, hi = args.tris * rank // world, args.tris * (rank + 1) // world
+    # strong scaling: every rank sees the whole (fixed) triangle stream; the library partitions the ACTIVE work items over the
+    # ranks (ommxSharded*), metadata are merged by an RCCL all-reduce and the surviving OMM blocks by an RCCL all-gather
+    lo, hi = 0, args.tris
 
     prod = ot.Lib("product")
     prod.dll.ommxGetLastBakeTimings.argtypes = [C.c_void_p, C.POINTER(BakeTimings)]
@@ -106,7 +108,11 @@ def main():
     desc = ot.BakeInputDesc.from_buffer_copy(host_desc)
     desc.texCoords, desc.indexBuffer = d_uv.data_ptr(), d_ix.data_ptr()
 
+    import omm_amd.sharded as shard
+
     def step():
+        if world > 1:
+            return shard.sharded_bake(prod.dll, baker, C.byref(desc), rank, world, torch, dist)
         out = C.c_void_p()
         r = prod.dll.ommxBakeDevice(baker, C.byref(desc), C.byref(out))
         assert r == ot.SUCCESS, "ommxBakeDevice failed: %d" % r
@@ -139,11 +145,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        mt = torch.tensor([float(tms[-1].microTriangles)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(mt, op=dist.ReduceOp.SUM)
-        micro_tris = float(mt.item())
-    else:
-        micro_tris = float(tms[-1].microTriangles)
+    micro_tris = float(tms[-1].microTriangles)  # whole job: every rank reports the full work-item list
 
     pd = C.POINTER(ot.BakeResultDesc)()
     prod.dll.ommxGetDeviceBakeResultDesc(last, C.byref(pd))
@@ -181,7 +183,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%d random-UV triangles (%.1f texels), %dx%d foliage-style UNORM8 alpha + SAT, subdiv level %d, 4-state, Wrap/Linear"
                                    % (args.tris, args.extent_texels, args.tex, args.tex, args.level),
-                       "entry": "ommxBakeDevice (ommCpuBake contract, UV/index inputs and result arrays resident in HBM)", "sharding": "contiguous triangle ranges per rank" if world > 1 else "none",
+                       "entry": ("ommxSharded* + torch.distributed" if world > 1 else "ommxBakeDevice") + " (ommCpuBake contract, UV/index inputs and result arrays resident in HBM)", "sharding": "active work items partitioned over ranks; RCCL all-reduce of item metadata + all-gather of OMM blocks" if world > 1 else "none",
                        "result": result_info, "unique_items": int(tms[-1].uniqueItems), "active_items": int(tms[-1].activeItems),
                        "fine_micro_triangles": int(tms[-1].fineMicroTriangles)},
             "bake_wall_time_ms": ms_per_step,

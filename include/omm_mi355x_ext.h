@@ -44,4 +44,25 @@ OMM_MI355X_API ommResult ommxBakeDevice(ommBaker baker, const ommCpuBakeInputDes
 OMM_MI355X_API ommResult ommxGetDeviceBakeResultDesc(ommxDeviceBakeResult result, const ommCpuBakeResultDesc** desc);
 OMM_MI355X_API ommResult ommxDestroyDeviceBakeResult(ommxDeviceBakeResult result);
 
+
+/* ---- multi-GPU sharded bake (one process per GPU) ----
+ * Every rank calls the same four functions with the SAME desc (device-resident inputs as for ommxBakeDevice); the caller
+ * performs the two collectives in between with whatever transport it has (bench.py: torch.distributed = RCCL over xGMI):
+ *
+ *   ommxShardedBegin   work-item setup + triage (replicated, cheap), then classification and digests of THIS rank's share of
+ *                      the active work items (contiguous ranges of the per-level lists)
+ *   ommxShardedGetMeta -> device array of `numWords` uint32 (4 per active item: state mask, known count, digest lo/hi), zero
+ *                      for items of other ranks.           CALLER: all-reduce(SUM) over all ranks, in place.
+ *   ommxShardedTail    replicated deterministic tail (promote, first-occurrence dedup, spatial sort, offsets) on the merged
+ *                      metadata; packs this rank's surviving OMM blocks -> `contribution` (device), its size, and the common
+ *                      padded size `strideBytes`.          CALLER: all-gather of strideBytes per rank into gathered[world][strideBytes].
+ *   ommxShardedFinish  places every rank's blocks at their final arrayData offsets -> the same ommxDeviceBakeResult on every
+ *                      rank, bit-identical to a single-GPU ommxBakeDevice of the same desc. */
+typedef struct _ommxShardedBake* ommxShardedBake;
+OMM_MI355X_API ommResult ommxShardedBegin(ommBaker baker, const ommCpuBakeInputDesc* deviceDesc, uint32_t rank, uint32_t worldSize, ommxShardedBake* out);
+OMM_MI355X_API ommResult ommxShardedGetMeta(ommxShardedBake bake, void** deviceWords, uint64_t* numWords);
+OMM_MI355X_API ommResult ommxShardedTail(ommxShardedBake bake, void** contribution, uint64_t* contributionBytes, uint64_t* strideBytes);
+OMM_MI355X_API ommResult ommxShardedFinish(ommxShardedBake bake, const void* gathered, ommxDeviceBakeResult* outResult);
+OMM_MI355X_API ommResult ommxShardedDestroy(ommxShardedBake bake);
+
 #endif

@@ -47,6 +47,21 @@ hipError_t run_setup_fix_pending(const SetupParams& S, void* scratch, size_t scr
 hipError_t run_setup_items(const SetupParams& S, void* scratch, size_t scratchBytes, SetupCounters* counters, float* itemUv, uint8_t* itemLevel,
                            uint8_t* itemDegenerate, int32_t* triToItem, uint32_t* itemIds, hipStream_t stream);
 
+// ---- multi-GPU sharding helpers (tail_kernels.hip) ----
+constexpr int kMaxRanks = 16;
+struct ShardBounds { uint32_t rank, world; uint32_t b[kNumLevels][kMaxRanks + 1]; }; // b[l][r]: first active-list position of rank r at level l
+void launch_shard_pack_meta(const ShardBounds& B, const uint32_t* activeIds, uint32_t numActive, const uint32_t* mask, const uint32_t* known,
+                            const uint64_t* digests, uint32_t* meta, hipStream_t stream);
+void launch_shard_unpack_meta(const ShardBounds& B, const uint32_t* activeIds, uint32_t numActive, const uint32_t* meta, uint32_t* mask, uint32_t* known,
+                              uint64_t* digests, uint8_t* owner, hipStream_t stream);
+hipError_t run_shard_layout(const uint32_t* order, const uint32_t* sizes, const uint8_t* active, const uint8_t* owner, uint32_t numOmms, uint32_t world,
+                            uint64_t* cofs, uint64_t* totalsDev, uint64_t* totalsHost, void* scratch, size_t scratchBytes, hipStream_t stream);
+void launch_shard_gather(const uint8_t* states, const uint64_t* stateOfs, const uint8_t* active, const uint8_t* owner, uint32_t rank, const uint32_t* order,
+                         const uint64_t* cofs, const uint32_t* sizes, uint32_t numOmms, uint8_t* contrib, hipStream_t stream);
+void launch_shard_scatter(const uint8_t* gathered, uint64_t strideBytes, const uint8_t* active, const uint8_t* owner, const uint32_t* stateMask,
+                          const uint8_t* level, int bits, const uint32_t* order, const uint64_t* cofs, const uint32_t* dstOfs, const uint32_t* sizes,
+                          uint32_t numOmms, uint8_t* arrayData, hipStream_t stream);
+
 // ---- device tail (tail_kernels.hip) ----
 struct TailInputs {
     uint32_t numItems, numTris;

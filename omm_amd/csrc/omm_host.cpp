@@ -314,6 +314,22 @@ struct DeviceInputs {           // raw triangle data, device resident
     const void* texCoords; const void* indices; const uint8_t* perTriLevels;
 };
 
+// Multi-GPU: state kept between the phases of a sharded bake (ommxSharded*).  The rank classifies its share of the active
+// work items; per-item metadata and surviving blocks are exchanged by the caller's collectives; the tail is replicated.
+struct ShardCtx {
+    uint32_t rank = 0, world = 1;
+    ShardBounds bounds;
+    TailInputs ti; TailOutputs to; TailCounts counts;
+    SetupCounters hc;
+    uint8_t *dStates = nullptr, *dActive = nullptr, *dLevel = nullptr, *dScratch = nullptr; uint64_t* dStateOfs = nullptr; uint32_t *dMask = nullptr, *dActiveIds = nullptr;
+    int32_t* dIndex = nullptr; uint32_t *dArrayHist = nullptr, *dIndexHist = nullptr;
+    size_t scratchBytes = 0; uint32_t flags = 0, T = 0; int bits = 2;
+    // owned device buffers
+    uint32_t* dMeta = nullptr; uint8_t* dOwner = nullptr; uint64_t *dCofs = nullptr, *dTotals = nullptr; uint8_t* dContrib = nullptr;
+    uint64_t totals[kMaxRanks]; uint64_t strideBytes = 0;
+    ~ShardCtx() { for (void* p : { (void*)dMeta, (void*)dOwner, (void*)dCofs, (void*)dTotals, (void*)dContrib }) if (p) (void)hipFree(p); }
+};
+
 // host form of SetupWorkItems, used when the device setup reports a hash collision (never observed; 2^-64 class event)
 void setup_on_host(const ommCpuBakeInputDesc& d, uint32_t flags, const Texture& tex, std::vector<HostTri>& itemUv, std::vector<uint8_t>& itemLevel,
                    std::vector<uint8_t>& itemDegenerate, std::vector<int32_t>& triToItem, uint32_t& numDisabled)
@@ -344,7 +360,8 @@ void setup_on_host(const ommCpuBakeInputDesc& d, uint32_t flags, const Texture& 
 // caller's texCoords / indexBuffer / subdivisionLevels; `hostDesc` (may be null for device-resident callers) is the
 // same desc with host pointers, needed only by the serial fallbacks.
 ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInputs& din, const ommCpuBakeInputDesc* hostDesc,
-                    DeviceArena* arena, DeviceArena* statesArena, hipStream_t stream, EventTimer& et, DeviceResult& R, ommxBakeTimings& tm)
+                    DeviceArena* arena, DeviceArena* statesArena, hipStream_t stream, EventTimer& et, DeviceResult& R, ommxBakeTimings& tm,
+                    ShardCtx* sh = nullptr)
 {
     const Logger& L = baker.log;
     const uint32_t flags = (uint32_t)d.bakeFlags;
@@ -484,13 +501,20 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     // ---- ResampleCoarse + ResampleFine (bake_cpu_impl.cpp:715-1029) on the active items ----
     ItemArrays A; A.uv = dUv; A.degenerate = dDegen; A.stateOfs = dStateOfs; A.states = dStates; A.stateMask = dMask; A.knownCount = dKnown; A.fineCount = dFine;
     if (!HIP_OK(hipMemsetAsync(dFine, 0, 8, stream))) return L.failure("[Failure] - device memset failed");
+    // single GPU: every rank range is the whole level group
+    ShardBounds bounds; memset(&bounds, 0, sizeof bounds);
+    bounds.rank = sh ? sh->rank : 0; bounds.world = sh ? sh->world : 1;
+    for (int l = 0; l < kNumLevels; ++l) {
+        const uint64_t a = hc.activeStart[l], cnt = hc.activeStart[l + 1] - hc.activeStart[l];
+        for (uint32_t r = 0; r <= bounds.world; ++r) bounds.b[l][r] = (uint32_t)(a + cnt * r / bounds.world);
+    }
     for (int l = 0; l < kNumLevels; ++l)
-        launch_classify(P, A, dActiveIds + hc.activeStart[l], hc.activeStart[l + 1] - hc.activeStart[l], (uint32_t)l, stream);
+        launch_classify(P, A, dActiveIds + bounds.b[l][bounds.rank], bounds.b[l][bounds.rank + 1] - bounds.b[l][bounds.rank], (uint32_t)l, stream);
     const int e2 = et.mark();
     // ---- CalcDigest (bake_cpu_impl.cpp:1038-1040): active items here, uniform ones from the table in the tail ----
     if (!(flags & (1u << 3)))
         for (int l = 0; l < kNumLevels; ++l)
-            launch_digest(dStates, dStateOfs, dActiveIds + hc.activeStart[l], hc.activeStart[l + 1] - hc.activeStart[l], (uint32_t)l, (uint32_t)bits, dDigests, stream);
+            launch_digest(dStates, dStateOfs, dActiveIds + bounds.b[l][bounds.rank], bounds.b[l][bounds.rank + 1] - bounds.b[l][bounds.rank], (uint32_t)l, (uint32_t)bits, dDigests, stream);
     if (!HIP_OK(hipGetLastError())) return L.failure("[Failure] - kernel launch failed");
     const int e3 = et.mark();
 
@@ -503,6 +527,21 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     TailOutputs to; memset(&to, 0, sizeof to);
     to.special = dSpecial; to.rep = dRep; to.order = dOrder; to.dstOfs = dDstOfs; to.sizes = dSizes; to.itemValue = dItemValue;
     to.indexBuffer = dIndex; to.arrayHist = dArrayHist; to.indexHist = dIndexHist;
+    if (sh) { // sharded bake: hand the per-item metadata of this rank's share to the caller and stop here (ommxShardedBegin)
+        const uint32_t numActive = hc.activeStart[kNumLevels];
+        sh->bounds = bounds; sh->ti = ti; sh->to = to; sh->hc = hc; sh->dStates = dStates; sh->dActive = dActive; sh->dLevel = dLevel; sh->dScratch = dScratch;
+        sh->dStateOfs = dStateOfs; sh->dMask = dMask; sh->dActiveIds = dActiveIds; sh->dIndex = dIndex; sh->dArrayHist = dArrayHist; sh->dIndexHist = dIndexHist;
+        sh->scratchBytes = scratchBytes; sh->flags = flags; sh->T = T; sh->bits = bits;
+        ok = HIP_OK(hipMalloc((void**)&sh->dMeta, (size_t)(numActive ? numActive : 1) * 16)) && HIP_OK(hipMalloc((void**)&sh->dOwner, maxItems))
+          && HIP_OK(hipMalloc((void**)&sh->dCofs, (size_t)maxItems * 8)) && HIP_OK(hipMalloc((void**)&sh->dTotals, sizeof(uint64_t) * kMaxRanks));
+        if (!ok) return L.failure("[Failure] - out of device memory for the sharded bake");
+        launch_shard_pack_meta(bounds, dActiveIds, numActive, dMask, dKnown, dDigests, sh->dMeta, stream);
+        if (!HIP_OK(hipStreamSynchronize(stream))) return L.failure("[Failure] - sharded classification failed");
+        tm.setupMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.digestMs = et.ms(e2, e3);
+        tm.uniqueItems = U; tm.activeItems = numActive; tm.stateBytes = hc.stateBytes;
+        for (int l = 0; l < kNumLevels; ++l) tm.microTriangles += (uint64_t)hc.levelCount[l] << (2 * l);
+        return ommResult_SUCCESS;
+    }
     TailCounts counts;
     if (!HIP_OK(run_tail(ti, to, dScratch, scratchBytes, &counts, stream))) return L.failure("[Failure] - device tail failed");
     if (counts.arrayDataSize > 0xFFFFFFFFull) return ommResult_FAILURE; // bake_cpu_impl.cpp:1774-1775
@@ -877,6 +916,130 @@ OMM_MI355X_API ommResult ommxBakeDevice(ommBaker baker, const ommCpuBakeInputDes
     tm.totalMs = (float)(now_ms() - t0);
     { std::lock_guard<std::mutex> g(b->timingsMu); b->timings = tm; b->haveTimings = true; }
     *outResult = (ommxDeviceBakeResult)res;
+    return ommResult_SUCCESS;
+}
+
+// ---- multi-GPU sharded bake (include/omm_mi355x_ext.h) ----
+namespace {
+struct ShardedBake {
+    Allocator mem; Baker* baker = nullptr; BakeSession ses; ShardCtx ctx; ommxBakeTimings tm; double t0 = 0;
+    explicit ShardedBake(Baker& b) : baker(&b), ses(b) { memset(&tm, 0, sizeof tm); }
+};
+}
+
+OMM_MI355X_API ommResult ommxShardedBegin(ommBaker baker, const ommCpuBakeInputDesc* desc, uint32_t rank, uint32_t worldSize, ommxShardedBake* out)
+{
+    if (baker == 0) return ommResult_INVALID_ARGUMENT;
+    Baker* b = untag<Baker>(baker);
+    if (desc == 0 || out == 0) return b->log.invalid("input desc was not set");
+    if (tag_of(baker) != kCpuBaker) return b->log.invalid("Baker was not created as the right type");
+    if (worldSize == 0 || worldSize > (uint32_t)kMaxRanks || rank >= worldSize) return b->log.invalid("[Invalid Argument] - rank / worldSize out of range (at most 16 ranks)");
+    if (desc->texture == 0) return b->log.invalid("[Invalid Argument] - ommCpuBakeInputDesc has no texture set");
+    if (tag_of(desc->texture) == kTexture &&
+        ((unsigned)desc->runtimeSamplerDesc.addressingMode >= (unsigned)ommTextureAddressMode_MAX_NUM ||
+         (unsigned)desc->runtimeSamplerDesc.filter >= (unsigned)ommTextureFilterMode_MAX_NUM))
+        return ommResult_FAILURE;
+    ommResult r = validate_desc(*b, *desc);
+    if (r != ommResult_SUCCESS) return r;
+    r = scope_fences(*b, *desc, false);
+    if (r != ommResult_SUCCESS) return r;
+    ShardedBake* sb = b->mem.make<ShardedBake>(*b);
+    if (!sb) return ommResult_FAILURE;
+    sb->mem = b->mem; sb->t0 = now_ms();
+    if (!sb->ses.open()) { b->mem.destroy(sb); return b->log.failure("[Failure] - no usable HIP device (the MI355X baker has no CPU fallback)"); }
+    sb->ctx.rank = rank; sb->ctx.world = worldSize;
+    EventTimer et(sb->ses.stream);
+    DeviceResult unused;
+    DeviceInputs din; din.texCoords = desc->texCoords; din.indices = desc->indexBuffer; din.perTriLevels = desc->subdivisionLevels;
+    r = bake_core(*b, *desc, din, nullptr, sb->ses.arena, sb->ses.states, sb->ses.stream, et, unused, sb->tm, &sb->ctx);
+    if (r != ommResult_SUCCESS) { b->mem.destroy(sb); return r; }
+    *out = (ommxShardedBake)sb;
+    return ommResult_SUCCESS;
+}
+
+OMM_MI355X_API ommResult ommxShardedGetMeta(ommxShardedBake h, void** deviceWords, uint64_t* numWords)
+{
+    if (h == 0 || deviceWords == nullptr || numWords == nullptr) return ommResult_INVALID_ARGUMENT;
+    ShardedBake* sb = (ShardedBake*)h;
+    *deviceWords = sb->ctx.dMeta; *numWords = 4ull * sb->ctx.hc.activeStart[kNumLevels];
+    return ommResult_SUCCESS;
+}
+
+OMM_MI355X_API ommResult ommxShardedTail(ommxShardedBake h, void** contribution, uint64_t* contributionBytes, uint64_t* strideBytes)
+{
+    if (h == 0 || contribution == nullptr || contributionBytes == nullptr || strideBytes == nullptr) return ommResult_INVALID_ARGUMENT;
+    ShardedBake* sb = (ShardedBake*)h; ShardCtx& c = sb->ctx; const Logger& L = sb->baker->log; hipStream_t stream = sb->ses.stream;
+    const double t1 = now_ms();
+    const uint32_t numActive = c.hc.activeStart[kNumLevels];
+    // the caller has SUM-all-reduced the metadata words: every rank now sees every active item's mask / known count / digest
+    if (!HIP_OK(hipMemsetAsync(c.dOwner, 0xFF, c.ti.numItems ? c.ti.numItems : 1, stream))) return L.failure("[Failure] - device memset failed");
+    launch_shard_unpack_meta(c.bounds, c.dActiveIds, numActive, c.dMeta, c.dMask, (uint32_t*)c.ti.knownCount, c.ti.digests, c.dOwner, stream);
+    if (!HIP_OK(run_tail(c.ti, c.to, c.dScratch, c.scratchBytes, &c.counts, stream))) return L.failure("[Failure] - device tail failed");
+    if (c.counts.arrayDataSize > 0xFFFFFFFFull) return ommResult_FAILURE; // bake_cpu_impl.cpp:1774-1775
+    if (!HIP_OK(run_shard_layout(c.to.order, c.to.sizes, c.dActive, c.dOwner, c.counts.numOmms, c.world, c.dCofs, c.dTotals, c.totals, c.dScratch, c.scratchBytes, stream)))
+        return L.failure("[Failure] - sharded layout failed");
+    uint64_t mx = 0; for (uint32_t r = 0; r < c.world; ++r) mx = c.totals[r] > mx ? c.totals[r] : mx;
+    c.strideBytes = (mx + 255) & ~255ull; if (c.strideBytes == 0) c.strideBytes = 256;
+    if (!HIP_OK(hipMalloc((void**)&c.dContrib, (size_t)c.strideBytes))) return L.failure("[Failure] - out of device memory for the shard contribution");
+    launch_shard_gather(c.dStates, c.dStateOfs, c.dActive, c.dOwner, c.rank, c.to.order, c.dCofs, c.to.sizes, c.counts.numOmms, c.dContrib, stream);
+    if (!HIP_OK(hipStreamSynchronize(stream))) return L.failure("[Failure] - shard gather failed");
+    *contribution = c.dContrib; *contributionBytes = c.totals[c.rank]; *strideBytes = c.strideBytes;
+    sb->tm.tailMs = (float)(now_ms() - t1);
+    return ommResult_SUCCESS;
+}
+
+OMM_MI355X_API ommResult ommxShardedFinish(ommxShardedBake h, const void* gathered, ommxDeviceBakeResult* outResult)
+{
+    if (h == 0 || outResult == nullptr) return ommResult_INVALID_ARGUMENT;
+    ShardedBake* sb = (ShardedBake*)h; ShardCtx& c = sb->ctx; Baker* b = sb->baker; const Logger& L = b->log; hipStream_t stream = sb->ses.stream;
+    const double t1 = now_ms();
+    const uint32_t E = c.counts.numOmms, T = c.T;
+    if (E && gathered == nullptr) return L.invalid("[Invalid Argument] - gathered contributions missing");
+    DeviceBakeResult* res = b->mem.make<DeviceBakeResult>();
+    if (!res) return ommResult_FAILURE;
+    res->mem = b->mem; memset(&res->desc, 0, sizeof res->desc);
+    DeviceResult& R = res->R;
+    R.bits = c.bits; R.numDescs = E; R.arrayDataSize = E ? c.counts.arrayDataSize : 0; R.numTris = T;
+    bool ok = true;
+    if (E) {
+        ok = HIP_OK(hipMalloc((void**)&R.arrayData, (size_t)c.counts.arrayDataSize)) && HIP_OK(hipMalloc((void**)&R.descs, sizeof(ommCpuOpacityMicromapDesc) * (size_t)E));
+        if (ok) {
+            launch_shard_scatter((const uint8_t*)gathered, c.strideBytes, c.dActive, c.dOwner, c.dMask, c.dLevel, c.bits, c.to.order, c.dCofs, c.to.dstOfs, c.to.sizes, E, R.arrayData, stream);
+            launch_write_descs(c.to.order, c.to.dstOfs, c.dLevel, c.bits, E, R.descs, stream);
+        }
+    }
+    const bool allow8 = (c.flags & (1u << 6)) != 0, force32 = (c.flags & (1u << 2)) != 0;
+    int idxBytes = 4; R.indexFormat = ommIndexFormat_UINT_32;
+    if (allow8 && T <= 127 && !force32) { idxBytes = 1; R.indexFormat = ommIndexFormat_UINT_8; }
+    else if (T <= 32767 && !force32) { idxBytes = 2; R.indexFormat = ommIndexFormat_UINT_16; }
+    ok = ok && HIP_OK(hipMalloc(&R.index, (size_t)(T ? T : 1) * 4));
+    if (ok) launch_narrow_indices(c.dIndex, T, idxBytes, R.index, stream);
+    ok = ok && HIP_OK(hipMemcpyAsync(R.hist, c.dArrayHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
+    ok = ok && HIP_OK(hipMemcpyAsync(R.hist + kNumLevels, c.dIndexHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
+    ok = ok && HIP_OK(hipStreamSynchronize(stream));
+    if (!ok) { b->mem.destroy(res); return L.failure("[Failure] - could not materialise the merged bake result on the device"); }
+    uint32_t nAH = 0, nIH = 0;
+    for (uint32_t l = 0; l < (uint32_t)kNumLevels; ++l) {
+        if (R.hist[l]) { res->arrayHist[nAH].count = R.hist[l]; res->arrayHist[nAH].subdivisionLevel = (uint16_t)l; res->arrayHist[nAH].format = (uint16_t)R.bits; nAH++; }
+        if (R.hist[kNumLevels + l]) { res->indexHist[nIH].count = R.hist[kNumLevels + l]; res->indexHist[nIH].subdivisionLevel = (uint16_t)l; res->indexHist[nIH].format = (uint16_t)R.bits; nIH++; }
+    }
+    res->desc.arrayData = R.arrayData; res->desc.arrayDataSize = (uint32_t)R.arrayDataSize;
+    res->desc.descArray = R.descs; res->desc.descArrayCount = R.numDescs;
+    res->desc.descArrayHistogram = res->arrayHist; res->desc.descArrayHistogramCount = nAH;
+    res->desc.indexBuffer = R.index; res->desc.indexCount = R.numTris; res->desc.indexFormat = R.indexFormat;
+    res->desc.indexHistogram = res->indexHist; res->desc.indexHistogramCount = nIH;
+    sb->tm.gatherMs = (float)(now_ms() - t1); sb->tm.totalMs = (float)(now_ms() - sb->t0);
+    { std::lock_guard<std::mutex> g(b->timingsMu); b->timings = sb->tm; b->haveTimings = true; }
+    *outResult = (ommxDeviceBakeResult)res;
+    return ommResult_SUCCESS;
+}
+
+OMM_MI355X_API ommResult ommxShardedDestroy(ommxShardedBake h)
+{
+    if (h == 0) return ommResult_INVALID_ARGUMENT;
+    ShardedBake* sb = (ShardedBake*)h;
+    const Allocator mem = sb->mem;
+    mem.destroy(sb);
     return ommResult_SUCCESS;
 }
 

@@ -211,6 +211,158 @@ hipError_t run_prep(const uint32_t* itemIds, const uint8_t* active, const uint8_
     return hipGetLastError();
 }
 
+// ---- multi-GPU sharding: work items are partitioned over ranks, the tail is replicated ----
+// rank ranges of the per-level active lists: rank r owns positions [bounds[l][r], bounds[l][r+1]) of the compacted list
+__device__ __forceinline__ uint32_t owner_of_position(const ShardBounds& B, uint32_t p)
+{
+    uint32_t l = 0;
+    while (l + 1 < (uint32_t)kNumLevels && p >= B.b[l + 1][0]) ++l;
+    uint32_t r = 0;
+    while (r + 1 < B.world && p >= B.b[l][r + 1]) ++r;
+    return r;
+}
+
+// compact metadata of the active items for the cross-rank SUM all-reduce: [mask | known | digest lo | digest hi] x numActive,
+// non-zero only in the positions this rank classified
+__global__ __launch_bounds__(256) void shard_pack_meta(ShardBounds B, const uint32_t* __restrict__ activeIds, uint32_t numActive,
+                                                       const uint32_t* __restrict__ mask, const uint32_t* __restrict__ known,
+                                                       const uint64_t* __restrict__ digests, uint32_t* __restrict__ meta)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= numActive) return;
+    const bool mine = owner_of_position(B, p) == B.rank;
+    const uint32_t item = activeIds[p];
+    const uint64_t dg = mine ? digests[item] : 0ull;
+    meta[p] = mine ? mask[item] : 0u;
+    meta[numActive + p] = mine ? known[item] : 0u;
+    meta[2u * numActive + p] = (uint32_t)dg;
+    meta[3u * numActive + p] = (uint32_t)(dg >> 32);
+}
+
+__global__ __launch_bounds__(256) void shard_unpack_meta(ShardBounds B, const uint32_t* __restrict__ activeIds, uint32_t numActive,
+                                                         const uint32_t* __restrict__ meta, uint32_t* __restrict__ mask, uint32_t* __restrict__ known,
+                                                         uint64_t* __restrict__ digests, uint8_t* __restrict__ owner)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= numActive) return;
+    const uint32_t item = activeIds[p];
+    mask[item] = meta[p]; known[item] = meta[numActive + p];
+    digests[item] = (uint64_t)meta[2u * numActive + p] | ((uint64_t)meta[3u * numActive + p] << 32);
+    owner[item] = (uint8_t)owner_of_position(B, p);
+}
+
+void launch_shard_pack_meta(const ShardBounds& B, const uint32_t* activeIds, uint32_t numActive, const uint32_t* mask, const uint32_t* known,
+                            const uint64_t* digests, uint32_t* meta, hipStream_t stream)
+{
+    if (numActive) hipLaunchKernelGGL(shard_pack_meta, dim3((numActive + 255u) / 256u), dim3(256), 0, stream, B, activeIds, numActive, mask, known, digests, meta);
+}
+void launch_shard_unpack_meta(const ShardBounds& B, const uint32_t* activeIds, uint32_t numActive, const uint32_t* meta, uint32_t* mask, uint32_t* known,
+                              uint64_t* digests, uint8_t* owner, hipStream_t stream)
+{
+    if (numActive) hipLaunchKernelGGL(shard_unpack_meta, dim3((numActive + 255u) / 256u), dim3(256), 0, stream, B, activeIds, numActive, meta, mask, known, digests, owner);
+}
+
+// per-rank layout of the surviving blocks: block j (final order) of owner r sits at cofs[j] inside rank r's contribution
+__global__ __launch_bounds__(256) void shard_masked_sizes(const uint32_t* __restrict__ order, const uint32_t* __restrict__ sizes, const uint8_t* __restrict__ active,
+                                                          const uint8_t* __restrict__ owner, uint32_t numOmms, uint32_t r, uint64_t* __restrict__ out)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= numOmms) return;
+    const uint32_t item = order[j];
+    out[j] = (active[item] && owner[item] == r) ? (uint64_t)sizes[j] : 0ull;
+}
+__global__ __launch_bounds__(256) void shard_take_offsets(const uint32_t* __restrict__ order, const uint8_t* __restrict__ active, const uint8_t* __restrict__ owner,
+                                                          const uint64_t* __restrict__ masked, const uint64_t* __restrict__ scan, uint32_t numOmms, uint32_t r,
+                                                          uint64_t* __restrict__ cofs, uint64_t* __restrict__ totals)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= numOmms) return;
+    const uint32_t item = order[j];
+    if (active[item] && owner[item] == r) cofs[j] = scan[j];
+    if (j == numOmms - 1) totals[r] = scan[j] + masked[j];
+}
+
+hipError_t run_shard_layout(const uint32_t* order, const uint32_t* sizes, const uint8_t* active, const uint8_t* owner, uint32_t numOmms, uint32_t world,
+                            uint64_t* cofs, uint64_t* totalsDev, uint64_t* totalsHost, void* scratch, size_t scratchBytes, hipStream_t stream)
+{
+    for (uint32_t r = 0; r < world; ++r) totalsHost[r] = 0;
+    if (numOmms == 0) return hipSuccess;
+    if (scratchBytes < tail_scratch_bytes(numOmms, 0)) return hipErrorInvalidValue;
+    uint8_t* p = (uint8_t*)scratch;
+    const size_t n64 = (((size_t)numOmms + 1) * 8 + 255) / 256 * 256;
+    uint64_t* masked = (uint64_t*)p; p += n64; uint64_t* scan = (uint64_t*)p; p += n64;
+    void* cub = p; const size_t cubBytes = scratchBytes - (size_t)(p - (uint8_t*)scratch);
+    const dim3 grid((numOmms + 255u) / 256u), block(256);
+    for (uint32_t r = 0; r < world; ++r) {
+        hipLaunchKernelGGL(shard_masked_sizes, grid, block, 0, stream, order, sizes, active, owner, numOmms, r, masked);
+        size_t tb = cubBytes;
+        TAIL_CHECK(hipcub::DeviceScan::ExclusiveSum(cub, tb, masked, scan, (int)numOmms, stream));
+        hipLaunchKernelGGL(shard_take_offsets, grid, block, 0, stream, order, active, owner, masked, scan, numOmms, r, cofs, totalsDev);
+    }
+    TAIL_CHECK(hipMemcpyAsync(totalsHost, totalsDev, sizeof(uint64_t) * world, hipMemcpyDeviceToHost, stream));
+    return hipStreamSynchronize(stream);
+}
+
+// rank-local gather: this rank's surviving blocks, densely, in final order
+__global__ __launch_bounds__(256) void shard_gather_contribution(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs,
+                                                                 const uint8_t* __restrict__ active, const uint8_t* __restrict__ owner, uint32_t rank,
+                                                                 const uint32_t* __restrict__ order, const uint64_t* __restrict__ cofs,
+                                                                 const uint32_t* __restrict__ sizes, uint32_t numOmms, uint8_t* __restrict__ contrib)
+{
+    for (uint32_t j = blockIdx.x; j < numOmms; j += gridDim.x) {
+        const uint32_t item = order[j];
+        if (!active[item] || owner[item] != rank) continue;
+        const uint8_t* src = states + stateOfs[item];
+        uint8_t* dst = contrib + cofs[j];
+        const uint32_t n = sizes[j];
+        if (n >= 16u) { const uint4* s4 = (const uint4*)src; uint4* d4 = (uint4*)dst; for (uint32_t k = threadIdx.x; k < n / 16u; k += blockDim.x) d4[k] = s4[k]; }
+        else if (threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
+    }
+}
+
+// after the all-gather: place every rank's blocks at their final arrayData offsets (uniform items: constant pattern, computed locally)
+__global__ __launch_bounds__(256) void shard_scatter_contributions(const uint8_t* __restrict__ gathered, uint64_t strideBytes,
+                                                                   const uint8_t* __restrict__ active, const uint8_t* __restrict__ owner,
+                                                                   const uint32_t* __restrict__ stateMask, const uint8_t* __restrict__ level, int bits,
+                                                                   const uint32_t* __restrict__ order, const uint64_t* __restrict__ cofs,
+                                                                   const uint32_t* __restrict__ dstOfs, const uint32_t* __restrict__ sizes, uint32_t numOmms,
+                                                                   uint8_t* __restrict__ arrayData)
+{
+    for (uint32_t j = blockIdx.x; j < numOmms; j += gridDim.x) {
+        const uint32_t item = order[j];
+        uint8_t* dst = arrayData + dstOfs[j];
+        const uint32_t n = sizes[j];
+        if (!active[item]) {
+            const uint32_t st = (uint32_t)(31 - __clz((int)stateMask[item]));
+            uint32_t usedBits = (1u << (2u * level[item])) * (uint32_t)bits; if (usedBits > 8u) usedBits = 8u;
+            uint32_t pat = 0;
+            for (uint32_t b = 0; b < usedBits; b += (uint32_t)bits) pat |= st << b;
+            for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) dst[k] = (uint8_t)pat;
+            continue;
+        }
+        const uint8_t* src = gathered + (uint64_t)owner[item] * strideBytes + cofs[j];
+        if (n >= 16u && ((cofs[j] | strideBytes) & 15ull) == 0) { const uint4* s4 = (const uint4*)src; uint4* d4 = (uint4*)dst; for (uint32_t k = threadIdx.x; k < n / 16u; k += blockDim.x) d4[k] = s4[k]; }
+        else for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) dst[k] = src[k];
+    }
+}
+
+void launch_shard_gather(const uint8_t* states, const uint64_t* stateOfs, const uint8_t* active, const uint8_t* owner, uint32_t rank, const uint32_t* order,
+                         const uint64_t* cofs, const uint32_t* sizes, uint32_t numOmms, uint8_t* contrib, hipStream_t stream)
+{
+    if (numOmms == 0) return;
+    const uint32_t grid = numOmms < 262144u ? numOmms : 262144u;
+    hipLaunchKernelGGL(shard_gather_contribution, dim3(grid), dim3(256), 0, stream, states, stateOfs, active, owner, rank, order, cofs, sizes, numOmms, contrib);
+}
+void launch_shard_scatter(const uint8_t* gathered, uint64_t strideBytes, const uint8_t* active, const uint8_t* owner, const uint32_t* stateMask,
+                          const uint8_t* level, int bits, const uint32_t* order, const uint64_t* cofs, const uint32_t* dstOfs, const uint32_t* sizes,
+                          uint32_t numOmms, uint8_t* arrayData, hipStream_t stream)
+{
+    if (numOmms == 0) return;
+    const uint32_t grid = numOmms < 262144u ? numOmms : 262144u;
+    hipLaunchKernelGGL(shard_scatter_contributions, dim3(grid), dim3(256), 0, stream, gathered, strideBytes, active, owner, stateMask, level, bits, order, cofs,
+                       dstOfs, sizes, numOmms, arrayData);
+}
+
 // ---- scratch layout ----
 struct Scratch {
     uint64_t *keysA, *keysB, *sizes64, *ofs64;

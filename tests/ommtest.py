@@ -331,8 +331,93 @@ class Hip:
             assert self.rt.hipMemcpy(out.ctypes.data, ptr, nbytes, 2) == 0
         return out.view(dtype)
 
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        assert self.rt.hipMalloc(C.byref(p), max(int(nbytes), 16)) == 0
+        return p
+
+    def copy_dtod(self, dst, src, nbytes):
+        if nbytes:
+            assert self.rt.hipMemcpy(dst, src, nbytes, 3) == 0
+
+    def copy_htod(self, dst, arr):
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes:
+            assert self.rt.hipMemcpy(dst, arr.ctypes.data, arr.nbytes, 1) == 0
+
     def free(self, p):
         self.rt.hipFree(p)
+
+
+def device_result_to_host(lib, hip, out):
+    """host copy (BakeResult) of an ommxDeviceBakeResult; destroys the device result"""
+    lib.dll.ommxGetDeviceBakeResultDesc.argtypes = [C.c_void_p, C.POINTER(C.POINTER(BakeResultDesc))]
+    lib.dll.ommxDestroyDeviceBakeResult.argtypes = [C.c_void_p]
+    pd = C.POINTER(BakeResultDesc)()
+    assert lib.dll.ommxGetDeviceBakeResultDesc(out, C.byref(pd)) == SUCCESS
+    dev = pd.contents
+    isz = {IDX_U8: 1, IDX_U16: 2, IDX_U32: 4}[dev.indexFormat]
+    host_arrays = [hip.download(dev.arrayData, dev.arrayDataSize), hip.download(dev.descArray, 8 * dev.descArrayCount),
+                   hip.download(dev.indexBuffer, isz * dev.indexCount)]
+    hd = BakeResultDesc.from_buffer_copy(dev)
+    hd.arrayData = host_arrays[0].ctypes.data
+    hd.descArray = C.cast(host_arrays[1].ctypes.data, C.POINTER(MicromapDesc))
+    hd.indexBuffer = host_arrays[2].ctypes.data
+    res = BakeResult(hd)
+    assert lib.dll.ommxDestroyDeviceBakeResult(out) == SUCCESS
+    return res
+
+
+def bake_sharded_simulated(lib, hip, baker, desc, uv, ix, world, levels=None):
+    """All `world` ranks of a sharded bake inside ONE process on one GPU; the two collectives are emulated with host arithmetic
+    (sum of the metadata words, concatenation of the padded contributions).  Returns one BakeResult per rank."""
+    import omm_amd.sharded as sh
+    dll = sh.bind(lib.dll)
+    d_uv, d_ix = hip.upload(uv), hip.upload(ix)
+    d_lv = hip.upload(np.ascontiguousarray(levels, dtype=np.uint8)) if levels is not None else None
+    dd = BakeInputDesc.from_buffer_copy(desc)
+    dd.texCoords, dd.indexBuffer, dd.subdivisionLevels = d_uv, d_ix, d_lv
+    handles = []
+    for r in range(world):
+        h = C.c_void_p()
+        rc = dll.ommxShardedBegin(baker, C.byref(dd), r, world, C.byref(h))
+        assert rc == SUCCESS, rc
+        handles.append(h)
+    # all-reduce(SUM) of the metadata words
+    metas = []
+    for h in handles:
+        w, n = C.c_void_p(), C.c_uint64()
+        assert dll.ommxShardedGetMeta(h, C.byref(w), C.byref(n)) == SUCCESS
+        metas.append((w, n.value))
+    if metas[0][1]:
+        total = np.zeros(metas[0][1], np.uint32)
+        for w, n in metas:
+            total += hip.download(w, 4 * n, np.uint32)
+        for w, n in metas:
+            hip.copy_htod(w, total)
+    # tail + all-gather of the padded contributions
+    contribs = []
+    for h in handles:
+        c, nb, st = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        rc = dll.ommxShardedTail(h, C.byref(c), C.byref(nb), C.byref(st))
+        assert rc == SUCCESS, rc
+        contribs.append((c, nb.value, st.value))
+    stride = contribs[0][2]
+    assert all(c[2] == stride for c in contribs)
+    gathered = hip.alloc(stride * world)
+    for r, (c, nb, st) in enumerate(contribs):
+        hip.copy_dtod(C.c_void_p(gathered.value + r * stride), c, stride)
+    results = []
+    for h in handles:
+        out = C.c_void_p()
+        rc = dll.ommxShardedFinish(h, gathered, C.byref(out))
+        assert rc == SUCCESS, rc
+        results.append(device_result_to_host(lib, hip, out))
+        assert dll.ommxShardedDestroy(h) == SUCCESS
+    for p in (d_uv, d_ix, d_lv, gathered):
+        if p is not None:
+            hip.free(p)
+    return results
 
 
 def bake_device(lib, hip, baker, desc, uv, ix, levels=None):

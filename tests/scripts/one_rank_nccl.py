@@ -1,0 +1,25 @@
+# exercises the torch.distributed plumbing (device_tensor over raw pointers, nccl all_reduce / all_gather) with world_size 1
+import os, sys, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np, torch, torch.distributed as dist
+import ommtest as ot, omm_amd.sharded as sh
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+dist.init_process_group("nccl", rank=0, world_size=1)
+torch.cuda.set_device(0)
+a = torch.arange(16, dtype=torch.int32, device="cuda")
+v = sh.device_tensor(torch, a.data_ptr(), 16, torch.int32); v += 1
+assert int(a.sum()) == 136, a
+dist.all_reduce(v); torch.cuda.synchronize()
+g = torch.empty(16, dtype=torch.uint8, device="cuda"); dist.all_gather_into_tensor(g, torch.arange(16, dtype=torch.uint8, device="cuda"))
+prod = ot.Lib("product"); b = prod.create_baker()
+tex = ot.foliage_texture(5, 1024, 1024, feature=48); t = prod.create_texture(b, [tex], alpha_cutoff=0.5)
+uv, ix = ot.random_triangles(808, 5000, 0.02)
+d = ot.make_desc(t, uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+ref = prod.bake(b, d)
+duv = torch.from_numpy(uv).cuda(); dix = torch.from_numpy(ix.astype(np.int32)).cuda()
+dd = ot.BakeInputDesc.from_buffer_copy(d); dd.texCoords, dd.indexBuffer = duv.data_ptr(), dix.data_ptr()
+out = sh.sharded_bake(prod.dll, b, C.byref(dd), 0, 1, torch, dist)
+res = ot.device_result_to_host(prod, ot.Hip(), out)
+assert res.same_as(ref), res.diff(ref)
+print("one-rank nccl plumbing ok", len(res.descs))
+dist.destroy_process_group()
