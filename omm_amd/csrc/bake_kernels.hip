@@ -35,7 +35,6 @@ namespace ommx {
 //        3. states are packed LSB-first into 32-bit words (coalesced stores) and the tile's state mask is OR-reduced
 //           for the uniform-OMM ("special index") detection.
 // ------------------------------------------------------------------------------------------------
-constexpr int TILE = 1024;
 constexpr int BLOCK = 256;
 constexpr int GROUP = 64;
 
@@ -62,7 +61,7 @@ __global__ __launch_bounds__(256) void triage_items(ClassifyParams P, const floa
     if (P.useCoarse) {
         const float* t = uv + 6ull * i;
         const MicroTri whole = micro_triangle(t, 0u, 0u);
-        st = region_state(P, whole, item_max_abs(t), no_window());
+        st = region_state<ModeDynamic>(P, whole, item_max_abs(t), no_window());
     }
     stateMask[i] = st >= 0 ? (1u << st) : 0u;
     active[i] = st >= 0 ? 0 : 1;
@@ -93,8 +92,12 @@ constexpr int WIN = 32; // largest LDS texel window edge
 
 // SLICED: 4^level >= TILE, the tile is a slice of ONE work item (block-uniform item data, LDS texel/SAT window).
 // !SLICED: the tile holds TILE / 4^level whole items.
-template <bool FP32, bool SLICED>
-__global__ __launch_bounds__(BLOCK, 4) void classify_tiles(ClassifyParams P, ItemArrays A, const uint32_t* __restrict__ itemIds,
+#ifndef OMMX_CLASSIFY_WAVES
+#define OMMX_CLASSIFY_WAVES 5
+#endif
+// TILE micro-triangles per workgroup: 4096 for levels >= 6, 1024 below (a level-5 item is exactly one 1024-tile)
+template <bool FP32, bool SLICED, int TILE, class MD>
+__global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(ClassifyParams P, ItemArrays A, const uint32_t* __restrict__ itemIds,
                                                         uint32_t numItems, uint32_t level, uint64_t numTiles)
 {
     __shared__ uint8_t  s_state[TILE];
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(BLOCK, 4) void classify_tiles(ClassifyParams P, Ite
     __shared__ uint32_t s_mask, s_known;
     __shared__ float    s_wtex[SLICED ? WIN * WIN : 1];
     __shared__ uint32_t s_wsat[SLICED ? (WIN + 1) * (WIN + 1) : 1];
+    constexpr uint32_t TILE_LOG4 = TILE == 4096 ? 6u : 5u; // the tile is the level-(N - TILE_LOG4) sub-triangle of its item
 
     const uint32_t M = 1u << (2 * level);
     const uint32_t tid = threadIdx.x;
@@ -132,8 +136,8 @@ __global__ __launch_bounds__(BLOCK, 4) void classify_tiles(ClassifyParams P, Ite
         uMaxAbs = item_max_abs(uUv);
         uDegenerate = A.degenerate[uItem] != 0;
         // ---- LDS window: every texel / SAT entry this tile can touch (footprint of its level-(N-5) sub-triangle) ----
-        const MicroTri sub = micro_triangle(uUv, base >> 10, level - 5);
-        const TexRect r = region_rect(P, sub, uMaxAbs);
+        const MicroTri sub = micro_triangle(uUv, base / (uint32_t)TILE, level - TILE_LOG4);
+        const TexRect r = region_rect<MD>(P, sub, uMaxAbs);
         const int ww = r.ex - r.sx + 1, wh = r.ey - r.sy + 1;
         if (r.ok && ww <= WIN && wh <= WIN) {
             const DevMip& m0 = P.mips[0];
@@ -153,10 +157,10 @@ __global__ __launch_bounds__(BLOCK, 4) void classify_tiles(ClassifyParams P, Ite
         __syncthreads();
         // ---- phase 0: one query for the whole tile (lane 0 of wave 0) and one per 64-micro-triangle group (wave 1) ----
         if (coarse) {
-            if (tid == 0) s_tile = region_state(P, sub, uMaxAbs, W);
-            if (tid >= 64 && tid < 64 + TILE / GROUP) {
+            if (tid == 0) s_tile = region_state<MD>(P, sub, uMaxAbs, W);
+            if (tid >= 64 && tid < 64 + TILE / GROUP) { // (4096-tile: 64 groups = all of wave 1; 1024-tile: 16 of its lanes)
                 const uint32_t g = tid - 64;
-                s_group[g] = region_state(P, micro_triangle(uUv, (base >> 6) + g, level - 3), uMaxAbs, W);
+                s_group[g] = region_state<MD>(P, micro_triangle(uUv, (base >> 6) + g, level - 3), uMaxAbs, W);
             }
         } else if (tid < (uint32_t)(TILE / GROUP)) s_group[tid] = -1;
         __syncthreads();
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(BLOCK, 4) void classify_tiles(ClassifyParams P, Ite
             const uint32_t i0 = tid * GROUP;
             if (coarse && level >= 3 && i0 < count) { // 64 consecutive micro-triangles = one level-(N-3) sub-triangle of one item
                 const float* uvp = A.uv + 6ull * itemIds[firstItem + (i0 >> (2 * level))];
-                gs = region_state(P, micro_triangle(uvp, (i0 & (M - 1u)) >> 6, level - 3), item_max_abs(uvp), W);
+                gs = region_state<MD>(P, micro_triangle(uvp, (i0 & (M - 1u)) >> 6, level - 3), item_max_abs(uvp), W);
             }
             s_group[tid] = gs;
         }
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(BLOCK, 4) void classify_tiles(ClassifyParams P, Ite
                 if (coarse) {
                     const uint32_t u = SLICED ? base + i : (i & (M - 1u));
                     const float* uvp = SLICED ? uUv : A.uv + 6ull * itemIds[firstItem + (i >> (2 * level))];
-                    st = coarse_state(P, micro_triangle(uvp, u, level), W);
+                    st = coarse_state<MD>(P, micro_triangle(uvp, u, level), W);
                 }
                 // the reference's fine pass re-classifies everything still "UnknownOpaque" (bake_cpu_impl.cpp:861)
                 unresolved = (st < 0) || (st == 3) || !P.filterLinear;
@@ -209,10 +213,10 @@ __global__ __launch_bounds__(BLOCK, 4) void classify_tiles(ClassifyParams P, Ite
             const uint32_t i = s_queue[q];
             const uint32_t u = SLICED ? base + i : (i & (M - 1u));
             if (SLICED) {
-                s_state[i] = (uint8_t)fine_state<FP32>(P, micro_triangle(uUv, u, level), uDegenerate, W);
+                s_state[i] = (uint8_t)fine_state<FP32, MD>(P, micro_triangle(uUv, u, level), uDegenerate, W);
             } else {
                 const uint32_t item = itemIds[firstItem + (i >> (2 * level))];
-                s_state[i] = (uint8_t)fine_state<FP32>(P, micro_triangle(A.uv + 6ull * item, u, level), A.degenerate[item] != 0, W);
+                s_state[i] = (uint8_t)fine_state<FP32, MD>(P, micro_triangle(A.uv + 6ull * item, u, level), A.degenerate[item] != 0, W);
             }
         }
         __syncthreads();
@@ -287,22 +291,35 @@ __global__ __launch_bounds__(BLOCK, 4) void classify_tiles(ClassifyParams P, Ite
     }
 }
 
-void launch_classify(const ClassifyParams& P, const ItemArrays& A, const uint32_t* itemIds, uint32_t numItems, uint32_t level, hipStream_t stream)
+template <bool FP32, class MD>
+static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, const uint32_t* itemIds, uint32_t numItems, uint32_t level, hipStream_t stream)
 {
-    if (numItems == 0) return;
     const uint64_t M = 1ull << (2 * level);
-    const bool sliced = M >= (uint64_t)TILE;
-    const uint64_t tiles = sliced ? (uint64_t)numItems * (M / TILE) : ((uint64_t)numItems * M + TILE - 1) / TILE;
+    const uint32_t tileSize = level >= 6 ? 4096u : 1024u;
+    const bool sliced = M >= (uint64_t)tileSize;
+    const uint64_t tiles = sliced ? (uint64_t)numItems * (M / tileSize) : ((uint64_t)numItems * M + tileSize - 1) / tileSize;
     if (tiles > 0xFFFFFFFFull) return; // cannot happen: the packed states of such a level group would not fit in HBM
     const uint32_t gx = tiles < (1u << 20) ? (uint32_t)tiles : (1u << 20);
     const uint32_t gy = (uint32_t)((tiles + gx - 1) / gx);
     const dim3 grid(gx, gy), block(BLOCK);
+    if (level >= 6)  hipLaunchKernelGGL((classify_tiles<FP32, true, 4096, MD>), grid, block, 0, stream, P, A, itemIds, numItems, level, tiles);
+    else if (sliced) hipLaunchKernelGGL((classify_tiles<FP32, true, 1024, MD>), grid, block, 0, stream, P, A, itemIds, numItems, level, tiles);
+    else             hipLaunchKernelGGL((classify_tiles<FP32, false, 1024, MD>), grid, block, 0, stream, P, A, itemIds, numItems, level, tiles);
+}
+
+void launch_classify(const ClassifyParams& P, const ItemArrays& A, const uint32_t* itemIds, uint32_t numItems, uint32_t level, hipStream_t stream)
+{
+    if (numItems == 0) return;
+    // the two address-mode/pow2 pairs that real assets use get their own instantiation (the reference has one per pair); the rest is dynamic
+    const bool wrapP2 = P.addrMode == 0 && P.pow2Dispatch, clampP2 = P.addrMode == 2 && P.pow2Dispatch;
     if (P.texIsFp32) {
-        if (sliced) hipLaunchKernelGGL((classify_tiles<true, true>), grid, block, 0, stream, P, A, itemIds, numItems, level, tiles);
-        else        hipLaunchKernelGGL((classify_tiles<true, false>), grid, block, 0, stream, P, A, itemIds, numItems, level, tiles);
+        if (wrapP2) launch_classify_md<true, ModeStatic<0, 1>>(P, A, itemIds, numItems, level, stream);
+        else if (clampP2) launch_classify_md<true, ModeStatic<2, 1>>(P, A, itemIds, numItems, level, stream);
+        else launch_classify_md<true, ModeDynamic>(P, A, itemIds, numItems, level, stream);
     } else {
-        if (sliced) hipLaunchKernelGGL((classify_tiles<false, true>), grid, block, 0, stream, P, A, itemIds, numItems, level, tiles);
-        else        hipLaunchKernelGGL((classify_tiles<false, false>), grid, block, 0, stream, P, A, itemIds, numItems, level, tiles);
+        if (wrapP2) launch_classify_md<false, ModeStatic<0, 1>>(P, A, itemIds, numItems, level, stream);
+        else if (clampP2) launch_classify_md<false, ModeStatic<2, 1>>(P, A, itemIds, numItems, level, stream);
+        else launch_classify_md<false, ModeDynamic>(P, A, itemIds, numItems, level, stream);
     }
 }
 

@@ -91,6 +91,17 @@ __device__ __forceinline__ MicroTri micro_triangle(const float* __restrict__ tri
     return t;
 }
 
+// Address-mode policy: the reference instantiates its kernels per (address mode, pow2) pair (bake_cpu_impl.cpp:128-228);
+// ModeStatic<> does the same for the common pairs so the switch in tex_coord() folds away, ModeDynamic reads the desc.
+struct ModeDynamic {
+    __device__ static __forceinline__ int addr(const ClassifyParams& P) { return P.addrMode; }
+    __device__ static __forceinline__ int pow2(const ClassifyParams& P) { return P.pow2Dispatch; }
+};
+template <int AM, int P2> struct ModeStatic {
+    __device__ static __forceinline__ int addr(const ClassifyParams&) { return AM; }
+    __device__ static __forceinline__ int pow2(const ClassifyParams&) { return P2; }
+};
+
 // ---- texture addressing (util/texture.h:34-91) ----
 __device__ __forceinline__ int tex_coord(int mode, int pow2, int x, int size, int sizeLog2)
 {
@@ -170,14 +181,14 @@ __device__ __forceinline__ uint32_t sat_sum(const DevMip& m, int sx, int sy, int
 
 // texture_impl.cpp:261-278 (centre vote).  Border texels take borderAlpha (the reference reads out of
 // bounds there -- documented fence).
-template <bool FP32>
+template <bool FP32, class MD>
 __device__ __forceinline__ float bilinear(const ClassifyParams& P, const DevMip& m, V2 p, const TexWindow& W)
 {
     const float px = p.x * m.fw - 0.5f, py = p.y * m.fh - 0.5f;
     const float fx = __builtin_floorf(px), fy = __builtin_floorf(py);
     const int ix = cvt_trunc_x86(fx), iy = cvt_trunc_x86(fy);
-    const int x0 = tex_coord(P.addrMode, m.pow2, ix, m.w, m.log2w), y0 = tex_coord(P.addrMode, m.pow2, iy, m.h, m.log2h);
-    const int x1 = tex_coord(P.addrMode, m.pow2, ix + 1, m.w, m.log2w), y1 = tex_coord(P.addrMode, m.pow2, iy + 1, m.h, m.log2h);
+    const int x0 = tex_coord(MD::addr(P), m.pow2, ix, m.w, m.log2w), y0 = tex_coord(MD::addr(P), m.pow2, iy, m.h, m.log2h);
+    const int x1 = tex_coord(MD::addr(P), m.pow2, ix + 1, m.w, m.log2w), y1 = tex_coord(MD::addr(P), m.pow2, iy + 1, m.h, m.log2h);
     const float a = load_texel_border<FP32>(m, x0, y0, P.borderAlpha, W);
     const float b = load_texel_border<FP32>(m, x0, y1, P.borderAlpha, W);
     const float c = load_texel_border<FP32>(m, x1, y0, P.borderAlpha, W);
@@ -224,8 +235,8 @@ __device__ __forceinline__ bool in_unit_square(float x, float y) { return x >= 0
 __device__ __forceinline__ bool edge_crosses_level_curve(V2 a0, V2 a1, float ha, float hb, float hc, float hd)
 {
     if (a0.x > a1.x) { V2 t = a0; a0 = a1; a1 = t; }
-    const float len = vlen(a1.x - a0.x, a1.y - a0.y);
-#define ON_EDGE(X, Y) near_zero(vlen((X) - a0.x, (Y) - a0.y) + vlen((X) - a1.x, (Y) - a1.y) - len, 1e-5f)
+    // Edge::_length (bake_kernels_cpu.h:115-133) is only consumed by IsPointOnEdge: evaluated lazily, same value
+#define ON_EDGE(X, Y) near_zero(vlen((X) - a0.x, (Y) - a0.y) + vlen((X) - a1.x, (Y) - a1.y) - vlen(a1.x - a0.x, a1.y - a0.y), 1e-5f)
     const float kd = a1.x - a0.x;
     if (near_zero(kd, 1e-6f)) {
         const float x = a0.x;
@@ -261,15 +272,15 @@ __device__ __forceinline__ bool edge_crosses_level_curve(V2 a0, V2 a1, float ha,
 }
 
 // bake_kernels_cpu.h:241-399 : one texel of the bilinear footprint grid.  Adds to (above, below).
-template <bool FP32, bool DEGENERATE>
+template <bool FP32, bool DEGENERATE, class MD>
 __device__ __forceinline__ void level_line_texel(const ClassifyParams& P, const DevMip& m, const MicroTri& t, int px, int py,
                                                  uint32_t& above, uint32_t& below, const TexWindow& W)
 {
     const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
-    const int x0 = tex_coord(P.addrMode, P.pow2Dispatch, px, m.w, m.log2w), y0 = tex_coord(P.addrMode, P.pow2Dispatch, py, m.h, m.log2h);
-    const int x1 = tex_coord(P.addrMode, P.pow2Dispatch, px + 1, m.w, m.log2w), y1 = tex_coord(P.addrMode, P.pow2Dispatch, py + 1, m.h, m.log2h);
+    const int x0 = tex_coord(MD::addr(P), MD::pow2(P), px, m.w, m.log2w), y0 = tex_coord(MD::addr(P), MD::pow2(P), py, m.h, m.log2h);
+    const int x1 = tex_coord(MD::addr(P), MD::pow2(P), px + 1, m.w, m.log2w), y1 = tex_coord(MD::addr(P), MD::pow2(P), py + 1, m.h, m.log2h);
     float gx, gy, gz, gw; // 00, 01, 11, 10
-    if (P.addrMode == 3) {
+    if (MD::addr(P) == 3) {
         gx = load_texel_border<FP32>(m, x0, y0, P.borderAlpha, W); gy = load_texel_border<FP32>(m, x0, y1, P.borderAlpha, W);
         gz = load_texel_border<FP32>(m, x1, y1, P.borderAlpha, W); gw = load_texel_border<FP32>(m, x1, y0, P.borderAlpha, W);
     } else {
@@ -314,11 +325,11 @@ __device__ __forceinline__ void level_line_texel(const ClassifyParams& P, const 
 }
 
 // bake_cpu_impl.cpp:994-1009
-template <bool FP32>
+template <bool FP32, class MD>
 __device__ __forceinline__ void nearest_texel(const ClassifyParams& P, const DevMip& m, int px, int py, uint32_t& above, uint32_t& below, const TexWindow& W)
 {
-    const int cx = tex_coord(P.addrMode, P.pow2Dispatch, px, m.w, m.log2w), cy = tex_coord(P.addrMode, P.pow2Dispatch, py, m.h, m.log2h);
-    const bool border = P.addrMode == 3 && (cx == kTexCoordBorder || cy == kTexCoordBorder);
+    const int cx = tex_coord(MD::addr(P), MD::pow2(P), px, m.w, m.log2w), cy = tex_coord(MD::addr(P), MD::pow2(P), py, m.h, m.log2h);
+    const bool border = MD::addr(P) == 3 && (cx == kTexCoordBorder || cy == kTexCoordBorder);
     const float alpha = border ? P.borderAlpha : load_texel<FP32>(m, cx, cy, W);
     if (P.cutoff < alpha) above++; else below++;
 }
@@ -342,7 +353,7 @@ __device__ __forceinline__ float eval_cons(const EdgeEq& e, float sx, float sy)
 }
 
 // KIND: 0 = level-line (linear filter), 1 = nearest vote
-template <bool FP32, int KIND>
+template <bool FP32, int KIND, class MD>
 __device__ __forceinline__ void raster_micro_triangle(const ClassifyParams& P, const DevMip& m, const MicroTri& t, float off,
                                                       uint32_t& above, uint32_t& below, const TexWindow& W)
 {
@@ -368,8 +379,8 @@ __device__ __forceinline__ void raster_micro_triangle(const ClassifyParams& P, c
             const float sx = (float)x, sy = (float)y;
             const bool inside = eval_cons(e0, sx, sy) < 0.f && eval_cons(e1, sx, sy) < 0.f && eval_cons(e2, sx, sy) < 0.f;
             if (inside) {
-                if (KIND == 0) level_line_texel<FP32, false>(P, m, t, x, y, above, below, W);
-                else nearest_texel<FP32>(P, m, x, y, above, below, W);
+                if (KIND == 0) level_line_texel<FP32, false, MD>(P, m, t, x, y, above, below, W);
+                else nearest_texel<FP32, MD>(P, m, x, y, above, below, W);
                 if (!countsMatter && above != 0 && below != 0) return;
                 wasInside = true;
             } else if (wasInside) break;
@@ -378,7 +389,7 @@ __device__ __forceinline__ void raster_micro_triangle(const ClassifyParams& P, c
 }
 
 // conservative line walk for degenerate work items (util/cpu_raster.h:486-555)
-template <bool FP32>
+template <bool FP32, class MD>
 __device__ __forceinline__ void raster_micro_segment(const ClassifyParams& P, const DevMip& m, const MicroTri& t,
                                                      uint32_t& above, uint32_t& below, const TexWindow& W)
 {
@@ -396,14 +407,14 @@ __device__ __forceinline__ void raster_micro_segment(const ClassifyParams& P, co
     float tMaxX = inf, tMaxY = inf;
     if (stepX != 0) tMaxX = (((float)x + (stepX > 0 ? 1.f : 0.f)) - p0.x) / dx;
     if (stepY != 0) tMaxY = (((float)y + (stepY > 0 ? 1.f : 0.f)) - p0.y) / dy;
-    if (stepX == 0 && stepY == 0) { level_line_texel<FP32, true>(P, m, t, x, y, above, below, W); return; }
+    if (stepX == 0 && stepY == 0) { level_line_texel<FP32, true, MD>(P, m, t, x, y, above, below, W); return; }
     const int yMin = cvt_trunc_x86(std_min(__builtin_floorf(p0.y), __builtin_floorf(p1.y)));
     const int yMax = cvt_trunc_x86(std_max(__builtin_ceilf(p0.y), __builtin_ceilf(p1.y)));
     const int xMin = cvt_trunc_x86(std_min(__builtin_floorf(p0.x), __builtin_floorf(p1.x)));
     const int xMax = cvt_trunc_x86(std_max(__builtin_ceilf(p0.x), __builtin_ceilf(p1.x)));
     const bool countsMatter = P.promotion == 0;
     while (x >= xMin && x <= xMax && y >= yMin && y <= yMax) {
-        level_line_texel<FP32, true>(P, m, t, x, y, above, below, W);
+        level_line_texel<FP32, true, MD>(P, m, t, x, y, above, below, W);
         if (!countsMatter && above != 0 && below != 0) return;
         if (tMaxX < tMaxY) { x += stepX; tMaxX += tDeltaX; }
         else { y += stepY; tMaxY += tDeltaY; }
@@ -412,16 +423,17 @@ __device__ __forceinline__ void raster_micro_segment(const ClassifyParams& P, co
 
 // ---- coarse pass: summed-area-table test of one micro-triangle (bake_cpu_impl.cpp:749-801) ----
 // returns -1 when the micro-triangle stays unresolved
+template <class MD>
 __device__ __forceinline__ int coarse_state(const ClassifyParams& P, const MicroTri& t, const TexWindow& W)
 {
     const DevMip& m = P.mips[0];
     if (cvt_trunc_x86(t.lo.x) != cvt_trunc_x86(t.hi.x) || cvt_trunc_x86(t.lo.y) != cvt_trunc_x86(t.hi.y)) return -1;
     const float fsx = t.lo.x * m.fw - 0.5f, fsy = t.lo.y * m.fh - 0.5f;
     const float fex = t.hi.x * m.fw - 0.5f, fey = t.hi.y * m.fh - 0.5f;
-    const int sx = tex_coord(P.addrMode, P.pow2Dispatch, cvt_trunc_x86(__builtin_floorf(fsx)), m.w, m.log2w);
-    const int sy = tex_coord(P.addrMode, P.pow2Dispatch, cvt_trunc_x86(__builtin_floorf(fsy)), m.h, m.log2h);
-    const int ex = tex_coord(P.addrMode, P.pow2Dispatch, cvt_trunc_x86(__builtin_floorf(fex)) + 1, m.w, m.log2w);
-    const int ey = tex_coord(P.addrMode, P.pow2Dispatch, cvt_trunc_x86(__builtin_floorf(fey)) + 1, m.h, m.log2h);
+    const int sx = tex_coord(MD::addr(P), MD::pow2(P), cvt_trunc_x86(__builtin_floorf(fsx)), m.w, m.log2w);
+    const int sy = tex_coord(MD::addr(P), MD::pow2(P), cvt_trunc_x86(__builtin_floorf(fsy)), m.h, m.log2h);
+    const int ex = tex_coord(MD::addr(P), MD::pow2(P), cvt_trunc_x86(__builtin_floorf(fex)) + 1, m.w, m.log2w);
+    const int ey = tex_coord(MD::addr(P), MD::pow2(P), cvt_trunc_x86(__builtin_floorf(fey)) + 1, m.h, m.log2h);
     if (ex < sx || ey < sy) return -1;
     if (!(sx >= 0 && sy >= 0 && sx < m.w && sy < m.h)) return -1;
     if (!(ex >= 0 && ey >= 0 && ex < m.w && ey < m.h)) return -1;
@@ -444,6 +456,7 @@ struct TexRect { int sx, sy, ex, ey; bool ok; };
 
 // addressed texel rectangle that contains the coarse-pass rectangle of every descendant of `sub`; ok == false when that
 // cannot be guaranteed (huge coordinates, UV-tile crossing, address-mode seam)
+template <class MD>
 __device__ __forceinline__ TexRect region_rect(const ClassifyParams& P, const MicroTri& sub, float maxAbs)
 {
     const DevMip& m = P.mips[0];
@@ -455,9 +468,9 @@ __device__ __forceinline__ TexRect region_rect(const ClassifyParams& P, const Mi
     const int X0 = cvt_trunc_x86(__builtin_floorf(lx * m.fw - 0.5f)), Y0 = cvt_trunc_x86(__builtin_floorf(ly * m.fh - 0.5f));
     const int X1 = cvt_trunc_x86(__builtin_floorf(hx * m.fw - 0.5f)) + 1, Y1 = cvt_trunc_x86(__builtin_floorf(hy * m.fh - 0.5f)) + 1;
     if (X1 - X0 >= m.w || Y1 - Y0 >= m.h) return r;
-    if (P.addrMode == 0) { // Wrap: any single period is fine as long as the rectangle does not cross the seam
-        r.sx = tex_coord(0, P.pow2Dispatch, X0, m.w, m.log2w); r.ex = tex_coord(0, P.pow2Dispatch, X1, m.w, m.log2w);
-        r.sy = tex_coord(0, P.pow2Dispatch, Y0, m.h, m.log2h); r.ey = tex_coord(0, P.pow2Dispatch, Y1, m.h, m.log2h);
+    if (MD::addr(P) == 0) { // Wrap: any single period is fine as long as the rectangle does not cross the seam
+        r.sx = tex_coord(0, MD::pow2(P), X0, m.w, m.log2w); r.ex = tex_coord(0, MD::pow2(P), X1, m.w, m.log2w);
+        r.sy = tex_coord(0, MD::pow2(P), Y0, m.h, m.log2h); r.ey = tex_coord(0, MD::pow2(P), Y1, m.h, m.log2h);
         if (r.ex - r.sx != X1 - X0 || r.ey - r.sy != Y1 - Y0) return r;
     } else {               // other modes: only the untouched interior [0,W) x [0,H)
         if (X0 < 0 || Y0 < 0 || X1 >= m.w || Y1 >= m.h) return r;
@@ -467,9 +480,10 @@ __device__ __forceinline__ TexRect region_rect(const ClassifyParams& P, const Mi
     return r;
 }
 
+template <class MD>
 __device__ __forceinline__ int region_state(const ClassifyParams& P, const MicroTri& sub, float maxAbs, const TexWindow& W)
 {
-    const TexRect r = region_rect(P, sub, maxAbs);
+    const TexRect r = region_rect<MD>(P, sub, maxAbs);
     if (!r.ok) return -1;
     const uint32_t area = (uint32_t)((r.ex - r.sx + 1) * (r.ey - r.sy + 1));
     const uint32_t sa = sat_sum(P.mips[0], r.sx, r.sy, r.ex, r.ey, W);
@@ -479,18 +493,18 @@ __device__ __forceinline__ int region_state(const ClassifyParams& P, const Micro
 }
 
 // ---- fine pass for one micro-triangle (bake_cpu_impl.cpp:859-914 linear, :983-1022 nearest) ----
-template <bool FP32>
+template <bool FP32, class MD>
 __device__ __forceinline__ int fine_state(const ClassifyParams& P, const MicroTri& t, bool degenerate, const TexWindow& W)
 {
     uint32_t above = 0, below = 0;
     for (int mip = 0; mip < P.mipCount; ++mip) {
         const DevMip& m = P.mips[mip];
         if (P.filterLinear) {
-            if (P.cutoff < bilinear<FP32>(P, m, t.p0, W)) above++; else below++;
-            if (!degenerate) raster_micro_triangle<FP32, 0>(P, m, t, -0.5f, above, below, W);
-            else raster_micro_segment<FP32>(P, m, t, above, below, W);
+            if (P.cutoff < bilinear<FP32, MD>(P, m, t.p0, W)) above++; else below++;
+            if (!degenerate) raster_micro_triangle<FP32, 0, MD>(P, m, t, -0.5f, above, below, W);
+            else raster_micro_segment<FP32, MD>(P, m, t, above, below, W);
         } else {
-            raster_micro_triangle<FP32, 1>(P, m, t, 0.f, above, below, W);
+            raster_micro_triangle<FP32, 1, MD>(P, m, t, 0.f, above, below, W);
         }
         if (state_is_unknown(state_from_coverage(P, above, below))) break;
     }

@@ -7,6 +7,7 @@
 #include "../../include/omm_mi355x_ext.h"
 #include "bake_types.h"
 #include "bake_kernels.h"
+#include "host_tail.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -330,6 +331,9 @@ struct ShardCtx {
     ~ShardCtx() { for (void* p : { (void*)dMeta, (void*)dOwner, (void*)dCofs, (void*)dTotals, (void*)dContrib }) if (p) (void)hipFree(p); }
 };
 
+// opt-in lossy reducers (near-duplicate merge, maxArrayDataSize): classification on the device, serial tail on the host
+struct HostTailRequest { std::vector<HostItem> items; };
+
 // host form of SetupWorkItems, used when the device setup reports a hash collision (never observed; 2^-64 class event)
 void setup_on_host(const ommCpuBakeInputDesc& d, uint32_t flags, const Texture& tex, std::vector<HostTri>& itemUv, std::vector<uint8_t>& itemLevel,
                    std::vector<uint8_t>& itemDegenerate, std::vector<int32_t>& triToItem, uint32_t& numDisabled)
@@ -361,7 +365,7 @@ void setup_on_host(const ommCpuBakeInputDesc& d, uint32_t flags, const Texture& 
 // same desc with host pointers, needed only by the serial fallbacks.
 ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInputs& din, const ommCpuBakeInputDesc* hostDesc,
                     DeviceArena* arena, DeviceArena* statesArena, hipStream_t stream, EventTimer& et, DeviceResult& R, ommxBakeTimings& tm,
-                    ShardCtx* sh = nullptr)
+                    ShardCtx* sh = nullptr, HostTailRequest* ht = nullptr)
 {
     const Logger& L = baker.log;
     const uint32_t flags = (uint32_t)d.bakeFlags;
@@ -511,6 +515,36 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     for (int l = 0; l < kNumLevels; ++l)
         launch_classify(P, A, dActiveIds + bounds.b[l][bounds.rank], bounds.b[l][bounds.rank + 1] - bounds.b[l][bounds.rank], (uint32_t)l, stream);
     const int e2 = et.mark();
+    if (ht) { // bring the per-micro-triangle states to the host for the serial tail (host_tail.cpp)
+        std::vector<float> hUv((size_t)U * 6); std::vector<uint8_t> hLevel(U), hActive(U), hStates((size_t)hc.stateBytes);
+        std::vector<uint32_t> hMask(U); std::vector<uint64_t> hOfs(U); std::vector<int32_t> hTri(T);
+        ok = true;
+        if (U) {
+            ok = HIP_OK(hipMemcpyAsync(hUv.data(), dUv, (size_t)U * 24, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipMemcpyAsync(hLevel.data(), dLevel, U, hipMemcpyDeviceToHost, stream))
+              && HIP_OK(hipMemcpyAsync(hActive.data(), dActive, U, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipMemcpyAsync(hMask.data(), dMask, (size_t)U * 4, hipMemcpyDeviceToHost, stream))
+              && HIP_OK(hipMemcpyAsync(hOfs.data(), dStateOfs, (size_t)U * 8, hipMemcpyDeviceToHost, stream));
+        }
+        if (ok && hc.stateBytes) ok = HIP_OK(hipMemcpyAsync(hStates.data(), dStates, (size_t)hc.stateBytes, hipMemcpyDeviceToHost, stream));
+        if (ok && T) ok = HIP_OK(hipMemcpyAsync(hTri.data(), dTriToItem, (size_t)T * 4, hipMemcpyDeviceToHost, stream));
+        ok = ok && HIP_OK(hipStreamSynchronize(stream));
+        if (!ok) return L.failure("[Failure] - device to host transfer of the micro-triangle states failed");
+        ht->items.resize(U);
+        for (uint32_t i = 0; i < U; ++i) {
+            HostItem& it = ht->items[i];
+            it.level = hLevel[i]; it.format = bits; memcpy(it.uv, &hUv[(size_t)i * 6], 24);
+            const size_t n = (size_t)1 << (2 * it.level);
+            it.st.resize(n);
+            if (!hActive[i]) { uint32_t st = 0; while (!((hMask[i] >> st) & 1u) && st < 3) ++st; memset(it.st.data(), (int)st, n); }
+            else {
+                const uint8_t* p = hStates.data() + hOfs[i];
+                if (bits == 2) for (size_t u = 0; u < n; ++u) it.st[u] = (p[u >> 2] >> ((u & 3) << 1)) & 3u;
+                else for (size_t u = 0; u < n; ++u) it.st[u] = (p[u >> 3] >> (u & 7)) & 1u;
+            }
+        }
+        for (uint32_t t = 0; t < T; ++t) if (hTri[t] >= 0) ht->items[(size_t)hTri[t]].prims.push_back(t);
+        tm.setupMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.uniqueItems = U;
+        return ommResult_SUCCESS;
+    }
     // ---- CalcDigest (bake_cpu_impl.cpp:1038-1040): active items here, uniform ones from the table in the tail ----
     if (!(flags & (1u << 3)))
         for (int l = 0; l < kNumLevels; ++l)
@@ -579,14 +613,14 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     return ommResult_SUCCESS;
 }
 
+inline bool wants_host_tail(const ommCpuBakeInputDesc& d) { return ((uint32_t)d.bakeFlags & ((1u << 4) | (1u << 10))) != 0 || d.maxArrayDataSize != 0xFFFFFFFFu; }
+
 ommResult scope_fences(const Baker& baker, const ommCpuBakeInputDesc& d, bool formatsOnHost)
 {
     const Logger& L = baker.log;
     const uint32_t flags = (uint32_t)d.bakeFlags;
-    if ((flags & ((1u << 4) | (1u << 10))) != 0)
-        { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - near-duplicate merging (EnableNearDuplicateDetection) is not available in the MI355X baker yet"); return ommResult_NOT_IMPLEMENTED; }
-    if (d.maxArrayDataSize != 0xFFFFFFFFu)
-        { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - maxArrayDataSize budgets are not available in the MI355X baker yet"); return ommResult_NOT_IMPLEMENTED; }
+    if (wants_host_tail(d) && !formatsOnHost) // the serial reducers need the host: only ommCpuBake offers them
+        { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - near-duplicate merging / maxArrayDataSize budgets are only available through ommCpuBake"); return ommResult_NOT_IMPLEMENTED; }
     if ((flags & ((1u << 7) | (1u << 8) | (1u << 9) | (1u << 11))) != 0)
         { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - internal bake flags (bits 7-11) are not supported"); return ommResult_NOT_IMPLEMENTED; }
     if (d.formats) { // the reference sizes its arrays from the global format only (bake_cpu_impl.cpp:1763-1772): mixed formats corrupt its heap
@@ -648,6 +682,45 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     const int u1 = et.mark();
 
     DeviceResult R; ommxBakeTimings tm; memset(&tm, 0, sizeof tm);
+    if (wants_host_tail(d)) {
+        // near-duplicate merge / size budget: device classification, then the reference's serial tail on the host (host_tail.cpp)
+        HostTailRequest ht;
+        const ommResult hr = bake_core(baker, d, din, &d, ses.arena, ses.states, stream, et, R, tm, nullptr, &ht);
+        if (hr != ommResult_SUCCESS) return hr;
+        const uint32_t fl = (uint32_t)d.bakeFlags;
+        HostTailDesc td; td.format = (int)d.format; td.disableSpecial = (fl & (1u << 1)) != 0; td.disableDedup = (fl & (1u << 3)) != 0;
+        td.nearDup = (fl & (1u << 4)) != 0; td.nearDupBrute = (fl & (1u << 10)) != 0; td.rejectionThreshold = d.rejectionThreshold;
+        td.nearDupFactor = d.nearDuplicateDeduplicationFactor; td.maxArrayDataSize = d.maxArrayDataSize; td.numTris = T; td.unresolved = (int32_t)d.unresolvedTriState;
+        HostTailResult hres;
+        if (run_host_tail(td, ht.items, hres)) return ommResult_FAILURE;
+        BakeResult* res = baker.mem.make<BakeResult>();
+        if (!res) return ommResult_FAILURE;
+        res->mem = baker.mem;
+        const uint32_t E = (uint32_t)hres.descs.size();
+        if (E) {
+            res->arrayData = baker.mem.allocate(hres.arrayData.size(), 64); res->descs = (ommCpuOpacityMicromapDesc*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, 16);
+            memcpy(res->arrayData, hres.arrayData.data(), hres.arrayData.size()); memcpy(res->descs, hres.descs.data(), sizeof(ommCpuOpacityMicromapDesc) * (size_t)E);
+        }
+        res->index = (int32_t*)baker.mem.allocate(sizeof(int32_t) * (size_t)(T ? T : 1), 16);
+        memcpy(res->index, hres.index.data(), sizeof(int32_t) * (size_t)T);
+        res->arrayHist = (ommCpuOpacityMicromapUsageCount*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapUsageCount) * 2 * kNumLevels, 16);
+        res->indexHist = (ommCpuOpacityMicromapUsageCount*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapUsageCount) * 2 * kNumLevels, 16);
+        memcpy(res->arrayHist, hres.arrayHist.data(), sizeof(ommCpuOpacityMicromapUsageCount) * hres.arrayHist.size());
+        memcpy(res->indexHist, hres.indexHist.data(), sizeof(ommCpuOpacityMicromapUsageCount) * hres.indexHist.size());
+        ommIndexFormat ifmt = ommIndexFormat_UINT_32; // index narrowing in place (bake_cpu_impl.cpp:1872-1902)
+        const bool allow8 = (fl & (1u << 6)) != 0, force32 = (fl & (1u << 2)) != 0;
+        if (allow8 && T <= 127 && !force32) { int8_t* p8 = (int8_t*)res->index; for (uint32_t i = 0; i < T; ++i) { const int32_t v = res->index[i]; p8[i] = (int8_t)v; } ifmt = ommIndexFormat_UINT_8; }
+        else if (T <= 32767 && !force32) { int16_t* p16 = (int16_t*)res->index; for (uint32_t i = 0; i < T; ++i) { const int32_t v = res->index[i]; p16[i] = (int16_t)v; } ifmt = ommIndexFormat_UINT_16; }
+        res->desc.arrayData = E ? res->arrayData : nullptr; res->desc.arrayDataSize = E ? (uint32_t)hres.arrayData.size() : 0;
+        res->desc.descArray = E ? res->descs : nullptr; res->desc.descArrayCount = E;
+        res->desc.descArrayHistogram = res->arrayHist; res->desc.descArrayHistogramCount = (uint32_t)hres.arrayHist.size();
+        res->desc.indexBuffer = res->index; res->desc.indexCount = T; res->desc.indexFormat = ifmt;
+        res->desc.indexHistogram = res->indexHist; res->desc.indexHistogramCount = (uint32_t)hres.indexHist.size();
+        tm.totalMs = (float)(now_ms() - t0);
+        { std::lock_guard<std::mutex> g(baker.timingsMu); baker.timings = tm; baker.haveTimings = true; }
+        *out = (ommCpuBakeResult)res;
+        return ommResult_SUCCESS;
+    }
     const ommResult br = bake_core(baker, d, din, &d, ses.arena, ses.states, stream, et, R, tm);
     if (br != ommResult_SUCCESS) return br;
 

@@ -132,7 +132,8 @@ def oracle_path():
 
 
 def product_path():
-    return os.path.join(ROOT, "omm_amd", "lib", "libomm-lib.so")
+    # OMM_AMD_LIBRARY: A/B builds of the same sources (kernel tuning experiments); default = the in-tree build
+    return os.environ.get("OMM_AMD_LIBRARY") or os.path.join(ROOT, "omm_amd", "lib", "libomm-lib.so")
 
 
 _KAT = None

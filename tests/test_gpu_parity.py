@@ -9,7 +9,7 @@ from test_golden_blob import BLOBS, PAIRS, STATS, bake_input_blob, check_against
 import blobfmt
 
 pytestmark = pytest.mark.gpu
-GPU_KATS = [c for c in CASES if not c["opt"].get("merge_similar")]  # near-duplicate merging: next-tier (NOT_IMPLEMENTED)
+GPU_KATS = CASES  # incl. the near-duplicate-merge KATs (device classification + serial host tail, host_tail.cpp)
 
 
 @pytest.mark.parametrize("case", GPU_KATS, ids=[c["name"] for c in GPU_KATS])
@@ -383,3 +383,26 @@ def test_torch_distributed_plumbing_one_rank():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "scripts", "one_rank_nccl.py")], cwd=root, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0 and "one-rank nccl plumbing ok" in r.stdout, r.stdout[-3000:]
+
+
+def test_near_duplicate_merge_and_size_budget(product, oracle):
+    """opt-in lossy reducers (bake_cpu_impl.cpp:1068-1430 LSH merge, :1474-1688 Compress): device classification + host tail vs oracle"""
+    tex = ot.kat_texture("hexagons", 1024, 1024)
+    from kat_cases import hex_grid
+    uv, ix = hex_grid()
+    both(product, oracle, [tex], uv, ix, 4, addr=ot.CLAMP, promo=ot.PROMO_NEAREST, flags=ot.FLAG_THREADS | ot.FLAG_NEAR_DUP, sat=False)
+    both(product, oracle, [tex], uv, ix, 3, addr=ot.CLAMP, promo=ot.PROMO_FORCE_OPAQUE, flags=ot.FLAG_THREADS | ot.FLAG_NEAR_DUP | (1 << 10), sat=True)
+    # maxArrayDataSize budgets (distinct coverage-per-byte values: the reference's std::sort tie order is not pinned)
+    uv2, ix2 = ot.random_triangles(777, 60, 0.2)
+    for budget in (20000, 4000, 600):
+        out = []
+        for lib in (product, oracle):
+            b = lib.create_baker()
+            t = lib.create_texture(b, [tex], alpha_cutoff=0.5)
+            d = ot.make_desc(t, uv2, ix2, 5, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+            d.maxArrayDataSize = budget
+            out.append(lib.bake(b, d))
+            lib.destroy_texture(b, t)
+            lib.destroy_baker(b)
+        assert out[0].same_as(out[1]), (budget, out[0].diff(out[1]))
+        assert out[0].array_data.size <= budget or len(out[0].descs) == 0 or budget < 100
