@@ -345,6 +345,15 @@ OMM_MI355X_API ommResult ommCpuBake(ommBaker baker, const ommCpuBakeInputDesc* b
 OMM_MI355X_API ommResult ommCpuDestroyBakeResult(ommCpuBakeResult bakeResult);
 /* include/omm.h:578, src/bake.cpp:129-135 */
 OMM_MI355X_API ommResult ommCpuGetBakeResultDesc(ommCpuBakeResult bakeResult, const ommCpuBakeResultDesc** desc);
+/* ---- blob (de)serialisation: include/omm.h:580-594, src/bake.cpp:136-260, src/serialize_impl.cpp (format v5, reads v1..v5, LZ4 optional).
+ * The SDK header declares the desc arguments of ommCpuSerialize / ommCpuDeserialize as C++ references inside extern "C"; a
+ * reference is passed as a pointer, so these pointer declarations are binary compatible with it. ---- */
+OMM_MI355X_API ommResult ommCpuSerialize(ommBaker baker, const ommCpuDeserializedDesc* desc, ommCpuSerializedResult* outResult);
+OMM_MI355X_API ommResult ommCpuGetSerializedResultDesc(ommCpuSerializedResult result, const ommCpuBlobDesc** desc);
+OMM_MI355X_API ommResult ommCpuDestroySerializedResult(ommCpuSerializedResult result);
+OMM_MI355X_API ommResult ommCpuDeserialize(ommBaker baker, const ommCpuBlobDesc* desc, ommCpuDeserializedResult* outResult);
+OMM_MI355X_API ommResult ommCpuGetDeserializedDesc(ommCpuDeserializedResult result, const ommCpuDeserializedDesc** desc);
+OMM_MI355X_API ommResult ommCpuDestroyDeserializedResult(ommCpuDeserializedResult result);
 /* include/omm.h:1201, src/debug_impl.cpp:643-652 */
 OMM_MI355X_API ommResult ommDebugGetStats(ommBaker baker, const ommCpuBakeResultDesc* res, ommDebugStats* out);
 

@@ -802,13 +802,10 @@ OMM_MI355X_API ommResult ommDestroyBaker(ommBaker baker)
     return ommResult_SUCCESS;
 }
 
-OMM_MI355X_API ommResult ommCpuCreateTexture(ommBaker baker, const ommCpuTextureDesc* desc, ommCpuTexture* outTexture)
+namespace {
+ommResult create_texture_impl(Baker* b, const ommCpuTextureDesc* desc, ommCpuTexture* outTexture)
 {
-    if (baker == 0) return ommResult_INVALID_ARGUMENT;
-    Baker* b = untag<Baker>(baker);
     const Logger& L = b->log;
-    if (desc == 0) return L.invalid("texture desc was not set");
-    if (tag_of(baker) != kCpuBaker) return L.invalid("Baker was not created as the right type");
     // texture_impl.cpp:44-65
     if (desc->mipCount == 0) return L.invalid("[Invalid Arg] - mipCount must be non-zero");
     if (desc->format == ommCpuTextureFormat_MAX_NUM) return L.invalid("[Invalid Arg] - format is not set");
@@ -851,6 +848,16 @@ OMM_MI355X_API ommResult ommCpuCreateTexture(ommBaker baker, const ommCpuTexture
     if (!ok) { (void)hipGetLastError(); b->mem.destroy(t); return L.failure("[Failure] - could not create the texture on the HIP device (no CPU fallback)"); }
     *outTexture = (ommCpuTexture)((uintptr_t)t | kTexture);
     return ommResult_SUCCESS;
+}
+} // namespace
+
+OMM_MI355X_API ommResult ommCpuCreateTexture(ommBaker baker, const ommCpuTextureDesc* desc, ommCpuTexture* outTexture)
+{
+    if (baker == 0) return ommResult_INVALID_ARGUMENT;
+    Baker* b = untag<Baker>(baker);
+    if (desc == 0) return b->log.invalid("texture desc was not set");
+    if (tag_of(baker) != kCpuBaker) return b->log.invalid("Baker was not created as the right type");
+    return create_texture_impl(b, desc, outTexture);
 }
 
 OMM_MI355X_API ommResult ommCpuGetTextureDesc(ommCpuTexture texture, ommCpuTextureDesc* outDesc)
@@ -1141,3 +1148,5 @@ OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings*
     *out = b->timings;
     return ommResult_SUCCESS;
 }
+
+#include "serialize.inc"

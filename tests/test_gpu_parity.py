@@ -406,3 +406,108 @@ def test_near_duplicate_merge_and_size_budget(product, oracle):
             lib.destroy_baker(b)
         assert out[0].same_as(out[1]), (budget, out[0].diff(out[1]))
         assert out[0].array_data.size <= budget or len(out[0].descs) == 0 or budget < 100
+
+
+# ---------------------------------------------------------------------------------------------
+# blob (de)serialisation -- SURVEY.md section 8(f) #1
+# ---------------------------------------------------------------------------------------------
+class BlobDesc(__import__("ctypes").Structure):
+    _fields_ = [("data", __import__("ctypes").c_void_p), ("size", __import__("ctypes").c_uint64)]
+
+
+class DeserializedDesc(__import__("ctypes").Structure):
+    import ctypes as _C
+    _fields_ = [("flags", _C.c_int), ("numInputDescs", _C.c_int), ("inputDescs", _C.POINTER(ot.BakeInputDesc)),
+                ("numResultDescs", _C.c_int), ("resultDescs", _C.POINTER(ot.BakeResultDesc))]
+
+
+def _bind_serialize(dll):
+    import ctypes as C
+    dll.ommCpuSerialize.argtypes = [C.c_void_p, C.POINTER(DeserializedDesc), C.POINTER(C.c_void_p)]
+    dll.ommCpuGetSerializedResultDesc.argtypes = [C.c_void_p, C.POINTER(C.POINTER(BlobDesc))]
+    dll.ommCpuDestroySerializedResult.argtypes = [C.c_void_p]
+    dll.ommCpuDeserialize.argtypes = [C.c_void_p, C.POINTER(BlobDesc), C.POINTER(C.c_void_p)]
+    dll.ommCpuGetDeserializedDesc.argtypes = [C.c_void_p, C.POINTER(C.POINTER(DeserializedDesc))]
+    dll.ommCpuDestroyDeserializedResult.argtypes = [C.c_void_p]
+
+
+def _deserialize(product, baker, blob_bytes, expect=ot.SUCCESS):
+    import ctypes as C
+    buf = C.create_string_buffer(blob_bytes, len(blob_bytes))
+    bd = BlobDesc(C.cast(buf, C.c_void_p), len(blob_bytes))
+    h = C.c_void_p()
+    r = product.dll.ommCpuDeserialize(baker, C.byref(bd), C.byref(h))
+    assert r == expect, r
+    if r != ot.SUCCESS:
+        return None, None
+    pd = C.POINTER(DeserializedDesc)()
+    assert product.dll.ommCpuGetDeserializedDesc(h, C.byref(pd)) == ot.SUCCESS
+    return h, pd.contents
+
+
+def test_golden_blobs_through_the_library_deserializer(product):
+    """test_omm_bake_cpu.cpp:2034-2304: every embedded blob (v1.4.0 .. v1.7.0, plain and LZ4) decodes; inputs bake to the golden output"""
+    _bind_serialize(product.dll)
+    b = product.create_baker()
+    golden = blobfmt.parse_blob(BLOBS["output_v1_4_0"])["results"][0]
+    for name, blob in BLOBS.items():
+        h, dd = _deserialize(product, b, blob)
+        if name.startswith("input"):
+            assert dd.numInputDescs == 1 and dd.numResultDescs == 0
+            res = product.bake(b, dd.inputDescs[0])
+            check_against_output_blob(res, golden)
+            assert res.stats_tuple() == STATS
+        else:
+            assert dd.numInputDescs == 0 and dd.numResultDescs == 1
+            res = ot.BakeResult(dd.resultDescs[0])
+            check_against_output_blob(res, golden)
+        assert product.dll.ommCpuDestroyDeserializedResult(h) == ot.SUCCESS
+    # truncated blob -> digest mismatch -> INVALID_ARGUMENT (test_omm_bake_cpu.cpp:241-251)
+    _deserialize(product, b, BLOBS["input_v1_5_0"][:-4], expect=ot.INVALID_ARGUMENT)
+    product.destroy_baker(b)
+
+
+@pytest.mark.parametrize("compress", [0, 1])
+@pytest.mark.parametrize("zorder_disabled,sat", [(False, False), (True, True)])
+def test_serialize_round_trip(product, oracle, compress, zorder_disabled, sat):
+    """Serialize(input + result) -> independent python parser (tests/blobfmt.py) and -> Deserialize -> re-bake == original"""
+    import ctypes as C
+    _bind_serialize(product.dll)
+    tex = np.ascontiguousarray(noise_u8()[:200, :300])     # non-pow2: Morton storage is padded to 512^2
+    uv, ix = ot.random_triangles(4242, 50, 0.2)
+    lv = (np.arange(50) % 5).astype(np.uint8)
+    b = product.create_baker()
+    t = product.create_texture(b, [tex, np.ascontiguousarray(tex[::2, ::2])], alpha_cutoff=0.5 if sat else -1.0, disable_zorder=zorder_disabled)
+    d = ot.make_desc(t, uv, ix, 5, addr=ot.MIRROR, promo=ot.PROMO_NEAREST, levels=lv)
+    r, out = product.bake_raw(b, d)
+    assert r == ot.SUCCESS
+    prd = C.POINTER(ot.BakeResultDesc)()
+    assert product.fn("ommCpuGetBakeResultDesc")(out, C.byref(prd)) == ot.SUCCESS
+    ref = ot.BakeResult(prd.contents)
+    dd = DeserializedDesc(compress, 1, C.pointer(d), 1, prd)
+    sh = C.c_void_p()
+    assert product.dll.ommCpuSerialize(b, C.byref(dd), C.byref(sh)) == ot.SUCCESS
+    pb = C.POINTER(BlobDesc)()
+    assert product.dll.ommCpuGetSerializedResultDesc(sh, C.byref(pb)) == ot.SUCCESS
+    blob = C.string_at(pb.contents.data, pb.contents.size)
+    assert product.dll.ommCpuDestroySerializedResult(sh) == ot.SUCCESS
+    # independent parse
+    oracle.dll.orc_xxh64.restype = C.c_uint64
+    oracle.dll.orc_xxh64.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
+    parsed = blobfmt.parse_blob(blob, xxh64=lambda dat, s: oracle.dll.orc_xxh64(dat, len(dat), s))
+    assert parsed["version"] == (1, 9, 0, 5)
+    pin = parsed["inputs"][0]
+    assert np.array_equal(pin["texture"]["mips"][0], tex) and pin["texture"]["tiling"] == (0 if zorder_disabled else 1)
+    assert pin["texCoords"] == uv.tobytes() and pin["indexBuffer"] == ix.tobytes() 
+    assert len(pin["subdivisionLevels"]) == 150 and pin["subdivisionLevels"][:50] == lv.tobytes()   # count is indexCount (serialize_impl.cpp:147)
+    assert parsed["results"][0]["arrayData"] == ref.array_data.tobytes() and parsed["results"][0]["descArray"] == ref.desc_bytes
+    # library deserializer + re-bake
+    h, d2 = _deserialize(product, b, blob)
+    assert d2.numInputDescs == 1 and d2.numResultDescs == 1
+    again = product.bake(b, d2.inputDescs[0])
+    assert again.same_as(ref), again.diff(ref)
+    assert ot.BakeResult(d2.resultDescs[0]).same_as(ref)
+    assert product.dll.ommCpuDestroyDeserializedResult(h) == ot.SUCCESS
+    assert product.fn("ommCpuDestroyBakeResult")(out) == ot.SUCCESS
+    product.destroy_texture(b, t)
+    product.destroy_baker(b)
