@@ -207,7 +207,11 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         __syncthreads();
 
         // ---- phase 2: fine, dense over the queue ----
+#ifdef OMMX_DEBUG_SKIP_FINE   // timing experiments only (never shipped): how long do phases 0/1/3 take on their own?
+        const uint32_t qn = 0;
+#else
         const uint32_t qn = s_qcount;
+#endif
         if (tid == 0 && qn) atomicAdd(A.fineCount, (unsigned long long)qn);
         for (uint32_t q = tid; q < qn; q += BLOCK) {
             const uint32_t i = s_queue[q];

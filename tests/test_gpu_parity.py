@@ -511,3 +511,74 @@ def test_serialize_round_trip(product, oracle, compress, zorder_disabled, sat):
     assert product.fn("ommCpuDestroyBakeResult")(out) == ot.SUCCESS
     product.destroy_texture(b, t)
     product.destroy_baker(b)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configurations (configs[0], [1], [4]; configs[2]/[3] are the bench workload, covered above)
+# ---------------------------------------------------------------------------------------------
+def test_baseline_config0_quad_checker(product, oracle):
+    """configs[0]: single quad (2 tris), 256x256 32-px checkerboard (FP32), level 4, 2-state"""
+    yy, xx = np.mgrid[0:256, 0:256]
+    tex = (((xx // 32) + (yy // 32)) & 1).astype(np.float32)
+    uv = np.array([[0, 0], [1, 0], [0, 1], [1, 0], [1, 1], [0, 1]], np.float32)
+    ix = np.arange(6, dtype=np.uint32)
+    for sat in (True, False):
+        r = both(product, oracle, [tex], uv, ix, 4, fmt=ot.FMT_2STATE, addr=ot.WRAP, sat=sat)
+        assert r.index.size == 2 and len(r.descs) >= 1 and np.all(r.descs[:, 2] == 1)
+
+
+def test_baseline_config1_full_parity(product, oracle):
+    """configs[1]: 100k random-UV triangles, 2K multi-octave noise alpha, level 6, 4-state -- the WHOLE result, bit for bit"""
+    n = 100000
+    tex = (ot.value_noise(77, 2048, 2048, octaves=5, base_cell=128) * 255).astype(np.uint8)
+    uv, ix = ot.random_triangles(78, n, 10.0 / 2048)
+    r = both(product, oracle, [tex], uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+    assert r.index.size == n and len(r.descs) > 1000
+
+
+def c4_workload(n, seed, tex_size):
+    """configs[4] shape: per-triangle levels U{4..10} for 75 % of the triangles, 0xF (dynamic heuristic, scale 2, max 10) for the rest"""
+    uv, ix = ot.random_triangles(seed, n, 6.0 / tex_size)
+    h = ot.hash_u32(np.arange(n) + 1000 * seed)
+    lv = (4 + (h >> 8) % 7).astype(np.uint8)
+    lv[(h & 3) == 0] = 0xF
+    return uv, ix, lv
+
+
+def omm_by_triangle(res, t):
+    v = int(res.index[t])
+    if v < 0:
+        return v
+    off, lvl, fmt = (int(x) for x in res.descs[v])
+    return (lvl, fmt, bytes(res.array_data[off:off + max(1, ((4 ** lvl) * fmt) // 8)]))
+
+
+def test_baseline_config4_mixed_levels_dynamic_8k(product, oracle):
+    """configs[4] at reduced triangle count: full parity on 2500 triangles, then a 300k-triangle bake whose per-triangle OMMs must
+    equal the small bakes' (dedup on, so equal content may live at different offsets)"""
+    tex = ot.foliage_texture(4321, 8192, 8192, feature=96)
+    k, n = 2500, 300000
+    uv, ix, lv = c4_workload(n, 9, 8192)
+    kw = dict(addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=None, dyn_scale=2.0)
+    b = product.create_baker()
+    t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+    ob = oracle.create_baker()
+    otx = oracle.create_texture(ob, [tex], alpha_cutoff=0.5)
+    kw["levels"] = lv[:k]
+    small_p = product.bake(b, ot.make_desc(t, uv[:3 * k], ix[:3 * k], 10, **kw))
+    small_o = oracle.bake(ob, ot.make_desc(otx, uv[:3 * k], ix[:3 * k], 10, **kw))
+    assert small_p.same_as(small_o), small_p.diff(small_o)
+    assert len({int(d[1]) for d in small_p.descs}) >= 5           # several subdivision levels really present
+    kw["levels"] = lv
+    full = product.bake(b, ot.make_desc(t, uv, ix, 10, **kw), want_stats=False)
+    assert full.index.size == n
+    for tri in range(k):
+        assert omm_by_triangle(full, tri) == omm_by_triangle(small_o, tri), tri
+    # descriptor array is sorted by (level desc, morton) and offsets are contiguous per-block sizes (bake_cpu_impl.cpp:1742-1800)
+    sizes = np.maximum(1, (4 ** full.descs[:, 1]) * full.descs[:, 2] // 8)
+    assert np.array_equal(full.descs[:, 0], np.concatenate([[0], np.cumsum(sizes)[:-1]]))
+    assert full.array_data.size == int(sizes.sum())
+    assert sum(c for c, l, f in full.array_hist) == len(full.descs)
+    assert sum(c for c, l, f in full.index_hist) == int((full.index >= 0).sum())
+    oracle.destroy_texture(ob, otx); oracle.destroy_baker(ob)
+    product.destroy_texture(b, t); product.destroy_baker(b)
