@@ -16,7 +16,10 @@
 #include <string.h>
 #include <chrono>
 #include <mutex>
+#include <memory>
 #include <new>
+#include <thread>
+#include <sys/mman.h>
 #include <unordered_map>
 #include <vector>
 #include <xmmintrin.h>
@@ -81,8 +84,48 @@ struct DeviceArena {
 };
 inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// ---- warm host memory for the (large) result array -------------------------------------------------
+// A fresh 1.3 GB malloc costs more in page faults (70-100 ms) and munmap (95 ms) than the PCIe copy itself (24 ms at 57 GB/s), so
+// with the DEFAULT allocator the arrayData block of a destroyed result is kept by its baker and handed to the next bake; a new block
+// is 2 MiB aligned (transparent huge pages) and pre-faulted by a few threads.  User-supplied allocators are always honoured as given.
+struct HostPool {
+    struct Blk { void* p; size_t cap; bool used; };
+    std::mutex mu; std::vector<Blk> blks;
+    static constexpr size_t kMinBytes = 8u << 20, kHuge = 2u << 20;
+    ~HostPool() { for (auto& b : blks) free(b.p); }
+    void* acquire(size_t bytes) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (auto& b : blks) if (!b.used && b.cap >= bytes && b.cap / 2 <= bytes + kHuge) { b.used = true; return b.p; }
+        }
+        const size_t cap = (bytes + kHuge - 1) & ~(kHuge - 1);
+        void* p = aligned_alloc(kHuge, cap);
+        if (!p) return nullptr;
+        (void)madvise(p, cap, MADV_HUGEPAGE);
+        unsigned nt = std::thread::hardware_concurrency(); nt = nt > 8 ? 8 : (nt ? nt : 1);
+        if (cap < (64u << 20)) nt = 1;
+        std::vector<std::thread> th;
+        const size_t per = ((cap / nt) + kHuge - 1) & ~(kHuge - 1);
+        auto touch = [p](size_t lo, size_t hi) { for (size_t o = lo; o < hi; o += 4096) ((volatile uint8_t*)p)[o] = 0; };
+        for (unsigned k = 1; k < nt; ++k) { const size_t lo = per * k, hi = lo + per < cap ? lo + per : cap; if (lo < cap) th.emplace_back(touch, lo, hi); }
+        touch(0, per < cap ? per : cap);
+        for (auto& t : th) t.join();
+        std::lock_guard<std::mutex> g(mu);
+        blks.push_back({ p, cap, true });
+        return p;
+    }
+    void release(void* p) {
+        std::lock_guard<std::mutex> g(mu);
+        size_t freeBlocks = 0;
+        for (auto& b : blks) { if (b.p == p) b.used = false; if (!b.used) freeBlocks++; }
+        for (size_t i = 0; i < blks.size() && freeBlocks > 2; ) // keep at most two idle blocks
+            if (!blks[i].used && blks[i].p != p) { free(blks[i].p); blks.erase(blks.begin() + (long)i); freeBlocks--; } else ++i;
+    }
+};
+
 struct Baker {
     Allocator mem; Logger log; ommBakerType type;
+    std::shared_ptr<HostPool> hostPool = std::make_shared<HostPool>();
     DeviceArena arena;        // per-item tables + scratch
     DeviceArena statesArena;  // packed states of the active (non-uniform) items; guarded by arena.mu
     std::mutex timingsMu; ommxBakeTimings timings; bool haveTimings = false;
@@ -111,9 +154,10 @@ struct BakeResult {
     void* arrayData = nullptr; ommCpuOpacityMicromapDesc* descs = nullptr;
     ommCpuOpacityMicromapUsageCount* arrayHist = nullptr; ommCpuOpacityMicromapUsageCount* indexHist = nullptr;
     int32_t* index = nullptr;
+    std::shared_ptr<HostPool> pool; // set when arrayData came from the baker's warm pool (results may outlive their baker)
     ommCpuBakeResultDesc desc;
     BakeResult() { memset(&desc, 0, sizeof desc); }
-    ~BakeResult() { mem.release(arrayData); mem.release(descs); mem.release(arrayHist); mem.release(indexHist); mem.release(index); }
+    ~BakeResult() { if (pool) pool->release(arrayData); else mem.release(arrayData); mem.release(descs); mem.release(arrayHist); mem.release(indexHist); mem.release(index); }
 };
 
 // ---- XXH64 of a constant byte stream: digests of uniform OMMs (bake_cpu_impl.cpp:1038-1040 applied to 4^level equal bytes) ----
@@ -731,7 +775,11 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     const int d0 = et.mark();
     const uint32_t E = R.numDescs;
     if (E) {
-        res->arrayData = baker.mem.allocate((size_t)R.arrayDataSize, 64);
+        if (baker.mem.alloc == default_alloc && (size_t)R.arrayDataSize >= HostPool::kMinBytes) {
+            res->arrayData = baker.hostPool->acquire((size_t)R.arrayDataSize);
+            if (res->arrayData) res->pool = baker.hostPool;
+        }
+        if (!res->arrayData) res->arrayData = baker.mem.allocate((size_t)R.arrayDataSize, 64);
         res->descs = (ommCpuOpacityMicromapDesc*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, 16);
         ok = res->arrayData && res->descs;
         ok = ok && HIP_OK(hipMemcpyAsync(res->arrayData, R.arrayData, (size_t)R.arrayDataSize, hipMemcpyDeviceToHost, stream));
