@@ -93,7 +93,7 @@ constexpr int WIN = 32; // largest LDS texel window edge
 // SLICED: 4^level >= TILE, the tile is a slice of ONE work item (block-uniform item data, LDS texel/SAT window).
 // !SLICED: the tile holds TILE / 4^level whole items.
 #ifndef OMMX_CLASSIFY_WAVES
-#define OMMX_CLASSIFY_WAVES 5
+#define OMMX_CLASSIFY_WAVES 6
 #endif
 // TILE micro-triangles per workgroup: 4096 for levels >= 6, 1024 below (a level-5 item is exactly one 1024-tile)
 template <bool FP32, bool SLICED, int TILE, class MD>

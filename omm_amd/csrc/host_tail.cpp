@@ -50,7 +50,6 @@ uint64_t xxh64(const uint8_t* p, size_t len, uint64_t seed)
     return h;
 }
 
-void set_state(HostItem& it, uint32_t i, uint8_t s) { it.st[i] = s; }
 
 // bake_cpu_impl.cpp:1432-1472
 void promote(const HostTailDesc& d, std::vector<HostItem>& items)
