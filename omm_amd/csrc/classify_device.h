@@ -237,13 +237,35 @@ __device__ __forceinline__ bool point_in_triangle(const MicroTri& t, float px, f
 __device__ __forceinline__ bool near_zero(float v, float eps) { return v < eps && v > -eps; }
 __device__ __forceinline__ bool in_unit_square(float x, float y) { return x >= 0.f && x <= 1.f && y >= 0.f && y <= 1.f; }
 
+// Edge::IsPointOnEdge (bake_kernels_cpu.h:115-142): |P-a0| + |P-a1| - |a1-a0| within 1e-5 of zero -- three IEEE square roots.
+// Only ~1 % of the candidate roots are anywhere near the segment, and a wave pays for the square roots as soon as ONE lane needs
+// them, so a sqrt-free test first discards points that are PROVABLY off the segment:
+//   with s = projection of P on the edge direction, slack S = |P-a0| + |P-a1| - L >= 2 (s - L) beyond the far end and >= -2 s before
+//   the near end; s - L = (w - L^2) / L with w = (P-a0).(a1-a0), and L <= M = |dx| + |dy|.  The fp32 evaluation of the reference's
+//   expression is within 5.4e-7 (|P-a0| + |P-a1|) of S and that of w - L^2 within 2.4e-7 M (U + M), U = |ux| + |uy|; the threshold
+//   T = M (1e-4 + 1e-5 (U + M)) leaves a >10x margin over both, so "w - L^2 > T or -w > T" implies the reference's value exceeds
+//   1e-5 (measured: smallest |value| among discarded points 2.2e-4 over 2.5e7 calls, no disagreement).  NaN/inf compare false
+//   and take the exact path.  Everything not discarded is evaluated exactly as the reference does.
+__device__ __forceinline__ bool point_on_edge(V2 a0, V2 a1, float x, float y)
+{
+    const float ux = x - a0.x, uy = y - a0.y;
+    const float dx = a1.x - a0.x, dy = a1.y - a0.y;
+#ifndef OMMX_NO_EDGE_PREFILTER
+    const float w = ux * dx + uy * dy, l2 = dx * dx + dy * dy;
+    const float M = __builtin_fabsf(dx) + __builtin_fabsf(dy), U = __builtin_fabsf(ux) + __builtin_fabsf(uy);
+    const float T = M * (1e-4f + 1e-5f * (U + M));
+    if (w - l2 > T || -w > T) return false;
+#endif
+    return near_zero(vlen(ux, uy) + vlen(x - a1.x, y - a1.y) - vlen(dx, dy), 1e-5f);
+}
+
 // bake_kernels_cpu.h:144-238 -- does segment (a0,a1) cross the level curve
 // h.x + h.y*x + h.z*y + h.w*x*y = 0 inside the unit texel?
 __device__ __forceinline__ bool edge_crosses_level_curve(V2 a0, V2 a1, float ha, float hb, float hc, float hd)
 {
     if (a0.x > a1.x) { V2 t = a0; a0 = a1; a1 = t; }
     // Edge::_length (bake_kernels_cpu.h:115-133) is only consumed by IsPointOnEdge: evaluated lazily, same value
-#define ON_EDGE(X, Y) near_zero(vlen((X) - a0.x, (Y) - a0.y) + vlen((X) - a1.x, (Y) - a1.y) - vlen(a1.x - a0.x, a1.y - a0.y), 1e-5f)
+#define ON_EDGE(X, Y) point_on_edge(a0, a1, (X), (Y))
     const float kd = a1.x - a0.x;
     if (near_zero(kd, 1e-6f)) {
         const float x = a0.x;
@@ -343,8 +365,12 @@ __device__ __forceinline__ void level_line_texel(const ClassifyParams& P, const 
     const V2 q0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy);
     const V2 q1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy);
     const V2 q2 = mk2(m.fw * t.p2.x - pfx, m.fh * t.p2.y - pfy);
+#ifdef OMMX_DEBUG_NO_EDGES      // timing attribution only (never shipped)
+    if (q0.x + q1.x + q2.x == 12345.f) {
+#else
     if (edge_crosses_level_curve(q0, q1, ha, b, c, d) || edge_crosses_level_curve(q1, q2, ha, b, c, d) ||
         edge_crosses_level_curve(q2, q0, ha, b, c, d)) {
+#endif
         above += 1; below += 1;
     }
 }
@@ -400,6 +426,9 @@ __device__ __forceinline__ void raster_micro_triangle(const ClassifyParams& P, c
     // Only the Nearest promotion looks at the counts (bake_kernels_cpu.h:38,49); for the forced promotions the state is
     // final as soon as both counters are non-zero, so the remaining texels cannot change the result.
     const bool countsMatter = P.promotion == 0;
+#ifdef OMMX_DEBUG_NO_TEXELS     // timing attribution only (never shipped)
+    if (minx != -123456789) return;
+#endif
     for (int y = miny; y < maxy; ++y) {
         bool wasInside = false;
         for (int x = minx; x < maxx; ++x) {
