@@ -195,8 +195,21 @@ def main():
             "phases_ms": {k: avg(k) for k in ("uploadMs", "setupMs", "triageMs", "classifyMs", "digestMs", "tailMs", "gatherMs", "downloadMs", "totalMs")},
             "roofline": {"bound": "hbm", "kernel": "classify_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": classify_ms / launches,
+                         "algorithmic_bytes_per_launch": alg_bytes / launches,
                          "note": "classification is fp32-VALU/sqrt/div bound, not HBM bound (SURVEY.md section 8d)"},
         }
+        # HBM bytes per launch from the PMC counters cannot be read from inside this process: they come from the separate
+        # rocprofv3 --pmc passes of profiles/collect.sh (FETCH_SIZE x2 on gfx950, WRITE_SIZE x1), committed under profiles/,
+        # and apply only to the workload they were collected on.
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+        default_workload = (args.tris, args.level, args.tex, args.feature, args.extent_texels, args.seed) == (1000000, 8, 4096, 64, 8.0, 1234)
+        if world == 1 and default_workload and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            line["roofline"]["traffic"] = tj.get("traffic_bytes_per_launch")
+            line["roofline"]["traffic_source"] = "profiles/hbm_traffic_latest.json (%s; %s)" % (tj.get("command"), tj.get("corrections"))
+            if tj.get("valu_busy") is not None:
+                line["roofline"]["valu_issue_utilisation"] = tj["valu_busy"]
+                line["roofline"]["valu_lane_utilisation"] = tj.get("valu_lane_util")
         if args.cpu_sample > 0 and world == 1:
             cb, cpu_res = cpu_baseline(args, tex, uv, ix)
             line["cpu_baseline"] = cb
