@@ -414,10 +414,66 @@ __global__ __launch_bounds__(256) void digest_items(const uint8_t* __restrict__ 
     if (live && acc == 0) digests[item] = h;
 }
 
+// Same digest for items of >= 256 packed bytes (4-state: level >= 5, 2-state: level >= 6).  In digest_items a wave reads 2-byte
+// pieces of 16 items that lie 16 KiB apart, and rocprofv3 counted 4.6x the states' bytes in HBM fetches.  Here a workgroup
+// (64 items x 4 accumulators) stages 256 packed bytes per item through LDS with 16-byte coalesced loads (row stride 65 words:
+// the 64 rows start in different banks), then every lane walks its accumulator's pieces out of LDS.
+constexpr int DG_ITEMS = 64, DG_CHUNK = 256, DG_STRIDE = DG_CHUNK / 4 + 1;
+__global__ __launch_bounds__(256) void digest_items_lds(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs,
+                                                        const uint32_t* __restrict__ itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
+                                                        uint64_t* __restrict__ digests)
+{
+    __shared__ uint32_t s_buf[DG_ITEMS * DG_STRIDE];
+    __shared__ const uint8_t* s_ptr[DG_ITEMS];
+    const uint32_t tid = threadIdx.x, first = blockIdx.x * DG_ITEMS;
+    const uint32_t il = tid >> 2, acc = tid & 3u, it = first + il;
+    const bool live = it < numItems;
+    if (tid < DG_ITEMS) { const uint32_t j = first + tid; s_ptr[tid] = j < numItems ? states + stateOfs[itemIds[j]] : nullptr; }
+    const uint32_t M = 1u << (2 * level);
+    const uint32_t bytesPerItem = (M * bits) >> 3;            // multiple of DG_CHUNK (launch_digest)
+    const uint32_t stripesPerChunk = DG_CHUNK / (4u * bits);  // a 32-byte stripe of the byte stream = 4*bits packed bytes
+    const uint64_t seed = 42;
+    uint64_t v = acc == 0 ? seed + XP1 + XP2 : (acc == 1 ? seed + XP2 : (acc == 2 ? seed : seed - XP1));
+    __syncthreads();
+    for (uint32_t chunk = 0; chunk < bytesPerItem; chunk += DG_CHUNK) {
+        for (uint32_t k = tid; k < DG_ITEMS * (DG_CHUNK / 16); k += 256) {
+            const uint32_t row = k >> 4, part = k & 15u;
+            const uint8_t* src = s_ptr[row];
+            uint4 w = make_uint4(0u, 0u, 0u, 0u);
+            if (src) w = *(const uint4*)(src + chunk + part * 16u);
+            uint32_t* dst = s_buf + row * DG_STRIDE + part * 4u;
+            dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+        }
+        __syncthreads();
+        if (bits == 2) {
+            const uint16_t* q = (const uint16_t*)(s_buf + il * DG_STRIDE) + acc;
+            #pragma unroll 4
+            for (uint32_t st = 0; st < stripesPerChunk; ++st) v = xxh_round(v, expand8((uint32_t)q[4 * st], 2));
+        } else {
+            const uint8_t* q = (const uint8_t*)(s_buf + il * DG_STRIDE) + acc;
+            #pragma unroll 4
+            for (uint32_t st = 0; st < stripesPerChunk; ++st) v = xxh_round(v, expand8((uint32_t)q[4 * st], 1));
+        }
+        __syncthreads();
+    }
+    const uint32_t lane = tid & 63u, l0 = lane & ~3u;
+    const uint64_t v1 = __shfl(v, l0), v2 = __shfl(v, l0 + 1), v3 = __shfl(v, l0 + 2), v4 = __shfl(v, l0 + 3);
+    uint64_t h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+    h = xxh_merge(h, v1); h = xxh_merge(h, v2); h = xxh_merge(h, v3); h = xxh_merge(h, v4);
+    h += (uint64_t)M;
+    h = xxh_avalanche(h);
+    if (live && acc == 0) digests[itemIds[it]] = h;
+}
+
 void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
                    uint64_t* digests, hipStream_t stream)
 {
     if (numItems == 0) return;
+    const uint32_t bytesPerItem = ((1u << (2 * level)) * bits) >> 3;
+    if (bytesPerItem >= (uint32_t)DG_CHUNK) { // (powers of two: a multiple of DG_CHUNK)
+        hipLaunchKernelGGL(digest_items_lds, dim3((numItems + DG_ITEMS - 1) / DG_ITEMS), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests);
+        return;
+    }
     const uint32_t threads = numItems * 4u;
     hipLaunchKernelGGL(digest_items, dim3((threads + 255u) / 256u), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests);
 }

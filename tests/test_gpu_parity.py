@@ -582,3 +582,21 @@ def test_baseline_config4_mixed_levels_dynamic_8k(product, oracle):
     assert sum(c for c, l, f in full.index_hist) == int((full.index >= 0).sum())
     oracle.destroy_texture(ob, otx); oracle.destroy_baker(ob)
     product.destroy_texture(b, t); product.destroy_baker(b)
+
+
+def test_array_data_over_4gib_fails_cleanly(product):
+    """bake_cpu_impl.cpp:1774-1775: offsets are 32-bit, a bake whose OMM array would exceed UINT32_MAX bytes is a FAILURE, not a wrap-around.
+    300k large triangles at level 8 -> ~4.9 GB of mixed 16 KiB blocks."""
+    n = 300000
+    tex = ot.foliage_texture(77, 4096, 4096, feature=16)
+    uv, ix = ot.random_triangles(78, n, 60.0 / 4096)
+    b = product.create_baker()
+    t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+    d = ot.make_desc(t, uv, ix, 8, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, flags=ot.FLAG_THREADS | ot.FLAG_NO_DEDUP)
+    product.bake(b, d, expect=ot.FAILURE, want_stats=False)
+    # the baker is still usable afterwards
+    d2 = ot.make_desc(t, uv[:300], ix[:300], 8, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+    r = product.bake(b, d2, want_stats=False)
+    assert r.index.size == 100
+    product.destroy_texture(b, t)
+    product.destroy_baker(b)
