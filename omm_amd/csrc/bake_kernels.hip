@@ -141,16 +141,16 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         const int ww = r.ex - r.sx + 1, wh = r.ey - r.sy + 1;
         if (r.ok && ww <= WIN && wh <= WIN) {
             const DevMip& m0 = P.mips[0];
-            for (int k = (int)tid; k < ww * wh; k += BLOCK) {
-                const int x = r.sx + k % ww, y = r.sy + k / ww;
-                const size_t idx = (size_t)x + (size_t)y * (size_t)m0.w;
-                s_wtex[k] = FP32 ? ((const float*)m0.texels)[idx] : (float)((const uint8_t*)m0.texels)[idx] * (1.f / 255.f);
-            }
-            if (m0.sat) {
-                for (int k = (int)tid; k < (ww + 1) * (wh + 1); k += BLOCK) {
-                    const int x = r.sx - 1 + k % (ww + 1), y = r.sy - 1 + k / (ww + 1);
-                    s_wsat[k] = (x >= 0 && y >= 0) ? m0.sat[(size_t)x + (size_t)y * (size_t)m0.w] : 0u;
+            // 64 x 4 thread grid over the window (no integer division by the run-time width): column = lane, 4 rows per pass
+            const int cx = (int)(tid & 63u);
+            for (int cy = (int)(tid >> 6); cy <= wh; cy += BLOCK / 64) {
+                const int x = r.sx + cx, y = r.sy + cy;
+                if (cx < ww && cy < wh) {
+                    const size_t idx = (size_t)x + (size_t)y * (size_t)m0.w;
+                    s_wtex[cx + cy * ww] = FP32 ? ((const float*)m0.texels)[idx] : (float)((const uint8_t*)m0.texels)[idx] * (1.f / 255.f);
                 }
+                if (m0.sat && cx <= ww) // SAT entry (x-1, y-1); row / column -1 of the table is zero
+                    s_wsat[cx + cy * (ww + 1)] = (x >= 1 && y >= 1) ? m0.sat[(size_t)(x - 1) + (size_t)(y - 1) * (size_t)m0.w] : 0u;
             }
             W.tex = (lds_float*)s_wtex; W.sat = (lds_u32*)s_wsat; W.base = m0.texels; W.sx = r.sx; W.sy = r.sy; W.w = ww; W.h = wh; // (SAT part is only read when coarse is on)
         }
@@ -186,6 +186,10 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
             bool unresolved = false;
             if (i < count) {
                 int st = -1;
+#ifdef OMMX_DEBUG_SKIP_PHASE1  // timing attribution only (never shipped)
+                if (coarse) st = 0;
+                else
+#endif
                 if (coarse) {
                     const uint32_t u = SLICED ? base + i : (i & (M - 1u));
                     const float* uvp = SLICED ? uUv : A.uv + 6ull * itemIds[firstItem + (i >> (2 * level))];

@@ -67,7 +67,7 @@ def sharded_bake(dll, baker, desc_ptr, rank, world, torch, dist):
             raise RuntimeError("ommxShardedTail failed: %d" % r)
         gathered_ptr = contrib.value
         keep = None
-        if world > 1:
+        if world > 1 and stride.value:   # stride is the global maximum: zero means no rank has any block to contribute
             keep = allgather_padded(dist, torch, device_tensor(torch, contrib.value, stride.value, torch.uint8), world)
             torch.cuda.current_stream().synchronize()
             gathered_ptr = keep.data_ptr()
