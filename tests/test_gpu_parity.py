@@ -600,3 +600,78 @@ def test_array_data_over_4gib_fails_cleanly(product):
     assert r.index.size == 100
     product.destroy_texture(b, t)
     product.destroy_baker(b)
+
+
+def test_user_allocator_is_honoured_and_balanced(product):
+    """ommMemoryAllocatorInterface (omm.h:243-256): every host block the library hands out comes from the user's callbacks and is
+    returned to them; the warm result pool of the default allocator is bypassed (DESIGN.md fences)."""
+    import ctypes as C
+    libc = C.CDLL("libc.so.6")
+    libc.aligned_alloc.restype = C.c_void_p; libc.aligned_alloc.argtypes = [C.c_size_t, C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    live, stats = {}, dict(allocs=0, frees=0, biggest=0)
+    ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t)
+    REALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t)
+    FREE = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+
+    def do_alloc(user, size, align):
+        a = max(int(align), 16)
+        p = libc.aligned_alloc(a, (int(size) + a - 1) // a * a)
+        live[p] = size; stats["allocs"] += 1; stats["biggest"] = max(stats["biggest"], int(size))
+        return p
+
+    def do_free(user, p):
+        if p:
+            assert p in live, "free of a block this allocator never returned"
+            del live[p]; stats["frees"] += 1; libc.free(p)
+
+    def do_realloc(user, p, size, align):
+        q = do_alloc(user, size, align)
+        if p:
+            C.memmove(q, p, min(int(size), int(live[p]))); do_free(user, p)
+        return q
+
+    cbs = (ALLOC(do_alloc), REALLOC(do_realloc), FREE(do_free))
+    d = ot.BakerCreationDesc(); d.type = 1
+    d.memoryAllocatorInterface.allocate = C.cast(cbs[0], C.c_void_p)
+    d.memoryAllocatorInterface.reallocate = C.cast(cbs[1], C.c_void_p)
+    d.memoryAllocatorInterface.free = C.cast(cbs[2], C.c_void_p)
+    b = C.c_void_p()
+    assert product.fn("ommCreateBaker")(C.byref(d), C.byref(b)) == ot.SUCCESS
+    n = 4000
+    tex = ot.foliage_texture(8, 1024, 1024, feature=24)
+    uv, ix = ot.random_triangles(9, n, 10.0 / 1024)
+    t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+    desc = ot.make_desc(t, uv, ix, 8, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+    r1 = product.bake(b, desc)
+    assert r1.array_data.size > (8 << 20) and stats["biggest"] >= r1.array_data.size     # the big block came through the callbacks
+    r2 = product.bake(b, desc)
+    assert r1.same_as(r2)
+    product.destroy_texture(b, t)
+    assert product.destroy_baker(b) == ot.SUCCESS
+    assert not live and stats["allocs"] == stats["frees"] and stats["allocs"] >= 6, stats
+    # and the default-allocator path (warm pool, reused block) yields the same bytes
+    b2 = product.create_baker()
+    t2 = product.create_texture(b2, [tex], alpha_cutoff=0.5)
+    desc2 = ot.make_desc(t2, uv, ix, 8, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+    for _ in range(3):
+        assert product.bake(b2, desc2).same_as(r1)
+    product.destroy_texture(b2, t2); product.destroy_baker(b2)
+
+
+def test_bench_contract_small():
+    """bench.py prints exactly one JSON line with the driver's keys (tiny workload)"""
+    import json, subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--tris", "3000", "--level", "6", "--tex", "512", "--steps", "2", "--warmup", "1",
+                          "--cpu-sample", "300", "--host-api-steps", "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None and d["value"] > 0
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and d["roofline"]["traffic"] is None   # PMC traffic applies to the default workload only
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
+    assert "workload" in d["config"] and "model" not in d["config"]
