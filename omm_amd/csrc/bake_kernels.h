@@ -50,6 +50,7 @@ hipError_t run_setup_items(const SetupParams& S, void* scratch, size_t scratchBy
 // ---- multi-GPU sharding helpers (tail_kernels.hip) ----
 constexpr int kMaxRanks = 16;
 struct ShardBounds { uint32_t rank, world; uint32_t b[kNumLevels][kMaxRanks + 1]; }; // b[l][r]: first active-list position of rank r at level l
+void launch_shard_interleave(const uint32_t* in, uint32_t* out, uint32_t count, uint32_t stride, hipStream_t stream);
 void launch_shard_pack_meta(const ShardBounds& B, const uint32_t* activeIds, uint32_t numActive, const uint32_t* mask, const uint32_t* known,
                             const uint64_t* digests, uint32_t* meta, hipStream_t stream);
 void launch_shard_unpack_meta(const ShardBounds& B, const uint32_t* activeIds, uint32_t numActive, const uint32_t* meta, uint32_t* mask, uint32_t* known,

@@ -549,6 +549,24 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     // ---- ResampleCoarse + ResampleFine (bake_cpu_impl.cpp:715-1029) on the active items ----
     ItemArrays A; A.uv = dUv; A.degenerate = dDegen; A.stateOfs = dStateOfs; A.states = dStates; A.stateMask = dMask; A.knownCount = dKnown; A.fineCount = dFine;
     if (!HIP_OK(hipMemsetAsync(dFine, 0, 8, stream))) return L.failure("[Failure] - device memset failed");
+    if (sh && sh->world > 1) { // even out the per-rank cost: interleave every level's active list (tail_kernels.hip: shard_interleave)
+        const uint32_t numActiveAll = hc.activeStart[kNumLevels];
+        uint32_t* tmp = nullptr;
+        if (numActiveAll && !HIP_OK(hipMalloc((void**)&tmp, (size_t)numActiveAll * 4))) return L.failure("[Failure] - out of device memory for the shard permutation");
+        bool okp = true;
+        for (int l = 0; l < kNumLevels && okp; ++l) {
+            const uint32_t a = hc.activeStart[l], cnt = hc.activeStart[l + 1] - hc.activeStart[l];
+            if (cnt < 3) continue;
+            uint32_t stride = (uint32_t)((double)cnt * 0.6180339887498949); if (stride < 1) stride = 1;
+            auto gcd = [](uint32_t x, uint32_t y) { while (y) { const uint32_t t = x % y; x = y; y = t; } return x; };
+            while (gcd(stride, cnt) != 1) ++stride;   // (cnt - 1 is always coprime: terminates)
+            launch_shard_interleave(dActiveIds + a, tmp + a, cnt, stride % cnt, stream);
+            okp = HIP_OK(hipMemcpyAsync(dActiveIds + a, tmp + a, (size_t)cnt * 4, hipMemcpyDeviceToDevice, stream));
+        }
+        okp = okp && HIP_OK(hipStreamSynchronize(stream));
+        if (tmp) (void)hipFree(tmp);
+        if (!okp) return L.failure("[Failure] - shard permutation failed");
+    }
     // single GPU: every rank range is the whole level group
     ShardBounds bounds; memset(&bounds, 0, sizeof bounds);
     bounds.rank = sh ? sh->rank : 0; bounds.world = sh ? sh->world : 1;

@@ -211,6 +211,23 @@ hipError_t run_prep(const uint32_t* itemIds, const uint8_t* active, const uint8_
     return hipGetLastError();
 }
 
+// ---- multi-GPU load balance: interleave the active list of one level -------------------------------------------------------
+// Ranks own CONTIGUOUS position ranges of the per-level active list.  In input order neighbouring triangles of a real mesh have
+// similar classification cost, so a contiguous range can be much heavier than another.  Position j of the list handed to the
+// ranks takes the item from natural position (j * stride) mod count, stride ~ count / golden ratio and coprime to count: a
+// bijection under which every contiguous j-range samples the whole level evenly.  Same permutation on every rank (pure function
+// of count), and nothing downstream depends on the order of the list.
+__global__ __launch_bounds__(256) void shard_interleave(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t count, uint32_t stride)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < count) out[j] = in[(uint32_t)(((uint64_t)j * stride) % count)];
+}
+void launch_shard_interleave(const uint32_t* in, uint32_t* out, uint32_t count, uint32_t stride, hipStream_t stream)
+{
+    if (count == 0) return;
+    hipLaunchKernelGGL(shard_interleave, dim3((count + 255u) / 256u), dim3(256), 0, stream, in, out, count, stride);
+}
+
 // ---- multi-GPU sharding: work items are partitioned over ranks, the tail is replicated ----
 // rank ranges of the per-level active lists: rank r owns positions [bounds[l][r], bounds[l][r+1]) of the compacted list
 __device__ __forceinline__ uint32_t owner_of_position(const ShardBounds& B, uint32_t p)
