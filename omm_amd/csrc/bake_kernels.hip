@@ -109,6 +109,9 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     __shared__ float    s_wtex[SLICED ? WIN * WIN : 1];
     __shared__ uint32_t s_wsat[SLICED ? (WIN + 1) * (WIN + 1) : 1];
     constexpr uint32_t TILE_LOG4 = TILE == 4096 ? 6u : 5u; // the tile is the level-(N - TILE_LOG4) sub-triangle of its item
+    // a sliced tile implies 4^level >= TILE; without the hint clang hoists micro_triangle()'s level-0 branch (three loop-invariant
+    // vertices) out of the phase-1/2 loops and keeps them in VGPRs for the whole kernel
+    if (SLICED) __builtin_assume(level >= TILE_LOG4);
 
     const uint32_t M = 1u << (2 * level);
     const uint32_t tid = threadIdx.x;
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
             if (tid == 0) s_tile = region_state<MD>(P, sub, uMaxAbs, W);
             if (tid >= 64 && tid < 64 + TILE / GROUP) { // (4096-tile: 64 groups = all of wave 1; 1024-tile: 16 of its lanes)
                 const uint32_t g = tid - 64;
-                s_group[g] = region_state<MD>(P, micro_triangle(uUv, (base >> 6) + g, level - 3), uMaxAbs, W);
+                s_group[g] = region_state_ex<MD>(P, micro_triangle(uUv, (base >> 6) + g, level - 3), uMaxAbs, W);
             }
         } else if (tid < (uint32_t)(TILE / GROUP)) s_group[tid] = -1;
         __syncthreads();
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
             const uint32_t i0 = tid * GROUP;
             if (coarse && level >= 3 && i0 < count) { // 64 consecutive micro-triangles = one level-(N-3) sub-triangle of one item
                 const float* uvp = A.uv + 6ull * itemIds[firstItem + (i0 >> (2 * level))];
-                gs = region_state<MD>(P, micro_triangle(uvp, (i0 & (M - 1u)) >> 6, level - 3), item_max_abs(uvp), W);
+                gs = region_state_ex<MD>(P, micro_triangle(uvp, (i0 & (M - 1u)) >> 6, level - 3), item_max_abs(uvp), W);
             }
             s_group[tid] = gs;
         }
@@ -184,6 +187,9 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
             const int gs = s_group[i >> 6];      // wave-uniform: a wave is exactly one group
             if (gs >= 0) { if (i < count) s_state[i] = (uint8_t)gs; continue; }
             bool unresolved = false;
+            if (gs == kRegionAllOpen) { // the whole group is unresolved by construction: no per-micro-triangle SAT test
+                unresolved = i < count;   // (phase 2 writes the state of every queued micro-triangle)
+            } else
             if (i < count) {
                 int st = -1;
 #ifdef OMMX_DEBUG_SKIP_PHASE1  // timing attribution only (never shipped)

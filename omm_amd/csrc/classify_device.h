@@ -547,16 +547,34 @@ __device__ __forceinline__ TexRect region_rect(const ClassifyParams& P, const Mi
     return r;
 }
 
+constexpr int kRegionUnknown = -1;     // descendants must be tested one by one
+constexpr int kRegionAllOpen = -2;     // EVERY descendant stays unresolved in the coarse pass (region_state_ex only)
+
+template <class MD, bool WANT_OPEN>
+__device__ __forceinline__ int region_state_impl(const ClassifyParams& P, const MicroTri& sub, float maxAbs, const TexWindow& W)
+{
+    const TexRect r = region_rect<MD>(P, sub, maxAbs);
+    if (!r.ok) return kRegionUnknown;
+    const uint32_t area = (uint32_t)((r.ex - r.sx + 1) * (r.ey - r.sy + 1));
+    const uint32_t sa = sat_sum(P.mips[0], r.sx, r.sy, r.ex, r.ey, W);
+    int st = kRegionUnknown;
+    if (sa == 0) st = P.stateLE; else if (sa == area) st = P.stateGT;
+    // The converse shortcut.  A descendant's texel rectangle is at least 2 x 2 ([floor(lo), floor(hi) + 1], hi >= lo) and is contained
+    // in the ancestor's; when the ancestor's rectangle is itself 2 x 2 the two coincide, so a non-uniform SAT answer for the
+    // ancestor is the answer of every descendant: none of them is resolved by the coarse pass (their other early-outs,
+    // bake_cpu_impl.cpp:760-775, also leave them unresolved) and all go to the level-line pass without being tested.
+    else if (WANT_OPEN && area == 4u) return kRegionAllOpen;
+    return st == 3 ? kRegionUnknown : st;
+}
 template <class MD>
 __device__ __forceinline__ int region_state(const ClassifyParams& P, const MicroTri& sub, float maxAbs, const TexWindow& W)
 {
-    const TexRect r = region_rect<MD>(P, sub, maxAbs);
-    if (!r.ok) return -1;
-    const uint32_t area = (uint32_t)((r.ex - r.sx + 1) * (r.ey - r.sy + 1));
-    const uint32_t sa = sat_sum(P.mips[0], r.sx, r.sy, r.ex, r.ey, W);
-    int st = -1;
-    if (sa == 0) st = P.stateLE; else if (sa == area) st = P.stateGT;
-    return st == 3 ? -1 : st;
+    return region_state_impl<MD, false>(P, sub, maxAbs, W);
+}
+template <class MD>
+__device__ __forceinline__ int region_state_ex(const ClassifyParams& P, const MicroTri& sub, float maxAbs, const TexWindow& W)
+{
+    return region_state_impl<MD, true>(P, sub, maxAbs, W);
 }
 
 // ---- fine pass for one micro-triangle (bake_cpu_impl.cpp:859-914 linear, :983-1022 nearest) ----
