@@ -98,15 +98,30 @@ __global__ __launch_bounds__(256) void tail_order_sizes(const uint32_t* __restri
                                                         const uint8_t* __restrict__ level, int bits, uint32_t* __restrict__ order,
                                                         uint64_t* __restrict__ sizes64, uint32_t* __restrict__ sizes, uint32_t* __restrict__ arrayHist)
 {
+    // histogram through LDS: a bake usually has ONE level, and ~1e5 global atomics on one address cost 0.9 ms
+    __shared__ uint32_t h[kNumLevels];
+    if (threadIdx.x < kNumLevels) h[threadIdx.x] = 0;
+    __syncthreads();
     const uint32_t E = *numEmitted;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= E) return;
-    const uint32_t item = sortedItems[E - 1u - j];
-    order[j] = item;
-    const uint32_t lvl = level[item];
-    uint32_t n = ((1u << (2u * lvl)) * (uint32_t)bits) >> 3; if (n < 1u) n = 1u;
-    sizes[j] = n; sizes64[j] = n;
-    atomicAdd(&arrayHist[lvl], 1u);
+    if (j < E) {
+        const uint32_t item = sortedItems[E - 1u - j];
+        order[j] = item;
+        const uint32_t lvl = level[item];
+        uint32_t n = ((1u << (2u * lvl)) * (uint32_t)bits) >> 3; if (n < 1u) n = 1u;
+        sizes[j] = n; sizes64[j] = n;
+        // one LDS atomic per (wave, level): lanes of the same level elect a leader
+        unsigned long long todo = __ballot(1);
+        while (todo) {
+            const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+            const uint32_t l0 = (uint32_t)__shfl((int)lvl, (int)leader);
+            const unsigned long long same = __ballot(lvl == l0) & todo;
+            if ((threadIdx.x & 63u) == leader) atomicAdd(&h[l0], (uint32_t)__popcll(same));
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumLevels && h[threadIdx.x]) atomicAdd(&arrayHist[threadIdx.x], h[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256) void tail_item_values(const uint32_t* __restrict__ order, const uint32_t* __restrict__ numEmitted,
