@@ -222,7 +222,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
 #else
         const uint32_t qn = s_qcount;
 #endif
-        if (tid == 0 && qn) atomicAdd(A.fineCount, (unsigned long long)qn);
+        if (tid == 0 && qn) atomicAdd(A.fineCount + (size_t)((blockIdx.x + 7u * blockIdx.y) & (kFineSlots - 1)) * kFineStride, (unsigned long long)qn);
         for (uint32_t q = tid; q < qn; q += BLOCK) {
             const uint32_t i = s_queue[q];
             const uint32_t u = SLICED ? base + i : (i & (M - 1u));

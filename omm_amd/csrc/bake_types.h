@@ -38,6 +38,8 @@ struct ClassifyParams {
 };
 
 // Per work item, device resident (structure of arrays).
+// the level-line statistic is bumped once per tile (millions per bake): striped over 256 cache lines, summed on the host
+constexpr int kFineSlots = 256, kFineStride = 16;
 struct ItemArrays {
     const float*    uv;        // 6 floats per item: p0.x p0.y p1.x p1.y p2.x p2.y
     const uint8_t*  degenerate;// area < 1e-9 (util/geometry.h:44-47)
@@ -45,7 +47,7 @@ struct ItemArrays {
     uint8_t*        states;    // packed 1-/2-bit states, LSB first (bake_cpu_impl.cpp:1806-1816)
     uint32_t*       stateMask; // OR of (1 << state) over the item's micro-triangles
     uint32_t*       knownCount;// number of T/O micro-triangles (only when wantKnownCount)
-    unsigned long long* fineCount; // statistics: micro-triangles that went through the level-line pass
+    unsigned long long* fineCount; // statistics: micro-triangles that went through the level-line pass; kFineSlots counters, kFineStride apart
 };
 
 } // namespace ommx

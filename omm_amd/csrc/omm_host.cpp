@@ -422,7 +422,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     const size_t setupBytes = setup_scratch_bytes(T), tailBytes = tail_scratch_bytes(maxItems, T);
     const size_t scratchBytes = setupBytes > tailBytes ? setupBytes : tailBytes;
     const size_t i32 = pad256((size_t)maxItems * 4), i64 = pad256((size_t)maxItems * 8);
-    const size_t need = pad256((size_t)maxItems * 24) + 3 * pad256(maxItems) + i64 * 2 + i32 * 12 + pad256(sizeof(SetupCounters)) + 4096 + pad256(scratchBytes);
+    const size_t need = pad256((size_t)maxItems * 24) + 3 * pad256(maxItems) + i64 * 2 + i32 * 12 + pad256(sizeof(SetupCounters)) + 4096 + pad256(sizeof(unsigned long long) * kFineSlots * kFineStride) + pad256(scratchBytes);
     if (!arena->reserve(need)) return L.failure("[Failure] - out of device memory for the bake working set");
     float* dUv = arena->take<float>((size_t)maxItems * 6);
     uint8_t* dLevel = arena->take<uint8_t>(maxItems); uint8_t* dDegen = arena->take<uint8_t>(maxItems); uint8_t* dActive = arena->take<uint8_t>(maxItems);
@@ -436,7 +436,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     SetupCounters* dCounters = arena->take<SetupCounters>(1);
     uint64_t* dUniformDigest = arena->take<uint64_t>(kNumLevels * 4);
     uint32_t* dArrayHist = arena->take<uint32_t>(kNumLevels); uint32_t* dIndexHist = arena->take<uint32_t>(kNumLevels); uint32_t* dErr = arena->take<uint32_t>(1);
-    unsigned long long* dFine = arena->take<unsigned long long>(1);
+    unsigned long long* dFine = arena->take<unsigned long long>(kFineSlots * kFineStride); // striped statistic counter (bake_types.h)
     uint8_t* dScratch = arena->take<uint8_t>(scratchBytes);
 
     // ---- SetupWorkItems (bake_cpu_impl.cpp:589-660) on the device ----
@@ -548,7 +548,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
 
     // ---- ResampleCoarse + ResampleFine (bake_cpu_impl.cpp:715-1029) on the active items ----
     ItemArrays A; A.uv = dUv; A.degenerate = dDegen; A.stateOfs = dStateOfs; A.states = dStates; A.stateMask = dMask; A.knownCount = dKnown; A.fineCount = dFine;
-    if (!HIP_OK(hipMemsetAsync(dFine, 0, 8, stream))) return L.failure("[Failure] - device memset failed");
+    if (!HIP_OK(hipMemsetAsync(dFine, 0, sizeof(unsigned long long) * kFineSlots * kFineStride, stream))) return L.failure("[Failure] - device memset failed");
     if (sh && sh->world > 1) { // even out the per-rank cost: interleave every level's active list (tail_kernels.hip: shard_interleave)
         const uint32_t numActiveAll = hc.activeStart[kNumLevels];
         uint32_t* tmp = nullptr;
@@ -663,13 +663,15 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     ok = ok && HIP_OK(hipMemcpyAsync(R.hist, dArrayHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
     ok = ok && HIP_OK(hipMemcpyAsync(R.hist + kNumLevels, dIndexHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
     unsigned long long fineCount = 0;
-    ok = ok && HIP_OK(hipMemcpyAsync(&fineCount, dFine, 8, hipMemcpyDeviceToHost, stream));
+    std::vector<unsigned long long> fineSlots((size_t)kFineSlots * kFineStride, 0ull);
+    ok = ok && HIP_OK(hipMemcpyAsync(fineSlots.data(), dFine, sizeof(unsigned long long) * fineSlots.size(), hipMemcpyDeviceToHost, stream));
     const int e5 = et.mark();
     ok = ok && HIP_OK(hipStreamSynchronize(stream));
     if (!ok) return L.failure("[Failure] - could not materialise the bake result on the device");
 
     tm.uploadMs = 0.f; tm.hostSetupMs = 0.f; tm.setupMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.digestMs = et.ms(e2, e3);
     tm.tailMs = et.ms(e3, e4); tm.gatherMs = et.ms(e4, e5);
+    for (int k = 0; k < kFineSlots; ++k) fineCount += fineSlots[(size_t)k * kFineStride];
     tm.fineMicroTriangles = fineCount; tm.uniqueItems = U; tm.activeItems = hc.activeStart[kNumLevels]; tm.stateBytes = hc.stateBytes; tm.microTriangles = 0;
     for (int l = 0; l < kNumLevels; ++l) { tm.microTriangles += (uint64_t)hc.levelCount[l] << (2 * l); tm.classifyLaunches += hc.activeStart[l + 1] != hc.activeStart[l]; }
     return ommResult_SUCCESS;
