@@ -210,6 +210,13 @@ def main():
             if tj.get("valu_busy") is not None:
                 line["roofline"]["valu_issue_utilisation"] = tj["valu_busy"]
                 line["roofline"]["valu_lane_utilisation"] = tj.get("valu_lane_util")
+        # the streaming part of the path for comparison: final gather of the surviving OMM blocks into arrayData order
+        # (read + write of arrayData, HIP events around gather + index narrowing)
+        gather_ms = avg("gatherMs")
+        if gather_ms > 0 and world == 1:
+            gb = 2.0 * result_info["arrayDataBytes"] + 8.0 * result_info["descs"] + 8.0 * result_info["triangles"]
+            line["roofline_streaming"] = {"bound": "hbm", "kernel": "tail_gather_omms (+ narrow_indices)", "achieved": gb / (gather_ms * 1e-3) / 1e9,
+                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / (gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if args.cpu_sample > 0 and world == 1:
             cb, cpu_res = cpu_baseline(args, tex, uv, ix)
             line["cpu_baseline"] = cb
