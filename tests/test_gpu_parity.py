@@ -675,3 +675,58 @@ def test_bench_contract_small():
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and d["roofline"]["traffic"] is None   # PMC traffic applies to the default workload only
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and "model" not in d["config"]
+
+
+# ---------------------------------------------------------------------------------------------
+# randomized differential test: every knob of the bake desc at once
+# ---------------------------------------------------------------------------------------------
+def _fuzz_case(seed):
+    h = lambda k: int(ot.hash_u32(np.array([seed * 131 + k], dtype=np.int64))[0])
+    pick = lambda k, options: options[h(k) % len(options)]
+    w, hgt = pick(1, [(256, 256), (512, 128), (300, 200), (64, 96), (1024, 1024)])
+    fp32 = pick(2, [False, True, False])
+    kind = pick(3, ["noise", "foliage", "checker"])
+    if kind == "noise":
+        tex = ot.value_noise(seed, w, hgt, octaves=pick(4, [2, 4, 5]), base_cell=pick(5, [8, 32, 64]))
+    elif kind == "foliage":
+        tex = ot.foliage_texture(seed, w, hgt, feature=pick(4, [6, 16, 48])).astype(np.float32) / 255.0
+    else:
+        yy, xx = np.mgrid[0:hgt, 0:w]
+        c = pick(4, [1, 3, 16])
+        tex = (((xx // c) + (yy // c)) & 1).astype(np.float32)
+    tex = np.ascontiguousarray(tex.astype(np.float32) if fp32 else (tex * 255).astype(np.uint8))
+    mips = [tex]
+    if pick(6, [False, False, True]) and min(w, hgt) >= 64:
+        mips.append(np.ascontiguousarray(tex[::2, ::2]))
+    level = pick(7, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+    n = max(4, min(400, 3000000 // (4 ** level)))
+    ext = pick(8, [0.5, 2.0, 8.0, 40.0, 0.05]) / max(w, hgt)
+    uv, ix = ot.random_triangles(seed + 7, n, ext * pick(9, [1.0, 1.0, 8.0]))
+    uv = (uv + np.float32(pick(10, [0.0, 0.0, -3.0, 17.0]))).astype(np.float32)
+    if pick(11, [False, False, True]):   # shared vertices / repeated triangles (UV dedup, digest dedup)
+        ix = (ix // 6 * 3 + ix % 3).astype(ix.dtype)
+    kw = dict(addr=pick(12, [ot.WRAP, ot.MIRROR, ot.CLAMP, ot.BORDER, ot.MIRROR_ONCE]), filt=pick(13, [ot.LINEAR, ot.LINEAR, ot.NEAREST]),
+              fmt=pick(14, [ot.FMT_4STATE, ot.FMT_2STATE]), promo=pick(15, [ot.PROMO_NEAREST, ot.PROMO_FORCE_OPAQUE, ot.PROMO_FORCE_TRANSPARENT]),
+              border_alpha=pick(16, [0.0, 1.0, 0.4]), rejection=pick(17, [0.0, 0.0, 0.3]), dyn_scale=pick(18, [0.0, 0.0, 1.5]))
+    le, gt = pick(19, [(ot.T, ot.O), (ot.O, ot.T), (ot.UT, ot.UO), (ot.T, ot.UO)])
+    if kw["fmt"] == ot.FMT_2STATE:
+        le, gt = (le & 1, gt & 1) if (le & 1) != (gt & 1) else (ot.T, ot.O)
+    kw["le"], kw["gt"] = le, gt
+    flags = ot.FLAG_THREADS
+    for k, f in ((20, ot.FLAG_NO_SPECIAL), (21, ot.FLAG_NO_DEDUP), (22, ot.FLAG_FORCE32), (23, ot.FLAG_ALLOW8)):
+        if pick(k, [False, False, True]):
+            flags |= f
+    kw["flags"] = flags
+    if pick(24, [False, True]):
+        lv = (ot.hash_u32(np.arange(n) + seed) % (level + 1)).astype(np.uint8)
+        lv[ot.hash_u32(np.arange(n) + seed + 99) % 7 == 0] = 0xF
+        kw["levels"] = lv
+    cutoff = pick(25, [0.5, 0.5, 0.25, 0.8])
+    sat = pick(26, [True, True, False])
+    return mips, uv, ix, level, cutoff, sat, kw
+
+
+@pytest.mark.parametrize("seed", range(160))
+def test_fuzz_all_knobs(product, oracle, seed):
+    mips, uv, ix, level, cutoff, sat, kw = _fuzz_case(seed)
+    both(product, oracle, mips, uv, ix, level, sat=sat, cutoff=cutoff, **kw)
