@@ -104,6 +104,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     __shared__ uint16_t s_queue[TILE];
     __shared__ int      s_group[TILE / GROUP];
     __shared__ int      s_tile;
+    __shared__ int      s_rect[5];
     __shared__ uint32_t s_qcount;
     __shared__ uint32_t s_mask, s_known;
     __shared__ float    s_wtex[SLICED ? WIN * WIN : 1];
@@ -138,35 +139,46 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         for (int k = 0; k < 6; ++k) uUv[k] = A.uv[6ull * uItem + k];
         uMaxAbs = item_max_abs(uUv);
         uDegenerate = A.degenerate[uItem] != 0;
-        // ---- LDS window: every texel / SAT entry this tile can touch (footprint of its level-(N-5) sub-triangle) ----
-        const MicroTri sub = micro_triangle(uUv, base / (uint32_t)TILE, level - TILE_LOG4);
-        const TexRect r = region_rect<MD>(P, sub, uMaxAbs);
-        const int ww = r.ex - r.sx + 1, wh = r.ey - r.sy + 1;
-        if (r.ok && ww <= WIN && wh <= WIN) {
-            const DevMip& m0 = P.mips[0];
-            // 64 x 4 thread grid over the window (no integer division by the run-time width): column = lane, 4 rows per pass
-            const int cx = (int)(tid & 63u);
-            for (int cy = (int)(tid >> 6); cy <= wh; cy += BLOCK / 64) {
-                const int x = r.sx + cx, y = r.sy + cy;
-                if (cx < ww && cy < wh) {
-                    const size_t idx = (size_t)x + (size_t)y * (size_t)m0.w;
-                    s_wtex[cx + cy * ww] = FP32 ? ((const float*)m0.texels)[idx] : (float)((const uint8_t*)m0.texels)[idx] * (1.f / 255.f);
-                }
-                if (m0.sat && cx <= ww) // SAT entry (x-1, y-1); row / column -1 of the table is zero
-                    s_wsat[cx + cy * (ww + 1)] = (x >= 1 && y >= 1) ? m0.sat[(size_t)(x - 1) + (size_t)(y - 1) * (size_t)m0.w] : 0u;
+        // ---- phase 0a (wave 0 only; the values are block-uniform and float math has no scalar unit): the tile's sub-triangle, the
+        //      texel rectangle it can touch, and the tile-level SAT query straight from HBM.  A settled tile never loads a window.
+        if (tid < 64u) {
+            const MicroTri sub = micro_triangle(uUv, base / (uint32_t)TILE, level - TILE_LOG4);
+            const TexRect r = region_rect<MD>(P, sub, uMaxAbs);
+            if (tid == 0) {
+                s_rect[0] = r.sx; s_rect[1] = r.sy; s_rect[2] = r.ex; s_rect[3] = r.ey; s_rect[4] = r.ok ? 1 : 0;
+                if (coarse) s_tile = region_state<MD>(P, sub, uMaxAbs, W); // (W is still empty: global SAT reads)
             }
-            W.tex = (lds_float*)s_wtex; W.sat = (lds_u32*)s_wsat; W.base = m0.texels; W.sx = r.sx; W.sy = r.sy; W.w = ww; W.h = wh; // (SAT part is only read when coarse is on)
         }
         __syncthreads();
-        // ---- phase 0: one query for the whole tile (lane 0 of wave 0) and one per 64-micro-triangle group (wave 1) ----
-        if (coarse) {
-            if (tid == 0) s_tile = region_state<MD>(P, sub, uMaxAbs, W);
-            if (tid >= 64 && tid < 64 + TILE / GROUP) { // (4096-tile: 64 groups = all of wave 1; 1024-tile: 16 of its lanes)
-                const uint32_t g = tid - 64;
-                s_group[g] = region_state_ex<MD>(P, micro_triangle(uUv, (base >> 6) + g, level - 3), uMaxAbs, W);
+        if (s_tile < 0) {
+            // ---- phase 0b: LDS window = every texel / SAT entry this tile can touch ----
+            TexRect r; r.sx = s_rect[0]; r.sy = s_rect[1]; r.ex = s_rect[2]; r.ey = s_rect[3]; r.ok = s_rect[4] != 0;
+            const int ww = r.ex - r.sx + 1, wh = r.ey - r.sy + 1;
+            if (r.ok && ww <= WIN && wh <= WIN) {
+                const DevMip& m0 = P.mips[0];
+                // 64 x 4 thread grid over the window (no integer division by the run-time width): column = lane, 4 rows per pass
+                const int cx = (int)(tid & 63u);
+                for (int cy = (int)(tid >> 6); cy <= wh; cy += BLOCK / 64) {
+                    const int x = r.sx + cx, y = r.sy + cy;
+                    if (cx < ww && cy < wh) {
+                        const size_t idx = (size_t)x + (size_t)y * (size_t)m0.w;
+                        s_wtex[cx + cy * ww] = FP32 ? ((const float*)m0.texels)[idx] : (float)((const uint8_t*)m0.texels)[idx] * (1.f / 255.f);
+                    }
+                    if (m0.sat && cx <= ww) // SAT entry (x-1, y-1); row / column -1 of the table is zero
+                        s_wsat[cx + cy * (ww + 1)] = (x >= 1 && y >= 1) ? m0.sat[(size_t)(x - 1) + (size_t)(y - 1) * (size_t)m0.w] : 0u;
+                }
+                W.tex = (lds_float*)s_wtex; W.sat = (lds_u32*)s_wsat; W.base = m0.texels; W.sx = r.sx; W.sy = r.sy; W.w = ww; W.h = wh; // (SAT part is only read when coarse is on)
             }
-        } else if (tid < (uint32_t)(TILE / GROUP)) s_group[tid] = -1;
-        __syncthreads();
+            __syncthreads();
+            // ---- phase 0c: one query per 64-micro-triangle group (wave 1) ----
+            if (coarse) {
+                if (tid >= 64 && tid < 64 + TILE / GROUP) { // (4096-tile: 64 groups = all of wave 1; 1024-tile: 16 of its lanes)
+                    const uint32_t g = tid - 64;
+                    s_group[g] = region_state_ex<MD>(P, micro_triangle(uUv, (base >> 6) + g, level - 3), uMaxAbs, W);
+                }
+            } else if (tid < (uint32_t)(TILE / GROUP)) s_group[tid] = -1;
+            __syncthreads();
+        }
     } else {
         __syncthreads();
         if (tid < (uint32_t)(TILE / GROUP)) {
