@@ -730,3 +730,36 @@ def _fuzz_case(seed):
 def test_fuzz_all_knobs(product, oracle, seed):
     mips, uv, ix, level, cutoff, sat, kw = _fuzz_case(seed)
     both(product, oracle, mips, uv, ix, level, sat=sat, cutoff=cutoff, **kw)
+
+
+def test_concurrent_bakes_on_one_baker(product):
+    """ommCpuBake is re-entrant (the reference bakes are independent objects, bake.cpp:103-116): four host threads share one baker
+    and one texture; a call that finds the baker's device arena busy works in a private one."""
+    import threading
+    tex = ot.foliage_texture(21, 1024, 1024, feature=20)
+    b = product.create_baker()
+    t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+    jobs = []
+    for k in range(4):
+        uv, ix = ot.random_triangles(300 + k, 1500 + 200 * k, 9.0 / 1024)
+        jobs.append((uv, ix, ot.make_desc(t, uv, ix, 6 + (k & 1), addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)))
+    expected = [product.bake(b, d, want_stats=False) for (_, _, d) in jobs]
+    errors = []
+
+    def worker(k):
+        try:
+            for _ in range(4):
+                r = product.bake(b, jobs[k][2], want_stats=False)
+                if not r.same_as(expected[k]):
+                    errors.append("thread %d: %s" % (k, r.diff(expected[k])))
+        except Exception as e:  # noqa: BLE001
+            errors.append("thread %d: %r" % (k, e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    product.destroy_texture(b, t)
+    product.destroy_baker(b)
