@@ -763,3 +763,15 @@ def test_concurrent_bakes_on_one_baker(product):
     assert not errors, errors
     product.destroy_texture(b, t)
     product.destroy_baker(b)
+
+
+def test_log_cases(product):
+    """support/tests/test_omm_log.cpp:146-209 through the HIP library: same messages, same order, same results"""
+    import log_cases
+    log_cases.run_log_cases(product)
+
+
+def test_basic_cases(product):
+    """support/tests/test_basic.cpp:28-51,217-279 through the HIP library"""
+    import basic_cases
+    basic_cases.run_basic_cases(product)
