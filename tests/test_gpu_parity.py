@@ -775,3 +775,17 @@ def test_basic_cases(product):
     """support/tests/test_basic.cpp:28-51,217-279 through the HIP library"""
     import basic_cases
     basic_cases.run_basic_cases(product)
+
+
+def test_minimal_sample(product, oracle):
+    """support/tests/test_minimal_sample.cpp:17-150: triangle fan over a donut, per-triangle levels 2..5, 2-state, shared vertices"""
+    j, i = np.mgrid[0:256, 0:256]
+    dx = (i.astype(np.float32) / np.float32(256)) - np.float32(0.5)
+    dy = (j.astype(np.float32) / np.float32(256)) - np.float32(0.5)
+    ln = np.sqrt((dx * dx + dy * dy).astype(np.float32)).astype(np.float32)
+    tex = np.where((ln > np.float32(0.2)) & (ln < np.float32(0.3)), 1.0, 0.0).astype(np.float32)
+    uv = np.array([[0.05, 0.50], [0.50, 0.05], [0.50, 0.50], [0.95, 0.50], [0.50, 0.95]], np.float32)
+    ix = np.array([0, 1, 2, 1, 3, 2, 3, 4, 2, 2, 4, 0], np.uint32)
+    r = both(product, oracle, [tex], uv, ix, 8, sat=False, cutoff=0.5, addr=ot.CLAMP, filt=ot.LINEAR, fmt=ot.FMT_2STATE,
+             promo=ot.PROMO_FORCE_OPAQUE, flags=0, levels=np.array([2, 3, 4, 5], np.uint8))   # (the sample adds EnableValidation + a log callback)
+    assert sorted(int(l) for l in r.descs[:, 1]) == [2, 3, 4, 5] and np.all(r.descs[:, 2] == 1)
