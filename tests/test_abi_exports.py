@@ -56,3 +56,20 @@ def test_host_side_argument_checks_need_no_gpu():
     b = lib.create_baker()
     assert lib.bake_raw(b, d)[0] == ot.INVALID_ARGUMENT   # no texture set
     assert lib.destroy_baker(b) == ot.SUCCESS
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    """the product has no CPU path.  On a machine without a HIP device texture creation (the first call that
+    needs HBM) fails loudly -- FAILURE + a Fatal log line -- instead of computing anything on the host."""
+    hip = C.CDLL("libamdhip64.so")
+    n = C.c_int(0)
+    if hip.hipGetDeviceCount(C.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a HIP device is present: the fail-loudly path cannot be exercised here")
+    import numpy as np
+    lib = ot.Lib("product")
+    msgs = []
+    b = lib.create_baker(callback=lambda sev, msg, user: msgs.append((sev, msg.decode())))
+    t = lib.create_texture(b, [np.zeros((16, 16), np.float32)], expect=ot.FAILURE)
+    assert t is None
+    assert msgs and msgs[-1][0] == 3 and "no CPU fallback" in msgs[-1][1], msgs       # ommMessageSeverity_Fatal
+    assert lib.destroy_baker(b) == ot.SUCCESS
