@@ -265,27 +265,56 @@ hipError_t run_setup_fetch(const SetupParams& S, void* scratch, size_t scratchBy
 }
 
 // host-computed levels for the pending (degenerate, dynamic) triangles: levels[k] belongs to triangle pendingHost[k]
+// pending = triangles whose level needs glibc's log2f (degenerate triangles under dynamic subdivision).  Usually a handful, but a
+// mesh of tiny triangles can have tens of thousands: their UVs and levels move in ONE transfer each way.
+__global__ __launch_bounds__(256) void setup_gather_pending(const float* __restrict__ triUv, const uint32_t* __restrict__ pending, uint32_t n, float* __restrict__ out)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float* src = triUv + 6ull * pending[k];
+    #pragma unroll
+    for (int j = 0; j < 6; ++j) out[6ull * k + j] = src[j];
+}
+__global__ __launch_bounds__(256) void setup_scatter_levels(const uint32_t* __restrict__ pending, const uint8_t* __restrict__ levels, uint32_t n, uint8_t* __restrict__ triLevel)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) triLevel[pending[k]] = levels[k];
+}
+
 hipError_t run_setup_fix_pending(const SetupParams& S, void* scratch, size_t scratchBytes, const uint32_t* pendingTris /*host*/, const uint8_t* levels /*host*/,
                                  uint32_t numPending, hipStream_t stream)
 {
     if (numPending == 0) return hipSuccess;
     SetupScratch s = carve_setup(scratch, scratchBytes, S.numTris);
-    for (uint32_t k = 0; k < numPending; ++k) // rare path (degenerate triangles under dynamic subdivision): a few bytes each
-        SETUP_CHECK(hipMemcpyAsync(s.triLevel + pendingTris[k], levels + k, 1, hipMemcpyHostToDevice, stream));
-    SETUP_CHECK(hipMemcpyAsync(s.pending, pendingTris, (size_t)numPending * 4, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(setup_rehash_pending, dim3((numPending + 255u) / 256u), dim3(256), 0, stream, S, s.triUv, s.triLevel, s.pending, numPending, s.keysA);
-    return hipGetLastError();
+    uint8_t* dLevels = nullptr;
+    SETUP_CHECK(hipMalloc((void**)&dLevels, numPending));
+    hipError_t e = hipMemcpyAsync(dLevels, levels, numPending, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s.pending, pendingTris, (size_t)numPending * 4, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) {
+        const dim3 grid((numPending + 255u) / 256u), block(256);
+        hipLaunchKernelGGL(setup_scatter_levels, grid, block, 0, stream, s.pending, dLevels, numPending, s.triLevel);
+        hipLaunchKernelGGL(setup_rehash_pending, grid, block, 0, stream, S, s.triUv, s.triLevel, s.pending, numPending, s.keysA);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(dLevels);
+    return e;
 }
 
 hipError_t copy_pending_to_host(void* scratch, size_t scratchBytes, uint32_t numTris, uint32_t numPending, uint32_t* pendingTris /*host*/, float* pendingUv /*host, 6 each*/,
                                 hipStream_t stream)
 {
+    if (numPending == 0) return hipSuccess;
     SetupScratch s = carve_setup(scratch, scratchBytes, numTris);
-    SETUP_CHECK(hipMemcpyAsync(pendingTris, s.pending, (size_t)numPending * 4, hipMemcpyDeviceToHost, stream));
-    SETUP_CHECK(hipStreamSynchronize(stream));
-    for (uint32_t k = 0; k < numPending; ++k)
-        SETUP_CHECK(hipMemcpyAsync(pendingUv + 6ull * k, s.triUv + 6ull * pendingTris[k], 24, hipMemcpyDeviceToHost, stream));
-    return hipStreamSynchronize(stream);
+    float* dUv = nullptr;
+    SETUP_CHECK(hipMalloc((void**)&dUv, (size_t)numPending * 24));
+    hipLaunchKernelGGL(setup_gather_pending, dim3((numPending + 255u) / 256u), dim3(256), 0, stream, s.triUv, s.pending, numPending, dUv);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(pendingTris, s.pending, (size_t)numPending * 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(pendingUv, dUv, (size_t)numPending * 24, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(dUv);
+    return e;
 }
 
 hipError_t run_setup_items(const SetupParams& S, void* scratch, size_t scratchBytes, SetupCounters* counters, float* itemUv, uint8_t* itemLevel,
