@@ -1,3 +1,6 @@
+"""Measurement probe (not a test): cost of allocating / first-touching / freeing a 1.3 GB host block in the ways the host path of
+ommCpuBake could obtain its result memory, and the D2H rate into each.  Result on the MI355X box (DESIGN.md fences, HostPool in
+omm_host.cpp): fresh malloc = 72-103 ms first D2H (page faults) + 95 ms free; warm pages = 24 ms (57 GB/s); hipHostMalloc = 235 ms."""
 import ctypes as C, time
 hip = C.CDLL("libamdhip64.so")
 n = 1300 * 1024 * 1024
