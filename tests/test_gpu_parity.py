@@ -789,3 +789,50 @@ def test_minimal_sample(product, oracle):
     r = both(product, oracle, [tex], uv, ix, 8, sat=False, cutoff=0.5, addr=ot.CLAMP, filt=ot.LINEAR, fmt=ot.FMT_2STATE,
              promo=ot.PROMO_FORCE_OPAQUE, flags=0, levels=np.array([2, 3, 4, 5], np.uint8))   # (the sample adds EnableValidation + a log callback)
     assert sorted(int(l) for l in r.descs[:, 1]) == [2, 3, 4, 5] and np.all(r.descs[:, 2] == 1)
+
+
+def _texture_pitch_and_desc(lib):
+    """rowPitch is in BYTES for DisableZOrder textures and in TEXELS otherwise (texture_impl.cpp:141-142,169,179); ommCpuGetTextureDesc
+    returns the tight texels with rowPitch = width (texture_impl.cpp:280-325).  Returns the bake results for comparison."""
+    import ctypes as C
+    w, h, pad = 96, 40, 7
+    out = []
+    for dtype in (np.uint8, np.float32):
+        tight = ot.value_noise(31, w, h, octaves=3, base_cell=16)
+        tight = np.ascontiguousarray((tight * 255).astype(np.uint8) if dtype == np.uint8 else tight.astype(np.float32))
+        padded = np.zeros((h, w + pad), dtype)
+        padded[:, :w] = tight
+        uv, ix = ot.random_triangles(32, 60, 0.3)
+        for linear in (True, False):
+            b = lib.create_baker()
+            pitch = (w + pad) * padded.itemsize if linear else (w + pad)
+            md = (ot.TextureMipDesc * 1)()
+            md[0].width, md[0].height, md[0].rowPitch, md[0].textureData = w, h, pitch, padded.ctypes.data
+            td = ot.TextureDesc()
+            td.format, td.flags, td.mips, td.mipCount, td.alphaCutoff = (ot.TEX_FP32 if dtype == np.float32 else ot.TEX_UNORM8), (ot.TEXFLAG_DISABLE_ZORDER if linear else 0), md, 1, 0.5
+            t = C.c_void_p()
+            assert lib.fn("ommCpuCreateTexture")(b, C.byref(td), C.byref(t)) == ot.SUCCESS
+            r_pitched = lib.bake(b, ot.make_desc(t, uv, ix, 5, addr=ot.WRAP))
+            if hasattr(lib.dll, lib.prefix + "ommCpuGetTextureDesc"):   # (the oracle restates the bake only)
+                q = ot.TextureDesc()
+                assert lib.fn("ommCpuGetTextureDesc")(t, C.byref(q)) == ot.SUCCESS          # mips == NULL: header only
+                assert (q.format, q.flags, q.mipCount) == (td.format, td.flags, 1) and abs(q.alphaCutoff - 0.5) < 1e-7
+                back = np.full((h, w), 77, dtype)
+                md2 = (ot.TextureMipDesc * 1)(); md2[0].textureData = back.ctypes.data
+                q.mips = md2
+                assert lib.fn("ommCpuGetTextureDesc")(t, C.byref(q)) == ot.SUCCESS
+                assert (md2[0].width, md2[0].height, md2[0].rowPitch) == (w, h, w)
+                assert np.array_equal(back, tight)
+            lib.destroy_texture(b, t)
+            t2 = lib.create_texture(b, [tight], alpha_cutoff=0.5, disable_zorder=linear)
+            r_tight = lib.bake(b, ot.make_desc(t2, uv, ix, 5, addr=ot.WRAP))
+            assert r_pitched.same_as(r_tight), r_pitched.diff(r_tight)
+            lib.destroy_texture(b, t2); lib.destroy_baker(b)
+            out.append(r_tight)
+    return out
+
+
+def test_texture_row_pitch_and_get_desc(product, oracle):
+    a, b = _texture_pitch_and_desc(product), _texture_pitch_and_desc(oracle)
+    for x, y in zip(a, b):
+        assert x.same_as(y), x.diff(y)
