@@ -92,8 +92,11 @@ constexpr int WIN = 32; // largest LDS texel window edge
 
 // SLICED: 4^level >= TILE, the tile is a slice of ONE work item (block-uniform item data, LDS texel/SAT window).
 // !SLICED: the tile holds TILE / 4^level whole items.
+// 7 waves/SIMD = 72 VGPRs (and 7 x 21.5 KB of LDS per CU).  The level-line body needs one register more, so the sliced
+// instantiations spill ONE dword per unresolved micro-triangle (its queue entry, dead across the pass): 52.3 -> 50.0 ms against
+// the spill-free 6-wave build, and the extra HBM writes stay below the kernel's algorithmic bytes (profiles/).
 #ifndef OMMX_CLASSIFY_WAVES
-#define OMMX_CLASSIFY_WAVES 6
+#define OMMX_CLASSIFY_WAVES 7
 #endif
 // TILE micro-triangles per workgroup: 4096 for levels >= 6, 1024 below (a level-5 item is exactly one 1024-tile)
 template <bool FP32, bool SLICED, int TILE, class MD>
@@ -235,14 +238,17 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         const uint32_t qn = s_qcount;
 #endif
         if (tid == 0 && qn) atomicAdd(A.fineCount + (size_t)((blockIdx.x + 7u * blockIdx.y) & (kFineSlots - 1)) * kFineStride, (unsigned long long)qn);
-        for (uint32_t q = tid; q < qn; q += BLOCK) {
-            const uint32_t i = s_queue[q];
-            const uint32_t u = SLICED ? base + i : (i & (M - 1u));
-            if (SLICED) {
-                s_state[i] = (uint8_t)fine_state<FP32, MD>(P, micro_triangle(uUv, u, level), uDegenerate, W);
-            } else {
-                const uint32_t item = itemIds[firstItem + (i >> (2 * level))];
-                s_state[i] = (uint8_t)fine_state<FP32, MD>(P, micro_triangle(A.uv + 6ull * item, u, level), A.degenerate[item] != 0, W);
+        for (uint32_t q0 = 0; q0 < qn; q0 += BLOCK) { // q0 is block-uniform (scalar loop counter): one VGPR less across the level-line pass
+            const uint32_t q = q0 + tid;
+            if (q < qn) {
+                const uint32_t i = s_queue[q];
+                const uint32_t u = SLICED ? base + i : (i & (M - 1u));
+                if (SLICED) {
+                    s_state[i] = (uint8_t)fine_state<FP32, MD>(P, micro_triangle(uUv, u, level), uDegenerate, W);
+                } else {
+                    const uint32_t item = itemIds[firstItem + (i >> (2 * level))];
+                    s_state[i] = (uint8_t)fine_state<FP32, MD>(P, micro_triangle(A.uv + 6ull * item, u, level), A.degenerate[item] != 0, W);
+                }
             }
         }
         __syncthreads();
