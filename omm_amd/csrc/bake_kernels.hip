@@ -370,18 +370,22 @@ __device__ __forceinline__ uint64_t xxh_round(uint64_t acc, uint64_t in) { acc +
 __device__ __forceinline__ uint64_t xxh_merge(uint64_t h, uint64_t v) { h ^= xxh_round(0, v); return h * XP1 + XP4; }
 __device__ __forceinline__ uint64_t xxh_avalanche(uint64_t h) { h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32; return h; }
 
-// 8 consecutive micro-triangle states -> 8 bytes (little endian), UT(2) -> UO(3)
+// 8 consecutive micro-triangle states -> 8 bytes (little endian), UT(2) -> UO(3).  Bit-spreading instead of a per-state loop:
+// four 2-bit (or 1-bit) fields of a byte are moved to the low bits of four bytes with two shift/or/and steps.
+__device__ __forceinline__ uint32_t spread4x2(uint32_t b) // b: 8 bits = 4 states -> 4 bytes, UT folded into UO
+{
+    uint32_t y = (b | (b << 12)) & 0x000F000Fu;
+    y = (y | (y << 6)) & 0x03030303u;
+    return y | ((y >> 1) & 0x01010101u); // 2 -> 3, 3 stays 3, 0/1 unchanged
+}
+__device__ __forceinline__ uint32_t spread4x1(uint32_t n) // n: 4 bits = 4 states -> 4 bytes
+{
+    return (n | (n << 7) | (n << 14) | (n << 21)) & 0x01010101u;
+}
 __device__ __forceinline__ uint64_t expand8(uint32_t packed, uint32_t bits)
 {
-    uint64_t out = 0;
-    if (bits == 2) {
-        #pragma unroll
-        for (int k = 0; k < 8; ++k) { uint32_t s = (packed >> (2 * k)) & 3u; s = (s == 2u) ? 3u : s; out |= (uint64_t)s << (8 * k); }
-    } else {
-        #pragma unroll
-        for (int k = 0; k < 8; ++k) { const uint32_t s = (packed >> k) & 1u; out |= (uint64_t)s << (8 * k); }
-    }
-    return out;
+    if (bits == 2) return (uint64_t)spread4x2(packed & 0xffu) | ((uint64_t)spread4x2((packed >> 8) & 0xffu) << 32);
+    return (uint64_t)spread4x1(packed & 0xfu) | ((uint64_t)spread4x1((packed >> 4) & 0xfu) << 32);
 }
 
 __device__ __forceinline__ uint32_t state_at(const uint8_t* p, uint32_t u, uint32_t bits)
