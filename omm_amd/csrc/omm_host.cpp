@@ -84,6 +84,41 @@ struct DeviceArena {
 };
 inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// ---- device blocks of bake results, reused across bakes (hipMalloc / hipFree of a 1.3 GB block are synchronous and cost ~1 ms) ----
+struct DevPool {
+    struct Blk { void* p; size_t cap; bool used; };
+    std::mutex mu; std::vector<Blk> blks;
+    ~DevPool() { for (auto& b : blks) (void)hipFree(b.p); }
+    void* acquire(size_t bytes) {
+        if (bytes == 0) bytes = 1;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (auto& b : blks) if (!b.used && b.cap >= bytes && b.cap / 2 <= bytes + 4096) { b.used = true; return b.p; }
+        }
+        void* p = nullptr;
+        const size_t cap = (bytes + 4095) & ~(size_t)4095;
+        if (hipMalloc(&p, cap) != hipSuccess) {
+            (void)hipGetLastError();
+            trim(0);                                  // give the idle blocks back and retry once
+            if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        }
+        std::lock_guard<std::mutex> g(mu);
+        blks.push_back({ p, cap, true });
+        return p;
+    }
+    void release(void* p) {
+        if (!p) return;
+        { std::lock_guard<std::mutex> g(mu); for (auto& b : blks) if (b.p == p) b.used = false; }
+        trim(6);                                      // at most two idle result sets (arrayData, descs, index)
+    }
+    void trim(size_t keepIdle) {
+        std::lock_guard<std::mutex> g(mu);
+        size_t idle = 0; for (auto& b : blks) idle += !b.used;
+        for (size_t i = 0; i < blks.size() && idle > keepIdle; )
+            if (!blks[i].used) { (void)hipFree(blks[i].p); blks.erase(blks.begin() + (long)i); idle--; } else ++i;
+    }
+};
+
 // ---- warm host memory for the (large) result array -------------------------------------------------
 // A fresh 1.3 GB malloc costs more in page faults (70-100 ms) and munmap (95 ms) than the PCIe copy itself (24 ms at 57 GB/s), so
 // with the DEFAULT allocator the arrayData block of a destroyed result is kept by its baker and handed to the next bake; a new block
@@ -126,6 +161,7 @@ struct HostPool {
 struct Baker {
     Allocator mem; Logger log; ommBakerType type;
     std::shared_ptr<HostPool> hostPool = std::make_shared<HostPool>();
+    std::shared_ptr<DevPool> devPool = std::make_shared<DevPool>();
     DeviceArena arena;        // per-item tables + scratch
     DeviceArena statesArena;  // packed states of the active (non-uniform) items; guarded by arena.mu
     std::mutex timingsMu; ommxBakeTimings timings; bool haveTimings = false;
@@ -351,8 +387,12 @@ struct DeviceResult {
     ommCpuOpacityMicromapDesc* descs = nullptr; uint32_t numDescs = 0;
     void* index = nullptr; uint32_t numTris = 0; ommIndexFormat indexFormat = ommIndexFormat_UINT_32;
     uint32_t hist[2 * kNumLevels]; int bits = 2;
+    std::shared_ptr<DevPool> pool;   // the baker's (results may outlive their baker)
     DeviceResult() { memset(hist, 0, sizeof hist); }
-    ~DeviceResult() { if (arrayData) (void)hipFree(arrayData); if (descs) (void)hipFree(descs); if (index) (void)hipFree(index); }
+    DeviceResult(const DeviceResult&) = delete;
+    DeviceResult& operator=(const DeviceResult&) = delete;
+    void* dev_alloc(size_t bytes) { return pool ? pool->acquire(bytes) : nullptr; }
+    ~DeviceResult() { if (pool) { pool->release(arrayData); pool->release(descs); pool->release(index); } }
 };
 
 struct DeviceInputs {           // raw triangle data, device resident
@@ -413,6 +453,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
 {
     const Logger& L = baker.log;
     const uint32_t flags = (uint32_t)d.bakeFlags;
+    if (!R.pool) R.pool = baker.devPool;
     const Texture& tex = *untag<Texture>(d.texture);
     const uint32_t T = d.indexCount / 3u;
     const int bits = (int)d.format;
@@ -648,7 +689,8 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     R.bits = bits; R.numDescs = E; R.arrayDataSize = E ? counts.arrayDataSize : 0; R.numTris = T;
     ok = true;
     if (E) {
-        ok = HIP_OK(hipMalloc((void**)&R.arrayData, (size_t)counts.arrayDataSize)) && HIP_OK(hipMalloc((void**)&R.descs, sizeof(ommCpuOpacityMicromapDesc) * (size_t)E));
+        R.arrayData = (uint8_t*)R.dev_alloc((size_t)counts.arrayDataSize); R.descs = (ommCpuOpacityMicromapDesc*)R.dev_alloc(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E);
+        ok = R.arrayData != nullptr && R.descs != nullptr;
         if (ok) {
             launch_gather_omms(dStates, dStateOfs, dActive, dMask, dLevel, bits, dOrder, dDstOfs, dSizes, E, R.arrayData, stream);
             launch_write_descs(dOrder, dDstOfs, dLevel, bits, E, R.descs, stream);
@@ -658,7 +700,8 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     int idxBytes = 4; R.indexFormat = ommIndexFormat_UINT_32;
     if (allow8 && T <= 127 && !force32) { idxBytes = 1; R.indexFormat = ommIndexFormat_UINT_8; }
     else if (T <= 32767 && !force32) { idxBytes = 2; R.indexFormat = ommIndexFormat_UINT_16; }
-    ok = ok && HIP_OK(hipMalloc(&R.index, (size_t)(T ? T : 1) * 4)); // the reference narrows in place inside an int32 vector (:1882-1900)
+    R.index = R.dev_alloc((size_t)(T ? T : 1) * 4); // the reference narrows in place inside an int32 vector (:1882-1900)
+    ok = ok && R.index != nullptr;
     if (ok) launch_narrow_indices(dIndex, T, idxBytes, R.index, stream);
     ok = ok && HIP_OK(hipMemcpyAsync(R.hist, dArrayHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
     ok = ok && HIP_OK(hipMemcpyAsync(R.hist + kNumLevels, dIndexHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
@@ -732,9 +775,9 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     const uint32_t stride = d.texCoordStrideInBytes ? d.texCoordStrideInBytes : (d.texCoordFormat == ommTexCoordFormat_UV32_FLOAT ? 8u : 4u);
     const size_t elem = d.texCoordFormat == ommTexCoordFormat_UV32_FLOAT ? 8 : 4;
     const size_t uvBytes = T ? (size_t)stride * maxIndex + elem : 0, idxBytes = idxSize * 3ull * T, lvlBytes = d.subdivisionLevels ? T : 0;
-    uint8_t* dRaw = nullptr;
-    if (!HIP_OK(hipMalloc((void**)&dRaw, pad256(uvBytes) + pad256(idxBytes) + pad256(lvlBytes) + 256))) return L.failure("[Failure] - out of device memory for the triangle data");
-    struct RawGuard { uint8_t* p; ~RawGuard() { (void)hipFree(p); } } rawGuard{ dRaw };
+    uint8_t* dRaw = (uint8_t*)baker.devPool->acquire(pad256(uvBytes) + pad256(idxBytes) + pad256(lvlBytes) + 256);
+    if (!dRaw) return L.failure("[Failure] - out of device memory for the triangle data");
+    struct RawGuard { DevPool* pool; uint8_t* p; ~RawGuard() { pool->release(p); } } rawGuard{ baker.devPool.get(), dRaw };
     EventTimer et(stream);
     const int u0 = et.mark();
     DeviceInputs din; din.texCoords = dRaw; din.indices = dRaw + pad256(uvBytes); din.perTriLevels = lvlBytes ? dRaw + pad256(uvBytes) + pad256(idxBytes) : nullptr;
@@ -1147,10 +1190,12 @@ OMM_MI355X_API ommResult ommxShardedFinish(ommxShardedBake h, const void* gather
     if (!res) return ommResult_FAILURE;
     res->mem = b->mem; memset(&res->desc, 0, sizeof res->desc);
     DeviceResult& R = res->R;
+    R.pool = b->devPool;
     R.bits = c.bits; R.numDescs = E; R.arrayDataSize = E ? c.counts.arrayDataSize : 0; R.numTris = T;
     bool ok = true;
     if (E) {
-        ok = HIP_OK(hipMalloc((void**)&R.arrayData, (size_t)c.counts.arrayDataSize)) && HIP_OK(hipMalloc((void**)&R.descs, sizeof(ommCpuOpacityMicromapDesc) * (size_t)E));
+        R.arrayData = (uint8_t*)R.dev_alloc((size_t)c.counts.arrayDataSize); R.descs = (ommCpuOpacityMicromapDesc*)R.dev_alloc(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E);
+        ok = R.arrayData != nullptr && R.descs != nullptr;
         if (ok) {
             launch_shard_scatter((const uint8_t*)gathered, c.strideBytes, c.dActive, c.dOwner, c.dMask, c.dLevel, c.bits, c.to.order, c.dCofs, c.to.dstOfs, c.to.sizes, E, R.arrayData, stream);
             launch_write_descs(c.to.order, c.to.dstOfs, c.dLevel, c.bits, E, R.descs, stream);
@@ -1160,7 +1205,8 @@ OMM_MI355X_API ommResult ommxShardedFinish(ommxShardedBake h, const void* gather
     int idxBytes = 4; R.indexFormat = ommIndexFormat_UINT_32;
     if (allow8 && T <= 127 && !force32) { idxBytes = 1; R.indexFormat = ommIndexFormat_UINT_8; }
     else if (T <= 32767 && !force32) { idxBytes = 2; R.indexFormat = ommIndexFormat_UINT_16; }
-    ok = ok && HIP_OK(hipMalloc(&R.index, (size_t)(T ? T : 1) * 4));
+    R.index = R.dev_alloc((size_t)(T ? T : 1) * 4);
+    ok = ok && R.index != nullptr;
     if (ok) launch_narrow_indices(c.dIndex, T, idxBytes, R.index, stream);
     ok = ok && HIP_OK(hipMemcpyAsync(R.hist, c.dArrayHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
     ok = ok && HIP_OK(hipMemcpyAsync(R.hist + kNumLevels, c.dIndexHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
