@@ -789,6 +789,8 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     const int u1 = et.mark();
 
     DeviceResult R; ommxBakeTimings tm; memset(&tm, 0, sizeof tm);
+    // declared after R and the upload guard, so destroyed first: pooled blocks are only handed back once the stream is idle (error paths too)
+    struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } } syncOnExit{ stream };
     if (wants_host_tail(d)) {
         // near-duplicate merge / size budget: device classification, then the reference's serial tail on the host (host_tail.cpp)
         HostTailRequest ht;
@@ -1093,7 +1095,7 @@ OMM_MI355X_API ommResult ommxBakeDevice(ommBaker baker, const ommCpuBakeInputDes
     ommxBakeTimings tm; memset(&tm, 0, sizeof tm);
     DeviceInputs din; din.texCoords = desc->texCoords; din.indices = desc->indexBuffer; din.perTriLevels = desc->subdivisionLevels;
     r = bake_core(*b, *desc, din, nullptr, ses.arena, ses.states, ses.stream, et, res->R, tm);
-    if (r != ommResult_SUCCESS) { b->mem.destroy(res); return r; }
+    if (r != ommResult_SUCCESS) { (void)hipStreamSynchronize(ses.stream); b->mem.destroy(res); return r; } // (pooled blocks go back only when the stream is idle)
     uint32_t nAH = 0, nIH = 0;
     for (uint32_t l = 0; l < (uint32_t)kNumLevels; ++l) {
         if (res->R.hist[l]) { res->arrayHist[nAH].count = res->R.hist[l]; res->arrayHist[nAH].subdivisionLevel = (uint16_t)l; res->arrayHist[nAH].format = (uint16_t)res->R.bits; nAH++; }
@@ -1211,7 +1213,7 @@ OMM_MI355X_API ommResult ommxShardedFinish(ommxShardedBake h, const void* gather
     ok = ok && HIP_OK(hipMemcpyAsync(R.hist, c.dArrayHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
     ok = ok && HIP_OK(hipMemcpyAsync(R.hist + kNumLevels, c.dIndexHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
     ok = ok && HIP_OK(hipStreamSynchronize(stream));
-    if (!ok) { b->mem.destroy(res); return L.failure("[Failure] - could not materialise the merged bake result on the device"); }
+    if (!ok) { (void)hipStreamSynchronize(stream); b->mem.destroy(res); return L.failure("[Failure] - could not materialise the merged bake result on the device"); }
     uint32_t nAH = 0, nIH = 0;
     for (uint32_t l = 0; l < (uint32_t)kNumLevels; ++l) {
         if (R.hist[l]) { res->arrayHist[nAH].count = R.hist[l]; res->arrayHist[nAH].subdivisionLevel = (uint16_t)l; res->arrayHist[nAH].format = (uint16_t)R.bits; nAH++; }
