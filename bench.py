@@ -124,6 +124,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if world > 1:
+        # communicator set-up (seconds, once per process) is not part of a bake: force it before any step, whatever --warmup says
+        w0 = torch.zeros(4, dtype=torch.int32, device="cuda")
+        dist.all_reduce(w0)
+        g0 = torch.empty(4 * world, dtype=torch.int32, device="cuda")
+        dist.all_gather_into_tensor(g0, w0)
+        torch.cuda.synchronize()
     last = None
     for _ in range(args.warmup):
         if last is not None:
