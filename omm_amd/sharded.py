@@ -35,7 +35,10 @@ def allgather_padded(dist, torch, contribution, world):
     if dist is None or not dist.is_initialized() or world == 1:
         return contribution
     out = torch.empty(world * contribution.numel(), dtype=contribution.dtype, device=contribution.device)
-    dist.all_gather_into_tensor(out, contribution)
+    if dist.get_backend() == "gloo":   # (tests: gloo has no all_gather_into_tensor for device tensors)
+        dist.all_gather(list(out.view(world, -1).unbind(0)), contribution)
+    else:
+        dist.all_gather_into_tensor(out, contribution)
     return out
 
 

@@ -836,3 +836,12 @@ def test_texture_row_pitch_and_get_desc(product, oracle):
     a, b = _texture_pitch_and_desc(product), _texture_pitch_and_desc(oracle)
     for x, y in zip(a, b):
         assert x.same_as(y), x.diff(y)
+
+
+def test_two_process_sharded_bake_on_one_gpu():
+    """two real processes + torch.distributed collectives on device tensors (gloo: RCCL refuses two ranks on one GPU): every rank ends with
+    the single-GPU result (tests/scripts/two_rank_gloo_gpu.py)"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "scripts", "two_rank_gloo_gpu.py"), "2"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "two-process sharded bake ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
