@@ -85,9 +85,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local)
+    # self-test hooks (tests only): OMM_BENCH_ONE_GPU=1 puts every rank on GPU 0 and OMM_BENCH_BACKEND=gloo replaces RCCL, which
+    # refuses two ranks on one device -- the driver's runs use neither
+    torch.cuda.set_device(0 if os.environ.get("OMM_BENCH_ONE_GPU") == "1" else local)
     if world > 1:
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("OMM_BENCH_BACKEND", "nccl"))
 
     tex, uv, ix = make_workload(args)
     # strong scaling: every rank sees the whole (fixed) triangle stream; the library partitions the ACTIVE work items over the

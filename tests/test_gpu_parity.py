@@ -845,3 +845,20 @@ def test_two_process_sharded_bake_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "scripts", "two_rank_gloo_gpu.py"), "2"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "two-process sharded bake ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 path end to end (launch through torch.distributed.run, barrier + max-over-ranks timing, one JSON line from rank 0),
+    with both ranks on GPU 0 over gloo (self-test hooks of bench.py)"""
+    import json, subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMM_BENCH_ONE_GPU="1", OMM_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--tris", "20000", "--level", "7", "--tex", "1024"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["sharding"] != "none"
+    assert "cpu_baseline" not in d          # rank 0 at N = 1 only
