@@ -38,6 +38,9 @@ OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings*
  *        desc->formats must be NULL.  All other fields, validation, result codes and log messages are those of ommCpuBake.
  *   out: an ommCpuBakeResultDesc whose arrayData, descArray and indexBuffer are DEVICE pointers; the two histograms are
  *        host arrays.  Buffers stay valid until ommxDestroyDeviceBakeResult.
+ * Stream ordering: the library works on its own non-blocking HIP stream, which does NOT order against the caller's streams or the
+ * null stream.  Device buffers handed in (inputs here, `words` / `gathered` of the sharded bake below) must be complete -- the
+ * producing stream synchronised -- before the call; everything handed back is complete when the call returns.
  * The call returns when the result is complete (the library synchronises its own stream). */
 typedef struct _ommxDeviceBakeResult* ommxDeviceBakeResult;
 OMM_MI355X_API ommResult ommxBakeDevice(ommBaker baker, const ommCpuBakeInputDesc* deviceDesc, ommxDeviceBakeResult* outResult);

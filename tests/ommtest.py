@@ -340,6 +340,9 @@ class Hip:
     def copy_dtod(self, dst, src, nbytes):
         if nbytes:
             assert self.rt.hipMemcpy(dst, src, nbytes, 3) == 0
+            # a device-to-device hipMemcpy returns before the copy has finished, and the library's streams are non-blocking (they do
+            # not order against the null stream): wait, as a real caller's collective does before it hands the buffer over
+            assert self.rt.hipDeviceSynchronize() == 0
 
     def copy_htod(self, dst, arr):
         arr = np.ascontiguousarray(arr)
