@@ -73,3 +73,19 @@ def test_no_cpu_fallback_without_a_gpu():
     assert t is None
     assert msgs and msgs[-1][0] == 3 and "no CPU fallback" in msgs[-1][1], msgs       # ommMessageSeverity_Fatal
     assert lib.destroy_baker(b) == ot.SUCCESS
+
+
+def _build_example(std_args, out):
+    import subprocess
+    lib_dir = os.path.join(ROOT, "omm_amd", "lib")
+    cmd = std_args + ["-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "minimal_sample.c"), "-o", out,
+                      "-L" + lib_dir, "-lomm-lib", "-lm", "-Wl,-rpath," + lib_dir]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0 and not r.stderr.strip(), r.stderr
+
+
+def test_header_is_valid_c99_and_cpp17_and_the_example_links(tmp_path):
+    """include/omm_mi355x.h is what a C or C++ caller compiles against: examples/minimal_sample.c builds warning-free in both languages
+    and links against the drop-in library"""
+    _build_example(["gcc", "-std=c99", "-pedantic"], str(tmp_path / "sample_c"))
+    _build_example(["g++", "-std=c++17", "-x", "c++"], str(tmp_path / "sample_cpp"))

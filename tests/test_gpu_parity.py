@@ -862,3 +862,33 @@ def test_bench_two_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["sharding"] != "none"
     assert "cpu_baseline" not in d          # rank 0 at N = 1 only
+
+
+def test_c_example_program(product, tmp_path):
+    """examples/minimal_sample.c (plain C against include/omm_mi355x.h) prints the same micro-maps as the same bake through ctypes"""
+    import subprocess, re
+    from test_abi_exports import _build_example
+    exe = str(tmp_path / "minimal_sample")
+    _build_example(["gcc", "-std=c99", "-pedantic"], exe)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = [tuple(int(x) for x in m.groups()) for m in re.finditer(r"omm \d+: level (\d+) offset (\d+) opaque (\d+) / (\d+)", out.stdout)]
+    j, i = np.mgrid[0:256, 0:256]
+    dx = (i.astype(np.float32) / np.float32(256)) - np.float32(0.5)
+    dy = (j.astype(np.float32) / np.float32(256)) - np.float32(0.5)
+    ln = np.sqrt((dx * dx + dy * dy).astype(np.float32)).astype(np.float32)
+    tex = np.where((ln > np.float32(0.2)) & (ln < np.float32(0.3)), 1.0, 0.0).astype(np.float32)
+    uv = np.array([[0.05, 0.50], [0.50, 0.05], [0.50, 0.50], [0.95, 0.50], [0.50, 0.95]], np.float32)
+    ix = np.array([0, 1, 2, 1, 3, 2, 3, 4, 2, 2, 4, 0], np.uint32)
+    b = product.create_baker(callback=lambda s, m, u: None)
+    t = product.create_texture(b, [tex], alpha_cutoff=-1.0)
+    d = ot.make_desc(t, uv, ix, 8, addr=ot.CLAMP, filt=ot.LINEAR, fmt=ot.FMT_2STATE, promo=ot.PROMO_FORCE_OPAQUE, flags=ot.FLAG_VALIDATION,
+                     levels=np.array([2, 3, 4, 5], np.uint8), dyn_scale=2.0)
+    r = product.bake(b, d)
+    want = []
+    for off, lvl, fmt in r.descs:
+        n = 4 ** int(lvl)
+        bits = np.unpackbits(r.array_data[int(off):int(off) + max(1, n // 8)], bitorder="little")[:n]
+        want.append((int(lvl), int(off), int(bits.sum()), n))
+    assert got == want and len(got) == 4, (got, want)
+    product.destroy_texture(b, t); product.destroy_baker(b)
