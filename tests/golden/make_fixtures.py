@@ -60,3 +60,15 @@ if __name__ == "__main__":
     open(os.path.join(HERE, "leaflet_b.bin"), "wb").write(blue)
     json.dump({"width": w, "height": h, "channels": ch, "channel": 2}, open(os.path.join(HERE, "leaflet.json"), "w"))
     print("leaflet:", w, h, ch)
+
+
+def make_abi_layout():
+    """tests/golden/abi_layout_sdk.txt: output of tests/native/abi_layout.c compiled against the SDK's own omm.h (146 sizeof / offsetof /
+    enumerator facts of the CPU-baker interface).  tests/test_abi_exports.py compares include/omm_mi355x.h against it."""
+    import subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "abi_ref")
+        subprocess.check_call(["g++", "-std=c++17", "-x", "c++", "-Wno-deprecated-declarations", "-I/root/reference/libraries/omm-lib/include",
+                               "-DOMM_HEADER=<omm.h>", os.path.join(root, "tests", "native", "abi_layout.c"), "-o", exe])
+        open(os.path.join(root, "tests", "golden", "abi_layout_sdk.txt"), "w").write(subprocess.check_output([exe], text=True))

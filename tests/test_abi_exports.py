@@ -89,3 +89,53 @@ def test_header_is_valid_c99_and_cpp17_and_the_example_links(tmp_path):
     and links against the drop-in library"""
     _build_example(["gcc", "-std=c99", "-pedantic"], str(tmp_path / "sample_c"))
     _build_example(["g++", "-std=c++17", "-x", "c++"], str(tmp_path / "sample_cpp"))
+
+
+def _abi_facts(include_dir, header, tmp_path, tag):
+    import subprocess
+    exe = str(tmp_path / ("abi_" + tag))
+    subprocess.check_call(["g++", "-std=c++17", "-x", "c++", "-Wno-deprecated-declarations", "-I" + include_dir, "-DOMM_HEADER=" + header,
+                           os.path.join(ROOT, "tests", "native", "abi_layout.c"), "-o", exe])
+    return subprocess.check_output([exe], text=True)
+
+
+def test_struct_layouts_and_enum_values_equal_the_sdk_header(tmp_path):
+    """146 sizeof / offsetof / enumerator facts of the CPU-baker interface: include/omm_mi355x.h vs the SDK's omm.h (committed output of
+    the same probe compiled against the SDK header; regenerated and re-checked when the reference checkout is present)"""
+    mine = _abi_facts(os.path.join(ROOT, "include"), '"omm_mi355x.h"', tmp_path, "mine")
+    golden = open(os.path.join(ROOT, "tests", "golden", "abi_layout_sdk.txt")).read()
+    assert mine == golden
+    sdk = "/root/reference/libraries/omm-lib/include"
+    if os.path.exists(os.path.join(sdk, "omm.h")):
+        assert _abi_facts(sdk, "<omm.h>", tmp_path, "sdk") == golden
+
+
+def test_sdk_header_user_links_against_the_drop_in(tmp_path):
+    """A translation unit compiled against the SDK's OWN omm.h (C++: that header is not valid C) links against libomm-lib.so:
+    every CPU-baker symbol it references resolves.  Only where the reference checkout exists."""
+    import subprocess
+    sdk = "/root/reference/libraries/omm-lib/include"
+    if not os.path.exists(os.path.join(sdk, "omm.h")):
+        pytest.skip("reference checkout not present")
+    src = tmp_path / "user.cpp"
+    src.write_text('''#include <omm.h>
+int main() {
+    ommBakerCreationDesc bd = ommBakerCreationDescDefault(); bd.type = ommBakerType_CPU;
+    ommBaker baker = 0; if (ommCreateBaker(&bd, &baker) != ommResult_SUCCESS) return 1;
+    ommCpuTextureDesc td = ommCpuTextureDescDefault(); ommCpuTexture tex = 0; (void)ommCpuCreateTexture(baker, &td, &tex);
+    ommCpuBakeInputDesc in = ommCpuBakeInputDescDefault(); ommCpuBakeResult res = 0; (void)ommCpuBake(baker, &in, &res);
+    const ommCpuBakeResultDesc* out = 0; (void)ommCpuGetBakeResultDesc(res, &out);
+    ommDebugStats st = ommDebugStatsDefault(); (void)ommDebugGetStats(baker, out, &st);
+    ommCpuDeserializedDesc dd = ommCpuDeserializedDescDefault(); ommCpuSerializedResult sr = 0; (void)ommCpuSerialize(baker, dd, &sr);
+    const ommCpuBlobDesc* blob = 0; (void)ommCpuGetSerializedResultDesc(sr, &blob); (void)ommCpuDestroySerializedResult(sr);
+    ommCpuBlobDesc bdsc = ommCpuBlobDescDefault(); ommCpuDeserializedResult dr = 0; (void)ommCpuDeserialize(baker, bdsc, &dr);
+    const ommCpuDeserializedDesc* ddo = 0; (void)ommCpuGetDeserializedDesc(dr, &ddo); (void)ommCpuDestroyDeserializedResult(dr);
+    ommCpuTextureDesc q = ommCpuTextureDescDefault(); (void)ommCpuGetTextureDesc(tex, &q);
+    (void)ommCpuDestroyBakeResult(res); (void)ommCpuDestroyTexture(baker, tex); (void)ommGetLibraryDesc();
+    return ommDestroyBaker(baker) == ommResult_SUCCESS ? 0 : 2;
+}
+''')
+    lib_dir = os.path.join(ROOT, "omm_amd", "lib")
+    r = subprocess.run(["g++", "-std=c++17", "-Wno-deprecated-declarations", "-I" + sdk, str(src), "-o", str(tmp_path / "user"), "-L" + lib_dir, "-lomm-lib",
+                        "-Wl,-rpath," + lib_dir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
