@@ -139,3 +139,21 @@ int main() {
     r = subprocess.run(["g++", "-std=c++17", "-Wno-deprecated-declarations", "-I" + sdk, str(src), "-o", str(tmp_path / "user"), "-L" + lib_dir, "-lomm-lib",
                         "-Wl,-rpath," + lib_dir], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    # the SDK's header-only C++ wrapper (omm.hpp:1003-1013 forwards to the same C symbols)
+    src2 = tmp_path / "user_hpp.cpp"
+    src2.write_text('''#include <omm.hpp>
+int main() {
+    omm::BakerCreationDesc bd; bd.type = omm::BakerType::CPU;
+    omm::Baker baker = 0; if (omm::CreateBaker(bd, &baker) != omm::Result::SUCCESS) return 1;
+    omm::Cpu::TextureDesc td; omm::Cpu::Texture tex = 0; (void)omm::Cpu::CreateTexture(baker, td, &tex);
+    omm::Cpu::BakeInputDesc in; omm::Cpu::BakeResult res = 0; (void)omm::Cpu::Bake(baker, in, &res);
+    const omm::Cpu::BakeResultDesc* out = 0; (void)omm::Cpu::GetBakeResultDesc(res, &out);
+    (void)omm::Cpu::DestroyBakeResult(res); (void)omm::Cpu::DestroyTexture(baker, tex);
+    return omm::DestroyBaker(baker) == omm::Result::SUCCESS ? 0 : 2;
+}
+''')
+    exe2 = str(tmp_path / "user_hpp")
+    r = subprocess.run(["g++", "-std=c++17", "-Wno-deprecated-declarations", "-I" + sdk, str(src2), "-o", exe2, "-L" + lib_dir, "-lomm-lib",
+                        "-Wl,-rpath," + lib_dir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert subprocess.run([exe2]).returncode == 0      # baker create/destroy and the argument checks need no GPU
