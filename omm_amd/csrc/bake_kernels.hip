@@ -108,6 +108,8 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     __shared__ int      s_group[TILE / GROUP];
     __shared__ int      s_tile;
     __shared__ int      s_rect[5];
+    __shared__ uint16_t s_glist[TILE / GROUP];   // sliced tiles: the groups that are not settled, compacted (phase 1 walks only these)
+    __shared__ uint32_t s_gcount;
     __shared__ uint32_t s_qcount;
     __shared__ uint32_t s_mask, s_known;
     __shared__ float    s_wtex[SLICED ? WIN * WIN : 1];
@@ -177,9 +179,13 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
             if (coarse) {
                 if (tid >= 64 && tid < 64 + TILE / GROUP) { // (4096-tile: 64 groups = all of wave 1; 1024-tile: 16 of its lanes)
                     const uint32_t g = tid - 64;
-                    s_group[g] = region_state_ex<MD>(P, micro_triangle(uUv, (base >> 6) + g, level - 3), uMaxAbs, W);
+                    const int gs = region_state_ex<MD>(P, micro_triangle(uUv, (base >> 6) + g, level - 3), uMaxAbs, W);
+                    s_group[g] = gs;
+                    const unsigned long long open = __ballot(gs < 0);
+                    if (gs < 0) s_glist[__popcll(open & ((1ull << g) - 1ull))] = (uint16_t)g;
+                    if (g == 0) s_gcount = (uint32_t)__popcll(open);
                 }
-            } else if (tid < (uint32_t)(TILE / GROUP)) s_group[tid] = -1;
+            } else if (tid < (uint32_t)(TILE / GROUP)) { s_group[tid] = -1; s_glist[tid] = (uint16_t)tid; if (tid == 0) s_gcount = (uint32_t)(TILE / GROUP); }
             __syncthreads();
         }
     } else {
@@ -198,9 +204,8 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     const int tileState = s_tile;
     if (tileState < 0) {
         // ---- phase 1: per-micro-triangle coarse test in the unsettled groups ----
-        for (uint32_t i = tid; i < ((count + 63u) & ~63u); i += BLOCK) {
-            const int gs = s_group[i >> 6];      // wave-uniform: a wave is exactly one group
-            if (gs >= 0) { if (i < count) s_state[i] = (uint8_t)gs; continue; }
+        // one wave = one 64-group; gs (wave-uniform) is < 0 here: kRegionAllOpen or kRegionUnknown
+        auto phase1_group = [&](uint32_t i, int gs) {
             bool unresolved = false;
             if (gs == kRegionAllOpen) { // the whole group is unresolved by construction: no per-micro-triangle SAT test
                 unresolved = i < count;   // (phase 2 writes the state of every queued micro-triangle)
@@ -227,6 +232,19 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 if (lane == 0) wbase = atomicAdd(&s_qcount, (uint32_t)__popcll(vote));
                 wbase = __shfl(wbase, 0);
                 if (unresolved) s_queue[wbase + __popcll(vote & ((1ull << lane) - 1ull))] = (uint16_t)i;
+            }
+        };
+        if (SLICED) { // walk the compacted list of open groups: settled groups cost nothing here (phase 3 packs them from s_group)
+            const uint32_t gcount = s_gcount;
+            for (uint32_t k = tid >> 6; k < gcount; k += BLOCK / 64) {
+                const uint32_t g = s_glist[k];
+                phase1_group(g * 64u + (tid & 63u), s_group[g]);
+            }
+        } else {
+            for (uint32_t i = tid; i < ((count + 63u) & ~63u); i += BLOCK) {
+                const int gs = s_group[i >> 6];      // wave-uniform: a wave is exactly one group
+                if (gs >= 0) { if (i < count) s_state[i] = (uint8_t)gs; continue; }
+                phase1_group(i, gs);
             }
         }
         __syncthreads();
@@ -272,11 +290,18 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         uint32_t localMask = 0, localKnown = 0;
         for (uint32_t w = tid; w < (uint32_t)TILE / perWord; w += BLOCK) {
             uint32_t v = 0;
-            for (uint32_t k = 0; k < perWord; ++k) {
-                const uint32_t st = s_state[w * perWord + k];
-                v |= st << (k * bits);
-                localMask |= 1u << st;
-                localKnown += st < 2u;
+            const int gs = s_group[(w * perWord) >> 6];   // a word never straddles two 64-groups (perWord is 16 or 32)
+            if (gs >= 0) { // settled group: constant word (phase 1 wrote no states for it)
+                for (uint32_t k = 0; k < perWord; ++k) v |= (uint32_t)gs << (k * bits);
+                localMask |= 1u << gs;
+                localKnown += gs < 2 ? perWord : 0u;
+            } else {
+                for (uint32_t k = 0; k < perWord; ++k) {
+                    const uint32_t st = s_state[w * perWord + k];
+                    v |= st << (k * bits);
+                    localMask |= 1u << st;
+                    localKnown += st < 2u;
+                }
             }
             dst[w] = v;
         }
