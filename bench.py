@@ -67,8 +67,8 @@ def cpu_baseline(args, tex, uv, ix):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tris", type=int, default=1000000)
     ap.add_argument("--level", type=int, default=8)
     ap.add_argument("--tex", type=int, default=4096)
