@@ -133,7 +133,12 @@ def oracle_path():
 
 def product_path():
     # OMM_AMD_LIBRARY: A/B builds of the same sources (kernel tuning experiments); default = the in-tree build
-    return os.environ.get("OMM_AMD_LIBRARY") or os.path.join(ROOT, "omm_amd", "lib", "libomm-lib.so")
+    if os.environ.get("OMM_AMD_LIBRARY"):
+        return os.environ["OMM_AMD_LIBRARY"]
+    p = os.path.join(ROOT, "omm_amd", "lib", "libomm-lib.so")
+    if not os.path.exists(p):   # clean checkout: same as __graft_entry__.build() (hipcc cross-compiles gfx950 without a GPU)
+        _run(["make", "-C", os.path.join(ROOT, "omm_amd", "csrc"), "-j4"], ROOT)
+    return p
 
 
 _KAT = None
