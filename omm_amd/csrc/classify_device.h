@@ -161,6 +161,35 @@ __device__ __forceinline__ float load_texel_border(const DevMip& m, int x, int y
     return (x == kTexCoordBorder || y == kTexCoordBorder) ? borderAlpha : load_texel<FP32>(m, x, y, W);
 }
 
+// The 2 x 2 texels of the cell whose low corner is the (unaddressed) texel (px, py): 00, 01 (y+1), 11, 10 (x+1), each addressed like
+// the reference does (GatherTexCoord4, util/texture.h:130-148).  When the whole cell lies in the tile's LDS window -- where
+// addressing is a pure translation, which is re-checked here through x1 == x0 + 1, y1 == y0 + 1 -- the four values come from one
+// index computation; otherwise every texel goes through load_texel() / the border rule on its own.
+template <bool FP32, class MD>
+__device__ __forceinline__ void fetch_cell(const ClassifyParams& P, const DevMip& m, int pow2, int px, int py, const TexWindow& W,
+                                           float& g00, float& g01, float& g11, float& g10)
+{
+    const int x0 = tex_coord(MD::addr(P), pow2, px, m.w, m.log2w), y0 = tex_coord(MD::addr(P), pow2, py, m.h, m.log2h);
+    const int x1 = tex_coord(MD::addr(P), pow2, px + 1, m.w, m.log2w), y1 = tex_coord(MD::addr(P), pow2, py + 1, m.h, m.log2h);
+#ifndef OMMX_NO_CELL_FETCH
+    {
+        const uint32_t wx = (uint32_t)(x0 - W.sx), wy = (uint32_t)(y0 - W.sy);
+        if (wx + 1u < (uint32_t)W.w && wy + 1u < (uint32_t)W.h && x1 == x0 + 1 && y1 == y0 + 1 && m.texels == W.base) {
+            const uint32_t i = wx + wy * (uint32_t)W.w;
+            g00 = W.tex[i]; g10 = W.tex[i + 1u]; g01 = W.tex[i + (uint32_t)W.w]; g11 = W.tex[i + (uint32_t)W.w + 1u];
+            return;
+        }
+    }
+#endif
+    if (MD::addr(P) == 3) {
+        g00 = load_texel_border<FP32>(m, x0, y0, P.borderAlpha, W); g01 = load_texel_border<FP32>(m, x0, y1, P.borderAlpha, W);
+        g11 = load_texel_border<FP32>(m, x1, y1, P.borderAlpha, W); g10 = load_texel_border<FP32>(m, x1, y0, P.borderAlpha, W);
+    } else {
+        g00 = load_texel<FP32>(m, x0, y0, W); g01 = load_texel<FP32>(m, x0, y1, W);
+        g11 = load_texel<FP32>(m, x1, y1, W); g10 = load_texel<FP32>(m, x1, y0, W);
+    }
+}
+
 // one summed-area-table entry of mip 0 (x, y >= 0)
 __device__ __forceinline__ uint32_t load_sat(const DevMip& m, int x, int y, const TexWindow& W)
 {
@@ -187,12 +216,8 @@ __device__ __forceinline__ float bilinear(const ClassifyParams& P, const DevMip&
     const float px = p.x * m.fw - 0.5f, py = p.y * m.fh - 0.5f;
     const float fx = __builtin_floorf(px), fy = __builtin_floorf(py);
     const int ix = cvt_trunc_x86(fx), iy = cvt_trunc_x86(fy);
-    const int x0 = tex_coord(MD::addr(P), m.pow2, ix, m.w, m.log2w), y0 = tex_coord(MD::addr(P), m.pow2, iy, m.h, m.log2h);
-    const int x1 = tex_coord(MD::addr(P), m.pow2, ix + 1, m.w, m.log2w), y1 = tex_coord(MD::addr(P), m.pow2, iy + 1, m.h, m.log2h);
-    const float a = load_texel_border<FP32>(m, x0, y0, P.borderAlpha, W);
-    const float b = load_texel_border<FP32>(m, x0, y1, P.borderAlpha, W);
-    const float c = load_texel_border<FP32>(m, x1, y0, P.borderAlpha, W);
-    const float d = load_texel_border<FP32>(m, x1, y1, P.borderAlpha, W);
+    float a, b, c, d; // 00, 01, 10, 11 (the sentinel of Border addressing reads borderAlpha: documented fence)
+    fetch_cell<FP32, MD>(P, m, m.pow2, ix, iy, W, a, b, d, c);
     const float wx = px - fx, wy = py - fy;
     const float ac = a * (1.f - wx) + c * wx;
     const float bd = b * (1.f - wx) + d * wx;
@@ -306,16 +331,8 @@ __device__ __forceinline__ void level_line_texel(const ClassifyParams& P, const 
                                                  uint32_t& above, uint32_t& below, const TexWindow& W)
 {
     const float pfx = (float)px + 0.5f, pfy = (float)py + 0.5f;
-    const int x0 = tex_coord(MD::addr(P), MD::pow2(P), px, m.w, m.log2w), y0 = tex_coord(MD::addr(P), MD::pow2(P), py, m.h, m.log2h);
-    const int x1 = tex_coord(MD::addr(P), MD::pow2(P), px + 1, m.w, m.log2w), y1 = tex_coord(MD::addr(P), MD::pow2(P), py + 1, m.h, m.log2h);
     float gx, gy, gz, gw; // 00, 01, 11, 10
-    if (MD::addr(P) == 3) {
-        gx = load_texel_border<FP32>(m, x0, y0, P.borderAlpha, W); gy = load_texel_border<FP32>(m, x0, y1, P.borderAlpha, W);
-        gz = load_texel_border<FP32>(m, x1, y1, P.borderAlpha, W); gw = load_texel_border<FP32>(m, x1, y0, P.borderAlpha, W);
-    } else {
-        gx = load_texel<FP32>(m, x0, y0, W); gy = load_texel<FP32>(m, x0, y1, W);
-        gz = load_texel<FP32>(m, x1, y1, W); gw = load_texel<FP32>(m, x1, y0, W);
-    }
+    fetch_cell<FP32, MD>(P, m, MD::pow2(P), px, py, W, gx, gy, gz, gw);
     if (!DEGENERATE) {
         const float ipx = pfx * m.rw, ipy = pfy * m.rh;
         const bool o0 = P.cutoff < gx, o1 = P.cutoff < gy, o2 = P.cutoff < gz, o3 = P.cutoff < gw;
