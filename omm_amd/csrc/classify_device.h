@@ -201,6 +201,15 @@ __device__ __forceinline__ uint32_t load_sat(const DevMip& m, int x, int y, cons
 // texture_impl.h:110-125
 __device__ __forceinline__ uint32_t sat_sum(const DevMip& m, int sx, int sy, int ex, int ey, const TexWindow& W)
 {
+#ifndef OMMX_NO_CELL_FETCH
+    {   // all four corners in the LDS window: its entry (i, j) is SAT(W.sx - 1 + i, W.sy - 1 + j) with the zero row / column for -1
+        // already stored, so the "sx > 0 / sy > 0" selections below are table look-ups
+        const uint32_t i0 = (uint32_t)(sx - W.sx), j0 = (uint32_t)(sy - W.sy), i1 = (uint32_t)(ex - W.sx + 1), j1 = (uint32_t)(ey - W.sy + 1);
+        const uint32_t pitch = (uint32_t)W.w + 1u;
+        if (W.w != 0 && i0 <= (uint32_t)W.w && i1 <= (uint32_t)W.w && j0 <= (uint32_t)W.h && j1 <= (uint32_t)W.h)
+            return W.sat[i1 + j1 * pitch] + W.sat[i0 + j0 * pitch] - W.sat[i1 + j0 * pitch] - W.sat[i0 + j1 * pitch];
+    }
+#endif
     const uint32_t A = (sx > 0 && sy > 0) ? load_sat(m, sx - 1, sy - 1, W) : 0u;
     const uint32_t B = sy > 0 ? load_sat(m, ex, sy - 1, W) : 0u;
     const uint32_t C = sx > 0 ? load_sat(m, sx - 1, ey, W) : 0u;
