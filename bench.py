@@ -43,7 +43,7 @@ def bake_desc(tex_handle, uv, ix, args, lo, hi):
                         promo=ot.PROMO_FORCE_OPAQUE, fmt=ot.FMT_4STATE, flags=ot.FLAG_THREADS)
 
 
-def cpu_baseline(args, tex, uv, ix):
+def cpu_baseline(args, tex, uv, ix, sat=True, sample=None):
     """The oracle (bit-exact restatement of the reference CPU baker, OpenMP over work items like the reference) timed on a
     bounded sample of the same triangle stream: the reference needs 2 * 4^N bytes per work item (131 GB at full size)."""
     import multiprocessing
@@ -51,8 +51,8 @@ def cpu_baseline(args, tex, uv, ix):
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     orc = ot.Lib("oracle")
     b = orc.create_baker()
-    t = orc.create_texture(b, [tex], alpha_cutoff=0.5)
-    k = min(args.cpu_sample, args.tris)
+    t = orc.create_texture(b, [tex], alpha_cutoff=0.5 if sat else -1.0)
+    k = min(sample if sample is not None else args.cpu_sample, args.tris)
     d = bake_desc(t, uv, ix, args, 0, k)
     t0 = time.time()
     res = orc.bake(b, d, want_stats=False)
@@ -61,7 +61,7 @@ def cpu_baseline(args, tex, uv, ix):
     orc.destroy_baker(b)
     mt = k * 4 ** args.level
     return {"value": mt / dt, "unit": "micro-triangles/s", "cores": cores, "kind": "port",
-            "sample": "first %d triangles of the same seeded stream (%.3g micro-triangles), SAT on, %.1f s" % (k, mt, dt)}, res
+            "sample": "first %d triangles of the same seeded stream (%.3g micro-triangles), SAT %s, %.1f s" % (k, mt, "on" if sat else "off", dt)}, res
 
 
 def main():
@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--host-api-steps", type=int, default=2, help="extra untimed-for-value bakes through ommCpuBake (host arrays)")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="triangles baked by the CPU baseline (0 = skip)")
+    ap.add_argument("--sat-off-sample", type=int, default=50000, help="triangles of the SAT-off (no coarse pass) GPU measurement; CPU uses 1/20 of it (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -230,6 +231,27 @@ def main():
             cb, cpu_res = cpu_baseline(args, tex, uv, ix)
             line["cpu_baseline"] = cb
             line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"]
+            # correctness gate of the same run: the HIP library bakes the CPU sample, byte-for-byte comparison
+            k = min(args.cpu_sample, args.tris)
+            gpu_res = prod.bake(baker, bake_desc(th, uv, ix, args, 0, k), want_stats=False)
+            assert gpu_res.same_as(cpu_res), "GPU result differs from the CPU baseline on its sample: " + gpu_res.diff(cpu_res)
+            line["parity_vs_cpu_baseline"] = "bit-exact on the CPU sample (arrayData %d B, %d descs, index buffer, histograms, index format)" % (gpu_res.array_data.size, len(gpu_res.descs))
+            # second texture mode (no summed-area table: every micro-triangle takes the level-line pass), bounded samples on both sides
+            if args.sat_off_sample > 0:
+                ks = min(args.sat_off_sample, args.tris)
+                th2 = prod.create_texture(baker, [tex], alpha_cutoff=-1.0)
+                d2 = bake_desc(th2, uv, ix, args, 0, ks)
+                prod.bake(baker, d2, want_stats=False)
+                t2 = time.perf_counter()
+                prod.bake(baker, d2, want_stats=False)
+                gpu_dt = time.perf_counter() - t2
+                kc = min(max(args.sat_off_sample // 20, 200), ks)
+                cb2, cpu_res2 = cpu_baseline(args, tex, uv, ix, sat=False, sample=kc)
+                gpu_res2 = prod.bake(baker, bake_desc(th2, uv, ix, args, 0, kc), want_stats=False)
+                assert gpu_res2.same_as(cpu_res2), "SAT-off GPU result differs from the CPU baseline: " + gpu_res2.diff(cpu_res2)
+                prod.destroy_texture(baker, th2)
+                line["sat_off"] = {"entry": "ommCpuBake (host arrays, PCIe inclusive), texture without alphaCutoff", "gpu_micro_triangles_per_s": ks * 4.0 ** args.level / gpu_dt,
+                                   "gpu_sample": "first %d triangles, %.1f ms" % (ks, gpu_dt * 1e3), "cpu_baseline": cb2, "parity": "bit-exact on the CPU sample"}
         print(json.dumps(line))
     prod.destroy_texture(baker, th)
     prod.destroy_baker(baker)

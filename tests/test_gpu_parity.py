@@ -664,7 +664,7 @@ def test_bench_contract_small():
     import json, subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--tris", "3000", "--level", "6", "--tex", "512", "--steps", "2", "--warmup", "1",
-                          "--cpu-sample", "300", "--host-api-steps", "1"], capture_output=True, text=True, timeout=600)
+                          "--cpu-sample", "300", "--sat-off-sample", "400", "--host-api-steps", "1"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -675,6 +675,7 @@ def test_bench_contract_small():
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and d["roofline"]["traffic"] is None   # PMC traffic applies to the default workload only
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["parity_vs_cpu_baseline"].startswith("bit-exact") and d["sat_off"]["parity"].startswith("bit-exact")
 
 
 # ---------------------------------------------------------------------------------------------
