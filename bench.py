@@ -60,7 +60,16 @@ def cpu_baseline(args, tex, uv, ix, sat=True, sample=None):
     orc.destroy_texture(b, t)
     orc.destroy_baker(b)
     mt = k * 4 ** args.level
-    return {"value": mt / dt, "unit": "micro-triangles/s", "cores": cores, "kind": "port",
+    model, sockets = "unknown", set()
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                sockets.add(ln.split(":", 1)[1].strip())
+    except OSError:
+        pass
+    return {"value": mt / dt, "unit": "micro-triangles/s", "cores": cores, "kind": "port", "host": "%s, %d socket(s), %d hardware threads" % (model, max(1, len(sockets)), cores),
             "sample": "first %d triangles of the same seeded stream (%.3g micro-triangles), SAT %s, %.1f s" % (k, mt, "on" if sat else "off", dt)}, res
 
 
