@@ -7,8 +7,9 @@
  * Every declaration cites the reference interface it replaces
  * (paths relative to /root/reference/libraries/omm-lib/).
  *
- * Only the CPU-baker subset of the SDK surface is declared; the
- * GPU-baker / debug-image entry points are out of scope for this build.
+ * All 25 `omm*` exports of the SDK library are present: the CPU-baker
+ * surface is implemented; the GPU-baker / debug-image entry points are link-compatible stubs
+ * that return ommResult_NOT_IMPLEMENTED (out of scope for this build).
  *
  * Plain C: no torch types, no C++ types, pointers + sizes only.
  */
@@ -354,7 +355,43 @@ OMM_MI355X_API ommResult ommCpuDestroySerializedResult(ommCpuSerializedResult re
 OMM_MI355X_API ommResult ommCpuDeserialize(ommBaker baker, const ommCpuBlobDesc* desc, ommCpuDeserializedResult* outResult);
 OMM_MI355X_API ommResult ommCpuGetDeserializedDesc(ommCpuDeserializedResult result, const ommCpuDeserializedDesc** desc);
 OMM_MI355X_API ommResult ommCpuDestroyDeserializedResult(ommCpuDeserializedResult result);
-/* include/omm.h:1201, src/debug_impl.cpp:643-652 */
+/* include/omm.h:1201, src/debug_impl.cpp:643-652 -- statistics of a result desc; knownAreaMetric stays 0 (no per-triangle areas). */
 OMM_MI355X_API ommResult ommDebugGetStats(ommBaker baker, const ommCpuBakeResultDesc* res, ommDebugStats* out);
+/* include/omm.h:1202, src/bake.cpp:359-386, src/debug_impl.cpp:512-641 -- the same on a result OBJECT of ommCpuBake, which keeps the
+ * UV-space area of every input triangle (src/bake_cpu_impl.cpp:1904-1915): knownAreaMetric = area-weighted known fraction. */
+OMM_MI355X_API ommResult ommDebugGetStats2(ommBaker baker, ommCpuBakeResult res, ommDebugStats* out);
+/* include/omm.h:1204, src/bake.cpp:388-408, src/debug_impl.cpp:654-670 -- writes blob bytes to `path` (the SDK declares `data` as a
+ * C++ reference inside extern "C": a pointer at the ABI level, like ommCpuSerialize above). */
+OMM_MI355X_API ommResult ommDebugSaveBinaryToDisk(ommBaker baker, const ommCpuBlobDesc* data, const char* path);
+
+/* ---- link compatibility with the rest of the SDK's export list --------------------------------------------
+ * The SDK's GPU baker (include/omm.h:596-1141: a dispatch-chain generator for the client's D3D12 / Vulkan RHI, HLSL shaders) and its
+ * PNG debug dump are out of scope for this build.  Their seven entry points are exported so that any binary linked against the SDK's
+ * libomm-lib.so -- which may reference them without calling them -- also loads against this library; called, they validate the
+ * handles like src/bake.cpp:262-336 and return ommResult_NOT_IMPLEMENTED with a log line.  The desc types are opaque here: only
+ * pointers cross the ABI. */
+typedef struct _ommGpuPipeline*             ommGpuPipeline;             /* include/omm.h:596-597 */
+typedef struct ommGpuPipelineConfigDesc     ommGpuPipelineConfigDesc;   /* include/omm.h:944-948 (opaque) */
+typedef struct ommGpuPipelineInfoDesc       ommGpuPipelineInfoDesc;     /* include/omm.h:1085-1095 (opaque) */
+typedef struct ommGpuDispatchConfigDesc     ommGpuDispatchConfigDesc;   /* include/omm.h:997-1055 (opaque) */
+typedef struct ommGpuPreDispatchInfo        ommGpuPreDispatchInfo;      /* include/omm.h:958-980 (opaque) */
+typedef struct ommGpuDispatchChain          ommGpuDispatchChain;        /* include/omm.h:1116-1122 (opaque) */
+typedef struct ommDebugSaveImagesDesc       ommDebugSaveImagesDesc;     /* include/omm.h:1143-1156 (opaque) */
+typedef enum ommGpuResourceType {                                       /* include/omm.h:608-636 (passed by value) */
+    ommGpuResourceType_IN_ALPHA_TEXTURE, ommGpuResourceType_IN_TEXCOORD_BUFFER, ommGpuResourceType_IN_INDEX_BUFFER,
+    ommGpuResourceType_IN_SUBDIVISION_LEVEL_BUFFER, ommGpuResourceType_OUT_OMM_ARRAY_DATA, ommGpuResourceType_OUT_OMM_DESC_ARRAY,
+    ommGpuResourceType_OUT_OMM_DESC_ARRAY_HISTOGRAM, ommGpuResourceType_OUT_OMM_INDEX_BUFFER, ommGpuResourceType_OUT_OMM_INDEX_HISTOGRAM,
+    ommGpuResourceType_OUT_POST_DISPATCH_INFO, ommGpuResourceType_TRANSIENT_POOL_BUFFER, ommGpuResourceType_STATIC_VERTEX_BUFFER,
+    ommGpuResourceType_STATIC_INDEX_BUFFER, ommGpuResourceType_MAX_NUM
+} ommGpuResourceType;
+/* include/omm.h:1127-1141, src/bake.cpp:262-312 */
+OMM_MI355X_API ommResult ommGpuGetStaticResourceData(ommGpuResourceType resource, uint8_t* data, size_t* outByteSize);
+OMM_MI355X_API ommResult ommGpuCreatePipeline(ommBaker baker, const ommGpuPipelineConfigDesc* pipelineCfg, ommGpuPipeline* outPipeline);
+OMM_MI355X_API ommResult ommGpuDestroyPipeline(ommBaker baker, ommGpuPipeline pipeline);
+OMM_MI355X_API ommResult ommGpuGetPipelineDesc(ommGpuPipeline pipeline, const ommGpuPipelineInfoDesc** outPipelineDesc);
+OMM_MI355X_API ommResult ommGpuGetPreDispatchInfo(ommGpuPipeline pipeline, const ommGpuDispatchConfigDesc* config, ommGpuPreDispatchInfo* outPreDispatchInfo);
+OMM_MI355X_API ommResult ommGpuDispatch(ommGpuPipeline pipeline, const ommGpuDispatchConfigDesc* config, const ommGpuDispatchChain** outDispatchDesc);
+/* include/omm.h:1199, src/bake.cpp:314-336 */
+OMM_MI355X_API ommResult ommDebugSaveAsImages(ommBaker baker, const ommCpuBakeInputDesc* bakeInputDesc, const ommCpuBakeResultDesc* res, const ommDebugSaveImagesDesc* desc);
 
 #endif /* OMM_MI355X_H */

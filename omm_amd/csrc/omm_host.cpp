@@ -10,6 +10,7 @@
 #include "host_tail.h"
 
 #include <hip/hip_runtime.h>
+#include <malloc.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -18,8 +19,10 @@
 #include <mutex>
 #include <memory>
 #include <new>
+#include <exception>
 #include <thread>
 #include <sys/mman.h>
+#include <unistd.h>
 #include <unordered_map>
 #include <vector>
 #include <xmmintrin.h>
@@ -45,7 +48,7 @@ void* default_alloc(void*, size_t size, size_t alignment)
 void* default_realloc(void* u, void* mem, size_t size, size_t alignment)
 {
     void* n = default_alloc(u, size, alignment);
-    if (n && mem) { memcpy(n, mem, size); free(mem); } // conservative: size of the old block is unknown
+    if (n && mem) { const size_t old = malloc_usable_size(mem); memcpy(n, mem, old < size ? old : size); free(mem); } // never reads past the old block
     return n;
 }
 void default_free(void*, void* mem) { free(mem); }
@@ -66,6 +69,17 @@ struct Logger {
     ommResult invalid(const char* m) const { msg(ommMessageSeverity_Fatal, m); return ommResult_INVALID_ARGUMENT; }
     ommResult failure(const char* m) const { msg(ommMessageSeverity_Fatal, m); return ommResult_FAILURE; }
 };
+
+// ---- nothing may unwind through the C ABI (the SDK "never throws"): std::bad_alloc / length_error from the
+//      host-side containers become ommResult_FAILURE with a log line ----
+template <class F> ommResult guarded(const Logger* log, F&& body) noexcept
+{
+    try { return body(); }
+    catch (const std::bad_alloc&) { if (log) log->msg(ommMessageSeverity_Fatal, "[Failure] - out of host memory"); }
+    catch (const std::exception& e) { if (log) { char buf[256]; snprintf(buf, sizeof buf, "[Failure] - %s", e.what()); log->msg(ommMessageSeverity_Fatal, buf); } }
+    catch (...) { if (log) log->msg(ommMessageSeverity_Fatal, "[Failure] - unexpected exception"); }
+    return ommResult_FAILURE;
+}
 
 // ---- device arena: one grow-only HBM block per baker, reused across bakes ----
 struct DeviceArena {
@@ -190,10 +204,11 @@ struct BakeResult {
     void* arrayData = nullptr; ommCpuOpacityMicromapDesc* descs = nullptr;
     ommCpuOpacityMicromapUsageCount* arrayHist = nullptr; ommCpuOpacityMicromapUsageCount* indexHist = nullptr;
     int32_t* index = nullptr;
+    float* triArea = nullptr;       // UV-space area per input triangle (bake_cpu_impl.cpp:1904-1915): ommDebugGetStats2's side channel
     std::shared_ptr<HostPool> pool; // set when arrayData came from the baker's warm pool (results may outlive their baker)
     ommCpuBakeResultDesc desc;
     BakeResult() { memset(&desc, 0, sizeof desc); }
-    ~BakeResult() { if (pool) pool->release(arrayData); else mem.release(arrayData); mem.release(descs); mem.release(arrayHist); mem.release(indexHist); mem.release(index); }
+    ~BakeResult() { if (pool) pool->release(arrayData); else mem.release(arrayData); mem.release(descs); mem.release(arrayHist); mem.release(indexHist); mem.release(index); mem.release(triArea); }
 };
 
 // ---- XXH64 of a constant byte stream: digests of uniform OMMs (bake_cpu_impl.cpp:1038-1040 applied to 4^level equal bytes) ----
@@ -387,6 +402,7 @@ struct DeviceResult {
     ommCpuOpacityMicromapDesc* descs = nullptr; uint32_t numDescs = 0;
     void* index = nullptr; uint32_t numTris = 0; ommIndexFormat indexFormat = ommIndexFormat_UINT_32;
     uint32_t hist[2 * kNumLevels]; int bits = 2;
+    const float* triAreaScratch = nullptr; // per-triangle UV areas in the bake's arena: valid until the session ends (ommCpuBake copies them out)
     std::shared_ptr<DevPool> pool;   // the baker's (results may outlive their baker)
     DeviceResult() { memset(hist, 0, sizeof hist); }
     DeviceResult(const DeviceResult&) = delete;
@@ -463,7 +479,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     const size_t setupBytes = setup_scratch_bytes(T), tailBytes = tail_scratch_bytes(maxItems, T);
     const size_t scratchBytes = setupBytes > tailBytes ? setupBytes : tailBytes;
     const size_t i32 = pad256((size_t)maxItems * 4), i64 = pad256((size_t)maxItems * 8);
-    const size_t need = pad256((size_t)maxItems * 24) + 3 * pad256(maxItems) + i64 * 2 + i32 * 12 + pad256(sizeof(SetupCounters)) + 4096 + pad256(sizeof(unsigned long long) * kFineSlots * kFineStride) + pad256(scratchBytes);
+    const size_t need = pad256((size_t)maxItems * 24) + 3 * pad256(maxItems) + i64 * 2 + i32 * 13 + pad256(sizeof(SetupCounters)) + 4096 + pad256(sizeof(unsigned long long) * kFineSlots * kFineStride) + pad256(scratchBytes);
     if (!arena->reserve(need)) return L.failure("[Failure] - out of device memory for the bake working set");
     float* dUv = arena->take<float>((size_t)maxItems * 6);
     uint8_t* dLevel = arena->take<uint8_t>(maxItems); uint8_t* dDegen = arena->take<uint8_t>(maxItems); uint8_t* dActive = arena->take<uint8_t>(maxItems);
@@ -474,6 +490,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     int32_t* dSpecial = arena->take<int32_t>(maxItems); uint32_t* dRep = arena->take<uint32_t>(maxItems);
     uint32_t* dOrder = arena->take<uint32_t>(maxItems); uint32_t* dDstOfs = arena->take<uint32_t>(maxItems);
     uint32_t* dSizes = arena->take<uint32_t>(maxItems); int32_t* dItemValue = arena->take<int32_t>(maxItems);
+    float* dTriArea = arena->take<float>(maxItems); R.triAreaScratch = dTriArea;
     SetupCounters* dCounters = arena->take<SetupCounters>(1);
     uint64_t* dUniformDigest = arena->take<uint64_t>(kNumLevels * 4);
     uint32_t* dArrayHist = arena->take<uint32_t>(kNumLevels); uint32_t* dIndexHist = arena->take<uint32_t>(kNumLevels); uint32_t* dErr = arena->take<uint32_t>(1);
@@ -508,7 +525,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             if (!HIP_OK(run_setup_fix_pending(S, dScratch, scratchBytes, pend.data(), plv.data(), hc.numPending, stream))) return L.failure("[Failure] - device work-item setup failed");
         }
     }
-    if (!HIP_OK(run_setup_items(S, dScratch, scratchBytes, dCounters, dUv, dLevel, dDegen, dTriToItem, dItemIds, stream)))
+    if (!HIP_OK(run_setup_items(S, dScratch, scratchBytes, dCounters, dUv, dLevel, dDegen, dTriToItem, dItemIds, dTriArea, stream)))
         return L.failure("[Failure] - device work-item setup failed");
     const int e1 = et.mark();
 
@@ -619,6 +636,13 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         launch_classify(P, A, dActiveIds + bounds.b[l][bounds.rank], bounds.b[l][bounds.rank + 1] - bounds.b[l][bounds.rank], (uint32_t)l, stream);
     const int e2 = et.mark();
     if (ht) { // bring the per-micro-triangle states to the host for the serial tail (host_tail.cpp)
+        // the serial reducers work on one byte per micro-triangle of EVERY work item, like the reference (bake_cpu_impl.cpp:401-411):
+        // refuse cleanly when that cannot fit in host memory instead of dying in std::bad_alloc half way
+        {
+            uint64_t bytes = hc.stateBytes; for (int l = 0; l < kNumLevels; ++l) bytes += (uint64_t)hc.levelCount[l] << (2 * l);
+            const uint64_t phys = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGE_SIZE);
+            if (bytes > phys / 2) return L.failure("[Failure] - near-duplicate merging / maxArrayDataSize need one byte per micro-triangle of every work item on the host: not enough host memory for this bake");
+        }
         std::vector<float> hUv((size_t)U * 6); std::vector<uint8_t> hLevel(U), hActive(U), hStates((size_t)hc.stateBytes);
         std::vector<uint32_t> hMask(U); std::vector<uint64_t> hOfs(U); std::vector<int32_t> hTri(T);
         ok = true;
@@ -808,12 +832,17 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
         const uint32_t E = (uint32_t)hres.descs.size();
         if (E) {
             res->arrayData = baker.mem.allocate(hres.arrayData.size(), 64); res->descs = (ommCpuOpacityMicromapDesc*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, 16);
-            memcpy(res->arrayData, hres.arrayData.data(), hres.arrayData.size()); memcpy(res->descs, hres.descs.data(), sizeof(ommCpuOpacityMicromapDesc) * (size_t)E);
         }
         res->index = (int32_t*)baker.mem.allocate(sizeof(int32_t) * (size_t)(T ? T : 1), 16);
-        memcpy(res->index, hres.index.data(), sizeof(int32_t) * (size_t)T);
+        res->triArea = (float*)baker.mem.allocate(sizeof(float) * (size_t)(T ? T : 1), 16);
         res->arrayHist = (ommCpuOpacityMicromapUsageCount*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapUsageCount) * 2 * kNumLevels, 16);
         res->indexHist = (ommCpuOpacityMicromapUsageCount*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapUsageCount) * 2 * kNumLevels, 16);
+        if ((E && (!res->arrayData || !res->descs)) || !res->index || !res->triArea || !res->arrayHist || !res->indexHist)
+            { baker.mem.destroy(res); return L.failure("[Failure] - the memory allocator returned null for the bake result"); }
+        if (T && (!HIP_OK(hipMemcpyAsync(res->triArea, R.triAreaScratch, sizeof(float) * (size_t)T, hipMemcpyDeviceToHost, stream)) || !HIP_OK(hipStreamSynchronize(stream))))
+            { baker.mem.destroy(res); return L.failure("[Failure] - device to host transfer of the bake result failed"); }
+        if (E) { memcpy(res->arrayData, hres.arrayData.data(), hres.arrayData.size()); memcpy(res->descs, hres.descs.data(), sizeof(ommCpuOpacityMicromapDesc) * (size_t)E); }
+        memcpy(res->index, hres.index.data(), sizeof(int32_t) * (size_t)T);
         memcpy(res->arrayHist, hres.arrayHist.data(), sizeof(ommCpuOpacityMicromapUsageCount) * hres.arrayHist.size());
         memcpy(res->indexHist, hres.indexHist.data(), sizeof(ommCpuOpacityMicromapUsageCount) * hres.indexHist.size());
         ommIndexFormat ifmt = ommIndexFormat_UINT_32; // index narrowing in place (bake_cpu_impl.cpp:1872-1902)
@@ -851,9 +880,11 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
         ok = ok && HIP_OK(hipMemcpyAsync(res->descs, R.descs, sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, hipMemcpyDeviceToHost, stream));
     }
     res->index = (int32_t*)baker.mem.allocate(sizeof(int32_t) * (size_t)(T ? T : 1), 16);
-    ok = ok && res->index != nullptr;
+    res->triArea = (float*)baker.mem.allocate(sizeof(float) * (size_t)(T ? T : 1), 16);
+    ok = ok && res->index != nullptr && res->triArea != nullptr;
     const size_t outIdx = R.indexFormat == ommIndexFormat_UINT_8 ? 1 : (R.indexFormat == ommIndexFormat_UINT_16 ? 2 : 4);
     if (ok && T) ok = HIP_OK(hipMemcpyAsync(res->index, R.index, outIdx * T, hipMemcpyDeviceToHost, stream));
+    if (ok && T) ok = HIP_OK(hipMemcpyAsync(res->triArea, R.triAreaScratch, sizeof(float) * (size_t)T, hipMemcpyDeviceToHost, stream));
     const int d1 = et.mark();
     ok = ok && HIP_OK(hipStreamSynchronize(stream));
     if (!ok) { baker.mem.destroy(res); return L.failure("[Failure] - device to host transfer of the bake result failed"); }
@@ -861,6 +892,7 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     // histograms: format {2-state, 4-state} x level ascending, non-zero entries only (:1833-1850); one global format here
     res->arrayHist = (ommCpuOpacityMicromapUsageCount*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapUsageCount) * 2 * kNumLevels, 16);
     res->indexHist = (ommCpuOpacityMicromapUsageCount*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapUsageCount) * 2 * kNumLevels, 16);
+    if (!res->arrayHist || !res->indexHist) { baker.mem.destroy(res); return L.failure("[Failure] - the memory allocator returned null for the bake result"); }
     uint32_t nAH = 0, nIH = 0;
     for (uint32_t l = 0; l < (uint32_t)kNumLevels; ++l) {
         if (R.hist[l]) { res->arrayHist[nAH].count = R.hist[l]; res->arrayHist[nAH].subdivisionLevel = (uint16_t)l; res->arrayHist[nAH].format = (uint16_t)R.bits; nAH++; }
@@ -897,11 +929,15 @@ OMM_MI355X_API ommResult ommCreateBaker(const ommBakerCreationDesc* desc, ommBak
         mem.alloc = desc->memoryAllocatorInterface.allocate; mem.realloc_ = desc->memoryAllocatorInterface.reallocate;
         mem.free_ = desc->memoryAllocatorInterface.free; mem.user = desc->memoryAllocatorInterface.userArg;
     }
-    Baker* b = mem.make<Baker>();
-    if (!b) return ommResult_FAILURE;
-    b->mem = mem; b->log.iface = desc->messageInterface; b->type = desc->type;
-    *outBaker = (ommBaker)((uintptr_t)b | (desc->type == ommBakerType_CPU ? kCpuBaker : kGpuBaker));
-    return ommResult_SUCCESS;
+    // ommBakerType_GPU bakers are creatable and destroyable like in the SDK (support/tests/test_basic.cpp:46-51); every ommGpu* entry
+    // point answers NOT_IMPLEMENTED and the ommCpu* ones reject them ("Baker was not created as the right type")
+    return guarded(nullptr, [&] {
+        Baker* b = mem.make<Baker>();
+        if (!b) return ommResult_FAILURE;
+        b->mem = mem; b->log.iface = desc->messageInterface; b->type = desc->type;
+        *outBaker = (ommBaker)((uintptr_t)b | (desc->type == ommBakerType_CPU ? kCpuBaker : kGpuBaker));
+        return ommResult_SUCCESS;
+    });
 }
 
 OMM_MI355X_API ommResult ommDestroyBaker(ommBaker baker)
@@ -970,7 +1006,7 @@ OMM_MI355X_API ommResult ommCpuCreateTexture(ommBaker baker, const ommCpuTexture
     Baker* b = untag<Baker>(baker);
     if (desc == 0) return b->log.invalid("texture desc was not set");
     if (tag_of(baker) != kCpuBaker) return b->log.invalid("Baker was not created as the right type");
-    return create_texture_impl(b, desc, outTexture);
+    return guarded(&b->log, [&] { return create_texture_impl(b, desc, outTexture); });
 }
 
 OMM_MI355X_API ommResult ommCpuGetTextureDesc(ommCpuTexture texture, ommCpuTextureDesc* outDesc)
@@ -1014,7 +1050,7 @@ OMM_MI355X_API ommResult ommCpuBake(ommBaker baker, const ommCpuBakeInputDesc* d
         return ommResult_FAILURE;
     const ommResult v = validate_desc(*b, *desc);
     if (v != ommResult_SUCCESS) return v;
-    return bake_impl(*b, *desc, outBakeResult);
+    return guarded(&b->log, [&] { return bake_impl(*b, *desc, outBakeResult); });
 }
 
 OMM_MI355X_API ommResult ommCpuDestroyBakeResult(ommCpuBakeResult bakeResult)
@@ -1034,23 +1070,33 @@ OMM_MI355X_API ommResult ommCpuGetBakeResultDesc(ommCpuBakeResult bakeResult, co
     return ommResult_SUCCESS;
 }
 
-// debug_impl.cpp:512-641 (host-side parse of a finished result; knownAreaMetric needs the per-triangle areas -> 0 here)
-OMM_MI355X_API ommResult ommDebugGetStats(ommBaker baker, const ommCpuBakeResultDesc* res, ommDebugStats* out)
+namespace {
+// CollectStats (debug_impl.cpp:512-641), in the reference's evaluation order: per-descriptor micro-triangle counts are uint32, the
+// per-reference products are taken in 32 bits before they are added to the 64-bit totals (`uint * uint32_t`, :630-633), the areas of
+// the triangles that share a descriptor are summed in triangle order and the descriptors are visited in ascending index order
+// (std::map, :523,621).  `area` == nullptr (ommDebugGetStats) leaves knownAreaMetric at 0.
+ommResult collect_stats(const ommCpuBakeResultDesc* res, const float* area, ommDebugStats* out)
 {
-    if (baker == 0) return ommResult_INVALID_ARGUMENT;
     if (res == nullptr || out == nullptr) return ommResult_INVALID_ARGUMENT;
     ommDebugStats st; memset(&st, 0, sizeof st);
+    const uint32_t T = res->indexCount;
+    float totalArea = 0.f, knownArea = 0.f;
+    if (area) for (uint32_t i = 0; i < T; ++i) totalArea += area[i];
     std::vector<uint32_t> refs((size_t)res->descArrayCount + 1, 0);
-    for (uint32_t i = 0; i < res->indexCount; ++i) {
+    std::vector<float> refArea(area ? (size_t)res->descArrayCount + 1 : 0, 0.f);
+    for (uint32_t i = 0; i < T; ++i) {
         int32_t v;
         if (res->indexFormat == ommIndexFormat_UINT_8) v = ((const int8_t*)res->indexBuffer)[i];
         else if (res->indexFormat == ommIndexFormat_UINT_16) v = ((const int16_t*)res->indexBuffer)[i];
         else v = ((const int32_t*)res->indexBuffer)[i];
-        if (v == ommSpecialIndex_FullyTransparent) st.totalFullyTransparent++;
-        else if (v == ommSpecialIndex_FullyOpaque) st.totalFullyOpaque++;
+        if (v == ommSpecialIndex_FullyTransparent) { st.totalFullyTransparent++; knownArea += area ? area[i] : 0; }
+        else if (v == ommSpecialIndex_FullyOpaque) { st.totalFullyOpaque++; knownArea += area ? area[i] : 0; }
         else if (v == ommSpecialIndex_FullyUnknownTransparent) st.totalFullyUnknownTransparent++;
         else if (v == ommSpecialIndex_FullyUnknownOpaque) st.totalFullyUnknownOpaque++;
-        else if (v >= 0 && (uint32_t)v < res->descArrayCount) refs[(size_t)v]++;
+        else if (v >= 0 && (uint32_t)v < res->descArrayCount) {
+            if (area) { if (refs[(size_t)v] == 0) refArea[(size_t)v] = area[i]; else refArea[(size_t)v] += area[i]; }
+            refs[(size_t)v]++;
+        }
     }
     for (uint32_t i = 0; i < res->descArrayCount; ++i) {
         if (!refs[i]) continue;
@@ -1058,16 +1104,109 @@ OMM_MI355X_API ommResult ommDebugGetStats(ommBaker baker, const ommCpuBakeResult
         const uint8_t* data = (const uint8_t*)res->arrayData + dd.offset;
         const uint32_t nM = 1u << (dd.subdivisionLevel << 1);
         const uint32_t is2 = dd.format == ommFormat_OC1_2_State;
-        uint64_t c[4] = { 0, 0, 0, 0 };
+        uint32_t c[4] = { 0, 0, 0, 0 };
         for (uint32_t u = 0; u < nM; ++u) {
             const uint8_t v = data[u >> (2 + is2)];
             c[is2 ? ((v >> (u & 7)) & 1u) : ((v >> ((u << 1) & 7)) & 3u)]++;
         }
-        st.totalTransparent += (uint64_t)refs[i] * c[0]; st.totalOpaque += (uint64_t)refs[i] * c[1];
-        st.totalUnknownTransparent += (uint64_t)refs[i] * c[2]; st.totalUnknownOpaque += (uint64_t)refs[i] * c[3];
+        if (area) {
+            const uint32_t totalKnown = c[0] + c[1], totalUnknown = c[2] + c[3];
+            const float known = (float)totalKnown / (float)(totalKnown + totalUnknown);
+            knownArea += known * refArea[i];
+        }
+        st.totalTransparent += (uint32_t)(refs[i] * c[0]); st.totalOpaque += (uint32_t)(refs[i] * c[1]);
+        st.totalUnknownTransparent += (uint32_t)(refs[i] * c[2]); st.totalUnknownOpaque += (uint32_t)(refs[i] * c[3]);
     }
+    st.knownAreaMetric = area ? knownArea / totalArea : 0;
     *out = st;
     return ommResult_SUCCESS;
+}
+const Logger* baker_log(ommBaker baker) { return baker ? &untag<Baker>(baker)->log : nullptr; }
+} // namespace
+
+// include/omm.h:1201, bake.cpp:338-357
+OMM_MI355X_API ommResult ommDebugGetStats(ommBaker baker, const ommCpuBakeResultDesc* res, ommDebugStats* out)
+{
+    if (baker == 0) return ommResult_INVALID_ARGUMENT;
+    if (tag_of(baker) != kCpuBaker && tag_of(baker) != kGpuBaker) return ommResult_INVALID_ARGUMENT;
+    return guarded(baker_log(baker), [&] { return collect_stats(res, nullptr, out); });
+}
+
+// include/omm.h:1202, bake.cpp:359-386: statistics of a result OBJECT, with the per-triangle areas it carries
+OMM_MI355X_API ommResult ommDebugGetStats2(ommBaker baker, ommCpuBakeResult res, ommDebugStats* out)
+{
+    if (baker == 0) return ommResult_INVALID_ARGUMENT;
+    if (res == 0) return ommResult_INVALID_ARGUMENT;   // (the reference dereferences a null result here)
+    if (tag_of(baker) != kCpuBaker && tag_of(baker) != kGpuBaker) return ommResult_INVALID_ARGUMENT;
+    const BakeResult* r = (const BakeResult*)res;
+    return guarded(baker_log(baker), [&] { return collect_stats(&r->desc, r->triArea, out); });
+}
+
+// include/omm.h:1204, bake.cpp:388-408, debug_impl.cpp:654-670
+OMM_MI355X_API ommResult ommDebugSaveBinaryToDisk(ommBaker baker, const ommCpuBlobDesc* data, const char* path)
+{
+    if (baker == 0) return ommResult_INVALID_ARGUMENT;
+    if (path == 0) return ommResult_INVALID_ARGUMENT;
+    if (tag_of(baker) != kCpuBaker && tag_of(baker) != kGpuBaker) return ommResult_INVALID_ARGUMENT;
+    const Logger& L = untag<Baker>(baker)->log;
+    FILE* f = data ? fopen(path, "wb") : nullptr;
+    bool ok = f != nullptr;
+    if (ok && data->size) ok = fwrite(data->data, 1, (size_t)data->size, f) == (size_t)data->size;
+    if (f) ok = (fclose(f) == 0) && ok;
+    if (!ok) { char buf[512]; snprintf(buf, sizeof buf, "Unable to save file %s", path); L.msg(ommMessageSeverity_Error, buf); return ommResult_INVALID_ARGUMENT; } // log.ErrorArgf
+    return ommResult_SUCCESS;
+}
+
+// ---- link-compatible stubs of the SDK's GPU baker and PNG dump (include/omm.h:1127-1141,1199; bake.cpp:262-336) ----
+// Argument checks follow the reference; past them the answer is NOT_IMPLEMENTED (+ a log line where a baker is at hand).
+namespace {
+ommResult gpu_baker_not_built(const Logger* L, const char* fn)
+{
+    if (L) { char buf[256]; snprintf(buf, sizeof buf, "[Not Implemented] - %s: the SDK's D3D12/Vulkan GPU baker is not part of the MI355X build (use ommCpuBake, which runs on the GPU here)", fn); L->msg(ommMessageSeverity_Fatal, buf); }
+    return ommResult_NOT_IMPLEMENTED;
+}
+}
+OMM_MI355X_API ommResult ommGpuGetStaticResourceData(ommGpuResourceType, uint8_t*, size_t* outByteSize)
+{
+    if (outByteSize == nullptr) return ommResult_INVALID_ARGUMENT;
+    return gpu_baker_not_built(nullptr, "ommGpuGetStaticResourceData");
+}
+OMM_MI355X_API ommResult ommGpuCreatePipeline(ommBaker baker, const ommGpuPipelineConfigDesc* config, ommGpuPipeline* outPipeline)
+{
+    if (baker == 0) return ommResult_INVALID_ARGUMENT;
+    const Logger& L = untag<Baker>(baker)->log;
+    if (config == 0) return L.invalid("[Invalid Arg] - pipeline config desc must be provided");
+    if (tag_of(baker) != kGpuBaker) return L.invalid("[Invalid Arg] - invalid baker type");
+    if (outPipeline) *outPipeline = nullptr;
+    return gpu_baker_not_built(&L, "ommGpuCreatePipeline");
+}
+OMM_MI355X_API ommResult ommGpuDestroyPipeline(ommBaker baker, ommGpuPipeline pipeline)
+{
+    if (pipeline == 0 || baker == 0 || tag_of(baker) != kGpuBaker) return ommResult_INVALID_ARGUMENT;
+    return gpu_baker_not_built(&untag<Baker>(baker)->log, "ommGpuDestroyPipeline");
+}
+OMM_MI355X_API ommResult ommGpuGetPipelineDesc(ommGpuPipeline pipeline, const ommGpuPipelineInfoDesc**)
+{
+    if (pipeline == 0) return ommResult_INVALID_ARGUMENT;
+    return gpu_baker_not_built(nullptr, "ommGpuGetPipelineDesc");   // (no pipeline handle can exist: CreatePipeline never succeeds)
+}
+OMM_MI355X_API ommResult ommGpuGetPreDispatchInfo(ommGpuPipeline pipeline, const ommGpuDispatchConfigDesc* config, ommGpuPreDispatchInfo*)
+{
+    if (pipeline == 0 || config == 0) return ommResult_INVALID_ARGUMENT;
+    return gpu_baker_not_built(nullptr, "ommGpuGetPreDispatchInfo");
+}
+OMM_MI355X_API ommResult ommGpuDispatch(ommGpuPipeline pipeline, const ommGpuDispatchConfigDesc* config, const ommGpuDispatchChain**)
+{
+    if (pipeline == 0 || config == 0) return ommResult_INVALID_ARGUMENT;
+    return gpu_baker_not_built(nullptr, "ommGpuDispatch");
+}
+OMM_MI355X_API ommResult ommDebugSaveAsImages(ommBaker baker, const ommCpuBakeInputDesc* bakeInputDesc, const ommCpuBakeResultDesc*, const ommDebugSaveImagesDesc* desc)
+{
+    if (baker == 0 || bakeInputDesc == 0 || desc == 0) return ommResult_INVALID_ARGUMENT;
+    if (tag_of(baker) != kCpuBaker && tag_of(baker) != kGpuBaker) return ommResult_INVALID_ARGUMENT;
+    const Logger& L = untag<Baker>(baker)->log;
+    L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - ommDebugSaveAsImages: the PNG overlay dump (stb) is not part of the MI355X build");
+    return ommResult_NOT_IMPLEMENTED;
 }
 
 OMM_MI355X_API ommResult ommxBakeDevice(ommBaker baker, const ommCpuBakeInputDesc* desc, ommxDeviceBakeResult* outResult)
@@ -1085,6 +1224,7 @@ OMM_MI355X_API ommResult ommxBakeDevice(ommBaker baker, const ommCpuBakeInputDes
     if (r != ommResult_SUCCESS) return r;
     r = scope_fences(*b, *desc, false);
     if (r != ommResult_SUCCESS) return r;
+    return guarded(&b->log, [&]() -> ommResult {
     const double t0 = now_ms();
     BakeSession ses(*b);
     if (!ses.open()) return b->log.failure("[Failure] - no usable HIP device (the MI355X baker has no CPU fallback)");
@@ -1110,6 +1250,7 @@ OMM_MI355X_API ommResult ommxBakeDevice(ommBaker baker, const ommCpuBakeInputDes
     { std::lock_guard<std::mutex> g(b->timingsMu); b->timings = tm; b->haveTimings = true; }
     *outResult = (ommxDeviceBakeResult)res;
     return ommResult_SUCCESS;
+    });
 }
 
 // ---- multi-GPU sharded bake (include/omm_mi355x_ext.h) ----

@@ -216,6 +216,23 @@ __global__ void setup_level_starts(SetupCounters* __restrict__ counters)
     }
 }
 
+// UV-space area of every input triangle (bake_cpu_impl.cpp:1904-1915, GetArea2D util/geometry.h:141-149): the side channel of
+// ommDebugGetStats2's knownAreaMetric.  Triangles that own no work item (NaN / Inf coordinates) keep area 0 like the reference's
+// value-initialised vector.
+__global__ __launch_bounds__(256) void setup_tri_areas(const float* __restrict__ triUv, const uint8_t* __restrict__ triFlags, uint32_t n, float* __restrict__ area)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float a = 0.f;
+    if (!(triFlags[t] & 1u)) {
+        const float* p = triUv + 6ull * t;
+        const float v0x = p[4] - p[0], v0y = p[5] - p[1], v1x = p[2] - p[0], v1y = p[3] - p[1];
+        const float nx = v0y * 0.f - v1y * 0.f, ny = 0.f * v1x - 0.f * v0x, nz = v0x * v1y - v1x * v0y;   // glm::cross(float3(v0, 0), float3(v1, 0))
+        a = 0.5f * __builtin_sqrtf(nx * nx + ny * ny + nz * nz);
+    }
+    area[t] = a;
+}
+
 size_t setup_scratch_bytes(uint32_t numTris)
 {
     const size_t n = numTris ? numTris : 1;
@@ -318,12 +335,13 @@ hipError_t copy_pending_to_host(void* scratch, size_t scratchBytes, uint32_t num
 }
 
 hipError_t run_setup_items(const SetupParams& S, void* scratch, size_t scratchBytes, SetupCounters* counters, float* itemUv, uint8_t* itemLevel,
-                           uint8_t* itemDegenerate, int32_t* triToItem, uint32_t* itemIds, hipStream_t stream)
+                           uint8_t* itemDegenerate, int32_t* triToItem, uint32_t* itemIds, float* triArea, hipStream_t stream)
 {
     const uint32_t n = S.numTris;
     if (n == 0) return hipSuccess;
     SetupScratch s = carve_setup(scratch, scratchBytes, n);
     const dim3 grid((n + 255u) / 256u), block(256);
+    if (triArea) hipLaunchKernelGGL(setup_tri_areas, grid, block, 0, stream, s.triUv, s.triFlags, n, triArea);
     size_t tb = s.cubBytes;
     SETUP_CHECK(hipcub::DeviceRadixSort::SortPairs(s.cub, tb, s.keysA, s.keysB, s.trisA, s.trisB, (int)n, 0, 64, stream));
     hipLaunchKernelGGL(setup_heads, grid, block, 0, stream, s.keysB, s.trisB, n, s.triUv, s.triLevel, s.headPos, counters);

@@ -20,6 +20,7 @@ ommResult oracle_ommCpuBake(ommBaker baker, const ommCpuBakeInputDesc* desc, omm
 ommResult oracle_ommCpuDestroyBakeResult(ommCpuBakeResult r);
 ommResult oracle_ommCpuGetBakeResultDesc(ommCpuBakeResult r, const ommCpuBakeResultDesc** desc);
 ommResult oracle_ommDebugGetStats(ommBaker baker, const ommCpuBakeResultDesc* res, ommDebugStats* out);
+ommResult oracle_ommDebugGetStats2(ommBaker baker, ommCpuBakeResult res, ommDebugStats* out);
 const float* oracle_bake_result_areas(ommCpuBakeResult r);
 
 /* unit-level probes used by tests */

@@ -12,6 +12,7 @@ Outputs (data only -- inputs and expected outputs, no reference source text):
                   (the reference tests read exactly this channel: test_omm_bake_cpu.cpp:662-669).
   leaflet.json    its dimensions.
   texcoord_kat.json  the GetTexCoord input/expected tables of support/tests/test_texture.cpp:40-266.
+  sdk_exports.txt    the names of the 25 OMM_API functions libraries/omm-lib/include/omm.h declares (= the SDK library's export list).
 """
 import json, os, re, sys
 
@@ -27,6 +28,11 @@ def extract_blobs():
         data = bytes(int(x, 16) for x in re.findall(r"0x([0-9A-Fa-f]{2})", body))
         blobs[name] = data.hex()
     return blobs
+
+
+def extract_sdk_exports():
+    src = open(os.path.join(REF, "libraries/omm-lib/include/omm.h")).read()
+    return sorted(set(re.findall(r"OMM_API\s+\w+\s+(?:OMM_CALL\s+)?(omm\w+)\s*\(", src)))
 
 
 def extract_texcoord_kats():
@@ -60,6 +66,9 @@ if __name__ == "__main__":
     open(os.path.join(HERE, "leaflet_b.bin"), "wb").write(blue)
     json.dump({"width": w, "height": h, "channels": ch, "channel": 2}, open(os.path.join(HERE, "leaflet.json"), "w"))
     print("leaflet:", w, h, ch)
+    ex = extract_sdk_exports()
+    open(os.path.join(HERE, "sdk_exports.txt"), "w").write("\n".join(ex) + "\n")
+    print("sdk exports:", len(ex))
 
 
 def make_abi_layout():

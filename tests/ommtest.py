@@ -199,11 +199,22 @@ class BakeResult:
         self.index_hist = [(desc.indexHistogram[i].count, desc.indexHistogram[i].subdivisionLevel,
                             desc.indexHistogram[i].format) for i in range(desc.indexHistogramCount)]
         self.stats = None
+        self.stats2 = None   # ommDebugGetStats2 on the result object (adds knownAreaMetric)
+
+    def stats2_key(self):
+        """every field of ommDebugGetStats2's answer, the float as its bit pattern (it may be NaN: 0 / 0 for zero total area)"""
+        if self.stats2 is None:
+            return None
+        s = self.stats2
+        return (s.totalOpaque, s.totalTransparent, s.totalUnknownTransparent, s.totalUnknownOpaque, s.totalFullyOpaque, s.totalFullyTransparent,
+                s.totalFullyUnknownOpaque, s.totalFullyUnknownTransparent, np.float32(s.knownAreaMetric).view(np.uint32).item())
 
     def same_as(self, other):
+        k0, k1 = self.stats2_key(), other.stats2_key()
         return (np.array_equal(self.array_data, other.array_data) and self.desc_bytes == other.desc_bytes
                 and self.index_format == other.index_format and np.array_equal(self.index, other.index)
-                and self.array_hist == other.array_hist and self.index_hist == other.index_hist)
+                and self.array_hist == other.array_hist and self.index_hist == other.index_hist
+                and (k0 is None or k1 is None or k0 == k1))
 
     def diff(self, other):
         out = []
@@ -224,6 +235,8 @@ class BakeResult:
             out.append("descArrayHistogram %r vs %r" % (self.array_hist, other.array_hist))
         if self.index_hist != other.index_hist:
             out.append("indexHistogram %r vs %r" % (self.index_hist, other.index_hist))
+        if self.stats2_key() is not None and other.stats2_key() is not None and self.stats2_key() != other.stats2_key():
+            out.append("ommDebugGetStats2 %r vs %r" % (self.stats2_key(), other.stats2_key()))
         return "; ".join(out)
 
     def stats_tuple(self):
@@ -258,6 +271,7 @@ class Lib:
         f("ommCpuDestroyBakeResult").argtypes = [C.c_void_p]
         f("ommCpuGetBakeResultDesc").argtypes = [C.c_void_p, C.POINTER(C.POINTER(BakeResultDesc))]
         f("ommDebugGetStats").argtypes = [C.c_void_p, C.POINTER(BakeResultDesc), C.POINTER(DebugStats)]
+        f("ommDebugGetStats2").argtypes = [C.c_void_p, C.c_void_p, C.POINTER(DebugStats)]
 
     def fn(self, name):
         return getattr(self.dll, self.prefix + name)
@@ -311,6 +325,11 @@ class Lib:
             st = DebugStats()
             assert self.fn("ommDebugGetStats")(baker, pd, C.byref(st)) == SUCCESS
             res.stats = st
+            st2 = DebugStats()
+            assert self.fn("ommDebugGetStats2")(baker, out, C.byref(st2)) == SUCCESS
+            res.stats2 = st2
+            assert (st2.totalOpaque, st2.totalTransparent, st2.totalFullyOpaque, st2.totalFullyUnknownTransparent) == \
+                   (st.totalOpaque, st.totalTransparent, st.totalFullyOpaque, st.totalFullyUnknownTransparent)
         assert self.fn("ommCpuDestroyBakeResult")(out) == SUCCESS
         return res
 

@@ -31,6 +31,98 @@ def test_library_exports_every_declared_symbol():
     assert (v & 0xff, (v >> 8) & 0xff, (v >> 16) & 0xff) == (1, 9, 0)
 
 
+def sdk_exports():
+    return open(os.path.join(ROOT, "tests", "golden", "sdk_exports.txt")).read().split()
+
+
+def test_every_export_of_the_sdk_library_is_present(tmp_path):
+    """The SDK's libomm-lib exports the 25 OMM_API functions of its omm.h.  The drop-in exports the same set under
+    the same SONAME, so a binary linked against the SDK library -- whichever of them it references -- loads against this one.
+    The list is a committed fixture; it is re-derived from the SDK header where the reference checkout exists."""
+    import subprocess
+    names = sdk_exports()
+    assert len(names) == 25
+    ref_h = "/root/reference/libraries/omm-lib/include/omm.h"
+    if os.path.exists(ref_h):
+        src = open(ref_h).read()
+        assert sorted(set(re.findall(r"OMM_API\s+\w+\s+(?:OMM_CALL\s+)?(omm\w+)\s*\(", src))) == names
+    path = ot.product_path()
+    dyn = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    exported = {ln.split()[-1] for ln in dyn.splitlines() if " T " in ln}
+    assert not [n for n in names if n not in exported]
+    assert set(declared_symbols()) >= set(names)          # and every one of them is declared in include/omm_mi355x.h
+    assert "libomm-lib.so" in subprocess.check_output(["readelf", "-d", path], text=True).split("SONAME")[1].splitlines()[0]
+    # a program that references every one of the 25 symbols links against the drop-in and loads (no GPU needed: nothing is called)
+    src = tmp_path / "all_symbols.c"
+    src.write_text("#include <stdio.h>\n" + "".join("extern void %s(void);\n" % n for n in names) +
+                   "int main(void) { void (*f[])(void) = { %s }; unsigned k = 0, i; for (i = 0; i < sizeof f / sizeof f[0]; ++i) k += f[i] != 0; printf(\"%%u\\n\", k); return 0; }\n"
+                   % ", ".join(names))
+    lib_dir = os.path.dirname(path)
+    exe = str(tmp_path / "all_symbols")
+    r = subprocess.run(["gcc", str(src), "-o", exe, "-L" + lib_dir, "-lomm-lib", "-Wl,-rpath," + lib_dir, "-Wl,--no-as-needed"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert subprocess.check_output([exe], text=True).strip() == "25"
+
+
+class _Blob(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("size", C.c_uint64)]
+
+
+def test_gpu_baker_and_debug_entry_points_answer_like_the_sdk(tmp_path):
+    """ommBakerType_GPU bakers are creatable (support/tests/test_basic.cpp:46-51); the SDK's GPU-baker / PNG-dump entry points validate their
+    arguments like src/bake.cpp:262-336 and then answer NOT_IMPLEMENTED with a log line; ommDebugSaveBinaryToDisk writes the blob
+    (debug_impl.cpp:654-670).  None of this touches the device."""
+    NOT_IMPLEMENTED = 4
+    lib = ot.Lib("product")
+    dll = lib.dll
+    msgs = []
+    gpu = lib.create_baker(baker_type=0, callback=lambda sev, msg, user: msgs.append((sev, msg.decode())))
+    cpu = ot.Lib("product").create_baker()    # (a Lib keeps ONE callback object alive: the second baker comes from a second Lib)
+    dummy = C.c_uint64(0)
+    out = C.c_void_p(0x1234)
+    dll.ommGpuCreatePipeline.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    assert dll.ommGpuCreatePipeline(None, C.byref(dummy), C.byref(out)) == ot.INVALID_ARGUMENT
+    assert dll.ommGpuCreatePipeline(gpu, None, C.byref(out)) == ot.INVALID_ARGUMENT
+    assert dll.ommGpuCreatePipeline(cpu, C.byref(dummy), C.byref(out)) == ot.INVALID_ARGUMENT           # "[Invalid Arg] - invalid baker type"
+    assert dll.ommGpuCreatePipeline(gpu, C.byref(dummy), C.byref(out)) == NOT_IMPLEMENTED and not out.value
+    assert msgs and msgs[-1][0] == 3 and "ommGpuCreatePipeline" in msgs[-1][1]
+    dll.ommGpuDestroyPipeline.argtypes = [C.c_void_p, C.c_void_p]
+    assert dll.ommGpuDestroyPipeline(gpu, None) == ot.INVALID_ARGUMENT
+    assert dll.ommGpuDestroyPipeline(cpu, C.c_void_p(8)) == ot.INVALID_ARGUMENT
+    for name in ("ommGpuGetPipelineDesc",):
+        getattr(dll, name).argtypes = [C.c_void_p, C.c_void_p]
+        assert getattr(dll, name)(None, None) == ot.INVALID_ARGUMENT
+        assert getattr(dll, name)(C.c_void_p(8), None) == NOT_IMPLEMENTED
+    for name in ("ommGpuGetPreDispatchInfo", "ommGpuDispatch"):
+        getattr(dll, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        assert getattr(dll, name)(None, C.byref(dummy), None) == ot.INVALID_ARGUMENT
+        assert getattr(dll, name)(C.c_void_p(8), None, None) == ot.INVALID_ARGUMENT
+        assert getattr(dll, name)(C.c_void_p(8), C.byref(dummy), None) == NOT_IMPLEMENTED
+    dll.ommGpuGetStaticResourceData.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_size_t)]
+    n = C.c_size_t(0)
+    assert dll.ommGpuGetStaticResourceData(11, None, C.byref(n)) == NOT_IMPLEMENTED
+    dll.ommDebugSaveAsImages.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert dll.ommDebugSaveAsImages(cpu, None, None, C.byref(dummy)) == ot.INVALID_ARGUMENT
+    assert dll.ommDebugSaveAsImages(cpu, C.byref(dummy), None, C.byref(dummy)) == NOT_IMPLEMENTED
+    # ommDebugSaveBinaryToDisk
+    dll.ommDebugSaveBinaryToDisk.argtypes = [C.c_void_p, C.POINTER(_Blob), C.c_char_p]
+    payload = bytes(range(256)) * 3
+    buf = C.create_string_buffer(payload, len(payload))
+    blob = _Blob(C.cast(buf, C.c_void_p), len(payload))
+    path = str(tmp_path / "blob.bin").encode()
+    assert dll.ommDebugSaveBinaryToDisk(None, C.byref(blob), path) == ot.INVALID_ARGUMENT
+    assert dll.ommDebugSaveBinaryToDisk(cpu, C.byref(blob), None) == ot.INVALID_ARGUMENT
+    assert dll.ommDebugSaveBinaryToDisk(cpu, C.byref(blob), path) == ot.SUCCESS
+    assert open(path, "rb").read() == payload
+    assert dll.ommDebugSaveBinaryToDisk(gpu, C.byref(blob), str(tmp_path / "no_such_dir" / "x.bin").encode()) == ot.INVALID_ARGUMENT
+    assert "Unable to save file" in msgs[-1][1] and msgs[-1][0] == 2
+    # ommDebugGetStats2 argument checks (bake.cpp:359-362)
+    st = ot.DebugStats()
+    assert lib.fn("ommDebugGetStats2")(None, None, C.byref(st)) == ot.INVALID_ARGUMENT
+    assert lib.fn("ommDebugGetStats2")(cpu, None, C.byref(st)) == ot.INVALID_ARGUMENT
+    assert lib.destroy_baker(gpu) == ot.SUCCESS and lib.destroy_baker(cpu) == ot.SUCCESS
+
+
 def test_struct_layouts():
     assert C.sizeof(ot.BakeInputDesc) == 136          # serialize_impl.cpp:86
     assert C.sizeof(ot.BakeResultDesc) == 80
