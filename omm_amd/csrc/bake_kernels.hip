@@ -112,6 +112,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     __shared__ uint32_t s_gcount;
     __shared__ uint32_t s_qcount;
     __shared__ uint32_t s_mask, s_known;
+    __shared__ uint32_t s_pending, s_fine;       // single-texel pass: micro-triangles left for the generic pass / level-line statistic
     __shared__ float    s_wtex[SLICED ? WIN * WIN : 1];
     __shared__ uint32_t s_wsat[SLICED ? (WIN + 1) * (WIN + 1) : 1];
     constexpr uint32_t TILE_LOG4 = TILE == 4096 ? 6u : 5u; // the tile is the level-(N - TILE_LOG4) sub-triangle of its item
@@ -137,7 +138,9 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     // block-uniform item data of a sliced tile
     uint32_t uItem = 0; float uUv[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }; float uMaxAbs = 0.f; bool uDegenerate = false;
     TexWindow W = no_window();
-    if (tid == 0) { s_qcount = 0; s_mask = 0; s_known = 0; s_tile = -1; }
+    if (tid == 0) { s_qcount = 0; s_mask = 0; s_known = 0; s_tile = -1; s_pending = 0; s_fine = 0; }
+    // the single-texel fast pass (fine_single_texel) covers Linear filtering of one mip on non-degenerate items; everything else is generic
+    const bool fastFine = SLICED && P.filterLinear != 0 && P.mipCount == 1;
     if (SLICED) {
         uItem = itemIds[firstItem];
         #pragma unroll
@@ -208,6 +211,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         auto phase1_group = [&](uint32_t i, int gs) {
             bool unresolved = false;
             if (gs == kRegionAllOpen) { // the whole group is unresolved by construction: no per-micro-triangle SAT test
+                if (fastFine && !uDegenerate) return;   // phase 2a takes the group as a whole, it needs no queue entries
                 unresolved = i < count;   // (phase 2 writes the state of every queued micro-triangle)
             } else
             if (i < count) {
@@ -256,6 +260,89 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         const uint32_t qn = s_qcount;
 #endif
         if (tid == 0 && qn) atomicAdd(A.fineCount + (size_t)((blockIdx.x + 7u * blockIdx.y) & (kFineSlots - 1)) * kFineStride, (unsigned long long)qn);
+#ifdef OMMX_STATS   // distribution counters for tuning (never shipped): entries 1.. of the tile's stripe
+        {
+            unsigned long long* st = A.fineCount + (size_t)((blockIdx.x + 7u * blockIdx.y) & (kFineSlots - 1)) * kFineStride;
+            if (tid == 0) {
+                atomicAdd(st + 1, 1ull);
+                if (SLICED) {
+                    unsigned long long ns = 0, no = 0, nu = 0;
+                    for (int g = 0; g < TILE / GROUP; ++g) { const int v = s_group[g]; ns += v >= 0; no += v == kRegionAllOpen; nu += v == kRegionUnknown; }
+                    atomicAdd(st + 2, ns); atomicAdd(st + 3, no); atomicAdd(st + 4, nu);
+                }
+            }
+            for (uint32_t q0 = 0; q0 < qn; q0 += BLOCK) {
+                const uint32_t q = q0 + tid;
+                int cat = -1;
+                if (q < qn && SLICED) {
+                    const uint32_t i = s_queue[q];
+                    const MicroTri t = micro_triangle(uUv, base + i, level);
+                    const DevMip& m = P.mips[0];
+                    const float ax = t.p0.x * m.fw - 0.5f, ay = t.p0.y * m.fh - 0.5f, bx = t.p1.x * m.fw - 0.5f, by = t.p1.y * m.fh - 0.5f, cx = t.p2.x * m.fw - 0.5f, cy = t.p2.y * m.fh - 0.5f;
+                    const float lox = std_min(std_min(ax, bx), cx), loy = std_min(std_min(ay, by), cy), hix = std_max(std_max(ax, bx), cx), hiy = std_max(std_max(ay, by), cy);
+                    const int w = cvt_trunc_x86(__builtin_ceilf(hix)) - cvt_trunc_x86(__builtin_floorf(lox)), h = cvt_trunc_x86(__builtin_ceilf(hiy)) - cvt_trunc_x86(__builtin_floorf(loy));
+                    const int area = w * h;
+                    cat = area <= 1 ? 0 : (area == 2 ? 1 : (area <= 4 ? 2 : 3));
+                    if (s_group[i >> 6] == kRegionAllOpen) cat += 4;
+                }
+                for (int c = 0; c < 8; ++c) { const unsigned long long b = __ballot(cat == c); if ((tid & 63u) == 0 && b) atomicAdd(st + 5 + c, (unsigned long long)__popcll(b)); }
+            }
+        }
+#endif
+        if (fastFine && !uDegenerate) {
+            // ---- phase 2a: all-open groups, one wave per group, straight-line single-texel pass ----
+            uint32_t pend = 0;
+            const uint32_t gcount = s_gcount;
+            for (uint32_t k = tid >> 6; k < gcount; k += BLOCK / 64) {
+                const uint32_t g = s_glist[k];
+                if (s_group[g] != kRegionAllOpen) continue;   // (wave-uniform)
+                const uint32_t i = g * 64u + (tid & 63u);
+                const int st = fine_single_texel<FP32, MD>(P, micro_triangle(uUv, base + i, level), W);
+                s_state[i] = (uint8_t)(st < 0 ? 0xFF : st);
+                pend |= st < 0 ? 1u : 0u;
+                if ((tid & 63u) == 0) atomicAdd(&s_fine, 64u);
+            }
+            // ---- phase 2b: the queued micro-triangles of the other open groups, same pass ----
+            for (uint32_t q0 = 0; q0 < qn; q0 += BLOCK) {
+                const uint32_t q = q0 + tid;
+                if (q < qn) {
+                    const uint32_t i = s_queue[q];
+                    const int st = fine_single_texel<FP32, MD>(P, micro_triangle(uUv, base + i, level), W);
+                    s_state[i] = (uint8_t)(st < 0 ? 0xFF : st);
+                    pend |= st < 0 ? 1u : 0u;
+                }
+            }
+            if (__any(pend != 0) && (tid & 63u) == 0) s_pending = 1u;
+            __syncthreads();
+            // ---- phase 2c: whatever did not fit the single-texel pattern (marked 0xFF) is compacted into the queue for the generic pass ----
+            uint32_t qn2 = 0;
+            if (s_pending) {   // (block-uniform)
+                if (tid == 0) s_qcount = 0;
+                __syncthreads();
+                for (uint32_t k = tid >> 6; k < gcount; k += BLOCK / 64) {
+                    const uint32_t i = s_glist[k] * 64u + (tid & 63u);
+                    const bool open = s_state[i] == 0xFF;
+                    const unsigned long long vote = __ballot(open);
+                    if (vote) {
+                        const uint32_t lane = tid & 63u;
+                        uint32_t wbase = 0;
+                        if (lane == 0) wbase = atomicAdd(&s_qcount, (uint32_t)__popcll(vote));
+                        wbase = __shfl(wbase, 0);
+                        if (open) s_queue[wbase + __popcll(vote & ((1ull << lane) - 1ull))] = (uint16_t)i;
+                    }
+                }
+                __syncthreads();
+                qn2 = s_qcount;
+            }
+            if (tid == 0 && s_fine) atomicAdd(A.fineCount + (size_t)((blockIdx.x + 7u * blockIdx.y) & (kFineSlots - 1)) * kFineStride, (unsigned long long)s_fine);
+            for (uint32_t q0 = 0; q0 < qn2; q0 += BLOCK) {
+                const uint32_t q = q0 + tid;
+                if (q < qn2) {
+                    const uint32_t i = s_queue[q];
+                    s_state[i] = (uint8_t)fine_state<FP32, MD>(P, micro_triangle(uUv, base + i, level), uDegenerate, W);
+                }
+            }
+        } else
         for (uint32_t q0 = 0; q0 < qn; q0 += BLOCK) { // q0 is block-uniform (scalar loop counter): one VGPR less across the level-line pass
             const uint32_t q = q0 + tid;
             if (q < qn) {

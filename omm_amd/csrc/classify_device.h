@@ -603,6 +603,85 @@ __device__ __forceinline__ int region_state_ex(const ClassifyParams& P, const Mi
     return region_state_impl<MD, true>(P, sub, maxAbs, W);
 }
 
+// ---- fine pass of a micro-triangle whose conservative raster covers ONE texel of mip 0 (Linear filter, non-degenerate item) ----
+// At the bench configuration 95 % of the micro-triangles that reach the level-line pass are far smaller than a texel (level 8 on an
+// 8-texel triangle: 1/32 texel), so their raster bounding box [floor(lo), ceil(hi)) is a single texel and that texel is also the cell
+// of the centre vote.  For those the generic code (fine_state -> bilinear + raster_micro_triangle -> level_line_texel) degenerates to
+// a fixed sequence; this function is that sequence written straight-line: no texel loops, one 2x2 texel fetch shared by the centre
+// vote and the level-line kernel, the raster-space vertices Q = P * size - 0.5 computed once.  Every fp32 expression is the one the
+// generic path evaluates (same operands, same association), so the state is bit-identical; micro-triangles that do not fit the pattern
+// return -1 and take the generic path.
+//   * Q: the centre vote uses `p * size - 0.5f` (texture_impl.cpp:264), the rasteriser `p * size + (-0.5f)` (cpu_raster.h:298-299):
+//     the same IEEE operation.
+//   * winding: sign of the fp64 difference of two products of fp32 values (geometry.h:49-55).  The products are exact in fp64, and
+//     rounding to fp32 is monotone, so whenever the fp32-rounded products differ their order IS the exact order; fp64 is evaluated
+//     only when they round to the same float.
+template <bool FP32, class MD>
+__device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const MicroTri& t, const TexWindow& W)
+{
+    const DevMip& m = P.mips[0];
+    const float q0x = t.p0.x * m.fw - 0.5f, q0y = t.p0.y * m.fh - 0.5f;
+    const float q1x = t.p1.x * m.fw - 0.5f, q1y = t.p1.y * m.fh - 0.5f;
+    const float q2x = t.p2.x * m.fw - 0.5f, q2y = t.p2.y * m.fh - 0.5f;
+    // winding (util/geometry.h:49-55): ccw = (double)(p2-p0).x * (double)(p1-p0).y - (double)(p1-p0).x * (double)(p2-p0).y < 0
+    const float ax = t.p2.x - t.p0.x, ay = t.p2.y - t.p0.y, bx = t.p1.x - t.p0.x, by = t.p1.y - t.p0.y;
+    const float l32 = ax * by, r32 = bx * ay;
+    bool ccw = l32 < r32;
+    if (!(l32 < r32) && !(r32 < l32)) ccw = ((double)ax * (double)by - (double)bx * (double)ay) < 0;   // equal or unordered in fp32: decide in fp64 like the reference
+    V2 a = mk2(q0x, q0y); const V2 b = mk2(q1x, q1y); V2 c = mk2(q2x, q2y);
+    if (!ccw) { V2 s = a; a = c; c = s; }
+    const float lox = std_min(std_min(a.x, b.x), c.x), loy = std_min(std_min(a.y, b.y), c.y);
+    const float hix = std_max(std_max(a.x, b.x), c.x), hiy = std_max(std_max(a.y, b.y), c.y);
+    const int minx = cvt_trunc_x86(__builtin_floorf(lox)), miny = cvt_trunc_x86(__builtin_floorf(loy));
+    const int maxx = cvt_trunc_x86(__builtin_ceilf(hix)), maxy = cvt_trunc_x86(__builtin_ceilf(hiy));
+    const float fx = __builtin_floorf(q0x), fy = __builtin_floorf(q0y);
+    const int ix = cvt_trunc_x86(fx), iy = cvt_trunc_x86(fy);
+    // one texel, which is also the centre-vote cell (NaN / overflowed coordinates fail these integer tests: INT_MIN arithmetic)
+    if (!(maxx - minx == 1 && maxy - miny == 1 && ix == minx && iy == miny && minx != (int)0x80000000 && miny != (int)0x80000000)) return -1;
+
+    float g00, g01, g11, g10;
+    fetch_cell<FP32, MD>(P, m, MD::pow2(P), minx, miny, W, g00, g01, g11, g10);
+    // (TextureImpl::Bilinear addresses with the per-mip pow2 flag, the level-line kernel with the dispatch flag = mip 0's: the same here)
+    uint32_t above = 0, below = 0;
+    {   // centre vote: TextureImpl::Bilinear at p0 (texture_impl.cpp:261-278); a = 00, b = 01, c = 10, d = 11
+        const float wx = q0x - fx, wy = q0y - fy;
+        const float ac = g00 * (1.f - wx) + g10 * wx;
+        const float bd = g01 * (1.f - wx) + g11 * wx;
+        vote(P.cutoff < ac * (1.f - wy) + bd * wy, above, below);
+    }
+    // conservative coverage test of the texel (cpu_raster.h:309-335 at x = minx, y = miny)
+    const float sx = (float)minx, sy = (float)miny;
+    const EdgeEq e0 = edge_eq(a, b), e1 = edge_eq(b, c), e2 = edge_eq(c, a);
+    const bool inside = eval_cons(e0, sx, sy) < 0.f && eval_cons(e1, sx, sy) < 0.f && eval_cons(e2, sx, sy) < 0.f;
+    if (inside) {
+        // LevelLineIntersectionKernel::run (bake_kernels_cpu.h:241-399), as level_line_texel<.., false, ..> above
+        const float pfx = sx + 0.5f, pfy = sy + 0.5f;
+        const float ipx = pfx * m.rw, ipy = pfy * m.rh;
+        const bool o0 = P.cutoff < g00, o1 = P.cutoff < g01, o2 = P.cutoff < g11, o3 = P.cutoff < g10;
+        const bool in0 = point_in_triangle(t, ipx, ipy);
+        const bool in1 = point_in_triangle(t, ipx + 0.0f, ipy + m.rh);
+        const bool in2 = point_in_triangle(t, ipx + m.rw, ipy + m.rh);
+        const bool in3 = point_in_triangle(t, ipx + m.rw, ipy + 0.0f);
+        const bool isO = (in0 && o0) || (in1 && o1) || (in2 && o2) || (in3 && o3);
+        const bool isT = (in0 && !o0) || (in1 && !o1) || (in2 && !o2) || (in3 && !o3);
+        if (isO) above += 1;
+        if (isT) below += 1;
+        if (!(isO && isT)) {
+            const float sa = g00, sb = g10 - g00, sc = g01 - g00, sd = g00 + g11 - g01 - g10;
+            if (near_zero(sb, 1e-6f) && near_zero(sc, 1e-6f) && near_zero(sd, 1e-6f)) vote(P.cutoff < sa, above, below);
+            else {
+                const float ha = sa - P.cutoff;
+                const V2 r0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy);
+                const V2 r1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy);
+                const V2 r2 = mk2(m.fw * t.p2.x - pfx, m.fh * t.p2.y - pfy);
+                if (edge_crosses_level_curve(r0, r1, ha, sb, sc, sd) || edge_crosses_level_curve(r1, r2, ha, sb, sc, sd) ||
+                    edge_crosses_level_curve(r2, r0, ha, sb, sc, sd)) { above += 1; below += 1; }
+            }
+        }
+    }
+    return state_from_coverage(P, above, below);
+}
+
 // ---- fine pass for one micro-triangle (bake_cpu_impl.cpp:859-914 linear, :983-1022 nearest) ----
 template <bool FP32, class MD>
 __device__ __forceinline__ int fine_state(const ClassifyParams& P, const MicroTri& t, bool degenerate, const TexWindow& W)

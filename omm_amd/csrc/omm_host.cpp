@@ -739,6 +739,13 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     tm.uploadMs = 0.f; tm.hostSetupMs = 0.f; tm.setupMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.digestMs = et.ms(e2, e3);
     tm.tailMs = et.ms(e3, e4); tm.gatherMs = et.ms(e4, e5);
     for (int k = 0; k < kFineSlots; ++k) fineCount += fineSlots[(size_t)k * kFineStride];
+#ifdef OMMX_STATS   // tuning builds only: distribution counters of classify_tiles (bake_kernels.hip), printed per bake
+    {
+        unsigned long long v[kFineStride]; for (int j = 0; j < kFineStride; ++j) { v[j] = 0; for (int k = 0; k < kFineSlots; ++k) v[j] += fineSlots[(size_t)k * kFineStride + j]; }
+        fprintf(stderr, "OMMX_STATS fine=%llu openTiles=%llu groups{settled=%llu allOpen=%llu unknown=%llu} footprint{1=%llu 2=%llu 4=%llu more=%llu} allOpenFootprint{1=%llu 2=%llu 4=%llu more=%llu}\n",
+                v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12]);
+    }
+#endif
     tm.fineMicroTriangles = fineCount; tm.uniqueItems = U; tm.activeItems = hc.activeStart[kNumLevels]; tm.stateBytes = hc.stateBytes; tm.microTriangles = 0;
     for (int l = 0; l < kNumLevels; ++l) { tm.microTriangles += (uint64_t)hc.levelCount[l] << (2 * l); tm.classifyLaunches += hc.activeStart[l + 1] != hc.activeStart[l]; }
     return ommResult_SUCCESS;
