@@ -289,6 +289,12 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
             }
         }
 #endif
+#ifdef OMMX_DEBUG_SKIP_PHASE2   // timing attribution only (never shipped)
+        if (fastFine) {
+            for (uint32_t k = tid >> 6; k < s_gcount; k += BLOCK / 64) { const uint32_t g = s_glist[k]; if (s_group[g] == kRegionAllOpen) s_state[g * 64u + (tid & 63u)] = 3; }
+            for (uint32_t q = tid; q < qn; q += BLOCK) s_state[s_queue[q]] = 3;
+        } else
+#endif
         if (fastFine && !uDegenerate) {
             // ---- phase 2a: all-open groups, one wave per group, straight-line single-texel pass ----
             uint32_t pend = 0;

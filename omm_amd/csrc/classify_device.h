@@ -293,6 +293,40 @@ __device__ __forceinline__ bool point_on_edge(V2 a0, V2 a1, float x, float y)
     return near_zero(vlen(ux, uy) + vlen(x - a1.x, y - a1.y) - vlen(dx, dy), 1e-5f);
 }
 
+// Root filter.  A root of the level curve on the edge's carrier line counts only if the reference's point
+// P = (x, y) passes in_unit_square AND IsPointOnEdge.  Measured on the bench workload 99.5 % of the roots lie outside the edge's x-range,
+// yet each costs an IEEE division (the most expensive operation of the kernel) before that is known.  The filter decides from the
+// division's OPERANDS whether its correctly rounded quotient x = RN(n / c) can lie in the only interval where the reference can accept:
+//   (i)  accepted  =>  P in [0,1]^2 and computed slack < 1e-5  =>  true slack S(P) = |P-a0| + |P-a1| - L <= eps = 2.4e-5 (the fp32
+//        evaluation error of the slack is <= 5.4e-7 (S + L), section 5.3, so S <= 1.11e-5 for L <= 2: eps allows 13x that error)  =>  P
+//        lies in the ellipse with foci a0, a1 and major axis L + eps, whose x-extent is sqrt((kd/2)^2 + B^2) <= kd/2 + B around the
+//        midpoint, B = sqrt(L eps / 2 + eps^2 / 4) < 4.9e-3 for L <= M = |dx| + |dy| <= 2.
+//        Hence x in I = [max(0, a0.x - 5e-3), min(1, a1.x + 5e-3)].
+//   (ii) with s = sign(c): n s > fl((hi + 1e-3) |c|)  =>  n / c > (hi + 1e-3)(1 - 2^-24) > hi + 9e-4  =>  RN(n / c) > hi (rounding is
+//        monotone); likewise below lo.  |c| >= 1e-6 and |hi + 1e-3| >= 1e-3, |lo - 1e-3| is 0 or >= 1e-10: no product underflows.
+// NaN / Inf operands compare false and take the exact path; so do edges with M > 2.  Everything not rejected is computed exactly as before.
+struct RootFilter { float lo, hi; bool on; };
+__device__ __forceinline__ RootFilter root_filter(V2 a0, V2 a1) // a0.x <= a1.x
+{
+    RootFilter f;
+#ifndef OMMX_NO_ROOT_FILTER
+    const float M = __builtin_fabsf(a1.x - a0.x) + __builtin_fabsf(a1.y - a0.y);
+    f.on = M <= 2.f;
+    float lo = a0.x - 5e-3f; lo = lo > 0.f ? lo : 0.f;
+    float hi = a1.x + 5e-3f; hi = hi < 1.f ? hi : 1.f;
+    f.lo = lo - 1e-3f; f.hi = hi + 1e-3f;
+#else
+    f.on = false; f.lo = f.hi = 0.f;
+#endif
+    return f;
+}
+// true when RN(n / c) is provably outside the acceptance interval
+__device__ __forceinline__ bool root_rejected(const RootFilter& f, float n, float c)
+{
+    const float ac = __builtin_fabsf(c), ns = c < 0.f ? -n : n;
+    return f.on && (ns > f.hi * ac || ns < f.lo * ac);
+}
+
 // bake_kernels_cpu.h:144-238 -- does segment (a0,a1) cross the level curve
 // h.x + h.y*x + h.z*y + h.w*x*y = 0 inside the unit texel?
 __device__ __forceinline__ bool edge_crosses_level_curve(V2 a0, V2 a1, float ha, float hb, float hc, float hd)
@@ -309,6 +343,7 @@ __device__ __forceinline__ bool edge_crosses_level_curve(V2 a0, V2 a1, float ha,
         const float y = -c1 / c0;
         return in_unit_square(x, y) && ON_EDGE(x, y);
     }
+    const RootFilter rf = root_filter(a0, a1);
     const float k = (a1.y - a0.y) / kd;
     const float m = a1.y - a1.x * k;
     const float c0 = hd * k;
@@ -316,6 +351,7 @@ __device__ __forceinline__ bool edge_crosses_level_curve(V2 a0, V2 a1, float ha,
     const float c2 = ha + hc * m;
     if (near_zero(c0, 1e-6f)) {
         if (near_zero(c1, 1e-6f)) return false;
+        if (root_rejected(rf, -c2, c1)) return false;
         const float x = -c2 / c1;
         const float y = k * x + m;
         return in_unit_square(x, y) && ON_EDGE(x, y);
@@ -323,11 +359,10 @@ __device__ __forceinline__ bool edge_crosses_level_curve(V2 a0, V2 a1, float ha,
     const float inner = c1 * c1 - 4 * c0 * c2;
     if (inner > 0.f) {
         const float root = __builtin_sqrtf(inner);
-        const float x0 = 0.5f * (-c1 + root) / c0;
-        const float x1 = 0.5f * (-c1 - root) / c0;
-        const float y0 = k * x0 + m, y1 = k * x1 + m;
-        const bool i0 = in_unit_square(x0, y0) && ON_EDGE(x0, y0);
-        const bool i1 = in_unit_square(x1, y1) && ON_EDGE(x1, y1);
+        const float n0 = 0.5f * (-c1 + root), n1 = 0.5f * (-c1 - root);
+        bool i0 = false, i1 = false;
+        if (!root_rejected(rf, n0, c0)) { const float x0 = n0 / c0, y0 = k * x0 + m; i0 = in_unit_square(x0, y0) && ON_EDGE(x0, y0); }
+        if (!root_rejected(rf, n1, c0)) { const float x1 = n1 / c0, y1 = k * x1 + m; i1 = in_unit_square(x1, y1) && ON_EDGE(x1, y1); }
         return i0 || i1;
     }
     return false;
@@ -639,6 +674,9 @@ __device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const 
     // one texel, which is also the centre-vote cell (NaN / overflowed coordinates fail these integer tests: INT_MIN arithmetic)
     if (!(maxx - minx == 1 && maxy - miny == 1 && ix == minx && iy == miny && minx != (int)0x80000000 && miny != (int)0x80000000)) return -1;
 
+#ifdef OMMX_DEBUG_ELIG_ONLY   // timing attribution only (never shipped)
+    if (minx != 123456789) return 3;
+#endif
     float g00, g01, g11, g10;
     fetch_cell<FP32, MD>(P, m, MD::pow2(P), minx, miny, W, g00, g01, g11, g10);
     // (TextureImpl::Bilinear addresses with the per-mip pow2 flag, the level-line kernel with the dispatch flag = mip 0's: the same here)
@@ -658,10 +696,14 @@ __device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const 
         const float pfx = sx + 0.5f, pfy = sy + 0.5f;
         const float ipx = pfx * m.rw, ipy = pfy * m.rh;
         const bool o0 = P.cutoff < g00, o1 = P.cutoff < g01, o2 = P.cutoff < g11, o3 = P.cutoff < g10;
+#ifdef OMMX_DEBUG_NO_CORNERS   // timing attribution only (never shipped)
+        const bool in0 = ipx == 12345.f, in1 = in0, in2 = in0, in3 = in0;
+#else
         const bool in0 = point_in_triangle(t, ipx, ipy);
         const bool in1 = point_in_triangle(t, ipx + 0.0f, ipy + m.rh);
         const bool in2 = point_in_triangle(t, ipx + m.rw, ipy + m.rh);
         const bool in3 = point_in_triangle(t, ipx + m.rw, ipy + 0.0f);
+#endif
         const bool isO = (in0 && o0) || (in1 && o1) || (in2 && o2) || (in3 && o3);
         const bool isT = (in0 && !o0) || (in1 && !o1) || (in2 && !o2) || (in3 && !o3);
         if (isO) above += 1;
@@ -669,7 +711,11 @@ __device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const 
         if (!(isO && isT)) {
             const float sa = g00, sb = g10 - g00, sc = g01 - g00, sd = g00 + g11 - g01 - g10;
             if (near_zero(sb, 1e-6f) && near_zero(sc, 1e-6f) && near_zero(sd, 1e-6f)) vote(P.cutoff < sa, above, below);
+#ifdef OMMX_DEBUG_NO_EDGES_FAST   // timing attribution only (never shipped)
+            else if (sa == 12345.f) {
+#else
             else {
+#endif
                 const float ha = sa - P.cutoff;
                 const V2 r0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy);
                 const V2 r1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy);

@@ -1,5 +1,6 @@
-"""Audit of the one place where the HIP kernel does NOT evaluate the reference's expression for every input: point_on_edge() in
-omm_amd/csrc/classify_device.h discards points that a sqrt-free bound proves to be off the segment.
+"""Audit of the two places where the HIP kernel does NOT evaluate the reference's expression for every input: point_on_edge() in
+omm_amd/csrc/classify_device.h discards points that a sqrt-free bound proves to be off the segment, and root_rejected()
+skips the division of a level-curve root that provably cannot be accepted (section 5.3b).
 The audit build of the oracle evaluates the reference expression AND the bound for every call and counts disagreements."""
 import ctypes as C
 import os
@@ -47,3 +48,7 @@ def test_bound_never_discards_a_point_the_reference_accepts(audit):
     assert calls > 1000000 and discarded > calls // 2
     assert bad == 0
     assert audit.dll.orc_audit_min_discarded() > 1e-4        # the reference's threshold is 1e-5: >= 10x margin observed
+    # the root filter (classify_device.h root_rejected): decided from the operands of the division, before the division
+    roots, rejected, bad_roots = (audit.dll.orc_audit_counter(i) for i in (4, 5, 6))
+    assert roots > 1000000 and rejected > 1000000   # (large micro-triangles, M > 2, are not filtered: most of this sweep)
+    assert bad_roots == 0
