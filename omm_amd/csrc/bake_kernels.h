@@ -8,8 +8,11 @@ namespace ommx {
 
 struct SetupCounters;
 
-// classification of one level group (items listed in itemIds, all at `level`)
-void launch_classify(const ClassifyParams& P, const ItemArrays& A, const uint32_t* itemIds, uint32_t numItems, uint32_t level, hipStream_t stream);
+// classification of the active items of ALL levels: level l = activeIds[first[l] .. first[l] + count[l]).  Items of level >= 5 are cut into
+// tiles; `queue` holds classify_queue_records(count) 16-byte tile records, `queueCtl` 4 words (zeroed here).  numCUs sizes the persistent grid.
+uint64_t classify_queue_records(const uint32_t count[kNumLevels]);
+hipError_t launch_classify(const ClassifyParams& P, const ItemArrays& A, const uint32_t* activeIds, const uint32_t first[kNumLevels], const uint32_t count[kNumLevels],
+                           void* queue, uint32_t* queueCtl, uint32_t numCUs, hipStream_t stream);
 // level-0 hierarchical query per work item: uniform items get stateMask = 1 << state and active = 0
 void launch_triage(const ClassifyParams& P, const float* uv, const SetupCounters* counters, uint32_t maxItems, uint32_t* stateMask, uint8_t* active, hipStream_t stream);
 // XXH64(seed 42) of the 3-state byte stream of each listed item -> digests[item]

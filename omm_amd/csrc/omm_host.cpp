@@ -396,6 +396,15 @@ bool is_pow2(int x) { return x > 0 && !(x & (x - 1)); }
 
 #define HIP_OK(call) ((call) == hipSuccess)
 
+uint32_t device_cu_count() // of the current device; sizes the persistent classification grid
+{
+    static std::mutex mu; static int cached[64]; static bool have[64];
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    std::lock_guard<std::mutex> g(mu);
+    if (!have[dev]) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; cached[dev] = n; have[dev] = true; }
+    return (uint32_t)cached[dev];
+}
+
 // Device-resident result of a bake (what ommxBakeDevice hands out, and what ommCpuBake copies to the host).
 struct DeviceResult {
     uint8_t* arrayData = nullptr; uint64_t arrayDataSize = 0;
@@ -600,18 +609,29 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             L.msg(ommMessageSeverity_PerfWarning, buf);
         }
     }
-    if (!statesArena->reserve(hc.stateBytes ? (size_t)hc.stateBytes : 256)) return L.failure("[Failure] - out of device memory for the packed micro-triangle states");
+    // rank ranges of the per-level active lists (single GPU: every range is the whole level group)
+    ShardBounds bounds; memset(&bounds, 0, sizeof bounds);
+    bounds.rank = sh ? sh->rank : 0; bounds.world = sh ? sh->world : 1;
+    uint32_t lvlFirst[kNumLevels], lvlCount[kNumLevels];
+    for (int l = 0; l < kNumLevels; ++l) {
+        const uint64_t a = hc.activeStart[l], cnt = hc.activeStart[l + 1] - hc.activeStart[l];
+        for (uint32_t r = 0; r <= bounds.world; ++r) bounds.b[l][r] = (uint32_t)(a + cnt * r / bounds.world);
+        lvlFirst[l] = bounds.b[l][bounds.rank]; lvlCount[l] = bounds.b[l][bounds.rank + 1] - bounds.b[l][bounds.rank];
+    }
+    // packed states of the active items + the queue of open tiles (16-byte records, bake_kernels.hip) + its 4 control words
+    const size_t stateBytes = pad256(hc.stateBytes ? (size_t)hc.stateBytes : 256), queueBytes = pad256((size_t)classify_queue_records(lvlCount) * 16 + 16);
+    if (!statesArena->reserve(stateBytes + queueBytes + 256)) return L.failure("[Failure] - out of device memory for the packed micro-triangle states");
     uint8_t* dStates = statesArena->base;
+    void* dTileQueue = statesArena->base + stateBytes; uint32_t* dQueueCtl = (uint32_t*)(statesArena->base + stateBytes + queueBytes);
     const int e1b = et.mark();
 
     // ---- ResampleCoarse + ResampleFine (bake_cpu_impl.cpp:715-1029) on the active items ----
     ItemArrays A; A.uv = dUv; A.degenerate = dDegen; A.stateOfs = dStateOfs; A.states = dStates; A.stateMask = dMask; A.knownCount = dKnown; A.fineCount = dFine;
     if (!HIP_OK(hipMemsetAsync(dFine, 0, sizeof(unsigned long long) * kFineSlots * kFineStride, stream))) return L.failure("[Failure] - device memset failed");
     if (sh && sh->world > 1) { // even out the per-rank cost: interleave every level's active list (tail_kernels.hip: shard_interleave)
-        const uint32_t numActiveAll = hc.activeStart[kNumLevels];
-        uint32_t* tmp = nullptr;
-        if (numActiveAll && !HIP_OK(hipMalloc((void**)&tmp, (size_t)numActiveAll * 4))) return L.failure("[Failure] - out of device memory for the shard permutation");
-        bool okp = true;
+        // the permuted copy goes through the (idle) setup / tail scratch block: no allocation, no synchronisation, stream ordered
+        uint32_t* tmp = (uint32_t*)dScratch;
+        bool okp = (size_t)hc.activeStart[kNumLevels] * 4 <= scratchBytes;
         for (int l = 0; l < kNumLevels && okp; ++l) {
             const uint32_t a = hc.activeStart[l], cnt = hc.activeStart[l + 1] - hc.activeStart[l];
             if (cnt < 3) continue;
@@ -621,19 +641,9 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             launch_shard_interleave(dActiveIds + a, tmp + a, cnt, stride % cnt, stream);
             okp = HIP_OK(hipMemcpyAsync(dActiveIds + a, tmp + a, (size_t)cnt * 4, hipMemcpyDeviceToDevice, stream));
         }
-        okp = okp && HIP_OK(hipStreamSynchronize(stream));
-        if (tmp) (void)hipFree(tmp);
         if (!okp) return L.failure("[Failure] - shard permutation failed");
     }
-    // single GPU: every rank range is the whole level group
-    ShardBounds bounds; memset(&bounds, 0, sizeof bounds);
-    bounds.rank = sh ? sh->rank : 0; bounds.world = sh ? sh->world : 1;
-    for (int l = 0; l < kNumLevels; ++l) {
-        const uint64_t a = hc.activeStart[l], cnt = hc.activeStart[l + 1] - hc.activeStart[l];
-        for (uint32_t r = 0; r <= bounds.world; ++r) bounds.b[l][r] = (uint32_t)(a + cnt * r / bounds.world);
-    }
-    for (int l = 0; l < kNumLevels; ++l)
-        launch_classify(P, A, dActiveIds + bounds.b[l][bounds.rank], bounds.b[l][bounds.rank + 1] - bounds.b[l][bounds.rank], (uint32_t)l, stream);
+    if (!HIP_OK(launch_classify(P, A, dActiveIds, lvlFirst, lvlCount, dTileQueue, dQueueCtl, device_cu_count(), stream))) return L.failure("[Failure] - kernel launch failed");
     const int e2 = et.mark();
     if (ht) { // bring the per-micro-triangle states to the host for the serial tail (host_tail.cpp)
         // the serial reducers work on one byte per micro-triangle of EVERY work item, like the reference (bake_cpu_impl.cpp:401-411):
@@ -747,7 +757,12 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     }
 #endif
     tm.fineMicroTriangles = fineCount; tm.uniqueItems = U; tm.activeItems = hc.activeStart[kNumLevels]; tm.stateBytes = hc.stateBytes; tm.microTriangles = 0;
-    for (int l = 0; l < kNumLevels; ++l) { tm.microTriangles += (uint64_t)hc.levelCount[l] << (2 * l); tm.classifyLaunches += hc.activeStart[l + 1] != hc.activeStart[l]; }
+    for (int l = 0; l < kNumLevels; ++l) tm.microTriangles += (uint64_t)hc.levelCount[l] << (2 * l);
+    {   // classify_tiles launches: one per level below 5, one for level 5, ONE for all levels >= 6 (bake_kernels.hip)
+        bool big = false;
+        for (int l = 0; l < kNumLevels; ++l) { const bool any = hc.activeStart[l + 1] != hc.activeStart[l]; if (l < 6) tm.classifyLaunches += any; else big = big || any; }
+        tm.classifyLaunches += big;
+    }
     return ommResult_SUCCESS;
 }
 
