@@ -47,6 +47,11 @@ __device__ __forceinline__ float item_max_abs(const float* __restrict__ uv)
     return m;
 }
 
+// Block-uniform values that arrive through vector loads / LDS (the tile record, the item's UVs) are moved to scalar registers: the
+// classification loops are VGPR-bound (72 VGPRs = 7 waves per SIMD), and a uniform value parked in a VGPR costs 64 lanes of it.
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ float uniform_f32(float v) { return __uint_as_float(uniform_u32(__float_as_uint(v))); }
+
 __device__ __forceinline__ TexWindow no_window()
 {
     TexWindow W; W.tex = (lds_float*)0; W.sat = (lds_u32*)0; W.base = nullptr; W.sx = W.sy = 0; W.w = W.h = 0;
@@ -173,7 +178,8 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     __shared__ uint16_t s_queue[TILE];
     __shared__ int      s_group[TILE / GROUP];
     __shared__ uint16_t s_glist[TILE / GROUP];   // sliced tiles: the groups that are not settled, compacted (phase 1 walks only these)
-    __shared__ uint32_t s_gcount;
+    __shared__ uint16_t s_olist[TILE / GROUP];   // ... and those of them that are all-open (taken as whole waves by the single-texel pass)
+    __shared__ uint32_t s_gcount, s_ocount;
     __shared__ uint32_t s_qcount;
     __shared__ uint32_t s_mask, s_known;
     __shared__ uint32_t s_pending, s_fine;       // single-texel pass: micro-triangles left for the generic pass / level-line statistic
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         qtotal = *queueCount;
         if (tid == 0) s_next = atomicAdd(queueHead, 1u);
         __syncthreads();
-        qpos = s_next;
+        qpos = uniform_u32(s_next);
     }
   for (;;) {
     uint32_t level = levelArg, tile = 0;
@@ -198,6 +204,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     if (SLICED) {
         if (qpos >= qtotal) return;
         rec = tileQueue[qpos];
+        rec.x = uniform_u32(rec.x); rec.y = uniform_u32(rec.y); rec.z = uniform_u32(rec.z); rec.w = uniform_u32(rec.w);
         if (tid == 0) nextPos = atomicAdd(queueHead, 1u);   // consumed at the end of this tile
         level = rec.y >> 24;
         // a sliced tile implies 4^level >= TILE; without the hint clang hoists micro_triangle()'s level-0 branch (three loop-invariant
@@ -227,9 +234,9 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     if (SLICED) {
         uItem = rec.x & 0x7FFFFFFFu;
         #pragma unroll
-        for (int k = 0; k < 6; ++k) uUv[k] = A.uv[6ull * uItem + k];
-        uMaxAbs = item_max_abs(uUv);
-        uDegenerate = A.degenerate[uItem] != 0;
+        for (int k = 0; k < 6; ++k) uUv[k] = uniform_f32(A.uv[6ull * uItem + k]);
+        uMaxAbs = uniform_f32(item_max_abs(uUv));
+        uDegenerate = uniform_u32(A.degenerate[uItem]) != 0;
         {
             // ---- phase 0b: LDS window = every texel / SAT entry this tile can touch ----
             // (the tile's texel rectangle was computed by triage_tiles: region_rect of its sub-triangle)
@@ -257,11 +264,12 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                     const uint32_t g = tid - 64;
                     const int gs = region_state_ex<MD>(P, micro_triangle(uUv, (base >> 6) + g, level - 3), uMaxAbs, W);
                     s_group[g] = gs;
-                    const unsigned long long open = __ballot(gs < 0);
+                    const unsigned long long open = __ballot(gs < 0), allOpen = __ballot(gs == kRegionAllOpen);
                     if (gs < 0) s_glist[__popcll(open & ((1ull << g) - 1ull))] = (uint16_t)g;
-                    if (g == 0) s_gcount = (uint32_t)__popcll(open);
+                    if (gs == kRegionAllOpen) s_olist[__popcll(allOpen & ((1ull << g) - 1ull))] = (uint16_t)g;
+                    if (g == 0) { s_gcount = (uint32_t)__popcll(open); s_ocount = (uint32_t)__popcll(allOpen); }
                 }
-            } else if (tid < (uint32_t)(TILE / GROUP)) { s_group[tid] = -1; s_glist[tid] = (uint16_t)tid; if (tid == 0) s_gcount = (uint32_t)(TILE / GROUP); }
+            } else if (tid < (uint32_t)(TILE / GROUP)) { s_group[tid] = -1; s_glist[tid] = (uint16_t)tid; if (tid == 0) { s_gcount = (uint32_t)(TILE / GROUP); s_ocount = 0; } }
             __syncthreads();
         }
     } else {
@@ -368,28 +376,21 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         } else
 #endif
         if (fastFine && !uDegenerate) {
-            // ---- phase 2a: all-open groups, one wave per group, straight-line single-texel pass ----
+            // ---- phase 2a: straight-line single-texel pass.  Work units of 64 lanes: first the all-open groups (one wave = one group, no
+            //      queue entries), then the queued micro-triangles of the other open groups, 64 at a time ----
             uint32_t pend = 0;
-            const uint32_t gcount = s_gcount;
-            for (uint32_t k = tid >> 6; k < gcount; k += BLOCK / 64) {
-                const uint32_t g = s_glist[k];
-                if (s_group[g] != kRegionAllOpen) continue;   // (wave-uniform)
-                const uint32_t i = g * 64u + (tid & 63u);
-                const int st = fine_single_texel<FP32, MD>(P, micro_triangle(uUv, base + i, level), W);
-                s_state[i] = (uint8_t)(st < 0 ? 0xFF : st);
-                pend |= st < 0 ? 1u : 0u;
-                if ((tid & 63u) == 0) atomicAdd(&s_fine, 64u);
-            }
-            // ---- phase 2b: the queued micro-triangles of the other open groups, same pass ----
-            for (uint32_t q0 = 0; q0 < qn; q0 += BLOCK) {
-                const uint32_t q = q0 + tid;
-                if (q < qn) {
-                    const uint32_t i = s_queue[q];
+            const uint32_t gcount = s_gcount, ocount = s_ocount, units = ocount + ((qn + 63u) >> 6);
+            for (uint32_t k = tid >> 6; k < units; k += BLOCK / 64) {   // (k is wave-uniform)
+                uint32_t i; bool live = true;
+                if (k < ocount) i = (uint32_t)s_olist[k] * 64u + (tid & 63u);
+                else { const uint32_t q = (k - ocount) * 64u + (tid & 63u); live = q < qn; i = live ? (uint32_t)s_queue[q] : 0u; }
+                if (live) {
                     const int st = fine_single_texel<FP32, MD>(P, micro_triangle(uUv, base + i, level), W);
                     s_state[i] = (uint8_t)(st < 0 ? 0xFF : st);
                     pend |= st < 0 ? 1u : 0u;
                 }
             }
+            if (tid == 0 && ocount) s_fine = ocount * 64u;
             if (__any(pend != 0) && (tid & 63u) == 0) s_pending = 1u;
             __syncthreads();
             // ---- phase 2c: whatever did not fit the single-texel pattern (marked 0xFF) is compacted into the queue for the generic pass ----
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     __syncthreads();
     if (tid == 0) s_next = nextPos;
     __syncthreads();
-    qpos = s_next;
+    qpos = uniform_u32(s_next);
   }
 }
 

@@ -662,17 +662,24 @@ __device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const 
     const float ax = t.p2.x - t.p0.x, ay = t.p2.y - t.p0.y, bx = t.p1.x - t.p0.x, by = t.p1.y - t.p0.y;
     const float l32 = ax * by, r32 = bx * ay;
     bool ccw = l32 < r32;
-    if (!(l32 < r32) && !(r32 < l32)) ccw = ((double)ax * (double)by - (double)bx * (double)ay) < 0;   // equal or unordered in fp32: decide in fp64 like the reference
+    const bool tie = !(l32 < r32) && !(r32 < l32);   // equal or unordered in fp32: decide in fp64 like the reference
+    if (__any(tie)) {                                // (wave-uniform branch: the fp64 sequence is skipped by all but a few waves)
+        const bool ccw64 = ((double)ax * (double)by - (double)bx * (double)ay) < 0;
+        ccw = tie ? ccw64 : ccw;
+    }
     V2 a = mk2(q0x, q0y); const V2 b = mk2(q1x, q1y); V2 c = mk2(q2x, q2y);
     if (!ccw) { V2 s = a; a = c; c = s; }
     const float lox = std_min(std_min(a.x, b.x), c.x), loy = std_min(std_min(a.y, b.y), c.y);
     const float hix = std_max(std_max(a.x, b.x), c.x), hiy = std_max(std_max(a.y, b.y), c.y);
-    const int minx = cvt_trunc_x86(__builtin_floorf(lox)), miny = cvt_trunc_x86(__builtin_floorf(loy));
-    const int maxx = cvt_trunc_x86(__builtin_ceilf(hix)), maxy = cvt_trunc_x86(__builtin_ceilf(hiy));
+    // all six float -> int conversions below take values of [lo, hi]: with that box inside +-2^30 none of them can leave the int range, so the
+    // x86 "integer indefinite" rule of cvt_trunc_x86() cannot apply and the plain conversion gives the same integers (NaN fails the test)
+    const bool inRange = lox >= -1073741824.f && hix <= 1073741824.f && loy >= -1073741824.f && hiy <= 1073741824.f;
+    const int minx = (int)__builtin_floorf(lox), miny = (int)__builtin_floorf(loy);
+    const int maxx = (int)__builtin_ceilf(hix), maxy = (int)__builtin_ceilf(hiy);
     const float fx = __builtin_floorf(q0x), fy = __builtin_floorf(q0y);
-    const int ix = cvt_trunc_x86(fx), iy = cvt_trunc_x86(fy);
-    // one texel, which is also the centre-vote cell (NaN / overflowed coordinates fail these integer tests: INT_MIN arithmetic)
-    if (!(maxx - minx == 1 && maxy - miny == 1 && ix == minx && iy == miny && minx != (int)0x80000000 && miny != (int)0x80000000)) return -1;
+    const int ix = (int)fx, iy = (int)fy;
+    // one texel, which is also the centre-vote cell
+    if (!(inRange && maxx - minx == 1 && maxy - miny == 1 && ix == minx && iy == miny)) return -1;
 
 #ifdef OMMX_DEBUG_ELIG_ONLY   // timing attribution only (never shipped)
     if (minx != 123456789) return 3;
