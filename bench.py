@@ -31,6 +31,31 @@ class BakeTimings(C.Structure):
                 ("stateBytes", C.c_uint64), ("triageMs", C.c_float), ("activeItems", C.c_uint32), ("fineMicroTriangles", C.c_uint64), ("setupMs", C.c_float)]
 
 
+def source_hash():
+    """sha256 (16 hex digits) over omm_amd/csrc, the same recipe as profiles/summarize_pmc.py: ties a committed PMC summary to the sources"""
+    import hashlib
+    d = os.path.join(ROOT, "omm_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp", ".inc")) or f == "Makefile":
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def create_texture_ms(prod, baker, size, seed):
+    """ommCpuCreateTexture of a size x size UNORM8 texture with alphaCutoff (upload + summed-area table on the device), best of two;
+    the reference builds the same object serially on one host thread (texture_impl.cpp:77-224)"""
+    tex = ot.foliage_texture(seed, size, size, feature=64)
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        th = prod.create_texture(baker, [tex], alpha_cutoff=0.5)
+        dt = (time.perf_counter() - t0) * 1e3
+        prod.destroy_texture(baker, th)
+        best = dt if best is None else min(best, dt)
+    return best
+
+
 def make_workload(args):
     """Seeded synthetic inputs (identical on every rank and for the CPU baseline)."""
     tex = ot.foliage_texture(args.seed, args.tex, args.tex, feature=args.feature)
@@ -86,6 +111,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--host-api-steps", type=int, default=2, help="extra untimed-for-value bakes through ommCpuBake (host arrays)")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="triangles baked by the CPU baseline (0 = skip)")
+    ap.add_argument("--create-texture", type=int, default=1, help="time ommCpuCreateTexture at 4K and 8K (0 = skip)")
     ap.add_argument("--sat-off-sample", type=int, default=50000, help="triangles of the SAT-off (no coarse pass) GPU measurement; CPU uses 1/20 of it (0 = skip)")
     args = ap.parse_args()
 
@@ -208,6 +234,14 @@ def main():
                        "result": result_info, "unique_items": int(tms[-1].uniqueItems), "active_items": int(tms[-1].activeItems),
                        "fine_micro_triangles": int(tms[-1].fineMicroTriangles)},
             "bake_wall_time_ms": ms_per_step,
+            # `value` is measured on the device-resident entry point (inputs and result arrays in HBM, the bench contract); its peer below
+            # is the SDK call proper, host arrays in and out, i.e. the same bake plus one PCIe copy of the result
+            "value_entry": "ommxBakeDevice" if world == 1 else "ommxShardedBakeRccl",
+            "rates": {"all_work_items": micro_tris / (elapsed / args.steps),
+                      "active_items_only": float(tms[-1].activeItems) * 4.0 ** args.level / (classify_ms * 1e-3) if classify_ms > 0 else None,
+                      "fine_pass_only": float(tms[-1].fineMicroTriangles) / (classify_ms * 1e-3) if classify_ms > 0 else None,
+                      "note": "`value` counts 4^level micro-triangles for every unique work item like the reference's loop does; most items are settled by one summed-area-table "
+                              "query (hierarchical culling), so the rate over the items that reach classify_tiles and over the micro-triangles that reach the level-line pass are given too"},
             "host_api": None if host_ms is None else {"entry": "ommCpuBake (host arrays in/out, PCIe inclusive)", "ms_per_bake": host_ms, "first_call_ms": host_first_ms,
                                                        "uploadMs": host_tm.uploadMs, "downloadMs": host_tm.downloadMs,
                                                        "micro_triangles_per_s": micro_tris / (host_ms * 1e-3)},
@@ -218,17 +252,22 @@ def main():
                          "note": "classification is fp32-VALU/sqrt/div bound, not HBM bound (SURVEY.md section 8d)"},
         }
         # HBM bytes per launch from the PMC counters cannot be read from inside this process: they come from the separate
-        # rocprofv3 --pmc passes of profiles/collect.sh (FETCH_SIZE x2 on gfx950, WRITE_SIZE x1), committed under profiles/,
-        # and apply only to the workload they were collected on.
+        # rocprofv3 --pmc passes of profiles/collect.sh (FETCH_SIZE x2 on gfx950, WRITE_SIZE x1), committed under profiles/, and
+        # apply only to the workload AND the library sources they were collected on: the summary carries a hash of omm_amd/csrc,
+        # and a summary older than the sources is not printed.
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
         default_workload = (args.tris, args.level, args.tex, args.feature, args.extent_texels, args.seed) == (1000000, 8, 4096, 64, 8.0, 1234)
         if world == 1 and default_workload and os.path.exists(tpath):
             tj = json.load(open(tpath))
-            line["roofline"]["traffic"] = tj.get("traffic_bytes_per_launch")
-            line["roofline"]["traffic_source"] = "profiles/hbm_traffic_latest.json (%s; %s)" % (tj.get("command"), tj.get("corrections"))
-            if tj.get("valu_busy") is not None:
-                line["roofline"]["valu_issue_utilisation"] = tj["valu_busy"]
-                line["roofline"]["valu_lane_utilisation"] = tj.get("valu_lane_util")
+            if tj.get("source_sha256_16") == source_hash():
+                line["roofline"]["traffic"] = tj.get("traffic_bytes_per_launch")
+                line["roofline"]["traffic_source"] = "profiles/%s_pmc.md (separate rocprofv3 --pmc passes of `%s`; %s; sources %s)" % (
+                    tj.get("tag"), tj.get("command"), tj.get("corrections"), tj.get("source_sha256_16"))
+                # issue-slot view of the same profile (profiles/summarize_pmc.py: SQ instruction classes x measured cycles per class)
+                line["roofline"]["issue"] = {"valu_issue_utilisation": tj.get("valu_issue_utilisation"), "scalar_issue_utilisation": tj.get("scalar_issue_utilisation"),
+                                             "valu_lane_utilisation": tj.get("valu_lane_util"), "valu_instr_per_cycle_per_simd": tj.get("valu_instr_per_cycle_per_simd")}
+            else:
+                line["roofline"]["traffic_source"] = "none: profiles/hbm_traffic_latest.json was collected on other sources (%s, tree is %s)" % (tj.get("source_sha256_16"), source_hash())
         # the streaming part of the path for comparison: final gather of the surviving OMM blocks into arrayData order
         # (read + write of arrayData, HIP events around gather + index narrowing)
         gather_ms = avg("gatherMs")
@@ -236,6 +275,9 @@ def main():
             gb = 2.0 * result_info["arrayDataBytes"] + 8.0 * result_info["descs"] + 8.0 * result_info["triangles"]
             line["roofline_streaming"] = {"bound": "hbm", "kernel": "tail_gather_omms (+ narrow_indices)", "achieved": gb / (gather_ms * 1e-3) / 1e9,
                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / (gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if world == 1 and args.create_texture:
+            line["create_texture_ms"] = {"entry": "ommCpuCreateTexture, UNORM8 + alphaCutoff (H2D + device summed-area table)", "4096": create_texture_ms(prod, baker, 4096, args.seed),
+                                         "8192": create_texture_ms(prod, baker, 8192, args.seed)}
         if args.cpu_sample > 0 and world == 1:
             cb, cpu_res = cpu_baseline(args, tex, uv, ix)
             line["cpu_baseline"] = cb

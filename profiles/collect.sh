@@ -1,19 +1,25 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): kernel-trace stats of the default bench command, then PMC passes (kernel-trace only, one counter
-# group per pass), all under gpurun_out/.  usage: bash profiles/collect.sh <tag>
+# Runs on the GPU box (via gpurun): the default bench, kernel-trace stats of the same command, then PMC passes (kernel-trace only, one
+# counter group per pass: HBM bytes, instruction classes, issue / wait cycles), all under gpurun_out/<tag>/.
+# usage: bash profiles/collect.sh <tag>      e.g.  gpurun -- 'bash profiles/collect.sh r02_v1'; then copy gpurun_out/<tag>/*.md|json -> profiles/
 tag=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd /tmp; export TMPDIR=/tmp
 O=$R/gpurun_out/$tag; mkdir -p $O
 BENCH="python $R/bench.py"
+[ -x $R/profiles/bin/valu_rates ] && $R/profiles/bin/valu_rates > $O/valu_rates.json 2> $O/valu_rates.err
 timeout 900 $BENCH > $O/bench.json 2> $O/bench.err
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- $BENCH > $O/trace.log 2>&1
-PM="--steps 2 --warmup 1 --cpu-sample 0 --host-api-steps 0"
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o pmc -- $BENCH $PM > $O/pmc_$c.log 2>&1
-done
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_SQ -o pmc -- $BENCH $PM > $O/pmc_SQ.log 2>&1
+# (the trace run skips the bench's small side bakes -- CPU-baseline parity samples, SAT-off sample -- so that every classify_tiles launch in the
+#  stats table is the full workload and its average is comparable with roofline.avg_launch_ms)
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- $BENCH --cpu-sample 0 --sat-off-sample 0 > $O/trace.log 2>&1
+PM="--steps 2 --warmup 1 --cpu-sample 0 --host-api-steps 0 --sat-off-sample 0"
+pass() { n=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$n -o pmc -- $BENCH $PM > $O/pmc_$n.log 2>&1; }
+pass FETCH_SIZE FETCH_SIZE
+pass WRITE_SIZE WRITE_SIZE
+pass C1 SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64
+pass C2 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
+pass C3 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT
+pass C4 SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_INSTS_VSKIPPED GRBM_GUI_ACTIVE
 cd $R
 python profiles/summarize_rocprof.py $(find $O/trace -name "*.db" | head -1) > $O/kernel_stats.md 2> $O/kernel_stats.err
 python profiles/summarize_pmc.py $tag $O "python bench.py $PM" > $O/pmc_summary.json 2> $O/pmc_summary.err
-cp profiles/${tag}_pmc.md profiles/${tag}_hbm_traffic.json $O/ 2>/dev/null   # gpurun merges only gpurun_out/: copy these four into profiles/ afterwards
-tail -c 600 $O/bench.json; echo; cat $O/pmc_summary.json; head -12 $O/kernel_stats.md
+tail -c 700 $O/bench.json; echo; cat $O/pmc_summary.json; head -14 $O/kernel_stats.md

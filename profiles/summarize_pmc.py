@@ -1,19 +1,32 @@
 #!/usr/bin/env python3
-"""Turns rocprofv3 `--pmc ... --output-format csv` runs of bench.py into (a) a per-kernel HBM traffic table and
-(b) profiles/<tag>_hbm_traffic.json, which bench.py reads to fill roofline.traffic for the matching workload.
+"""Turns the rocprofv3 `--pmc ... --output-format csv` passes of profiles/collect.sh into
+  <dir>/<tag>_pmc.md           per-kernel HBM traffic table + instruction-class / issue-cycle breakdown of classify_tiles
+  <dir>/<tag>_hbm_traffic.json the figures bench.py reports as roofline.traffic (stamped with the library they were measured on)
 
-usage: python profiles/summarize_pmc.py <tag> <dir with pmc_FETCH_SIZE/ pmc_WRITE_SIZE/ [pmc_SQ/]> "<bench command line>"
+usage: python profiles/summarize_pmc.py <tag> <dir with pmc_*/ passes> "<bench command line>"
+The two outputs are then copied into profiles/ (tracked) by hand: gpurun merges only gpurun_out/.
 
 Units and corrections (MI355X_MICROARCH.md, HBM section; calibrated here on kernels with a known byte count, sat_rows and
 sat_cols of the 4096^2 texture): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports HALF the bytes read
 (sat_rows reads 16.8 MB -> 8207.75 KiB reported; sat_cols reads 67.1 MB -> 32778 KiB) and is doubled below; WRITE_SIZE is
-exact (sat_rows writes 67.1 MB -> 65536 KiB) and is used as is.  The two counters are collected in separate passes."""
+exact (sat_rows writes 67.1 MB -> 65536 KiB) and is used as is.  Every counter group is collected in its own pass.
+
+Issue-cycle model: a wave64 VALU instruction occupies its SIMD for the number of cycles measured by profiles/valu_rates.hip on the same
+chip (profiles/valu_rates_mi355x.json: plain fp32 / int / mov ~2.5, conversions / shifts / v_pk_* / fp64 ~4.5, transcendentals ~8.2);
+instructions the SQ counters do not classify (moves, compares, selects, bit logic, lane moves) are priced as plain ones.  The scalar unit
+is shared by the 4 SIMDs of a CU and issues one SALU or branch instruction per cycle (measured: 4.2 SIMD-cycles per instruction with all
+four SIMDs issuing)."""
 import collections
 import csv
+import hashlib
 import json
 import os
 import re
 import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CLOCK_HZ = 2.4e9
+NUM_CU, SIMD_PER_CU = 256, 4
 
 
 def short(name):
@@ -26,18 +39,46 @@ def short(name):
 
 
 def load(path):
+    """per short kernel name: counter -> [launches, sum]; and the kernel durations of that pass"""
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     dur = collections.defaultdict(lambda: [0, 0.0])
     seen = set()
+    if not os.path.exists(path):
+        return agg, dur
     for r in csv.DictReader(open(path)):
         k = short(r["Kernel_Name"])
         a = agg[k][r["Counter_Name"]]
         a[0] += 1; a[1] += float(r["Counter_Value"])
-        key = (r["Dispatch_Id"],)
-        if key not in seen:
-            seen.add(key)
+        if r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"])
             dur[k][0] += 1; dur[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
     return agg, dur
+
+
+def lib_stamp():
+    """sha256 (16 hex digits) over the library's sources: bench.py prints roofline.traffic only while this still matches the tree"""
+    d = os.path.join(os.path.dirname(HERE), "omm_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp", ".inc")) or f == "Makefile":
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def rates():
+    """cycles per wave-instruction per SIMD by class, from the committed microbenchmark (defaults = its round-2 numbers)"""
+    r = {"plain": 2.5, "half": 4.5, "trans": 8.2, "salu_per_cu": 1.05}
+    p = os.path.join(HERE, "valu_rates_mi355x.json")
+    if os.path.exists(p):
+        c = {x["op"]: x["cycles_per_wave_instr_per_simd_at_2.4GHz"] for x in json.load(open(p))["cases"]}
+        plain = [c[k] for k in ("v_mul_f32", "v_add_f32", "v_fma_f32", "v_mov_b32", "v_and_b32", "v_add_u32") if k in c]
+        half = [c[k] for k in ("v_cvt_i32_f32", "v_floor_f32", "v_lshlrev_b32", "v_mul_lo_u32", "v_mul_f64", "v_add_f64", "v_div_fixup_f32") if k in c]
+        trans = [c[k] for k in ("v_sqrt_f32", "v_rcp_f32", "v_rsq_f32") if k in c]
+        if plain: r["plain"] = sum(plain) / len(plain)
+        if half: r["half"] = sum(half) / len(half)
+        if trans: r["trans"] = sum(trans) / len(trans)
+        if "s_add_u32/s_xor_b32" in c: r["salu_per_cu"] = c["s_add_u32/s_xor_b32"] / SIMD_PER_CU
+    return r
 
 
 def main():
@@ -56,31 +97,61 @@ def main():
            "| kernel | launches | read MB / launch | written MB / launch |", "|---|---|---|---|"]
     for k, n, rd, wr in rows[:24]:
         out.append("| `%s` | %d | %.2f | %.2f |" % (k, n, rd / 1e6, wr / 1e6))
-    sq_path = os.path.join(root, "pmc_SQ", "pmc_counter_collection.csv")
+
+    # ---- instruction classes and issue cycles of the classification kernel ----
+    c, dur_ms = {}, None
+    for p in ("C1", "C2", "C3", "C4", "SQ"):
+        agg, dur = load(os.path.join(root, "pmc_" + p, "pmc_counter_collection.csv"))
+        for n, v in agg.get("ommx::classify_tiles", {}).items():
+            c[n] = v[1] / max(1, v[0])
+        d = dur.get("ommx::classify_tiles")
+        if d and d[0] and dur_ms is None:
+            dur_ms = d[1] / d[0]
     summary = {}
-    if os.path.exists(sq_path):
-        sq, _ = load(sq_path)
-        c = {n: v[1] / max(1, v[0]) for n, v in sq.get("ommx::classify_tiles", {}).items()}
-        if c:
-            out += ["", "## `classify_tiles` SQ counters (per launch)", "", "| counter | value |", "|---|---|"]
-            out += ["| %s | %.4g |" % (n, v) for n, v in sorted(c.items())]
-            if "GRBM_GUI_ACTIVE" in c and "SQ_ACTIVE_INST_VALU" in c:
-                # GRBM_GUI_ACTIVE sums the 8 XCDs; SQ_ACTIVE_INST_* count quad-cycles (one wave64 VALU instruction = 1) over 1024 SIMDs
-                cap = 1024.0 * (c["GRBM_GUI_ACTIVE"] / 8.0) / 4.0
-                summary["valu_busy"] = c["SQ_ACTIVE_INST_VALU"] / cap
-                out += ["", "VALU issue utilisation = SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE/8 / 4) = **%.2f**" % summary["valu_busy"]]
-            if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
-                summary["valu_lane_util"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
-                out += ["", "VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) = **%.2f**" % summary["valu_lane_util"]]
-            if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
-                out += ["", "SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.2f" % (c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"])]
-    open(os.path.join(os.path.dirname(os.path.abspath(__file__)), tag + "_pmc.md"), "w").write("\n".join(out) + "\n")
+    if c:
+        R = rates()
+        cyc = (c["GRBM_GUI_ACTIVE"] / 8.0) if "GRBM_GUI_ACTIVE" in c else (dur_ms or 0) * 1e-3 * CLOCK_HZ   # shader cycles of one launch (GRBM sums the 8 XCDs)
+        simd_cycles, cu_cycles = cyc * NUM_CU * SIMD_PER_CU, cyc * NUM_CU
+        out += ["", "## `classify_tiles`: instructions per launch by class (SQ_INSTS_*, wave-instructions) and the SIMD cycles they occupy", "",
+                "kernel duration in the counter passes: %s ms; shader cycles per launch %.4g (GRBM_GUI_ACTIVE / 8 XCDs)" % ("%.2f" % dur_ms if dur_ms else "?", cyc), "",
+                "| class | counter | wave-instructions | cycles each (profiles/valu_rates_mi355x.json) | share of the VALU pipe (1024 SIMDs x cycles) |", "|---|---|---|---|---|"]
+        valu = c.get("SQ_INSTS_VALU", 0.0)
+        classes = [("fp32 add", "SQ_INSTS_VALU_ADD_F32", "plain"), ("fp32 mul", "SQ_INSTS_VALU_MUL_F32", "plain"), ("fp32 fma (IEEE div / sqrt expansions)", "SQ_INSTS_VALU_FMA_F32", "plain"),
+                   ("fp32 transcendental (v_rcp / v_sqrt / v_rsq)", "SQ_INSTS_VALU_TRANS_F32", "trans"), ("conversions", "SQ_INSTS_VALU_CVT", "half"),
+                   ("int32 arithmetic", "SQ_INSTS_VALU_INT32", "plain"), ("int64 arithmetic", "SQ_INSTS_VALU_INT64", "half"),
+                   ("fp64 (winding test)", None, "half")]
+        known, busy = 0.0, 0.0
+        for label, ctr, rate in classes:
+            n = c.get(ctr, 0.0) if ctr else sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"))
+            known += n; busy += n * R[rate]
+            out.append("| %s | %s | %.4g | %.1f | %.3f |" % (label, ctr or "SQ_INSTS_VALU_{ADD,MUL,FMA}_F64", n, R[rate], n * R[rate] / simd_cycles if simd_cycles else 0))
+        other = max(0.0, valu - known)
+        busy += other * R["plain"]
+        out.append("| moves, compares, selects, bit logic, lane moves (not classified by the SQ) | SQ_INSTS_VALU - sum of the above | %.4g | %.1f | %.3f |" % (other, R["plain"], other * R["plain"] / simd_cycles if simd_cycles else 0))
+        out.append("| **all VALU** | SQ_INSTS_VALU | %.4g | | **%.3f** |" % (valu, busy / simd_cycles if simd_cycles else 0))
+        scal = c.get("SQ_INSTS_SALU", 0.0) + c.get("SQ_INSTS_BRANCH", 0.0)
+        out += ["", "| other units | counter | wave-instructions | per VALU instruction |", "|---|---|---|---|"]
+        for label, ctr in (("scalar ALU", "SQ_INSTS_SALU"), ("branches", "SQ_INSTS_BRANCH"), ("scalar memory", "SQ_INSTS_SMEM"), ("LDS", "SQ_INSTS_LDS"),
+                           ("vector memory reads", "SQ_INSTS_VMEM_RD"), ("vector memory writes", "SQ_INSTS_VMEM_WR")):
+            if ctr in c:
+                out.append("| %s | %s | %.4g | %.3f |" % (label, ctr, c[ctr], c[ctr] / valu if valu else 0))
+        summary["valu_issue_utilisation"] = busy / simd_cycles if simd_cycles else None
+        summary["valu_instr_per_cycle_per_simd"] = valu / simd_cycles if simd_cycles else None
+        summary["scalar_issue_utilisation"] = scal * R["salu_per_cu"] / cu_cycles if cu_cycles else None
+        out += ["", "VALU issue utilisation (modelled: sum of class count x measured cycles / (1024 SIMDs x kernel cycles)) = **%.2f**; raw: %.3f VALU wave-instructions per cycle per SIMD" % (summary["valu_issue_utilisation"], summary["valu_instr_per_cycle_per_simd"]),
+                "", "Scalar-unit issue utilisation ((SALU + branch) x %.2f cycles / (256 CUs x kernel cycles), one scalar unit per CU) = **%.2f**" % (R["salu_per_cu"], summary["scalar_issue_utilisation"])]
+        if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
+            summary["valu_lane_util"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+            out += ["", "VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) = **%.2f**" % summary["valu_lane_util"]]
+        if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
+            out += ["", "SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.2f" % (c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"])]
+        out += ["", "raw counters: " + ", ".join("%s=%.4g" % kv for kv in sorted(c.items()))]
+    open(os.path.join(root, tag + "_pmc.md"), "w").write("\n".join(out) + "\n")
     ck = [r for r in rows if r[0] == "ommx::classify_tiles"]
-    js = {"command": cmd, "kernel": "classify_tiles", "read_bytes_per_launch": ck[0][2] if ck else None, "written_bytes_per_launch": ck[0][3] if ck else None,
+    js = {"tag": tag, "command": cmd, "kernel": "classify_tiles", "source_sha256_16": lib_stamp(),
+          "read_bytes_per_launch": ck[0][2] if ck else None, "written_bytes_per_launch": ck[0][3] if ck else None,
           "traffic_bytes_per_launch": (ck[0][2] + ck[0][3]) if ck else None, "corrections": "FETCH_SIZE KiB x2 (gfx950), WRITE_SIZE KiB x1", **summary}
-    here = os.path.dirname(os.path.abspath(__file__))
-    json.dump(js, open(os.path.join(here, tag + "_hbm_traffic.json"), "w"), indent=1)
-    json.dump(js, open(os.path.join(here, "hbm_traffic_latest.json"), "w"), indent=1)   # the one bench.py reads
+    json.dump(js, open(os.path.join(root, tag + "_hbm_traffic.json"), "w"), indent=1)
     print(json.dumps(js))
 
 

@@ -3,9 +3,11 @@
 // The bake's dominant kernel is bound by VALU issue, not by HBM (DESIGN.md "Roofline statement").  To turn the SQ instruction
 // counters of a profile into "where the cycles go" one needs the cost of one wave64 instruction of every class on a gfx950 SIMD.
 // This tool measures it: every kernel runs ITER x 8 copies of ONE instruction (inline asm, 8 independent register chains) on
-// every SIMD of the chip with W waves per SIMD, and reports SIMD cycles per wave-instruction = s_memtime ticks / (ITER * 8 * W).
+// every SIMD of the chip, once with 4 and once with 8 waves per SIMD; the time difference is four more waves' worth of instructions per
+// SIMD (launch overhead and single-wave issue latency cancel), reported as SIMD cycles per wave64 instruction at the 2.4 GHz peak clock.
 //
-//   hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_rates profiles/valu_rates.hip && /tmp/valu_rates > gpurun_out/valu_rates.json
+//   hipcc --offload-arch=gfx950 -O2 -o profiles/bin/valu_rates profiles/valu_rates.hip     (cross-compiles without a GPU)
+//   profiles/bin/valu_rates > gpurun_out/valu_rates.json                                   (on the GPU box; committed as profiles/valu_rates_mi355x.json)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
@@ -15,7 +17,7 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-constexpr int ITER = 2048;
+constexpr int ITER = 16384;
 
 #define REP8(S0, S1, S2, S3, S4, S5, S6, S7) S0 "\n" S1 "\n" S2 "\n" S3 "\n" S4 "\n" S5 "\n" S6 "\n" S7 "\n"
 
@@ -194,10 +196,14 @@ int main()
     };
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
-    printf("{\"device\": \"%s\", \"cus\": %d, \"iter\": %d, \"unit\": \"SIMD cycles (s_memtime ticks) per wave64 instruction = ticks / (instructions issued by one wave x waves per SIMD)\", \"cases\": [\n", prop.gcnArchName, cus, ITER);
+    printf("{\"device\": \"%s\", \"cus\": %d, \"iter\": %d, \"unit\": \"SIMD cycles per wave64 instruction at 2.4 GHz = (t[8 waves/SIMD] - t[4 waves/SIMD]) x 2.4e9 / (4 x instructions per wave)\", \"cases\": [\n", prop.gcnArchName, cus, ITER);
     bool first = true;
     for (const Case& c : cases) {
-        for (int wavesPerSimd : { 1, 2, 4, 8 }) {
+        // kernel time at 4 and at 8 waves per SIMD: the difference is 4 more waves' worth of instructions on every SIMD, free of launch
+        // overhead and of the single-wave issue latency (a lone wave issues one VALU instruction per ~4.8 cycles, two already saturate it)
+        double ms[2] = { 0, 0 };
+        for (int v = 0; v < 2; ++v) {
+            const int wavesPerSimd = v == 0 ? 4 : 8;
             const int blocks = cus * wavesPerSimd;          // 256 threads = 4 waves = one per SIMD of a CU
             const size_t threads = (size_t)blocks * 256;
             float* out = nullptr; long long* cyc = nullptr;
@@ -205,22 +211,20 @@ int main()
             CHECK(hipMemset(out, 0, threads * sizeof(float)));
             hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
             hipLaunchKernelGGL(c.fn, dim3(blocks), dim3(256), 0, 0, out, cyc);   // warm-up
-            CHECK(hipEventRecord(e0, 0));
-            hipLaunchKernelGGL(c.fn, dim3(blocks), dim3(256), 0, 0, out, cyc);
-            CHECK(hipEventRecord(e1, 0)); CHECK(hipDeviceSynchronize());
-            float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
-            std::vector<long long> h(threads / 64);
-            CHECK(hipMemcpy(h.data(), cyc, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-            double sum = 0; for (long long v : h) sum += (double)v;
-            const double ticksPerWave = sum / (double)h.size();
-            const double perInstr = ticksPerWave / ((double)ITER * c.instrPerIter * wavesPerSimd);
-            // s_memtime runs at a fixed reference clock (100 MHz class) on some parts: also report the wall-clock figure at 2.4 GHz
-            const double wallCyc = (double)ms * 1e-3 * 2.4e9 / ((double)ITER * c.instrPerIter * wavesPerSimd);
-            printf("%s  {\"op\": \"%s\", \"waves_per_simd\": %d, \"ticks_per_instr\": %.3f, \"wall_cycles_at_2.4GHz_per_instr\": %.3f, \"kernel_ms\": %.4f, \"note\": \"%s\"}",
-                   first ? "" : ",\n", c.name, wavesPerSimd, perInstr, wallCyc, ms, c.note);
-            first = false;
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                CHECK(hipEventRecord(e0, 0));
+                hipLaunchKernelGGL(c.fn, dim3(blocks), dim3(256), 0, 0, out, cyc);
+                CHECK(hipEventRecord(e1, 0)); CHECK(hipDeviceSynchronize());
+                float t = 0; CHECK(hipEventElapsedTime(&t, e0, e1)); best = t < best ? t : best;
+            }
+            ms[v] = best;
             CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1)); CHECK(hipFree(out)); CHECK(hipFree(cyc));
         }
+        const double perInstr = (ms[1] - ms[0]) * 1e-3 * 2.4e9 / ((double)ITER * c.instrPerIter * 4.0);
+        printf("%s  {\"op\": \"%s\", \"cycles_per_wave_instr_per_simd_at_2.4GHz\": %.2f, \"ms_4_waves\": %.4f, \"ms_8_waves\": %.4f, \"note\": \"%s\"}",
+               first ? "" : ",\n", c.name, perInstr, ms[0], ms[1], c.note);
+        first = false;
     }
     printf("\n]}\n");
     return 0;
