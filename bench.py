@@ -148,7 +148,14 @@ def main():
 
     import omm_amd.sharded as shard
 
+    # N > 1: the library's one-call sharded bake, RCCL collectives issued from C++ (ommxShardedBakeRccl); OMM_BENCH_COLLECTIVES=torch keeps
+    # the caller-driven path (collectives through torch.distributed) for the gloo self-tests
+    native = world > 1 and os.environ.get("OMM_BENCH_COLLECTIVES", "native") == "native" and os.environ.get("OMM_BENCH_BACKEND", "nccl") == "nccl"
+    comm = shard.rccl_comm(prod.dll, torch, dist, rank, world) if native else None
+
     def step():
+        if native:
+            return shard.sharded_bake_rccl(prod.dll, baker, C.byref(desc), comm)
         if world > 1:
             return shard.sharded_bake(prod.dll, baker, C.byref(desc), rank, world, torch, dist)
         out = C.c_void_p()
@@ -230,13 +237,13 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%d random-UV triangles (%.1f texels), %dx%d foliage-style UNORM8 alpha + SAT, subdiv level %d, 4-state, Wrap/Linear"
                                    % (args.tris, args.extent_texels, args.tex, args.tex, args.level),
-                       "entry": ("ommxSharded* + torch.distributed" if world > 1 else "ommxBakeDevice") + " (ommCpuBake contract, UV/index inputs and result arrays resident in HBM)", "sharding": "active work items partitioned over ranks; RCCL all-reduce of item metadata + all-gather of OMM blocks" if world > 1 else "none",
+                       "entry": (("ommxShardedBakeRccl (collectives issued by the library)" if native else "ommxSharded* + torch.distributed") if world > 1 else "ommxBakeDevice") + " (ommCpuBake contract, UV/index inputs and result arrays resident in HBM)", "sharding": "active work items partitioned over ranks; RCCL all-reduce of item metadata + chunked all-gather of OMM blocks" if world > 1 else "none",
                        "result": result_info, "unique_items": int(tms[-1].uniqueItems), "active_items": int(tms[-1].activeItems),
                        "fine_micro_triangles": int(tms[-1].fineMicroTriangles)},
             "bake_wall_time_ms": ms_per_step,
             # `value` is measured on the device-resident entry point (inputs and result arrays in HBM, the bench contract); its peer below
             # is the SDK call proper, host arrays in and out, i.e. the same bake plus one PCIe copy of the result
-            "value_entry": "ommxBakeDevice" if world == 1 else "ommxShardedBakeRccl",
+            "value_entry": "ommxBakeDevice" if world == 1 else ("ommxShardedBakeRccl" if native else "ommxSharded* + torch.distributed"),
             "rates": {"all_work_items": micro_tris / (elapsed / args.steps),
                       "active_items_only": float(tms[-1].activeItems) * 4.0 ** args.level / (classify_ms * 1e-3) if classify_ms > 0 else None,
                       "fine_pass_only": float(tms[-1].fineMicroTriangles) / (classify_ms * 1e-3) if classify_ms > 0 else None,
@@ -306,6 +313,8 @@ def main():
         print(json.dumps(line))
     prod.destroy_texture(baker, th)
     prod.destroy_baker(baker)
+    if comm is not None:
+        prod.dll.ommxRcclCommDestroy(comm)
     if world > 1:
         dist.destroy_process_group()
 

@@ -50,7 +50,9 @@ OMM_MI355X_API ommResult ommxDestroyDeviceBakeResult(ommxDeviceBakeResult result
 
 /* ---- multi-GPU sharded bake (one process per GPU) ----
  * Every rank calls the same four functions with the SAME desc (device-resident inputs as for ommxBakeDevice); the caller
- * performs the two collectives in between with whatever transport it has (bench.py: torch.distributed = RCCL over xGMI):
+ * performs the two collectives in between with whatever transport it has (MPI, torch.distributed, ...).  ommxShardedBakeRccl further
+ * down is the same bake as one call with the collectives done by the library.  The handle owns its device working set from Begin to
+ * Destroy and holds no lock in between: other bakes on the same baker run concurrently, Destroy may come from any thread.
  *
  *   ommxShardedBegin   work-item setup + triage (replicated, cheap), then classification and digests of THIS rank's share of
  *                      the active work items (contiguous ranges of the per-level lists)
@@ -67,5 +69,23 @@ OMM_MI355X_API ommResult ommxShardedGetMeta(ommxShardedBake bake, void** deviceW
 OMM_MI355X_API ommResult ommxShardedTail(ommxShardedBake bake, void** contribution, uint64_t* contributionBytes, uint64_t* strideBytes);
 OMM_MI355X_API ommResult ommxShardedFinish(ommxShardedBake bake, const void* gathered, ommxDeviceBakeResult* outResult);
 OMM_MI355X_API ommResult ommxShardedDestroy(ommxShardedBake bake);
+
+/* ---- the same sharded bake as ONE call, collectives included (RCCL over xGMI, issued by the library from C++) ----
+ * Every rank calls ommxShardedBakeRccl with the SAME desc; the library runs Begin, the SUM all-reduce of the metadata words
+ * (ncclAllReduce, in place, on the bake's own stream), Tail, the all-gather of the padded contributions (ncclAllGather in chunks of
+ * <= 64 MiB per rank on a second stream, each chunk scattered to its final arrayData offsets while the next one is on the wire) and
+ * Finish.  Every rank returns the same merged ommxDeviceBakeResult, bit-identical to a single-GPU ommxBakeDevice of the desc.
+ * librccl.so.1 is bound with dlopen at the first call: callers that never shard need no RCCL.
+ *
+ * Communicator: either wrap an ncclComm_t the application already owns (ommxRcclCommWrap; not destroyed by the library), or let the
+ * library create one: rank 0 calls ommxRcclGetUniqueId and distributes the 128 bytes by any means (MPI, a file, torch.distributed),
+ * then every rank calls ommxRcclCommInitRank on its own HIP device (collective: it returns once all ranks have joined). */
+typedef struct _ommxRcclComm* ommxRcclComm;
+#define OMMX_RCCL_UNIQUE_ID_BYTES 128
+OMM_MI355X_API ommResult ommxRcclGetUniqueId(void* outId, size_t idBytes);
+OMM_MI355X_API ommResult ommxRcclCommInitRank(const void* id, size_t idBytes, uint32_t rank, uint32_t worldSize, ommxRcclComm* outComm);
+OMM_MI355X_API ommResult ommxRcclCommWrap(void* ncclComm, ommxRcclComm* outComm);
+OMM_MI355X_API ommResult ommxRcclCommDestroy(ommxRcclComm comm);
+OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInputDesc* deviceDesc, ommxRcclComm comm, ommxDeviceBakeResult* outResult);
 
 #endif

@@ -62,7 +62,8 @@ hipError_t run_shard_layout(const uint32_t* order, const uint32_t* sizes, const 
                             uint64_t* cofs, uint64_t* totalsDev, uint64_t* totalsHost, void* scratch, size_t scratchBytes, hipStream_t stream);
 void launch_shard_gather(const uint8_t* states, const uint64_t* stateOfs, const uint8_t* active, const uint8_t* owner, uint32_t rank, const uint32_t* order,
                          const uint64_t* cofs, const uint32_t* sizes, uint32_t numOmms, uint8_t* contrib, hipStream_t stream);
-void launch_shard_scatter(const uint8_t* gathered, uint64_t strideBytes, const uint8_t* active, const uint8_t* owner, const uint32_t* stateMask,
+// gathered = bytes [lo, hi) of every rank's contribution, rank r at gathered + r * rankPitch (one call per all-gather chunk)
+void launch_shard_scatter(const uint8_t* gathered, uint64_t rankPitch, uint64_t lo, uint64_t hi, const uint8_t* active, const uint8_t* owner, const uint32_t* stateMask,
                           const uint8_t* level, int bits, const uint32_t* order, const uint64_t* cofs, const uint32_t* dstOfs, const uint32_t* sizes,
                           uint32_t numOmms, uint8_t* arrayData, hipStream_t stream);
 

@@ -12,9 +12,11 @@
 #include <hip/hip_runtime.h>
 #include <malloc.h>
 #include <math.h>
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <string>
 #include <chrono>
 #include <mutex>
 #include <memory>
@@ -83,7 +85,7 @@ template <class F> ommResult guarded(const Logger* log, F&& body) noexcept
 
 // ---- device arena: one grow-only HBM block per baker, reused across bakes ----
 struct DeviceArena {
-    std::mutex mu; uint8_t* base = nullptr; size_t cap = 0, used = 0;
+    uint8_t* base = nullptr; size_t cap = 0, used = 0;
     ~DeviceArena() { if (base) (void)hipFree(base); }
     bool reserve(size_t bytes) {
         if (bytes <= cap) { used = 0; return true; }
@@ -97,6 +99,19 @@ struct DeviceArena {
     }
 };
 inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// The device working set of one bake in flight: per-item tables + scratch, packed states + tile queue, and (sharded bakes) the exchange
+// buffers.  A baker keeps a small pool of these sets: a bake takes one for its duration -- concurrent bakes on one baker get different
+// sets, a sharded bake keeps its set from Begin to Destroy without holding any lock in between -- and steady-state bakes never hipMalloc.
+struct ArenaSet { DeviceArena tables, states, xchg; };
+struct ArenaPool {
+    std::mutex mu; std::vector<std::unique_ptr<ArenaSet>> idle;
+    std::unique_ptr<ArenaSet> acquire() {
+        { std::lock_guard<std::mutex> g(mu); if (!idle.empty()) { std::unique_ptr<ArenaSet> a = std::move(idle.back()); idle.pop_back(); return a; } }
+        return std::unique_ptr<ArenaSet>(new ArenaSet());
+    }
+    void release(std::unique_ptr<ArenaSet> a) { std::lock_guard<std::mutex> g(mu); if (idle.size() < 2) idle.push_back(std::move(a)); }   // (else freed here)
+};
 
 // ---- device blocks of bake results, reused across bakes (hipMalloc / hipFree of a 1.3 GB block are synchronous and cost ~1 ms) ----
 struct DevPool {
@@ -176,8 +191,7 @@ struct Baker {
     Allocator mem; Logger log; ommBakerType type;
     std::shared_ptr<HostPool> hostPool = std::make_shared<HostPool>();
     std::shared_ptr<DevPool> devPool = std::make_shared<DevPool>();
-    DeviceArena arena;        // per-item tables + scratch
-    DeviceArena statesArena;  // packed states of the active (non-uniform) items; guarded by arena.mu
+    std::shared_ptr<ArenaPool> arenas = std::make_shared<ArenaPool>();   // device working sets, one per bake in flight
     std::mutex timingsMu; ommxBakeTimings timings; bool haveTimings = false;
 };
 
@@ -433,11 +447,11 @@ struct ShardCtx {
     SetupCounters hc;
     uint8_t *dStates = nullptr, *dActive = nullptr, *dLevel = nullptr, *dScratch = nullptr; uint64_t* dStateOfs = nullptr; uint32_t *dMask = nullptr, *dActiveIds = nullptr;
     int32_t* dIndex = nullptr; uint32_t *dArrayHist = nullptr, *dIndexHist = nullptr;
-    size_t scratchBytes = 0; uint32_t flags = 0, T = 0; int bits = 2;
-    // owned device buffers
-    uint32_t* dMeta = nullptr; uint8_t* dOwner = nullptr; uint64_t *dCofs = nullptr, *dTotals = nullptr; uint8_t* dContrib = nullptr;
+    size_t scratchBytes = 0; uint32_t flags = 0, T = 0; int bits = 2; bool asyncBegin = false;
+    int ev[5] = { -1, -1, -1, -1, -1 };   // HIP event marks of Begin: setup | triage | classify | digest
+    // exchange buffers: carved from the session's arenas (tables: dMeta .. dTotals; xchg: contribution + gather staging), nothing to free
+    uint32_t* dMeta = nullptr; uint8_t* dOwner = nullptr; uint64_t *dCofs = nullptr, *dTotals = nullptr; uint8_t *dContrib = nullptr, *dGathered = nullptr;
     uint64_t totals[kMaxRanks]; uint64_t strideBytes = 0;
-    ~ShardCtx() { for (void* p : { (void*)dMeta, (void*)dOwner, (void*)dCofs, (void*)dTotals, (void*)dContrib }) if (p) (void)hipFree(p); }
 };
 
 // opt-in lossy reducers (near-duplicate merge, maxArrayDataSize): classification on the device, serial tail on the host
@@ -488,7 +502,8 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     const size_t setupBytes = setup_scratch_bytes(T), tailBytes = tail_scratch_bytes(maxItems, T);
     const size_t scratchBytes = setupBytes > tailBytes ? setupBytes : tailBytes;
     const size_t i32 = pad256((size_t)maxItems * 4), i64 = pad256((size_t)maxItems * 8);
-    const size_t need = pad256((size_t)maxItems * 24) + 3 * pad256(maxItems) + i64 * 2 + i32 * 13 + pad256(sizeof(SetupCounters)) + 4096 + pad256(sizeof(unsigned long long) * kFineSlots * kFineStride) + pad256(scratchBytes);
+    const size_t shardBytes = sh ? pad256((size_t)maxItems * 16) + pad256(maxItems) + i64 + pad256(sizeof(uint64_t) * kMaxRanks) : 0;
+    const size_t need = pad256((size_t)maxItems * 24) + 3 * pad256(maxItems) + i64 * 2 + i32 * 13 + pad256(sizeof(SetupCounters)) + 4096 + pad256(sizeof(unsigned long long) * kFineSlots * kFineStride) + pad256(scratchBytes) + shardBytes;
     if (!arena->reserve(need)) return L.failure("[Failure] - out of device memory for the bake working set");
     float* dUv = arena->take<float>((size_t)maxItems * 6);
     uint8_t* dLevel = arena->take<uint8_t>(maxItems); uint8_t* dDegen = arena->take<uint8_t>(maxItems); uint8_t* dActive = arena->take<uint8_t>(maxItems);
@@ -505,6 +520,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     uint32_t* dArrayHist = arena->take<uint32_t>(kNumLevels); uint32_t* dIndexHist = arena->take<uint32_t>(kNumLevels); uint32_t* dErr = arena->take<uint32_t>(1);
     unsigned long long* dFine = arena->take<unsigned long long>(kFineSlots * kFineStride); // striped statistic counter (bake_types.h)
     uint8_t* dScratch = arena->take<uint8_t>(scratchBytes);
+    if (sh) { sh->dMeta = arena->take<uint32_t>((size_t)maxItems * 4); sh->dOwner = arena->take<uint8_t>(maxItems); sh->dCofs = arena->take<uint64_t>(maxItems); sh->dTotals = arena->take<uint64_t>(kMaxRanks); }
 
     // ---- SetupWorkItems (bake_cpu_impl.cpp:589-660) on the device ----
     const int e0 = et.mark();
@@ -703,12 +719,9 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         sh->bounds = bounds; sh->ti = ti; sh->to = to; sh->hc = hc; sh->dStates = dStates; sh->dActive = dActive; sh->dLevel = dLevel; sh->dScratch = dScratch;
         sh->dStateOfs = dStateOfs; sh->dMask = dMask; sh->dActiveIds = dActiveIds; sh->dIndex = dIndex; sh->dArrayHist = dArrayHist; sh->dIndexHist = dIndexHist;
         sh->scratchBytes = scratchBytes; sh->flags = flags; sh->T = T; sh->bits = bits;
-        ok = HIP_OK(hipMalloc((void**)&sh->dMeta, (size_t)(numActive ? numActive : 1) * 16)) && HIP_OK(hipMalloc((void**)&sh->dOwner, maxItems))
-          && HIP_OK(hipMalloc((void**)&sh->dCofs, (size_t)maxItems * 8)) && HIP_OK(hipMalloc((void**)&sh->dTotals, sizeof(uint64_t) * kMaxRanks));
-        if (!ok) return L.failure("[Failure] - out of device memory for the sharded bake");
         launch_shard_pack_meta(bounds, dActiveIds, numActive, dMask, dKnown, dDigests, sh->dMeta, stream);
-        if (!HIP_OK(hipStreamSynchronize(stream))) return L.failure("[Failure] - sharded classification failed");
-        tm.setupMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.digestMs = et.ms(e2, e3);
+        if (!sh->asyncBegin && !HIP_OK(hipStreamSynchronize(stream))) return L.failure("[Failure] - sharded classification failed");   // (the one-call RCCL path stays on the stream)
+        sh->ev[0] = e0; sh->ev[1] = e1; sh->ev[2] = e1b; sh->ev[3] = e2; sh->ev[4] = e3;   // (read in Finish, when the events are complete)
         tm.uniqueItems = U; tm.activeItems = numActive; tm.stateBytes = hc.stateBytes;
         for (int l = 0; l < kNumLevels; ++l) tm.microTriangles += (uint64_t)hc.levelCount[l] << (2 * l);
         return ommResult_SUCCESS;
@@ -791,13 +804,17 @@ struct DeviceBakeResult {
     ommCpuBakeResultDesc desc;
 };
 
-struct BakeSession { // arenas + stream for one call
-    std::unique_lock<std::mutex> lock; DeviceArena local, localStates; DeviceArena* arena; DeviceArena* states; hipStream_t stream = nullptr;
-    explicit BakeSession(Baker& b) : lock(b.arena.mu, std::try_to_lock) {
-        arena = lock.owns_lock() ? &b.arena : &local; states = lock.owns_lock() ? &b.statesArena : &localStates; // concurrent bakes get private arenas
+struct BakeSession { // device working set + streams of one bake in flight
+    std::shared_ptr<ArenaPool> pool; std::unique_ptr<ArenaSet> set; DeviceArena* arena; DeviceArena* states; hipStream_t stream = nullptr, commStream = nullptr;
+    explicit BakeSession(Baker& b) : pool(b.arenas), set(pool->acquire()) { arena = &set->tables; states = &set->states; }
+    ~BakeSession() {
+        // the set goes back to the pool only when nothing on the device can still touch it
+        if (commStream) { (void)hipStreamSynchronize(commStream); (void)hipStreamDestroy(commStream); }
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        pool->release(std::move(set));
     }
-    ~BakeSession() { if (stream) (void)hipStreamDestroy(stream); }
     bool open() { return hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess; }
+    bool open_comm() { return commStream || hipStreamCreateWithFlags(&commStream, hipStreamNonBlocking) == hipSuccess; }
 };
 
 // ommCpuBake: host arrays in, host arrays out
@@ -1279,17 +1296,67 @@ OMM_MI355X_API ommResult ommxBakeDevice(ommBaker baker, const ommCpuBakeInputDes
 namespace {
 struct ShardedBake {
     Allocator mem; Baker* baker = nullptr; BakeSession ses; ShardCtx ctx; ommxBakeTimings tm; double t0 = 0;
+    std::unique_ptr<EventTimer> et;
     explicit ShardedBake(Baker& b) : baker(&b), ses(b) { memset(&tm, 0, sizeof tm); }
 };
+
+// ---- RCCL, bound at first use ----
+// The collectives of the sharded bake are RCCL calls made from this library on its own streams (ommxShardedBakeRccl).  librccl is
+// resolved with dlopen at the first call, so the drop-in keeps loading on machines (and for callers) that never shard a bake; when the
+// process already holds an RCCL (e.g. torch's) its SONAME librccl.so.1 resolves to that instance.
+typedef void* rcclComm_t;
+struct RcclUniqueId { char internal[128]; };                       // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+enum { kRcclSum = 0, kRcclUint8 = 1, kRcclUint32 = 3 };            // ncclRedOp_t / ncclDataType_t values of rccl.h
+struct RcclApi {
+    void* dso = nullptr; std::string error;
+    int (*getUniqueId)(RcclUniqueId*) = nullptr;
+    int (*commInitRank)(rcclComm_t*, int, RcclUniqueId, int) = nullptr;
+    int (*commDestroy)(rcclComm_t) = nullptr;
+    int (*commCount)(rcclComm_t, int*) = nullptr;
+    int (*commUserRank)(rcclComm_t, int*) = nullptr;
+    int (*allReduce)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+    int (*allGather)(const void*, void*, size_t, int, rcclComm_t, hipStream_t) = nullptr;
+    const char* (*getErrorString)(int) = nullptr;
+    bool ok() const { return dso != nullptr && error.empty(); }
+};
+const RcclApi& rccl()
+{
+    static const RcclApi api = [] {
+        RcclApi a;
+        for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) { a.dso = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (a.dso) break; }
+        if (!a.dso) { a.error = "librccl.so.1 could not be loaded"; return a; }
+        auto sym = [&](const char* n) { void* p = dlsym(a.dso, n); if (!p && a.error.empty()) a.error = std::string("librccl lacks ") + n; return p; };
+        a.getUniqueId = (int (*)(RcclUniqueId*))sym("ncclGetUniqueId");
+        a.commInitRank = (int (*)(rcclComm_t*, int, RcclUniqueId, int))sym("ncclCommInitRank");
+        a.commDestroy = (int (*)(rcclComm_t))sym("ncclCommDestroy");
+        a.commCount = (int (*)(rcclComm_t, int*))sym("ncclCommCount");
+        a.commUserRank = (int (*)(rcclComm_t, int*))sym("ncclCommUserRank");
+        a.allReduce = (int (*)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t))sym("ncclAllReduce");
+        a.allGather = (int (*)(const void*, void*, size_t, int, rcclComm_t, hipStream_t))sym("ncclAllGather");
+        a.getErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+        return a;
+    }();
+    return api;
+}
+struct RcclComm { rcclComm_t comm = nullptr; bool owned = false; int rank = 0, world = 1; };
+
+// The all-gather of the block contributions moves in chunks of <= 64 MiB per rank (at most 8 chunks, multiples of 256 bytes), so that the
+// scatter of one chunk overlaps the transfer of the next.  OMMX_SHARD_CHUNK_BYTES overrides the chunk size (tests use tiny chunks to force
+// blocks across chunk boundaries).
+uint64_t shard_chunk_bytes(uint64_t strideBytes)
+{
+    uint64_t want = 64ull << 20;
+    if (const char* e = getenv("OMMX_SHARD_CHUNK_BYTES")) { const unsigned long long v = strtoull(e, nullptr, 10); if (v >= 256) want = v; }
+    uint64_t chunks = (strideBytes + want - 1) / want; if (chunks > 8) chunks = 8; if (chunks < 1) chunks = 1;
+    return ((((strideBytes + chunks - 1) / chunks) + 255) & ~255ull);
 }
 
-OMM_MI355X_API ommResult ommxShardedBegin(ommBaker baker, const ommCpuBakeInputDesc* desc, uint32_t rank, uint32_t worldSize, ommxShardedBake* out)
+ommResult sharded_checks(ommBaker baker, const ommCpuBakeInputDesc* desc, Baker** outB)
 {
     if (baker == 0) return ommResult_INVALID_ARGUMENT;
     Baker* b = untag<Baker>(baker);
-    if (desc == 0 || out == 0) return b->log.invalid("input desc was not set");
+    if (desc == 0) return b->log.invalid("input desc was not set");
     if (tag_of(baker) != kCpuBaker) return b->log.invalid("Baker was not created as the right type");
-    if (worldSize == 0 || worldSize > (uint32_t)kMaxRanks || rank >= worldSize) return b->log.invalid("[Invalid Argument] - rank / worldSize out of range (at most 16 ranks)");
     if (desc->texture == 0) return b->log.invalid("[Invalid Argument] - ommCpuBakeInputDesc has no texture set");
     if (tag_of(desc->texture) == kTexture &&
         ((unsigned)desc->runtimeSamplerDesc.addressingMode >= (unsigned)ommTextureAddressMode_MAX_NUM ||
@@ -1299,35 +1366,34 @@ OMM_MI355X_API ommResult ommxShardedBegin(ommBaker baker, const ommCpuBakeInputD
     if (r != ommResult_SUCCESS) return r;
     r = scope_fences(*b, *desc, false);
     if (r != ommResult_SUCCESS) return r;
+    *outB = b;
+    return ommResult_SUCCESS;
+}
+
+// phase 1: replicated setup + triage, classification and digests of this rank's share, metadata words packed for the all-reduce.
+// async: nothing is synchronised at the end (the RCCL all-reduce follows on the same stream).
+ommResult sharded_begin(Baker* b, const ommCpuBakeInputDesc* desc, uint32_t rank, uint32_t worldSize, bool async, ShardedBake** out)
+{
     ShardedBake* sb = b->mem.make<ShardedBake>(*b);
     if (!sb) return ommResult_FAILURE;
     sb->mem = b->mem; sb->t0 = now_ms();
     if (!sb->ses.open()) { b->mem.destroy(sb); return b->log.failure("[Failure] - no usable HIP device (the MI355X baker has no CPU fallback)"); }
-    sb->ctx.rank = rank; sb->ctx.world = worldSize;
-    EventTimer et(sb->ses.stream);
+    sb->ctx.rank = rank; sb->ctx.world = worldSize; sb->ctx.asyncBegin = async;
+    sb->et.reset(new EventTimer(sb->ses.stream));
     DeviceResult unused;
     DeviceInputs din; din.texCoords = desc->texCoords; din.indices = desc->indexBuffer; din.perTriLevels = desc->subdivisionLevels;
-    r = bake_core(*b, *desc, din, nullptr, sb->ses.arena, sb->ses.states, sb->ses.stream, et, unused, sb->tm, &sb->ctx);
+    const ommResult r = bake_core(*b, *desc, din, nullptr, sb->ses.arena, sb->ses.states, sb->ses.stream, *sb->et, unused, sb->tm, &sb->ctx);
     if (r != ommResult_SUCCESS) { b->mem.destroy(sb); return r; }
-    *out = (ommxShardedBake)sb;
+    *out = sb;
     return ommResult_SUCCESS;
 }
 
-OMM_MI355X_API ommResult ommxShardedGetMeta(ommxShardedBake h, void** deviceWords, uint64_t* numWords)
+// phase 2 (after the metadata all-reduce): replicated tail, per-rank layout, this rank's surviving blocks packed into its contribution.
+// Ends with the contribution complete on the stream (not synchronised); the two host read-backs inside (OMM count, per-rank totals) remain.
+ommResult sharded_tail(ShardedBake* sb)
 {
-    if (h == 0 || deviceWords == nullptr || numWords == nullptr) return ommResult_INVALID_ARGUMENT;
-    ShardedBake* sb = (ShardedBake*)h;
-    *deviceWords = sb->ctx.dMeta; *numWords = 4ull * sb->ctx.hc.activeStart[kNumLevels];
-    return ommResult_SUCCESS;
-}
-
-OMM_MI355X_API ommResult ommxShardedTail(ommxShardedBake h, void** contribution, uint64_t* contributionBytes, uint64_t* strideBytes)
-{
-    if (h == 0 || contribution == nullptr || contributionBytes == nullptr || strideBytes == nullptr) return ommResult_INVALID_ARGUMENT;
-    ShardedBake* sb = (ShardedBake*)h; ShardCtx& c = sb->ctx; const Logger& L = sb->baker->log; hipStream_t stream = sb->ses.stream;
-    const double t1 = now_ms();
+    ShardCtx& c = sb->ctx; const Logger& L = sb->baker->log; hipStream_t stream = sb->ses.stream;
     const uint32_t numActive = c.hc.activeStart[kNumLevels];
-    // the caller has SUM-all-reduced the metadata words: every rank now sees every active item's mask / known count / digest
     if (!HIP_OK(hipMemsetAsync(c.dOwner, 0xFF, c.ti.numItems ? c.ti.numItems : 1, stream))) return L.failure("[Failure] - device memset failed");
     launch_shard_unpack_meta(c.bounds, c.dActiveIds, numActive, c.dMeta, c.dMask, (uint32_t*)c.ti.knownCount, c.ti.digests, c.dOwner, stream);
     if (!HIP_OK(run_tail(c.ti, c.to, c.dScratch, c.scratchBytes, &c.counts, stream))) return L.failure("[Failure] - device tail failed");
@@ -1336,21 +1402,21 @@ OMM_MI355X_API ommResult ommxShardedTail(ommxShardedBake h, void** contribution,
         return L.failure("[Failure] - sharded layout failed");
     uint64_t mx = 0; for (uint32_t r = 0; r < c.world; ++r) mx = c.totals[r] > mx ? c.totals[r] : mx;
     c.strideBytes = (mx + 255) & ~255ull; if (c.strideBytes == 0) c.strideBytes = 256;
-    if (!HIP_OK(hipMalloc((void**)&c.dContrib, (size_t)c.strideBytes))) return L.failure("[Failure] - out of device memory for the shard contribution");
+    // contribution + (for the RCCL path) the gather staging of all ranks: one grow-only block of the session's working set
+    const size_t gatherBytes = c.asyncBegin ? (size_t)c.strideBytes * c.world + 4096 : 0;
+    if (!sb->ses.set->xchg.reserve((size_t)c.strideBytes + 256 + gatherBytes)) return L.failure("[Failure] - out of device memory for the shard contribution");
+    c.dContrib = sb->ses.set->xchg.take<uint8_t>((size_t)c.strideBytes);
+    c.dGathered = gatherBytes ? sb->ses.set->xchg.take<uint8_t>(gatherBytes) : nullptr;
     launch_shard_gather(c.dStates, c.dStateOfs, c.dActive, c.dOwner, c.rank, c.to.order, c.dCofs, c.to.sizes, c.counts.numOmms, c.dContrib, stream);
-    if (!HIP_OK(hipStreamSynchronize(stream))) return L.failure("[Failure] - shard gather failed");
-    *contribution = c.dContrib; *contributionBytes = c.totals[c.rank]; *strideBytes = c.strideBytes;
-    sb->tm.tailMs = (float)(now_ms() - t1);
-    return ommResult_SUCCESS;
+    return HIP_OK(hipGetLastError()) ? ommResult_SUCCESS : L.failure("[Failure] - shard gather failed");
 }
 
-OMM_MI355X_API ommResult ommxShardedFinish(ommxShardedBake h, const void* gathered, ommxDeviceBakeResult* outResult)
+// phase 3: result buffers, descriptors, index buffer; `scatter` places the gathered blocks (one call or one per chunk)
+template <class ScatterFn>
+ommResult sharded_finish(ShardedBake* sb, ScatterFn&& scatter, ommxDeviceBakeResult* outResult)
 {
-    if (h == 0 || outResult == nullptr) return ommResult_INVALID_ARGUMENT;
-    ShardedBake* sb = (ShardedBake*)h; ShardCtx& c = sb->ctx; Baker* b = sb->baker; const Logger& L = b->log; hipStream_t stream = sb->ses.stream;
-    const double t1 = now_ms();
+    ShardCtx& c = sb->ctx; Baker* b = sb->baker; const Logger& L = b->log; hipStream_t stream = sb->ses.stream;
     const uint32_t E = c.counts.numOmms, T = c.T;
-    if (E && gathered == nullptr) return L.invalid("[Invalid Argument] - gathered contributions missing");
     DeviceBakeResult* res = b->mem.make<DeviceBakeResult>();
     if (!res) return ommResult_FAILURE;
     res->mem = b->mem; memset(&res->desc, 0, sizeof res->desc);
@@ -1362,7 +1428,7 @@ OMM_MI355X_API ommResult ommxShardedFinish(ommxShardedBake h, const void* gather
         R.arrayData = (uint8_t*)R.dev_alloc((size_t)c.counts.arrayDataSize); R.descs = (ommCpuOpacityMicromapDesc*)R.dev_alloc(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E);
         ok = R.arrayData != nullptr && R.descs != nullptr;
         if (ok) {
-            launch_shard_scatter((const uint8_t*)gathered, c.strideBytes, c.dActive, c.dOwner, c.dMask, c.dLevel, c.bits, c.to.order, c.dCofs, c.to.dstOfs, c.to.sizes, E, R.arrayData, stream);
+            ok = scatter(R.arrayData);
             launch_write_descs(c.to.order, c.to.dstOfs, c.dLevel, c.bits, E, R.descs, stream);
         }
     }
@@ -1387,10 +1453,74 @@ OMM_MI355X_API ommResult ommxShardedFinish(ommxShardedBake h, const void* gather
     res->desc.descArrayHistogram = res->arrayHist; res->desc.descArrayHistogramCount = nAH;
     res->desc.indexBuffer = R.index; res->desc.indexCount = R.numTris; res->desc.indexFormat = R.indexFormat;
     res->desc.indexHistogram = res->indexHist; res->desc.indexHistogramCount = nIH;
-    sb->tm.gatherMs = (float)(now_ms() - t1); sb->tm.totalMs = (float)(now_ms() - sb->t0);
+    // the bake's HIP events are complete now (Begin may have returned without synchronising)
+    const int* e = c.ev;
+    sb->tm.setupMs = sb->et->ms(e[0], e[1]); sb->tm.triageMs = sb->et->ms(e[1], e[2]); sb->tm.classifyMs = sb->et->ms(e[2], e[3]); sb->tm.digestMs = sb->et->ms(e[3], e[4]);
+    sb->tm.totalMs = (float)(now_ms() - sb->t0);
     { std::lock_guard<std::mutex> g(b->timingsMu); b->timings = sb->tm; b->haveTimings = true; }
     *outResult = (ommxDeviceBakeResult)res;
     return ommResult_SUCCESS;
+}
+} // namespace
+
+OMM_MI355X_API ommResult ommxShardedBegin(ommBaker baker, const ommCpuBakeInputDesc* desc, uint32_t rank, uint32_t worldSize, ommxShardedBake* out)
+{
+    Baker* b = nullptr;
+    if (out == 0) return ommResult_INVALID_ARGUMENT;
+    const ommResult r = sharded_checks(baker, desc, &b);
+    if (r != ommResult_SUCCESS) return r;
+    if (worldSize == 0 || worldSize > (uint32_t)kMaxRanks || rank >= worldSize) return b->log.invalid("[Invalid Argument] - rank / worldSize out of range (at most 16 ranks)");
+    return guarded(&b->log, [&]() -> ommResult {
+        ShardedBake* sb = nullptr;
+        const ommResult rr = sharded_begin(b, desc, rank, worldSize, false, &sb);
+        if (rr == ommResult_SUCCESS) *out = (ommxShardedBake)sb;
+        return rr;
+    });
+}
+
+OMM_MI355X_API ommResult ommxShardedGetMeta(ommxShardedBake h, void** deviceWords, uint64_t* numWords)
+{
+    if (h == 0 || deviceWords == nullptr || numWords == nullptr) return ommResult_INVALID_ARGUMENT;
+    ShardedBake* sb = (ShardedBake*)h;
+    *deviceWords = sb->ctx.dMeta; *numWords = 4ull * sb->ctx.hc.activeStart[kNumLevels];
+    return ommResult_SUCCESS;
+}
+
+OMM_MI355X_API ommResult ommxShardedTail(ommxShardedBake h, void** contribution, uint64_t* contributionBytes, uint64_t* strideBytes)
+{
+    if (h == 0 || contribution == nullptr || contributionBytes == nullptr || strideBytes == nullptr) return ommResult_INVALID_ARGUMENT;
+    ShardedBake* sb = (ShardedBake*)h; ShardCtx& c = sb->ctx;
+    return guarded(&sb->baker->log, [&]() -> ommResult {
+        const double t1 = now_ms();
+        const ommResult r = sharded_tail(sb);   // (a second call re-uses the same exchange block: nothing leaks)
+        if (r != ommResult_SUCCESS) return r;
+        if (!HIP_OK(hipStreamSynchronize(sb->ses.stream))) return sb->baker->log.failure("[Failure] - shard gather failed");
+        *contribution = c.dContrib; *contributionBytes = c.totals[c.rank]; *strideBytes = c.strideBytes;
+        sb->tm.tailMs = (float)(now_ms() - t1);
+        return ommResult_SUCCESS;
+    });
+}
+
+OMM_MI355X_API ommResult ommxShardedFinish(ommxShardedBake h, const void* gathered, ommxDeviceBakeResult* outResult)
+{
+    if (h == 0 || outResult == nullptr) return ommResult_INVALID_ARGUMENT;
+    ShardedBake* sb = (ShardedBake*)h; ShardCtx& c = sb->ctx;
+    if (c.counts.numOmms && gathered == nullptr) return sb->baker->log.invalid("[Invalid Argument] - gathered contributions missing");
+    return guarded(&sb->baker->log, [&]() -> ommResult {
+        const double t1 = now_ms();
+        const ommResult r = sharded_finish(sb, [&](uint8_t* arrayData) {
+            // same chunk walk as the RCCL path (there each chunk arrives separately): a block that straddles a chunk boundary is placed in pieces
+            const uint64_t chunkBytes = shard_chunk_bytes(c.strideBytes);
+            for (uint64_t lo = 0; lo < c.strideBytes; lo += chunkBytes) {
+                const uint64_t hi = lo + chunkBytes < c.strideBytes ? lo + chunkBytes : c.strideBytes;
+                launch_shard_scatter((const uint8_t*)gathered + lo, c.strideBytes, lo, hi, c.dActive, c.dOwner, c.dMask, c.dLevel, c.bits, c.to.order, c.dCofs, c.to.dstOfs, c.to.sizes,
+                                     c.counts.numOmms, arrayData, sb->ses.stream);
+            }
+            return true;
+        }, outResult);
+        sb->tm.gatherMs = (float)(now_ms() - t1);
+        return r;
+    });
 }
 
 OMM_MI355X_API ommResult ommxShardedDestroy(ommxShardedBake h)
@@ -1398,8 +1528,110 @@ OMM_MI355X_API ommResult ommxShardedDestroy(ommxShardedBake h)
     if (h == 0) return ommResult_INVALID_ARGUMENT;
     ShardedBake* sb = (ShardedBake*)h;
     const Allocator mem = sb->mem;
-    mem.destroy(sb);
+    mem.destroy(sb);   // (the session waits for its streams before its working set returns to the baker's pool)
     return ommResult_SUCCESS;
+}
+
+// ---- RCCL communicator helpers + the one-call sharded bake ----
+OMM_MI355X_API ommResult ommxRcclGetUniqueId(void* outId, size_t idBytes)
+{
+    if (outId == nullptr || idBytes < sizeof(RcclUniqueId)) return ommResult_INVALID_ARGUMENT;
+    if (!rccl().ok()) return ommResult_FAILURE;
+    return rccl().getUniqueId((RcclUniqueId*)outId) == 0 ? ommResult_SUCCESS : ommResult_FAILURE;
+}
+
+OMM_MI355X_API ommResult ommxRcclCommInitRank(const void* id, size_t idBytes, uint32_t rank, uint32_t worldSize, ommxRcclComm* outComm)
+{
+    if (id == nullptr || idBytes < sizeof(RcclUniqueId) || outComm == nullptr || worldSize == 0 || worldSize > (uint32_t)kMaxRanks || rank >= worldSize) return ommResult_INVALID_ARGUMENT;
+    if (!rccl().ok()) return ommResult_FAILURE;
+    RcclUniqueId uid; memcpy(&uid, id, sizeof uid);
+    RcclComm* c = new (std::nothrow) RcclComm();
+    if (!c) return ommResult_FAILURE;
+    if (rccl().commInitRank(&c->comm, (int)worldSize, uid, (int)rank) != 0) { delete c; return ommResult_FAILURE; }
+    c->owned = true; c->rank = (int)rank; c->world = (int)worldSize;
+    *outComm = (ommxRcclComm)c;
+    return ommResult_SUCCESS;
+}
+
+OMM_MI355X_API ommResult ommxRcclCommWrap(void* ncclComm, ommxRcclComm* outComm)
+{
+    if (ncclComm == nullptr || outComm == nullptr) return ommResult_INVALID_ARGUMENT;
+    if (!rccl().ok()) return ommResult_FAILURE;
+    RcclComm* c = new (std::nothrow) RcclComm();
+    if (!c) return ommResult_FAILURE;
+    c->comm = ncclComm; c->owned = false;
+    if (rccl().commCount(c->comm, &c->world) != 0 || rccl().commUserRank(c->comm, &c->rank) != 0 || c->world < 1 || c->world > kMaxRanks) { delete c; return ommResult_INVALID_ARGUMENT; }
+    *outComm = (ommxRcclComm)c;
+    return ommResult_SUCCESS;
+}
+
+OMM_MI355X_API ommResult ommxRcclCommDestroy(ommxRcclComm comm)
+{
+    if (comm == 0) return ommResult_INVALID_ARGUMENT;
+    RcclComm* c = (RcclComm*)comm;
+    if (c->owned && c->comm) (void)rccl().commDestroy(c->comm);
+    delete c;
+    return ommResult_SUCCESS;
+}
+
+OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInputDesc* desc, ommxRcclComm comm, ommxDeviceBakeResult* outResult)
+{
+    Baker* b = nullptr;
+    if (comm == 0 || outResult == nullptr) return ommResult_INVALID_ARGUMENT;
+    const ommResult r0 = sharded_checks(baker, desc, &b);
+    if (r0 != ommResult_SUCCESS) return r0;
+    const Logger& L = b->log;
+    if (!rccl().ok()) return L.failure(("[Failure] - RCCL is not available: " + rccl().error).c_str());
+    RcclComm* rc = (RcclComm*)comm;
+    return guarded(&L, [&]() -> ommResult {
+        auto nccl_fail = [&](int code, const char* what) {
+            char buf[256]; snprintf(buf, sizeof buf, "[Failure] - %s: %s", what, rccl().getErrorString ? rccl().getErrorString(code) : "RCCL error");
+            return L.failure(buf);
+        };
+        ShardedBake* sb = nullptr;
+        ommResult r = sharded_begin(b, desc, (uint32_t)rc->rank, (uint32_t)rc->world, true, &sb);
+        if (r != ommResult_SUCCESS) return r;
+        struct Owner { Baker* b; ShardedBake* sb; ~Owner() { b->mem.destroy(sb); } } owner{ b, sb };
+        ShardCtx& c = sb->ctx; hipStream_t stream = sb->ses.stream;
+        const double t1 = now_ms();
+        // exchange 1: per-item metadata, SUM all-reduce in place, on the bake's own stream right behind the digests
+        const size_t words = 4ull * c.hc.activeStart[kNumLevels];
+        if (words) { const int e = rccl().allReduce(c.dMeta, c.dMeta, words, kRcclUint32, kRcclSum, rc->comm, stream); if (e != 0) return nccl_fail(e, "ncclAllReduce of the work-item metadata"); }
+        r = sharded_tail(sb);
+        if (r != ommResult_SUCCESS) return r;
+        sb->tm.tailMs = (float)(now_ms() - t1);
+        const double t2 = now_ms();
+        // exchange 2: the padded contributions, all-gathered in chunks on a second stream; every chunk is scattered to its final arrayData
+        // offsets on the bake's stream while the next one is on the wire
+        const uint32_t E = c.counts.numOmms;
+        r = sharded_finish(sb, [&](uint8_t* arrayData) -> bool {
+            // (a one-rank communicator takes the same route: the collectives degenerate to copies, the plumbing is the same)
+            if (!sb->ses.open_comm()) return false;
+            hipStream_t cs = sb->ses.commStream;
+            const uint64_t chunkBytes = shard_chunk_bytes(c.strideBytes);              // per rank and chunk; at most 8 chunks
+            uint64_t chunks = (c.strideBytes + chunkBytes - 1) / chunkBytes;
+            hipEvent_t ready = nullptr, done[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+            bool ok = HIP_OK(hipEventCreateWithFlags(&ready, hipEventDisableTiming)) && HIP_OK(hipEventRecord(ready, stream)) && HIP_OK(hipStreamWaitEvent(cs, ready, 0));
+            int ncclErr = 0;
+            for (uint64_t k = 0; ok && k < chunks; ++k) {
+                const uint64_t lo = k * chunkBytes, hi = lo + chunkBytes < c.strideBytes ? lo + chunkBytes : c.strideBytes;
+                if (lo >= hi) { chunks = k; break; }
+                uint8_t* stage = c.dGathered + lo * (uint64_t)rc->world;               // chunk k of all ranks: world x (hi - lo) bytes
+                ncclErr = rccl().allGather(c.dContrib + lo, stage, (size_t)(hi - lo), kRcclUint8, rc->comm, cs);
+                ok = ncclErr == 0 && HIP_OK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming)) && HIP_OK(hipEventRecord(done[k], cs)) && HIP_OK(hipStreamWaitEvent(stream, done[k], 0));
+                if (ok) launch_shard_scatter(stage, hi - lo, lo, hi, c.dActive, c.dOwner, c.dMask, c.dLevel, c.bits, c.to.order, c.dCofs, c.to.dstOfs, c.to.sizes, E, arrayData, stream);
+            }
+            ok = ok && HIP_OK(hipStreamSynchronize(stream));
+            (void)hipStreamSynchronize(cs);
+            if (ready) (void)hipEventDestroy(ready);
+            for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
+            if (ncclErr != 0) (void)nccl_fail(ncclErr, "ncclAllGather of the OMM blocks");
+            return ok;
+        }, outResult);
+        sb->tm.gatherMs = (float)(now_ms() - t2);
+        if (r == ommResult_SUCCESS) { std::lock_guard<std::mutex> g(b->timingsMu); b->timings.tailMs = sb->tm.tailMs; b->timings.gatherMs = sb->tm.gatherMs; }
+        return r;
+    });
 }
 
 OMM_MI355X_API ommResult ommxGetDeviceBakeResultDesc(ommxDeviceBakeResult result, const ommCpuBakeResultDesc** desc)

@@ -352,8 +352,11 @@ __global__ __launch_bounds__(256) void shard_gather_contribution(const uint8_t* 
     }
 }
 
-// after the all-gather: place every rank's blocks at their final arrayData offsets (uniform items: constant pattern, computed locally)
-__global__ __launch_bounds__(256) void shard_scatter_contributions(const uint8_t* __restrict__ gathered, uint64_t strideBytes,
+// after the all-gather: place every rank's blocks at their final arrayData offsets (uniform items: constant pattern, computed locally).
+// `gathered` holds the bytes [lo, hi) of every rank's contribution, rank r at gathered + r * rankPitch: the all-gather may arrive in
+// chunks (omm_host.cpp), and each chunk is scattered while the next one is still on the wire; a block that straddles two chunks is
+// written in two pieces.
+__global__ __launch_bounds__(256) void shard_scatter_contributions(const uint8_t* __restrict__ gathered, uint64_t rankPitch, uint64_t lo, uint64_t hi,
                                                                    const uint8_t* __restrict__ active, const uint8_t* __restrict__ owner,
                                                                    const uint32_t* __restrict__ stateMask, const uint8_t* __restrict__ level, int bits,
                                                                    const uint32_t* __restrict__ order, const uint64_t* __restrict__ cofs,
@@ -365,6 +368,7 @@ __global__ __launch_bounds__(256) void shard_scatter_contributions(const uint8_t
         uint8_t* dst = arrayData + dstOfs[j];
         const uint32_t n = sizes[j];
         if (!active[item]) {
+            if (lo != 0) continue;   // (written with the first chunk)
             const uint32_t st = (uint32_t)(31 - __clz((int)stateMask[item]));
             uint32_t usedBits = (1u << (2u * level[item])) * (uint32_t)bits; if (usedBits > 8u) usedBits = 8u;
             uint32_t pat = 0;
@@ -372,9 +376,14 @@ __global__ __launch_bounds__(256) void shard_scatter_contributions(const uint8_t
             for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) dst[k] = (uint8_t)pat;
             continue;
         }
-        const uint8_t* src = gathered + (uint64_t)owner[item] * strideBytes + cofs[j];
-        if (n >= 16u && ((cofs[j] | strideBytes) & 15ull) == 0) { const uint4* s4 = (const uint4*)src; uint4* d4 = (uint4*)dst; for (uint32_t k = threadIdx.x; k < n / 16u; k += blockDim.x) d4[k] = s4[k]; }
-        else for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) dst[k] = src[k];
+        const uint64_t c0 = cofs[j], c1 = c0 + n;
+        const uint64_t a = c0 > lo ? c0 : lo, b = c1 < hi ? c1 : hi;   // the part of this block that lives in [lo, hi)
+        if (a >= b) continue;
+        const uint8_t* src = gathered + (uint64_t)owner[item] * rankPitch + (a - lo);
+        uint8_t* d = dst + (a - c0);
+        const uint64_t len = b - a;
+        if ((((uint64_t)src | (uint64_t)d | len) & 15ull) == 0) { const uint4* s4 = (const uint4*)src; uint4* d4 = (uint4*)d; for (uint64_t k = threadIdx.x; k < len / 16u; k += blockDim.x) d4[k] = s4[k]; }
+        else for (uint64_t k = threadIdx.x; k < len; k += blockDim.x) d[k] = src[k];
     }
 }
 
@@ -385,13 +394,13 @@ void launch_shard_gather(const uint8_t* states, const uint64_t* stateOfs, const 
     const uint32_t grid = numOmms < 262144u ? numOmms : 262144u;
     hipLaunchKernelGGL(shard_gather_contribution, dim3(grid), dim3(256), 0, stream, states, stateOfs, active, owner, rank, order, cofs, sizes, numOmms, contrib);
 }
-void launch_shard_scatter(const uint8_t* gathered, uint64_t strideBytes, const uint8_t* active, const uint8_t* owner, const uint32_t* stateMask,
+void launch_shard_scatter(const uint8_t* gathered, uint64_t rankPitch, uint64_t lo, uint64_t hi, const uint8_t* active, const uint8_t* owner, const uint32_t* stateMask,
                           const uint8_t* level, int bits, const uint32_t* order, const uint64_t* cofs, const uint32_t* dstOfs, const uint32_t* sizes,
                           uint32_t numOmms, uint8_t* arrayData, hipStream_t stream)
 {
     if (numOmms == 0) return;
     const uint32_t grid = numOmms < 262144u ? numOmms : 262144u;
-    hipLaunchKernelGGL(shard_scatter_contributions, dim3(grid), dim3(256), 0, stream, gathered, strideBytes, active, owner, stateMask, level, bits, order, cofs,
+    hipLaunchKernelGGL(shard_scatter_contributions, dim3(grid), dim3(256), 0, stream, gathered, rankPitch, lo, hi, active, owner, stateMask, level, bits, order, cofs,
                        dstOfs, sizes, numOmms, arrayData);
 }
 

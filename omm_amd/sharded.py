@@ -1,7 +1,10 @@
-"""Multi-GPU driver of the sharded bake (include/omm_mi355x_ext.h: ommxSharded*).
+"""Python callers of the sharded bake (include/omm_mi355x_ext.h).  One process per GPU; all compute is inside libomm-lib.so.
 
-One process per GPU.  All compute is inside libomm-lib.so; this module only moves the two exchange buffers between ranks with
-torch.distributed (backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests):
+  * native path (what bench.py --gpus N runs): ommxShardedBakeRccl -- the library itself issues the two RCCL collectives from C++ on its own
+    streams.  This module only helps with the communicator bootstrap: rank 0 asks the library for an RCCL unique id, the 128 bytes travel
+    through torch.distributed, every rank joins with ommxRcclCommInitRank (rccl_comm()).
+  * caller-driven path (tests, transports other than RCCL): the four ommxSharded* phases with the two exchanges done here through
+    torch.distributed ("gloo" in the CPU tests):
 
     begin  ->  all_reduce(SUM) of 4 uint32 words per active work item  ->  tail  ->  all_gather of the padded block
     contributions  ->  finish (every rank ends with the identical merged arrayData / descArray / indexBuffer in HBM)
@@ -39,6 +42,40 @@ def allgather_padded(dist, torch, contribution, world):
         dist.all_gather(list(out.view(world, -1).unbind(0)), contribution)
     else:
         dist.all_gather_into_tensor(out, contribution)
+    return out
+
+
+def rccl_comm(dll, torch, dist, rank, world):
+    """RCCL communicator owned by the library: the unique id is created by rank 0's library and broadcast through torch.distributed
+    (any initialised backend), then every rank joins.  Destroy with dll.ommxRcclCommDestroy."""
+    dll.ommxRcclGetUniqueId.argtypes = [C.c_void_p, C.c_size_t]
+    dll.ommxRcclCommInitRank.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+    dll.ommxRcclCommDestroy.argtypes = [C.c_void_p]
+    buf = (C.c_uint8 * 128)()
+    if rank == 0:
+        r = dll.ommxRcclGetUniqueId(buf, 128)
+        if r != 0:
+            raise RuntimeError("ommxRcclGetUniqueId failed: %d (is librccl.so.1 loadable?)" % r)
+    if world > 1:
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor(list(buf), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, 0)
+        for i, v in enumerate(t.cpu().tolist()):
+            buf[i] = v
+    comm = C.c_void_p()
+    r = dll.ommxRcclCommInitRank(buf, 128, rank, world, C.byref(comm))
+    if r != 0:
+        raise RuntimeError("ommxRcclCommInitRank failed: %d" % r)
+    return comm
+
+
+def sharded_bake_rccl(dll, baker, desc_ptr, comm):
+    """One sharded bake with the collectives inside the library; returns the ommxDeviceBakeResult handle."""
+    dll.ommxShardedBakeRccl.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    out = C.c_void_p()
+    r = dll.ommxShardedBakeRccl(baker, desc_ptr, comm, C.byref(out))
+    if r != 0:
+        raise RuntimeError("ommxShardedBakeRccl failed: %d" % r)
     return out
 
 

@@ -21,5 +21,11 @@ dd = ot.BakeInputDesc.from_buffer_copy(d); dd.texCoords, dd.indexBuffer = duv.da
 out = sh.sharded_bake(prod.dll, b, C.byref(dd), 0, 1, torch, dist)
 res = ot.device_result_to_host(prod, ot.Hip(), out)
 assert res.same_as(ref), res.diff(ref)
+# the native path next to torch's own RCCL process group: communicator bootstrap through torch.distributed, collectives inside the library
+comm = sh.rccl_comm(prod.dll, torch, dist, 0, 1)
+out2 = sh.sharded_bake_rccl(prod.dll, b, C.byref(dd), comm)
+res2 = ot.device_result_to_host(prod, ot.Hip(), out2)
+assert res2.same_as(ref), res2.diff(ref)
+prod.dll.ommxRcclCommDestroy(comm)
 print("one-rank nccl plumbing ok", len(res.descs))
 dist.destroy_process_group()

@@ -374,6 +374,47 @@ def test_sharded_bake_equals_single_gpu(product, oracle, world):
             assert res.same_as(ref), "rank %d/%d: %s" % (r, world, res.diff(ref))
 
 
+def test_sharded_scatter_in_small_chunks(product, oracle, monkeypatch):
+    """The gathered contributions are scattered chunk by chunk (the RCCL path receives them that way).  With 4 KiB chunks every block of a
+    level >= 7 item (4 KiB and more) straddles chunk boundaries and is placed in pieces: 3 simulated ranks must still reproduce the oracle."""
+    monkeypatch.setenv("OMMX_SHARD_CHUNK_BYTES", "4352")
+    hip = ot.Hip()
+    tex = ot.foliage_texture(9, 1024, 1024, feature=40)
+    n = 1500
+    uv, ix = ot.random_triangles(4242, n, 0.03)
+    lv = (5 + ot.hash_u32(np.arange(n) + 11) % 4).astype(np.uint8)          # levels 5..8: blocks of 256 B .. 16 KiB
+    kwargs = dict(addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+    ob = oracle.create_baker()
+    otx = oracle.create_texture(ob, [tex], alpha_cutoff=0.5)
+    ref = oracle.bake(ob, ot.make_desc(otx, uv, ix, 8, levels=lv, **kwargs))
+    oracle.destroy_texture(ob, otx)
+    oracle.destroy_baker(ob)
+    b = product.create_baker()
+    t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+    d = ot.make_desc(t, uv, ix, 8, levels=lv, **kwargs)
+    per_rank = ot.bake_sharded_simulated(product, hip, b, d, uv, ix, 3, levels=lv)
+    product.destroy_texture(b, t)
+    product.destroy_baker(b)
+    assert len(ref.array_data) > 200000
+    for r, res in enumerate(per_rank):
+        assert res.same_as(ref), "rank %d: %s" % (r, res.diff(ref))
+
+
+def test_cpp_user_of_the_rccl_entry_point(tmp_path):
+    """examples/sharded_rccl.cpp: a C++ program (no Python, no torch) creates an RCCL communicator through the library, runs
+    ommxShardedBakeRccl -- ncclAllReduce / ncclAllGather issued by the library on its own streams -- and compares the merged result
+    byte for byte with ommxBakeDevice.  One rank here (one GPU per box); the same binary takes <rank> <world> <id-file> on a node."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "omm_amd", "lib")
+    exe = str(tmp_path / "sharded_rccl")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "sharded_rccl.cpp"), "-o", exe,
+                        "-L" + lib_dir, "-lomm-lib", "-Wl,-rpath," + lib_dir], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sharded == single-GPU" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def test_torch_distributed_plumbing_one_rank():
     """omm_amd/sharded.py over a real (1-rank) RCCL process group: raw-pointer tensor views, all_reduce, all_gather_into_tensor, and a
     sharded bake compared with ommCpuBake (the multi-rank exchange itself is covered by test_sharded_bake_equals_single_gpu and the gloo test)."""
