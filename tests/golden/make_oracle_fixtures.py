@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Oracle-output fixtures for the BASELINE.json configurations (SURVEY.md section 8c "golden vectors to commit" (ii)-(iii)).
+
+    python tests/golden/make_oracle_fixtures.py          (build container: runs the CPU oracle, ~2 minutes on 8 cores)
+
+Writes tests/golden/oracle_fixtures.json: for every case the workload recipe (seeds and sizes -- the generators are repository code,
+tests/ommtest.py + tests/native/kat_textures.c), the result counts, and XXH64(seed 0) of every result array.  tests/test_oracle_fixtures.py
+re-checks the oracle against the cheap cases on CPU and the HIP library against ALL of them on the GPU box -- there the product is compared
+with committed answers, not with an oracle computed next to it.
+
+The two C0 cases additionally carry the answers the SURVEY's probe obtained from the reference's own translation units
+(2-state 32 bytes FC FF..FF, one descriptor, index [0,0]; 4-state XXH64 1055f30807d9815f); the script refuses to
+write the file if the oracle does not reproduce them."""
+import json, os, sys
+import numpy as np
+import xxhash
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import ommtest as ot  # noqa: E402
+
+
+def workload(case):
+    k = case["kind"]
+    if k == "c0":
+        yy, xx = np.mgrid[0:256, 0:256]
+        tex = (((xx // 32) + (yy // 32)) & 1).astype(np.float32)
+        uv = np.array([[0, 0], [0, 1], [1, 0], [1, 1]], np.float32)       # the SDK tests' quad (test_omm_bake_cpu.cpp:594-595)
+        ix = np.array([0, 1, 2, 3, 1, 2], np.uint32)
+        return tex, uv, ix, None, dict(level=4, fmt=case["fmt"], addr=ot.CLAMP, promo=ot.PROMO_FORCE_OPAQUE)
+    if k == "c1":
+        tex = (ot.value_noise(77, 2048, 2048, octaves=5, base_cell=128) * 255).astype(np.uint8)
+        uv, ix = ot.random_triangles(78, case["tris"], 10.0 / 2048)
+        return tex, uv, ix, None, dict(level=6, fmt=ot.FMT_4STATE, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+    if k == "c2":
+        tex = ot.foliage_texture(1234, 4096, 4096, feature=64)
+        uv, ix = ot.random_triangles(1235, case["tris"], 8.0 / 4096)
+        return tex, uv, ix, None, dict(level=8, fmt=ot.FMT_4STATE, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+    if k == "c4":
+        n = case["tris"]
+        tex = ot.foliage_texture(4321, 8192, 8192, feature=96)
+        uv, ix = ot.random_triangles(9, n, 3.0 / 8192)
+        h = ot.hash_u32(np.arange(n) + 9000)
+        lv = (4 + (h >> 8) % 7).astype(np.uint8); lv[(h & 3) == 0] = 0xF
+        return tex, uv, ix, lv, dict(level=10, fmt=ot.FMT_4STATE, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, dyn_scale=2.0)
+    raise ValueError(k)
+
+
+def bake(lib, case):
+    tex, uv, ix, lv, kw = workload(case)
+    b = lib.create_baker()
+    t = lib.create_texture(b, [tex], alpha_cutoff=0.5)
+    level = kw.pop("level")
+    res = lib.bake(b, ot.make_desc(t, uv, ix, level, levels=lv, filt=ot.LINEAR, flags=ot.FLAG_THREADS, **kw))
+    lib.destroy_texture(b, t)
+    lib.destroy_baker(b)
+    return res
+
+
+def digest(res):
+    x = lambda a: xxhash.xxh64(np.ascontiguousarray(a).tobytes(), seed=0).hexdigest()
+    return {"arrayDataSize": int(res.array_data.size), "descArrayCount": int(len(res.descs)), "indexCount": int(res.index.size), "indexFormat": int(res.index_format),
+            "arrayData": x(res.array_data), "descArray": xxhash.xxh64(res.desc_bytes, seed=0).hexdigest(), "indexBuffer": x(res.index),
+            "descArrayHistogram": [list(map(int, h)) for h in res.array_hist], "indexHistogram": [list(map(int, h)) for h in res.index_hist],
+            "stats2": [int(v) for v in res.stats2_key()]}
+
+
+CASES = [
+    {"name": "C0_2state", "kind": "c0", "fmt": ot.FMT_2STATE, "cpu": True},
+    {"name": "C0_4state", "kind": "c0", "fmt": ot.FMT_4STATE, "cpu": True},
+    {"name": "C1_replica_2k", "kind": "c1", "tris": 2000, "cpu": True},
+    {"name": "C1_full_100k", "kind": "c1", "tris": 100000, "cpu": False},
+    {"name": "C2_replica_2k", "kind": "c2", "tris": 2000, "cpu": True},
+    {"name": "C2_replica_20k", "kind": "c2", "tris": 20000, "cpu": False},
+    {"name": "C4_replica_2k", "kind": "c4", "tris": 2000, "cpu": True},
+]
+
+if __name__ == "__main__":
+    orc = ot.Lib("oracle")
+    out = []
+    for case in CASES:
+        res = bake(orc, dict(case))
+        d = digest(res)
+        if case["name"] == "C0_2state":   # SURVEY.md section 8c, from the reference's own translation units
+            assert res.array_data.tobytes() == bytes([0xFC] + [0xFF] * 31) and d["descArrayCount"] == 1 and list(res.index) == [0, 0], "oracle does not reproduce the reference's C0 answer"
+            d["reference_answer"] = {"arrayData_hex": res.array_data.tobytes().hex(), "index": [0, 0], "source": "SURVEY.md section 8(c): reference TUs compiled during the survey"}
+        if case["name"] == "C0_4state":
+            assert d["arrayData"] == "1055f30807d9815f" and d["arrayDataSize"] == 64, "oracle does not reproduce the reference's C0 answer"
+            d["reference_answer"] = {"arrayData_xxh64_seed0": "1055f30807d9815f", "source": "SURVEY.md section 8(c): reference TUs compiled during the survey"}
+        out.append({"case": case, "expect": d})
+        print(case["name"], d["arrayDataSize"], d["descArrayCount"], d["arrayData"])
+    json.dump(out, open(os.path.join(HERE, "oracle_fixtures.json"), "w"), indent=1)

@@ -161,9 +161,13 @@ def test_uniform_ut_uo_merge_keeps_first(product, oracle):
 
 
 @pytest.mark.parametrize("count,allow8,force32,expect_fmt", [
-    (1, False, False, ot.IDX_U16), (127, False, False, ot.IDX_U16), (128, False, False, ot.IDX_U16), (32767, False, False, ot.IDX_U16),
-    (32768, False, False, ot.IDX_U32), (1, False, True, ot.IDX_U32), (127, True, False, ot.IDX_U8), (128, True, False, ot.IDX_U16),
-    (127, True, True, ot.IDX_U32)])
+    # every case of support/tests/test_omm_indexing.cpp:122-232, at the reference's triangle counts
+    (1, False, False, ot.IDX_U16), (127, False, False, ot.IDX_U16), (128, False, False, ot.IDX_U16), (32766, False, False, ot.IDX_U16),
+    (32767, False, False, ot.IDX_U16), (32768, False, False, ot.IDX_U32), (65536, False, False, ot.IDX_U32),
+    (1, False, True, ot.IDX_U32), (127, False, True, ot.IDX_U32), (128, False, True, ot.IDX_U32), (32766, False, True, ot.IDX_U32),
+    (32767, False, True, ot.IDX_U32), (32768, False, True, ot.IDX_U32),
+    (1, True, False, ot.IDX_U8), (127, True, False, ot.IDX_U8), (128, True, False, ot.IDX_U16), (32766, True, False, ot.IDX_U16), (65536, True, False, ot.IDX_U32),
+    (1, True, True, ot.IDX_U32), (127, True, True, ot.IDX_U32), (32766, True, True, ot.IDX_U32), (65536, True, True, ot.IDX_U32)])
 def test_index_formats(product, oracle, count, allow8, force32, expect_fmt):
     """support/tests/test_omm_indexing.cpp:122-232"""
     uv, ix = ot.random_triangles(91, count, 0.3)
@@ -183,6 +187,29 @@ def test_per_triangle_levels_and_dynamic(product, oracle):
     assert sum(c for c, l, f in r.array_hist) == n
     both(product, oracle, [noise_u8()], uv, ix, 7, dyn_scale=2.0, addr=ot.WRAP)
     both(product, oracle, [noise_u8()], uv, ix, 6, dyn_scale=0.7, addr=ot.WRAP, levels=lv)
+
+
+@pytest.mark.parametrize("glob,n_global,n0,n1,n2,n3,n4", [
+    # the parameter sets of support/tests/test_subdiv.cpp:255-350 (BakeSubDiv: Mixed, Mixed2, Lvl0Only .. Lvl4Only, LvlGlobalOnly)
+    (2, 8, 4, 7, 7, 7, 7), (4, 84, 234, 0, 23, 34, 57), (2, 0, 56, 0, 0, 0, 0), (2, 0, 0, 526, 0, 0, 0), (2, 0, 0, 0, 91, 0, 0), (2, 0, 0, 0, 0, 391, 0), (2, 0, 0, 0, 0, 0, 391), (4, 430, 0, 0, 0, 0, 0)])
+def test_subdiv_level_histograms(product, oracle, glob, n_global, n0, n1, n2, n3, n4):
+    """support/tests/test_subdiv.cpp:80-172: per-triangle subdivision levels (0xF = global), 1-texel checkerboard so that no OMM is uniform,
+    Nearest filter, special indices / dedup off.  The numbers the reference test carries are its level distributions: the descriptor
+    histogram must hold exactly that many OMMs per level (ValidateDesc, :55-78), descriptors come out in the spatial order with the
+    level in the key's top bits, and the whole result equals the oracle's."""
+    lv = np.array([0xF] * n_global + [0] * n0 + [1] * n1 + [2] * n2 + [3] * n3 + [4] * n4, np.uint8)
+    n = lv.size
+    lv = lv[np.argsort(ot.hash_u32(np.arange(n) + 32), kind="stable")]                      # a seeded shuffle
+    uv, ix = ot.random_triangles(32, n, 0.6)
+    yy, xx = np.mgrid[0:1024, 0:1024]
+    tex = ((xx % 2) == (yy % 2)).astype(np.float32)                                          # test_subdiv.cpp:88-93
+    flags = ot.FLAG_THREADS | ot.FLAG_NO_SPECIAL | ot.FLAG_FORCE32 | ot.FLAG_NO_DEDUP
+    r = both(product, oracle, [tex], uv, ix, glob, filt=ot.NEAREST, addr=ot.CLAMP, flags=flags, cutoff=0.3, levels=lv, sat=True)
+    want = {0: n0, 1: n1, 2: n2, 3: n3, 4: n4}
+    want[glob] += n_global
+    assert {int(l): int(c) for c, l, f in r.array_hist} == {l: c for l, c in want.items() if c}
+    assert len(r.descs) == n and r.index_format == ot.IDX_U32
+    assert np.all(np.diff(r.descs[:, 1]) <= 0)                                               # std::sort(greater) on (level << 60 | morton): high levels first
 
 
 def test_rejection_threshold(product, oracle):

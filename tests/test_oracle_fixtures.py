@@ -1,0 +1,48 @@
+"""Committed oracle-output fixtures for the BASELINE.json configurations (tests/golden/oracle_fixtures.json, made by
+tests/golden/make_oracle_fixtures.py): XXH64 of every result array + counts + ommDebugGetStats2.
+
+CPU: the oracle still reproduces the cheap cases (and, for C0, the answers of the reference's own translation units recorded in SURVEY.md 8c).
+GPU: the HIP library reproduces ALL of them -- a comparison with committed answers, independent of an oracle run on the same machine."""
+import json
+import os
+import sys
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import ommtest as ot                      # noqa: E402
+import make_oracle_fixtures as mk         # noqa: E402
+
+FIXTURES = json.load(open(os.path.join(HERE, "golden", "oracle_fixtures.json")))
+
+
+def check(lib, fx):
+    res = mk.bake(lib, dict(fx["case"]))
+    got, want = mk.digest(res), fx["expect"]
+    for k in want:
+        if k != "reference_answer":
+            assert got[k] == want[k], (fx["case"]["name"], k, got[k], want[k])
+    ref = want.get("reference_answer", {})
+    if "arrayData_hex" in ref:
+        assert res.array_data.tobytes().hex() == ref["arrayData_hex"] and list(res.index) == ref["index"]
+    if "arrayData_xxh64_seed0" in ref:
+        assert got["arrayData"] == ref["arrayData_xxh64_seed0"]
+
+
+def test_fixture_file_covers_the_baseline_configs():
+    names = {f["case"]["name"] for f in FIXTURES}
+    assert {"C0_2state", "C0_4state", "C1_full_100k", "C2_replica_20k", "C4_replica_2k"} <= names
+    c0 = {f["case"]["name"]: f["expect"] for f in FIXTURES}
+    assert c0["C0_2state"]["reference_answer"]["arrayData_hex"] == "fc" + "ff" * 31
+    assert c0["C0_4state"]["reference_answer"]["arrayData_xxh64_seed0"] == "1055f30807d9815f"
+
+
+@pytest.mark.parametrize("fx", [f for f in FIXTURES if f["case"]["cpu"]], ids=lambda f: f["case"]["name"])
+def test_oracle_reproduces_fixture(fx):
+    check(ot.Lib("oracle"), fx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fx", FIXTURES, ids=lambda f: f["case"]["name"])
+def test_hip_library_reproduces_fixture(fx):
+    check(ot.Lib("product"), fx)
