@@ -448,6 +448,7 @@ struct ShardCtx {
     uint8_t *dStates = nullptr, *dActive = nullptr, *dLevel = nullptr, *dScratch = nullptr; uint64_t* dStateOfs = nullptr; uint32_t *dMask = nullptr, *dActiveIds = nullptr;
     int32_t* dIndex = nullptr; uint32_t *dArrayHist = nullptr, *dIndexHist = nullptr;
     size_t scratchBytes = 0; uint32_t flags = 0, T = 0; int bits = 2; bool asyncBegin = false;
+    bool mergeStates = false;   // host-tail bakes: the packed states are zeroed first so that a SUM all-reduce over them is a merge
     int ev[5] = { -1, -1, -1, -1, -1 };   // HIP event marks of Begin: setup | triage | classify | digest
     // exchange buffers: carved from the session's arenas (tables: dMeta .. dTotals; xchg: contribution + gather staging), nothing to free
     uint32_t* dMeta = nullptr; uint8_t* dOwner = nullptr; uint64_t *dCofs = nullptr, *dTotals = nullptr; uint8_t *dContrib = nullptr, *dGathered = nullptr;
@@ -481,6 +482,62 @@ void setup_on_host(const ommCpuBakeInputDesc& d, uint32_t flags, const Texture& 
             triToItem[i] = (int32_t)id;
         } else triToItem[i] = (int32_t)it->second;
     }
+}
+
+// One byte per micro-triangle of every work item on the host, for the serial reducers (host_tail.cpp): near-duplicate merge and the
+// maxArrayDataSize budget work on the reference's own data layout (bake_cpu_impl.cpp:401-411).  Synchronises the stream.
+ommResult gather_host_items(const Logger& L, hipStream_t stream, uint32_t U, uint32_t T, const SetupCounters& hc, const float* dUv, const uint8_t* dLevel,
+                            const uint8_t* dActive, const uint32_t* dMask, const uint64_t* dStateOfs, const uint8_t* dStates, const int32_t* dTriToItem, int bits,
+                            std::vector<HostItem>& items)
+{
+    {   // refuse cleanly when that cannot fit in host memory instead of dying in std::bad_alloc half way
+        uint64_t bytes = hc.stateBytes; for (int l = 0; l < kNumLevels; ++l) bytes += (uint64_t)hc.levelCount[l] << (2 * l);
+        const uint64_t phys = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGE_SIZE);
+        if (bytes > phys / 2) return L.failure("[Failure] - near-duplicate merging / maxArrayDataSize need one byte per micro-triangle of every work item on the host: not enough host memory for this bake");
+    }
+    std::vector<float> hUv((size_t)U * 6); std::vector<uint8_t> hLevel(U), hActive(U), hStates((size_t)hc.stateBytes);
+    std::vector<uint32_t> hMask(U); std::vector<uint64_t> hOfs(U); std::vector<int32_t> hTri(T);
+    bool ok = true;
+    if (U) {
+        ok = HIP_OK(hipMemcpyAsync(hUv.data(), dUv, (size_t)U * 24, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipMemcpyAsync(hLevel.data(), dLevel, U, hipMemcpyDeviceToHost, stream))
+          && HIP_OK(hipMemcpyAsync(hActive.data(), dActive, U, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipMemcpyAsync(hMask.data(), dMask, (size_t)U * 4, hipMemcpyDeviceToHost, stream))
+          && HIP_OK(hipMemcpyAsync(hOfs.data(), dStateOfs, (size_t)U * 8, hipMemcpyDeviceToHost, stream));
+    }
+    if (ok && hc.stateBytes) ok = HIP_OK(hipMemcpyAsync(hStates.data(), dStates, (size_t)hc.stateBytes, hipMemcpyDeviceToHost, stream));
+    if (ok && T) ok = HIP_OK(hipMemcpyAsync(hTri.data(), dTriToItem, (size_t)T * 4, hipMemcpyDeviceToHost, stream));
+    ok = ok && HIP_OK(hipStreamSynchronize(stream));
+    if (!ok) return L.failure("[Failure] - device to host transfer of the micro-triangle states failed");
+    items.resize(U);
+    for (uint32_t i = 0; i < U; ++i) {
+        HostItem& it = items[i];
+        it.level = hLevel[i]; it.format = bits; memcpy(it.uv, &hUv[(size_t)i * 6], 24);
+        const size_t n = (size_t)1 << (2 * it.level);
+        it.st.resize(n);
+        if (!hActive[i]) { uint32_t st = 0; while (!((hMask[i] >> st) & 1u) && st < 3) ++st; memset(it.st.data(), (int)st, n); }
+        else {
+            const uint8_t* p = hStates.data() + hOfs[i];
+            if (bits == 2) for (size_t u = 0; u < n; ++u) it.st[u] = (p[u >> 2] >> ((u & 3) << 1)) & 3u;
+            else for (size_t u = 0; u < n; ++u) it.st[u] = (p[u >> 3] >> (u & 7)) & 1u;
+        }
+    }
+    for (uint32_t t = 0; t < T; ++t) if (hTri[t] >= 0) items[(size_t)hTri[t]].prims.push_back(t);
+    return ommResult_SUCCESS;
+}
+
+// the serial tail itself (reference: bake_cpu_impl.cpp:1068-1688 on the classified states) + index narrowing in place (:1872-1902)
+ommResult run_host_tail_for(const ommCpuBakeInputDesc& d, uint32_t T, std::vector<HostItem>& items, HostTailResult& hres, ommIndexFormat& ifmt)
+{
+    const uint32_t fl = (uint32_t)d.bakeFlags;
+    HostTailDesc td; td.format = (int)d.format; td.disableSpecial = (fl & (1u << 1)) != 0; td.disableDedup = (fl & (1u << 3)) != 0;
+    td.nearDup = (fl & (1u << 4)) != 0; td.nearDupBrute = (fl & (1u << 10)) != 0; td.rejectionThreshold = d.rejectionThreshold;
+    td.nearDupFactor = d.nearDuplicateDeduplicationFactor; td.maxArrayDataSize = d.maxArrayDataSize; td.numTris = T; td.unresolved = (int32_t)d.unresolvedTriState;
+    if (run_host_tail(td, items, hres)) return ommResult_FAILURE;
+    hres.index.resize(T ? T : 1);
+    ifmt = ommIndexFormat_UINT_32;
+    const bool allow8 = (fl & (1u << 6)) != 0, force32 = (fl & (1u << 2)) != 0;
+    if (allow8 && T <= 127 && !force32) { int8_t* p8 = (int8_t*)hres.index.data(); for (uint32_t i = 0; i < T; ++i) { const int32_t v = hres.index[i]; p8[i] = (int8_t)v; } ifmt = ommIndexFormat_UINT_8; }
+    else if (T <= 32767 && !force32) { int16_t* p16 = (int16_t*)hres.index.data(); for (uint32_t i = 0; i < T; ++i) { const int32_t v = hres.index[i]; p16[i] = (int16_t)v; } ifmt = ommIndexFormat_UINT_16; }
+    return ommResult_SUCCESS;
 }
 
 // The bake proper: bake_cpu_impl.cpp:1923-1985 re-organised for the device.  `din` points at device copies of the
@@ -644,6 +701,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     // ---- ResampleCoarse + ResampleFine (bake_cpu_impl.cpp:715-1029) on the active items ----
     ItemArrays A; A.uv = dUv; A.degenerate = dDegen; A.stateOfs = dStateOfs; A.states = dStates; A.stateMask = dMask; A.knownCount = dKnown; A.fineCount = dFine;
     if (!HIP_OK(hipMemsetAsync(dFine, 0, sizeof(unsigned long long) * kFineSlots * kFineStride, stream))) return L.failure("[Failure] - device memset failed");
+    if (sh && sh->mergeStates && !HIP_OK(hipMemsetAsync(dStates, 0, stateBytes, stream))) return L.failure("[Failure] - device memset failed");
     if (sh && sh->world > 1) { // even out the per-rank cost: interleave every level's active list (tail_kernels.hip: shard_interleave)
         // the permuted copy goes through the (idle) setup / tail scratch block: no allocation, no synchronisation, stream ordered
         uint32_t* tmp = (uint32_t*)dScratch;
@@ -662,41 +720,9 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     if (!HIP_OK(launch_classify(P, A, dActiveIds, lvlFirst, lvlCount, dTileQueue, dQueueCtl, device_cu_count(), stream))) return L.failure("[Failure] - kernel launch failed");
     const int e2 = et.mark();
     if (ht) { // bring the per-micro-triangle states to the host for the serial tail (host_tail.cpp)
-        // the serial reducers work on one byte per micro-triangle of EVERY work item, like the reference (bake_cpu_impl.cpp:401-411):
-        // refuse cleanly when that cannot fit in host memory instead of dying in std::bad_alloc half way
-        {
-            uint64_t bytes = hc.stateBytes; for (int l = 0; l < kNumLevels; ++l) bytes += (uint64_t)hc.levelCount[l] << (2 * l);
-            const uint64_t phys = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGE_SIZE);
-            if (bytes > phys / 2) return L.failure("[Failure] - near-duplicate merging / maxArrayDataSize need one byte per micro-triangle of every work item on the host: not enough host memory for this bake");
-        }
-        std::vector<float> hUv((size_t)U * 6); std::vector<uint8_t> hLevel(U), hActive(U), hStates((size_t)hc.stateBytes);
-        std::vector<uint32_t> hMask(U); std::vector<uint64_t> hOfs(U); std::vector<int32_t> hTri(T);
-        ok = true;
-        if (U) {
-            ok = HIP_OK(hipMemcpyAsync(hUv.data(), dUv, (size_t)U * 24, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipMemcpyAsync(hLevel.data(), dLevel, U, hipMemcpyDeviceToHost, stream))
-              && HIP_OK(hipMemcpyAsync(hActive.data(), dActive, U, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipMemcpyAsync(hMask.data(), dMask, (size_t)U * 4, hipMemcpyDeviceToHost, stream))
-              && HIP_OK(hipMemcpyAsync(hOfs.data(), dStateOfs, (size_t)U * 8, hipMemcpyDeviceToHost, stream));
-        }
-        if (ok && hc.stateBytes) ok = HIP_OK(hipMemcpyAsync(hStates.data(), dStates, (size_t)hc.stateBytes, hipMemcpyDeviceToHost, stream));
-        if (ok && T) ok = HIP_OK(hipMemcpyAsync(hTri.data(), dTriToItem, (size_t)T * 4, hipMemcpyDeviceToHost, stream));
-        ok = ok && HIP_OK(hipStreamSynchronize(stream));
-        if (!ok) return L.failure("[Failure] - device to host transfer of the micro-triangle states failed");
-        ht->items.resize(U);
-        for (uint32_t i = 0; i < U; ++i) {
-            HostItem& it = ht->items[i];
-            it.level = hLevel[i]; it.format = bits; memcpy(it.uv, &hUv[(size_t)i * 6], 24);
-            const size_t n = (size_t)1 << (2 * it.level);
-            it.st.resize(n);
-            if (!hActive[i]) { uint32_t st = 0; while (!((hMask[i] >> st) & 1u) && st < 3) ++st; memset(it.st.data(), (int)st, n); }
-            else {
-                const uint8_t* p = hStates.data() + hOfs[i];
-                if (bits == 2) for (size_t u = 0; u < n; ++u) it.st[u] = (p[u >> 2] >> ((u & 3) << 1)) & 3u;
-                else for (size_t u = 0; u < n; ++u) it.st[u] = (p[u >> 3] >> (u & 7)) & 1u;
-            }
-        }
-        for (uint32_t t = 0; t < T; ++t) if (hTri[t] >= 0) ht->items[(size_t)hTri[t]].prims.push_back(t);
+        const ommResult gr = gather_host_items(L, stream, U, T, hc, dUv, dLevel, dActive, dMask, dStateOfs, dStates, dTriToItem, bits, ht->items);
         tm.setupMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.uniqueItems = U;
-        return ommResult_SUCCESS;
+        return gr;
     }
     // ---- CalcDigest (bake_cpu_impl.cpp:1038-1040): active items here, uniform ones from the table in the tail ----
     if (!(flags & (1u << 3)))
@@ -781,12 +807,12 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
 
 inline bool wants_host_tail(const ommCpuBakeInputDesc& d) { return ((uint32_t)d.bakeFlags & ((1u << 4) | (1u << 10))) != 0 || d.maxArrayDataSize != 0xFFFFFFFFu; }
 
-ommResult scope_fences(const Baker& baker, const ommCpuBakeInputDesc& d, bool formatsOnHost)
+ommResult scope_fences(const Baker& baker, const ommCpuBakeInputDesc& d, bool formatsOnHost, bool hostTailOk = true)
 {
     const Logger& L = baker.log;
     const uint32_t flags = (uint32_t)d.bakeFlags;
-    if (wants_host_tail(d) && !formatsOnHost) // the serial reducers need the host: only ommCpuBake offers them
-        { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - near-duplicate merging / maxArrayDataSize budgets are only available through ommCpuBake"); return ommResult_NOT_IMPLEMENTED; }
+    if (wants_host_tail(d) && !hostTailOk) // the serial reducers run on the host over the merged states: not in the caller-driven four-phase protocol
+        { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - near-duplicate merging / maxArrayDataSize budgets are available through ommCpuBake, ommxBakeDevice and ommxShardedBakeRccl, not through ommxShardedBegin/Tail/Finish"); return ommResult_NOT_IMPLEMENTED; }
     if ((flags & ((1u << 7) | (1u << 8) | (1u << 9) | (1u << 11))) != 0)
         { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - internal bake flags (bits 7-11) are not supported"); return ommResult_NOT_IMPLEMENTED; }
     if (d.formats) { // the reference sizes its arrays from the global format only (bake_cpu_impl.cpp:1763-1772): mixed formats corrupt its heap
@@ -803,6 +829,34 @@ struct DeviceBakeResult {
     ommCpuOpacityMicromapUsageCount arrayHist[2 * kNumLevels], indexHist[2 * kNumLevels];
     ommCpuBakeResultDesc desc;
 };
+
+// result of the serial host tail -> device-resident result (ommxBakeDevice / ommxShardedBakeRccl with the opt-in lossy reducers)
+ommResult upload_host_tail(Baker& b, const HostTailResult& hres, ommIndexFormat ifmt, uint32_t T, int bits, hipStream_t stream, DeviceBakeResult* res)
+{
+    DeviceResult& R = res->R;
+    R.pool = b.devPool; R.bits = bits; R.numTris = T; R.indexFormat = ifmt;
+    const uint32_t E = (uint32_t)hres.descs.size();
+    R.numDescs = E; R.arrayDataSize = E ? hres.arrayData.size() : 0;
+    bool ok = true;
+    if (E) {
+        R.arrayData = (uint8_t*)R.dev_alloc(hres.arrayData.size()); R.descs = (ommCpuOpacityMicromapDesc*)R.dev_alloc(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E);
+        ok = R.arrayData && R.descs && HIP_OK(hipMemcpyAsync(R.arrayData, hres.arrayData.data(), hres.arrayData.size(), hipMemcpyHostToDevice, stream))
+          && HIP_OK(hipMemcpyAsync(R.descs, hres.descs.data(), sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, hipMemcpyHostToDevice, stream));
+    }
+    R.index = R.dev_alloc((size_t)(T ? T : 1) * 4);
+    ok = ok && R.index && (!T || HIP_OK(hipMemcpyAsync(R.index, hres.index.data(), (size_t)T * 4, hipMemcpyHostToDevice, stream)));
+    ok = ok && HIP_OK(hipStreamSynchronize(stream));
+    if (!ok) return b.log.failure("[Failure] - could not materialise the bake result on the device");
+    const size_t nAH = hres.arrayHist.size() < 2 * (size_t)kNumLevels ? hres.arrayHist.size() : 2 * (size_t)kNumLevels, nIH = hres.indexHist.size() < 2 * (size_t)kNumLevels ? hres.indexHist.size() : 2 * (size_t)kNumLevels;
+    memcpy(res->arrayHist, hres.arrayHist.data(), sizeof(ommCpuOpacityMicromapUsageCount) * nAH);
+    memcpy(res->indexHist, hres.indexHist.data(), sizeof(ommCpuOpacityMicromapUsageCount) * nIH);
+    res->desc.arrayData = E ? R.arrayData : nullptr; res->desc.arrayDataSize = (uint32_t)R.arrayDataSize;
+    res->desc.descArray = E ? R.descs : nullptr; res->desc.descArrayCount = E;
+    res->desc.descArrayHistogram = res->arrayHist; res->desc.descArrayHistogramCount = (uint32_t)nAH;
+    res->desc.indexBuffer = R.index; res->desc.indexCount = T; res->desc.indexFormat = ifmt;
+    res->desc.indexHistogram = res->indexHist; res->desc.indexHistogramCount = (uint32_t)nIH;
+    return ommResult_SUCCESS;
+}
 
 struct BakeSession { // device working set + streams of one bake in flight
     std::shared_ptr<ArenaPool> pool; std::unique_ptr<ArenaSet> set; DeviceArena* arena; DeviceArena* states; hipStream_t stream = nullptr, commStream = nullptr;
@@ -859,12 +913,8 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
         HostTailRequest ht;
         const ommResult hr = bake_core(baker, d, din, &d, ses.arena, ses.states, stream, et, R, tm, nullptr, &ht);
         if (hr != ommResult_SUCCESS) return hr;
-        const uint32_t fl = (uint32_t)d.bakeFlags;
-        HostTailDesc td; td.format = (int)d.format; td.disableSpecial = (fl & (1u << 1)) != 0; td.disableDedup = (fl & (1u << 3)) != 0;
-        td.nearDup = (fl & (1u << 4)) != 0; td.nearDupBrute = (fl & (1u << 10)) != 0; td.rejectionThreshold = d.rejectionThreshold;
-        td.nearDupFactor = d.nearDuplicateDeduplicationFactor; td.maxArrayDataSize = d.maxArrayDataSize; td.numTris = T; td.unresolved = (int32_t)d.unresolvedTriState;
-        HostTailResult hres;
-        if (run_host_tail(td, ht.items, hres)) return ommResult_FAILURE;
+        HostTailResult hres; ommIndexFormat ifmt = ommIndexFormat_UINT_32;
+        if (run_host_tail_for(d, T, ht.items, hres, ifmt) != ommResult_SUCCESS) return ommResult_FAILURE;
         BakeResult* res = baker.mem.make<BakeResult>();
         if (!res) return ommResult_FAILURE;
         res->mem = baker.mem;
@@ -884,10 +934,6 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
         memcpy(res->index, hres.index.data(), sizeof(int32_t) * (size_t)T);
         memcpy(res->arrayHist, hres.arrayHist.data(), sizeof(ommCpuOpacityMicromapUsageCount) * hres.arrayHist.size());
         memcpy(res->indexHist, hres.indexHist.data(), sizeof(ommCpuOpacityMicromapUsageCount) * hres.indexHist.size());
-        ommIndexFormat ifmt = ommIndexFormat_UINT_32; // index narrowing in place (bake_cpu_impl.cpp:1872-1902)
-        const bool allow8 = (fl & (1u << 6)) != 0, force32 = (fl & (1u << 2)) != 0;
-        if (allow8 && T <= 127 && !force32) { int8_t* p8 = (int8_t*)res->index; for (uint32_t i = 0; i < T; ++i) { const int32_t v = res->index[i]; p8[i] = (int8_t)v; } ifmt = ommIndexFormat_UINT_8; }
-        else if (T <= 32767 && !force32) { int16_t* p16 = (int16_t*)res->index; for (uint32_t i = 0; i < T; ++i) { const int32_t v = res->index[i]; p16[i] = (int16_t)v; } ifmt = ommIndexFormat_UINT_16; }
         res->desc.arrayData = E ? res->arrayData : nullptr; res->desc.arrayDataSize = E ? (uint32_t)hres.arrayData.size() : 0;
         res->desc.descArray = E ? res->descs : nullptr; res->desc.descArrayCount = E;
         res->desc.descArrayHistogram = res->arrayHist; res->desc.descArrayHistogramCount = (uint32_t)hres.arrayHist.size();
@@ -1273,6 +1319,19 @@ OMM_MI355X_API ommResult ommxBakeDevice(ommBaker baker, const ommCpuBakeInputDes
     EventTimer et(ses.stream);
     ommxBakeTimings tm; memset(&tm, 0, sizeof tm);
     DeviceInputs din; din.texCoords = desc->texCoords; din.indices = desc->indexBuffer; din.perTriLevels = desc->subdivisionLevels;
+    if (wants_host_tail(*desc)) {
+        // near-duplicate merge / size budget: classification on the device, the reference's serial tail on the host, result uploaded again
+        HostTailRequest ht; DeviceResult scratchR;
+        ommResult hr = bake_core(*b, *desc, din, nullptr, ses.arena, ses.states, ses.stream, et, scratchR, tm, nullptr, &ht);
+        HostTailResult hres; ommIndexFormat ifmt = ommIndexFormat_UINT_32;
+        if (hr == ommResult_SUCCESS) hr = run_host_tail_for(*desc, desc->indexCount / 3u, ht.items, hres, ifmt);
+        if (hr == ommResult_SUCCESS) hr = upload_host_tail(*b, hres, ifmt, desc->indexCount / 3u, (int)desc->format, ses.stream, res);
+        if (hr != ommResult_SUCCESS) { (void)hipStreamSynchronize(ses.stream); b->mem.destroy(res); return hr; }
+        tm.totalMs = (float)(now_ms() - t0);
+        { std::lock_guard<std::mutex> g(b->timingsMu); b->timings = tm; b->haveTimings = true; }
+        *outResult = (ommxDeviceBakeResult)res;
+        return ommResult_SUCCESS;
+    }
     r = bake_core(*b, *desc, din, nullptr, ses.arena, ses.states, ses.stream, et, res->R, tm);
     if (r != ommResult_SUCCESS) { (void)hipStreamSynchronize(ses.stream); b->mem.destroy(res); return r; } // (pooled blocks go back only when the stream is idle)
     uint32_t nAH = 0, nIH = 0;
@@ -1351,7 +1410,7 @@ uint64_t shard_chunk_bytes(uint64_t strideBytes)
     return ((((strideBytes + chunks - 1) / chunks) + 255) & ~255ull);
 }
 
-ommResult sharded_checks(ommBaker baker, const ommCpuBakeInputDesc* desc, Baker** outB)
+ommResult sharded_checks(ommBaker baker, const ommCpuBakeInputDesc* desc, Baker** outB, bool hostTailOk)
 {
     if (baker == 0) return ommResult_INVALID_ARGUMENT;
     Baker* b = untag<Baker>(baker);
@@ -1364,7 +1423,7 @@ ommResult sharded_checks(ommBaker baker, const ommCpuBakeInputDesc* desc, Baker*
         return ommResult_FAILURE;
     ommResult r = validate_desc(*b, *desc);
     if (r != ommResult_SUCCESS) return r;
-    r = scope_fences(*b, *desc, false);
+    r = scope_fences(*b, *desc, false, hostTailOk);
     if (r != ommResult_SUCCESS) return r;
     *outB = b;
     return ommResult_SUCCESS;
@@ -1372,13 +1431,13 @@ ommResult sharded_checks(ommBaker baker, const ommCpuBakeInputDesc* desc, Baker*
 
 // phase 1: replicated setup + triage, classification and digests of this rank's share, metadata words packed for the all-reduce.
 // async: nothing is synchronised at the end (the RCCL all-reduce follows on the same stream).
-ommResult sharded_begin(Baker* b, const ommCpuBakeInputDesc* desc, uint32_t rank, uint32_t worldSize, bool async, ShardedBake** out)
+ommResult sharded_begin(Baker* b, const ommCpuBakeInputDesc* desc, uint32_t rank, uint32_t worldSize, bool async, ShardedBake** out, bool mergeStates = false)
 {
     ShardedBake* sb = b->mem.make<ShardedBake>(*b);
     if (!sb) return ommResult_FAILURE;
     sb->mem = b->mem; sb->t0 = now_ms();
     if (!sb->ses.open()) { b->mem.destroy(sb); return b->log.failure("[Failure] - no usable HIP device (the MI355X baker has no CPU fallback)"); }
-    sb->ctx.rank = rank; sb->ctx.world = worldSize; sb->ctx.asyncBegin = async;
+    sb->ctx.rank = rank; sb->ctx.world = worldSize; sb->ctx.asyncBegin = async; sb->ctx.mergeStates = mergeStates;
     sb->et.reset(new EventTimer(sb->ses.stream));
     DeviceResult unused;
     DeviceInputs din; din.texCoords = desc->texCoords; din.indices = desc->indexBuffer; din.perTriLevels = desc->subdivisionLevels;
@@ -1467,7 +1526,7 @@ OMM_MI355X_API ommResult ommxShardedBegin(ommBaker baker, const ommCpuBakeInputD
 {
     Baker* b = nullptr;
     if (out == 0) return ommResult_INVALID_ARGUMENT;
-    const ommResult r = sharded_checks(baker, desc, &b);
+    const ommResult r = sharded_checks(baker, desc, &b, false);
     if (r != ommResult_SUCCESS) return r;
     if (worldSize == 0 || worldSize > (uint32_t)kMaxRanks || rank >= worldSize) return b->log.invalid("[Invalid Argument] - rank / worldSize out of range (at most 16 ranks)");
     return guarded(&b->log, [&]() -> ommResult {
@@ -1578,7 +1637,7 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
 {
     Baker* b = nullptr;
     if (comm == 0 || outResult == nullptr) return ommResult_INVALID_ARGUMENT;
-    const ommResult r0 = sharded_checks(baker, desc, &b);
+    const ommResult r0 = sharded_checks(baker, desc, &b, true);
     if (r0 != ommResult_SUCCESS) return r0;
     const Logger& L = b->log;
     if (!rccl().ok()) return L.failure(("[Failure] - RCCL is not available: " + rccl().error).c_str());
@@ -1588,12 +1647,35 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
             char buf[256]; snprintf(buf, sizeof buf, "[Failure] - %s: %s", what, rccl().getErrorString ? rccl().getErrorString(code) : "RCCL error");
             return L.failure(buf);
         };
+        const bool hostTail = wants_host_tail(*desc);
         ShardedBake* sb = nullptr;
-        ommResult r = sharded_begin(b, desc, (uint32_t)rc->rank, (uint32_t)rc->world, true, &sb);
+        ommResult r = sharded_begin(b, desc, (uint32_t)rc->rank, (uint32_t)rc->world, true, &sb, hostTail);
         if (r != ommResult_SUCCESS) return r;
         struct Owner { Baker* b; ShardedBake* sb; ~Owner() { b->mem.destroy(sb); } } owner{ b, sb };
         ShardCtx& c = sb->ctx; hipStream_t stream = sb->ses.stream;
         const double t1 = now_ms();
+        if (hostTail) {
+            // opt-in lossy reducers (near-duplicate merge, maxArrayDataSize): the serial reference algorithms need the states of ALL work items.
+            // Every rank classified its share into a zeroed buffer, so SUM all-reduces of the metadata words and of the packed states merge
+            // them; each rank then runs the identical serial tail on the host and uploads the (identical) result.
+            const size_t words = 4ull * c.hc.activeStart[kNumLevels], stateWords = (size_t)(c.hc.stateBytes / 4);
+            int e = words ? rccl().allReduce(c.dMeta, c.dMeta, words, kRcclUint32, kRcclSum, rc->comm, stream) : 0;
+            if (e == 0 && stateWords) e = rccl().allReduce(c.dStates, c.dStates, stateWords, kRcclUint32, kRcclSum, rc->comm, stream);
+            if (e != 0) return nccl_fail(e, "ncclAllReduce of the micro-triangle states");
+            launch_shard_unpack_meta(c.bounds, c.dActiveIds, c.hc.activeStart[kNumLevels], c.dMeta, c.dMask, (uint32_t*)c.ti.knownCount, c.ti.digests, c.dOwner, stream);
+            std::vector<HostItem> items;
+            r = gather_host_items(L, stream, c.ti.numItems, c.T, c.hc, c.ti.uv, c.dLevel, c.dActive, c.dMask, c.dStateOfs, c.dStates, c.ti.triToItem, c.bits, items);
+            HostTailResult hres; ommIndexFormat ifmt = ommIndexFormat_UINT_32;
+            if (r == ommResult_SUCCESS) r = run_host_tail_for(*desc, c.T, items, hres, ifmt);
+            if (r != ommResult_SUCCESS) return r;
+            DeviceBakeResult* res = b->mem.make<DeviceBakeResult>();
+            if (!res) return ommResult_FAILURE;
+            res->mem = b->mem; memset(&res->desc, 0, sizeof res->desc);
+            r = upload_host_tail(*b, hres, ifmt, c.T, c.bits, stream, res);
+            if (r != ommResult_SUCCESS) { b->mem.destroy(res); return r; }
+            *outResult = (ommxDeviceBakeResult)res;
+            return ommResult_SUCCESS;
+        }
         // exchange 1: per-item metadata, SUM all-reduce in place, on the bake's own stream right behind the digests
         const size_t words = 4ull * c.hc.activeStart[kNumLevels];
         if (words) { const int e = rccl().allReduce(c.dMeta, c.dMeta, words, kRcclUint32, kRcclSum, rc->comm, stream); if (e != 0) return nccl_fail(e, "ncclAllReduce of the work-item metadata"); }

@@ -11,7 +11,8 @@
 // The one libm-dependent piece -- log2f in the edge heuristic for degenerate triangles under dynamic subdivision
 // (bake_cpu_impl.cpp:511-528) -- is not evaluated here: such triangles are reported in `pending` for the host.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <string.h>
+#include <rocprim/rocprim.hpp>
 #include <stdint.h>
 #include "bake_types.h"
 #include "bake_kernels.h"
@@ -237,10 +238,10 @@ size_t setup_scratch_bytes(uint32_t numTris)
 {
     const size_t n = numTris ? numTris : 1;
     size_t a = 0, b = 0, c = 0, d = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
-    (void)hipcub::DeviceScan::InclusiveScan(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, hipcub::Max(), (int)n);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, c, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, d, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+    (void)rocprim::radix_sort_pairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n);
+    (void)rocprim::inclusive_scan(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, rocprim::maximum<uint32_t>());
+    (void)rocprim::exclusive_scan(nullptr, c, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>());
+    (void)rocprim::radix_sort_pairs(nullptr, d, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n);
     size_t m = a; if (b > m) m = b; if (c > m) m = c; if (d > m) m = d;
     const size_t p256 = 256;
     auto pad = [&](size_t v) { return (v + p256 - 1) / p256 * p256; };
@@ -252,7 +253,7 @@ size_t setup_scratch_bytes(uint32_t numTris)
 // fixes those levels and calls setup_rehash().  phase B: dedup + item emission + level grouping.
 struct SetupScratch {
     float* triUv; uint64_t *keysA, *keysB; uint32_t *trisA, *trisB, *headPos, *headScan, *firstTri, *isItem, *itemOfTri, *pending, *lkeysA, *lkeysB;
-    uint8_t *triLevel, *triFlags; void* cub; size_t cubBytes;
+    uint8_t *triLevel, *triFlags; void* tmp; size_t tmpBytes;
 };
 static SetupScratch carve_setup(void* base, size_t bytes, uint32_t numTris)
 {
@@ -267,7 +268,7 @@ static SetupScratch carve_setup(void* base, size_t bytes, uint32_t numTris)
     s.triLevel = p; p += pad(n); s.triFlags = p; p += pad(n);
     s.pending = (uint32_t*)p; p += pad(n * 4);
     s.lkeysA = (uint32_t*)p; p += pad(n * 4); s.lkeysB = (uint32_t*)p; p += pad(n * 4);
-    s.cub = p; s.cubBytes = bytes - (size_t)(p - (uint8_t*)base);
+    s.tmp = p; s.tmpBytes = bytes - (size_t)(p - (uint8_t*)base);
     return s;
 }
 
@@ -342,19 +343,19 @@ hipError_t run_setup_items(const SetupParams& S, void* scratch, size_t scratchBy
     SetupScratch s = carve_setup(scratch, scratchBytes, n);
     const dim3 grid((n + 255u) / 256u), block(256);
     if (triArea) hipLaunchKernelGGL(setup_tri_areas, grid, block, 0, stream, s.triUv, s.triFlags, n, triArea);
-    size_t tb = s.cubBytes;
-    SETUP_CHECK(hipcub::DeviceRadixSort::SortPairs(s.cub, tb, s.keysA, s.keysB, s.trisA, s.trisB, (int)n, 0, 64, stream));
+    size_t tb = s.tmpBytes;
+    SETUP_CHECK(rocprim::radix_sort_pairs(s.tmp, tb, s.keysA, s.keysB, s.trisA, s.trisB, (size_t)n, (unsigned)0, (unsigned)64, stream));
     hipLaunchKernelGGL(setup_heads, grid, block, 0, stream, s.keysB, s.trisB, n, s.triUv, s.triLevel, s.headPos, counters);
-    tb = s.cubBytes;
-    SETUP_CHECK(hipcub::DeviceScan::InclusiveScan(s.cub, tb, s.headPos, s.headScan, hipcub::Max(), (int)n, stream));
+    tb = s.tmpBytes;
+    SETUP_CHECK(rocprim::inclusive_scan(s.tmp, tb, s.headPos, s.headScan, (size_t)n, rocprim::maximum<uint32_t>(), stream));
     hipLaunchKernelGGL(setup_first_tri, grid, block, 0, stream, s.trisB, s.headScan, n, s.triFlags, s.firstTri, s.isItem);
-    tb = s.cubBytes;
-    SETUP_CHECK(hipcub::DeviceScan::ExclusiveSum(s.cub, tb, s.isItem, s.itemOfTri, (int)n, stream));
+    tb = s.tmpBytes;
+    SETUP_CHECK(rocprim::exclusive_scan(s.tmp, tb, s.isItem, s.itemOfTri, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>(), stream));
     hipLaunchKernelGGL(setup_emit_items, grid, block, 0, stream, S, s.triUv, s.triLevel, s.triFlags, s.firstTri, s.isItem, s.itemOfTri, itemUv, itemLevel,
                        itemDegenerate, triToItem, s.lkeysA, s.trisA, counters);
     hipLaunchKernelGGL(setup_level_keys, grid, block, 0, stream, itemLevel, counters, n, s.lkeysA, s.trisA);
-    tb = s.cubBytes;
-    SETUP_CHECK(hipcub::DeviceRadixSort::SortPairs(s.cub, tb, s.lkeysA, s.lkeysB, s.trisA, itemIds, (int)n, 0, 4, stream));
+    tb = s.tmpBytes;
+    SETUP_CHECK(rocprim::radix_sort_pairs(s.tmp, tb, s.lkeysA, s.lkeysB, s.trisA, itemIds, (size_t)n, (unsigned)0, (unsigned)4, stream));
     hipLaunchKernelGGL(setup_level_starts, dim3(1), dim3(64), 0, stream, counters);
     return hipGetLastError();
 }

@@ -6,9 +6,10 @@
 //   * exact dedup     = stable radix sort of (digest, item) + segment heads  -> rep[item] = lowest item with that digest
 //   * spatial order   = stable radix sort ascending of (key, item), read back to front
 //                       == std::sort(std::greater<pair<key,item>>)
-// rocPRIM/hipCUB radix sort and scan are the only library calls.
+// rocPRIM radix sort, scan and reduce are the only library calls.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <string.h>
+#include <rocprim/rocprim.hpp>
 #include <stdint.h>
 #include "bake_types.h"
 #include "bake_kernels.h"
@@ -215,13 +216,13 @@ hipError_t run_prep(const uint32_t* itemIds, const uint8_t* active, const uint8_
     const size_t n64 = (((size_t)n + 1) * 8 + 255) / 256 * 256, n32 = (((size_t)n + 1) * 4 + 255) / 256 * 256;
     uint64_t* sizes = (uint64_t*)p; p += n64; uint64_t* ofs = (uint64_t*)p; p += n64;
     uint32_t* flags = (uint32_t*)p; p += n32; uint32_t* pos = (uint32_t*)p; p += n32;
-    void* cub = p; size_t cubBytes = scratchBytes - (size_t)(p - (uint8_t*)scratch);
+    void* tmp = p; size_t tmpBytes = scratchBytes - (size_t)(p - (uint8_t*)scratch);
     const dim3 grid((n + 255u) / 256u), block(256);
     hipLaunchKernelGGL(prep_flags, grid, block, 0, stream, itemIds, active, level, bits, counters, n, flags, sizes);
-    size_t tb = cubBytes;
-    TAIL_CHECK(hipcub::DeviceScan::ExclusiveSum(cub, tb, flags, pos, (int)n, stream));
-    tb = cubBytes;
-    TAIL_CHECK(hipcub::DeviceScan::ExclusiveSum(cub, tb, sizes, ofs, (int)n, stream));
+    size_t tb = tmpBytes;
+    TAIL_CHECK(rocprim::exclusive_scan(tmp, tb, flags, pos, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    tb = tmpBytes;
+    TAIL_CHECK(rocprim::exclusive_scan(tmp, tb, sizes, ofs, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), stream));
     hipLaunchKernelGGL(prep_scatter, grid, block, 0, stream, itemIds, flags, pos, ofs, sizes, n, counters, activeIds, stateOfs);
     return hipGetLastError();
 }
@@ -323,12 +324,12 @@ hipError_t run_shard_layout(const uint32_t* order, const uint32_t* sizes, const 
     uint8_t* p = (uint8_t*)scratch;
     const size_t n64 = (((size_t)numOmms + 1) * 8 + 255) / 256 * 256;
     uint64_t* masked = (uint64_t*)p; p += n64; uint64_t* scan = (uint64_t*)p; p += n64;
-    void* cub = p; const size_t cubBytes = scratchBytes - (size_t)(p - (uint8_t*)scratch);
+    void* tmp = p; const size_t tmpBytes = scratchBytes - (size_t)(p - (uint8_t*)scratch);
     const dim3 grid((numOmms + 255u) / 256u), block(256);
     for (uint32_t r = 0; r < world; ++r) {
         hipLaunchKernelGGL(shard_masked_sizes, grid, block, 0, stream, order, sizes, active, owner, numOmms, r, masked);
-        size_t tb = cubBytes;
-        TAIL_CHECK(hipcub::DeviceScan::ExclusiveSum(cub, tb, masked, scan, (int)numOmms, stream));
+        size_t tb = tmpBytes;
+        TAIL_CHECK(rocprim::exclusive_scan(tmp, tb, masked, scan, (uint64_t)0, (size_t)numOmms, rocprim::plus<uint64_t>(), stream));
         hipLaunchKernelGGL(shard_take_offsets, grid, block, 0, stream, order, active, owner, masked, scan, numOmms, r, cofs, totalsDev);
     }
     TAIL_CHECK(hipMemcpyAsync(totalsHost, totalsDev, sizeof(uint64_t) * world, hipMemcpyDeviceToHost, stream));
@@ -409,18 +410,18 @@ struct Scratch {
     uint64_t *keysA, *keysB, *sizes64, *ofs64;
     uint32_t *valsA, *valsB, *headPos, *headScan, *emitted, *numEmitted;
     uint64_t* total;
-    void* cub; size_t cubBytes;
+    void* tmp; size_t tmpBytes;
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static size_t cub_bytes(uint32_t n)
+static size_t prim_temp_bytes(uint32_t n)
 {
     size_t a = 0, b = 0, c = 0, d = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
-    (void)hipcub::DeviceScan::InclusiveScan(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, hipcub::Max(), (int)n);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, c, (uint64_t*)nullptr, (uint64_t*)nullptr, (int)n);
-    (void)hipcub::DeviceReduce::Sum(nullptr, d, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+    (void)rocprim::radix_sort_pairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n);
+    (void)rocprim::inclusive_scan(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, rocprim::maximum<uint32_t>());
+    (void)rocprim::exclusive_scan(nullptr, c, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>());
+    (void)rocprim::reduce(nullptr, d, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>());
     size_t m = a; if (b > m) m = b; if (c > m) m = c; if (d > m) m = d;
     return align_up(m, 256) + 256;
 }
@@ -433,7 +434,7 @@ static Scratch carve(void* base, uint32_t n)
     s.valsA = (uint32_t*)p; p += n32; s.valsB = (uint32_t*)p; p += n32; s.headPos = (uint32_t*)p; p += n32; s.headScan = (uint32_t*)p; p += n32;
     s.emitted = (uint32_t*)p; p += n32;
     s.numEmitted = (uint32_t*)p; p += 256; s.total = (uint64_t*)p; p += 256;
-    s.cub = p; s.cubBytes = cub_bytes(n);
+    s.tmp = p; s.tmpBytes = prim_temp_bytes(n);
     return s;
 }
 
@@ -441,7 +442,7 @@ size_t tail_scratch_bytes(uint32_t numItems, uint32_t numTris)
 {
     (void)numTris;
     const uint32_t n = numItems ? numItems : 1;
-    return 4 * align_up((size_t)n * 8, 256) + 5 * align_up((size_t)n * 4, 256) + 512 + cub_bytes(n);
+    return 4 * align_up((size_t)n * 8, 256) + 5 * align_up((size_t)n * 4, 256) + 512 + prim_temp_bytes(n);
 }
 
 hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch, size_t scratchBytes, TailCounts* counts, hipStream_t stream)
@@ -459,23 +460,23 @@ hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch,
         if (in.disableDedup) {
             hipLaunchKernelGGL(tail_iota, grid, block, 0, stream, out.rep, n);
         } else {
-            size_t tb = s.cubBytes;
-            TAIL_CHECK(hipcub::DeviceRadixSort::SortPairs(s.cub, tb, s.keysA, s.keysB, s.valsA, s.valsB, (int)n, 0, 64, stream));
+            size_t tb = s.tmpBytes;
+            TAIL_CHECK(rocprim::radix_sort_pairs(s.tmp, tb, s.keysA, s.keysB, s.valsA, s.valsB, (size_t)n, (unsigned)0, (unsigned)64, stream));
             hipLaunchKernelGGL(tail_head_pos, grid, block, 0, stream, s.keysB, n, s.headPos);
-            tb = s.cubBytes;
-            TAIL_CHECK(hipcub::DeviceScan::InclusiveScan(s.cub, tb, s.headPos, s.headScan, hipcub::Max(), (int)n, stream));
+            tb = s.tmpBytes;
+            TAIL_CHECK(rocprim::inclusive_scan(s.tmp, tb, s.headPos, s.headScan, (size_t)n, rocprim::maximum<uint32_t>(), stream));
             hipLaunchKernelGGL(tail_assign_rep, grid, block, 0, stream, s.valsB, s.headScan, n, out.rep);
         }
         hipLaunchKernelGGL(tail_sort_keys, grid, block, 0, stream, in, out.special, out.rep, s.keysA, s.emitted);
         hipLaunchKernelGGL(tail_iota, grid, block, 0, stream, s.valsA, n);
-        size_t tb = s.cubBytes;
-        TAIL_CHECK(hipcub::DeviceReduce::Sum(s.cub, tb, s.emitted, s.numEmitted, (int)n, stream));
-        tb = s.cubBytes;
-        TAIL_CHECK(hipcub::DeviceRadixSort::SortPairs(s.cub, tb, s.keysA, s.keysB, s.valsA, s.valsB, (int)n, 0, 64, stream));
+        size_t tb = s.tmpBytes;
+        TAIL_CHECK(rocprim::reduce(s.tmp, tb, s.emitted, s.numEmitted, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>(), stream));
+        tb = s.tmpBytes;
+        TAIL_CHECK(rocprim::radix_sort_pairs(s.tmp, tb, s.keysA, s.keysB, s.valsA, s.valsB, (size_t)n, (unsigned)0, (unsigned)64, stream));
         TAIL_CHECK(hipMemsetAsync(s.sizes64, 0, (size_t)n * 8, stream));
         hipLaunchKernelGGL(tail_order_sizes, grid, block, 0, stream, s.valsB, s.numEmitted, in.level, in.format, out.order, s.sizes64, out.sizes, out.arrayHist);
-        tb = s.cubBytes;
-        TAIL_CHECK(hipcub::DeviceScan::ExclusiveSum(s.cub, tb, s.sizes64, s.ofs64, (int)n, stream));
+        tb = s.tmpBytes;
+        TAIL_CHECK(rocprim::exclusive_scan(s.tmp, tb, s.sizes64, s.ofs64, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), stream));
         hipLaunchKernelGGL(tail_item_values, grid, block, 0, stream, out.order, s.numEmitted, s.ofs64, out.dstOfs, out.special, n, out.itemValue);
         // total = ofs[n-1] + sizes[n-1] (entries past numEmitted are zero-sized)
         uint32_t E = 0, err = 0; uint64_t lastOfs = 0, lastSize = 0;

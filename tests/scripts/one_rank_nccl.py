@@ -26,6 +26,13 @@ comm = sh.rccl_comm(prod.dll, torch, dist, 0, 1)
 out2 = sh.sharded_bake_rccl(prod.dll, b, C.byref(dd), comm)
 res2 = ot.device_result_to_host(prod, ot.Hip(), out2)
 assert res2.same_as(ref), res2.diff(ref)
+# ... and with the opt-in size budget: states merged by ncclAllReduce, serial tail on the host, result uploaded (== ommCpuBake with the same budget)
+d3 = ot.BakeInputDesc.from_buffer_copy(d); d3.maxArrayDataSize = 300000
+ref3 = prod.bake(b, d3)
+dd3 = ot.BakeInputDesc.from_buffer_copy(dd); dd3.maxArrayDataSize = 300000
+out3 = sh.sharded_bake_rccl(prod.dll, b, C.byref(dd3), comm)
+res3 = ot.device_result_to_host(prod, ot.Hip(), out3)
+assert res3.same_as(ref3) and res3.array_data.size <= 300000 < ref.array_data.size, (res3.diff(ref3), res3.array_data.size, ref.array_data.size)
 prod.dll.ommxRcclCommDestroy(comm)
 print("one-rank nccl plumbing ok", len(res.descs))
 dist.destroy_process_group()

@@ -548,6 +548,24 @@ def test_near_duplicate_merge_and_size_budget(product, oracle):
             lib.destroy_baker(b)
         assert out[0].same_as(out[1]), (budget, out[0].diff(out[1]))
         assert out[0].array_data.size <= budget or len(out[0].descs) == 0 or budget < 100
+    # the same reducers through the device-resident entry point (inputs and result in HBM; serial tail on the host in between)
+    hip = ot.Hip()
+    for flags, budget in ((ot.FLAG_THREADS | ot.FLAG_NEAR_DUP, 0xFFFFFFFF), (ot.FLAG_THREADS, 4000)):
+        ob = oracle.create_baker()
+        otx = oracle.create_texture(ob, [tex], alpha_cutoff=0.5)
+        d = ot.make_desc(otx, uv2, ix2, 5, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, flags=flags)
+        d.maxArrayDataSize = budget
+        ref = oracle.bake(ob, d)
+        oracle.destroy_texture(ob, otx)
+        oracle.destroy_baker(ob)
+        b = product.create_baker()
+        t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+        d = ot.make_desc(t, uv2, ix2, 5, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, flags=flags)
+        d.maxArrayDataSize = budget
+        dev = ot.bake_device(product, hip, b, d, uv2, ix2)
+        product.destroy_texture(b, t)
+        product.destroy_baker(b)
+        assert dev.same_as(ref), (flags, budget, dev.diff(ref))
 
 
 # ---------------------------------------------------------------------------------------------
