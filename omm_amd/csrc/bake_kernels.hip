@@ -184,6 +184,8 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     __shared__ uint32_t s_mask, s_known;
     __shared__ uint32_t s_pending, s_fine;       // single-texel pass: micro-triangles left for the generic pass / level-line statistic
     __shared__ uint32_t s_next;                  // sliced: next tile-queue position of this (persistent) workgroup
+    __shared__ uint32_t s_gdec[SLICED ? TILE / GROUP : 1];   // sliced: bird-curve decode of each 64-group of the tile (classify_device.h: BirdGroup)
+    __shared__ uint8_t  s_btab[SLICED ? 256 : 1];            // ... and the 4 x 64 table of the low decode bits, filled once per workgroup
     __shared__ float    s_wtex[SLICED ? WIN * WIN : 1];
     __shared__ uint32_t s_wsat[SLICED ? (WIN + 1) * (WIN + 1) : 1];
     constexpr uint32_t TILE_LOG4 = TILE == 4096 ? 6u : 5u; // the tile is the level-(N - TILE_LOG4) sub-triangle of its item
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     uint32_t qpos = 0, qtotal = 0;
     if (SLICED) {
         qtotal = *queueCount;
+        s_btab[tid] = (uint8_t)bird_table_entry(tid >> 6, tid & 63u);   // (BLOCK == 256 entries)
         if (tid == 0) s_next = atomicAdd(queueHead, 1u);
         __syncthreads();
         qpos = uniform_u32(s_next);
@@ -231,6 +234,11 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     if (tid == 0) { s_qcount = 0; s_mask = 0; s_known = 0; s_pending = 0; s_fine = 0; }
     // the single-texel fast pass (fine_single_texel) covers Linear filtering of one mip on non-degenerate items; everything else is generic
     const bool fastFine = SLICED && P.filterLinear != 0 && P.mipCount == 1;
+    // micro-triangle i (0 .. TILE) of a sliced tile through the split bird decode: group word + table entry instead of the full decode
+    auto tile_micro_triangle = [&](uint32_t i) {
+        BirdGroup bg; bg.word = s_gdec[SLICED ? i >> 6 : 0u];
+        return micro_triangle_grouped(uUv, bg, (uint32_t)s_btab[SLICED ? ((bg.word >> 24) & 3u) * 64u + (i & 63u) : 0u], level);
+    };
     if (SLICED) {
         uItem = rec.x & 0x7FFFFFFFu;
         #pragma unroll
@@ -264,12 +272,13 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                     const uint32_t g = tid - 64;
                     const int gs = region_state_ex<MD>(P, micro_triangle(uUv, (base >> 6) + g, level - 3), uMaxAbs, W);
                     s_group[g] = gs;
+                    s_gdec[g] = bird_group((base >> 6) + g, level - 3).word;
                     const unsigned long long open = __ballot(gs < 0), allOpen = __ballot(gs == kRegionAllOpen);
                     if (gs < 0) s_glist[__popcll(open & ((1ull << g) - 1ull))] = (uint16_t)g;
                     if (gs == kRegionAllOpen) s_olist[__popcll(allOpen & ((1ull << g) - 1ull))] = (uint16_t)g;
                     if (g == 0) { s_gcount = (uint32_t)__popcll(open); s_ocount = (uint32_t)__popcll(allOpen); }
                 }
-            } else if (tid < (uint32_t)(TILE / GROUP)) { s_group[tid] = -1; s_glist[tid] = (uint16_t)tid; if (tid == 0) { s_gcount = (uint32_t)(TILE / GROUP); s_ocount = 0; } }
+            } else if (tid < (uint32_t)(TILE / GROUP)) { s_group[tid] = -1; s_glist[tid] = (uint16_t)tid; s_gdec[tid] = bird_group((base >> 6) + tid, level - 3).word; if (tid == 0) { s_gcount = (uint32_t)(TILE / GROUP); s_ocount = 0; } }
             __syncthreads();
         }
     } else {
@@ -301,9 +310,8 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 else
 #endif
                 if (coarse) {
-                    const uint32_t u = SLICED ? base + i : (i & (M - 1u));
-                    const float* uvp = SLICED ? uUv : A.uv + 6ull * itemIds[firstItem + (i >> (2 * level))];
-                    st = coarse_state<MD>(P, micro_triangle(uvp, u, level), W);
+                    if (SLICED) st = coarse_state<MD>(P, tile_micro_triangle(i), W);
+                    else st = coarse_state<MD>(P, micro_triangle(A.uv + 6ull * itemIds[firstItem + (i >> (2 * level))], i & (M - 1u), level), W);
                 }
                 // the reference's fine pass re-classifies everything still "UnknownOpaque" (bake_cpu_impl.cpp:861)
                 unresolved = (st < 0) || (st == 3) || !P.filterLinear;
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 if (k < ocount) i = (uint32_t)s_olist[k] * 64u + (tid & 63u);
                 else { const uint32_t q = (k - ocount) * 64u + (tid & 63u); live = q < qn; i = live ? (uint32_t)s_queue[q] : 0u; }
                 if (live) {
-                    const int st = fine_single_texel<FP32, MD>(P, micro_triangle(uUv, base + i, level), W);
+                    const int st = fine_single_texel<FP32, MD>(P, tile_micro_triangle(i), W);
                     s_state[i] = (uint8_t)(st < 0 ? 0xFF : st);
                     pend |= st < 0 ? 1u : 0u;
                 }
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 const uint32_t q = q0 + tid;
                 if (q < qn2) {
                     const uint32_t i = s_queue[q];
-                    s_state[i] = (uint8_t)fine_state<FP32, MD>(P, micro_triangle(uUv, base + i, level), uDegenerate, W);
+                    s_state[i] = (uint8_t)fine_state<FP32, MD>(P, tile_micro_triangle(i), uDegenerate, W);
                 }
             }
         } else

@@ -42,7 +42,7 @@ __device__ __forceinline__ void finish_tri(MicroTri& t)
 }
 
 // ---- bird curve: micro-triangle index -> barycentrics (util/bird.h:34-118) ----
-__device__ __forceinline__ uint32_t even_bits(uint32_t x)
+__host__ __device__ __forceinline__ uint32_t even_bits(uint32_t x)
 {
     x &= 0x55555555u;
     x = (x | (x >> 1)) & 0x33333333u;
@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t even_bits(uint32_t x)
     x = (x | (x >> 8)) & 0x0000ffffu;
     return x;
 }
-__device__ __forceinline__ uint32_t prefix_xor(uint32_t x)
+__host__ __device__ __forceinline__ uint32_t prefix_xor(uint32_t x)
 {
     x ^= x >> 1; x ^= x >> 2; x ^= x >> 4; x ^= x >> 8;
     return x;
@@ -87,6 +87,54 @@ __device__ __forceinline__ MicroTri micro_triangle(const float* __restrict__ tri
         if (!upright) { du = -du; dv = -dv; }
         t.p0 = bary_point(tri, u, v); t.p1 = bary_point(tri, u + du, v); t.p2 = bary_point(tri, u, v + dv);
     }
+    finish_tri(t);
+    return t;
+}
+
+// ---- bird curve, split at the 64-group boundary ----
+// index = group * 64 + l.  Every step of the decode above is bitwise except the two prefix-xors, and bit i of a prefix-xor is the xor of the
+// bits >= i: the low three bits of fx / fy are the prefix-xor of the low three input bits, flipped when the high part has odd parity.
+// Hence the integer barycentrics of micro-triangle l of a group are
+//     iu = (IU << 3 | lo_u) + !upright,   iv = (IV << 3 | lo_v) + !upright
+// with (IU, IV) = the masked, un-adjusted (iu, iv) of the GROUP's own decode at level N - 3, and (lo_u, lo_v, upright) a function of l and
+// of the two parities (pX, pY) = low bits of the group's fx / fy only: a 4 x 64-entry table.  The group part is computed once per group
+// (by the lane that also asks the SAT about the group), the table once per workgroup; the per-micro-triangle decode shrinks from ~55
+// integer instructions to two LDS reads and a dozen bit operations.  Same integers, hence the same vertices.
+struct BirdGroup { uint32_t word; };   // IU | IV << 12 | (pX | pY << 1) << 24
+__host__ __device__ __forceinline__ BirdGroup bird_group(uint32_t group, uint32_t groupLevel)   // groupLevel = N - 3 >= 0
+{
+    BirdGroup g;
+    if (groupLevel == 0) { g.word = 0u; return g; }
+    const uint32_t b0 = even_bits(group), b1 = even_bits(group >> 1);
+    const uint32_t fx = prefix_xor(b0), fy = prefix_xor(b0 & ~b1);
+    const uint32_t tt = fy ^ b1;
+    const uint32_t mask = (1u << groupLevel) - 1u;
+    const uint32_t iu = ((fx & ~tt) | (b0 & ~tt) | (~b0 & ~fx & tt)) & mask, iv = (fy ^ b0) & mask;
+    g.word = iu | (iv << 12) | ((fx & 1u) << 24) | ((fy & 1u) << 25);
+    return g;
+}
+// table entry for (ctx = pX | pY << 1, l): lo_u | lo_v << 3 | upright << 6
+__host__ __device__ __forceinline__ uint32_t bird_table_entry(uint32_t ctx, uint32_t l)
+{
+    const uint32_t c0 = (l & 1u) | ((l >> 1) & 2u) | ((l >> 2) & 4u), c1 = ((l >> 1) & 1u) | ((l >> 2) & 2u) | ((l >> 3) & 4u);   // even / odd bits of l
+    auto pxor3 = [](uint32_t x) { x ^= x >> 1; x ^= x >> 2; return x & 7u; };
+    const uint32_t fx = pxor3(c0) ^ ((ctx & 1u) ? 7u : 0u), fy = pxor3(c0 & ~c1 & 7u) ^ ((ctx & 2u) ? 7u : 0u);
+    const uint32_t tt = fy ^ c1;
+    const uint32_t iu = ((fx & ~tt) | (c0 & ~tt) | (~c0 & ~fx & tt)) & 7u, iv = (fy ^ c0) & 7u, iw = ((~fx & ~tt) | (c0 & ~tt) | (~c0 & fx & tt)) & 7u;
+    return iu | (iv << 3) | (((iu ^ iv ^ iw) & 1u) << 6);
+}
+// micro-triangle l (0..63) of a group at level N >= 3, from the group word and the table entry: the same MicroTri as micro_triangle(tri, group * 64 + l, N)
+__device__ __forceinline__ MicroTri micro_triangle_grouped(const float* __restrict__ tri, BirdGroup g, uint32_t entry, uint32_t level)
+{
+    const bool upright = (entry >> 6) != 0u;
+    const uint32_t adj = upright ? 0u : 1u;
+    const uint32_t iu = ((((g.word & 0xFFFu) << 3) | (entry & 7u)) + adj), iv = (((((g.word >> 12) & 0xFFFu)) << 3) | ((entry >> 3) & 7u)) + adj;
+    const float ls = __uint_as_float((127u - level) << 23);
+    float du = 1.f * ls, dv = 1.f * ls;
+    const float u = (float)iu * ls, v = (float)iv * ls;
+    if (!upright) { du = -du; dv = -dv; }
+    MicroTri t;
+    t.p0 = bary_point(tri, u, v); t.p1 = bary_point(tri, u + du, v); t.p2 = bary_point(tri, u, v + dv);
     finish_tri(t);
     return t;
 }
@@ -727,8 +775,26 @@ __device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const 
                 const V2 r0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy);
                 const V2 r1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy);
                 const V2 r2 = mk2(m.fw * t.p2.x - pfx, m.fh * t.p2.y - pfy);
+#if defined(OMMX_EDGE_LOOP)
+                // one inlined copy of the edge test, walked three times (the reference breaks at the first crossing edge)
+                bool crossing = false;
+                V2 ea = r0, eb = r1;
+                #pragma nounroll
+                for (int k = 0; k < 3; ++k) {
+                    if (!crossing) crossing = edge_crosses_level_curve(ea, eb, ha, sb, sc, sd);
+                    const V2 nb = k == 0 ? r2 : r0;
+                    ea = eb; eb = nb;
+                }
+                if (crossing) { above += 1; below += 1; }
+#elif defined(OMMX_EDGE_SHORT_CIRCUIT)
                 if (edge_crosses_level_curve(r0, r1, ha, sb, sc, sd) || edge_crosses_level_curve(r1, r2, ha, sb, sc, sd) ||
                     edge_crosses_level_curve(r2, r0, ha, sb, sc, sd)) { above += 1; below += 1; }
+#else
+                // all three edges are evaluated by all lanes: the reference stops at the first crossing edge, but crossings are rare (0.4 % of
+                // the edge tests) and the lanes of a wave do not agree on them, so the short-circuit only adds divergent regions (33.1 -> 32.1 ms)
+                const bool x0 = edge_crosses_level_curve(r0, r1, ha, sb, sc, sd), x1 = edge_crosses_level_curve(r1, r2, ha, sb, sc, sd), x2 = edge_crosses_level_curve(r2, r0, ha, sb, sc, sd);
+                if (x0 | x1 | x2) { above += 1; below += 1; }
+#endif
             }
         }
     }

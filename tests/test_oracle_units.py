@@ -72,3 +72,17 @@ def test_bird_curve_is_hierarchical(oracle):
             P = [(b[0], b[1]), (b[2], b[3]), (b[4], b[5])]
             s = [side(P[k], P[(k + 1) % 3]) for k in range(3)]
             assert all(v > 0 for v in s) or all(v < 0 for v in s)
+
+
+def test_split_bird_decode_is_the_direct_decode_for_every_index(tmp_path):
+    """omm_amd/csrc/classify_device.h splits the bird-curve decode at the 64-group boundary (group word + 4 x 64 table).  Its integer part
+    is host-callable: tests/native/bird_check.hip compares it with the direct decode of util/bird.h:73-118 for every micro-triangle index
+    of every level 3..12 (22 M cases).  Needs hipcc, no GPU."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "bird_check")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "--offload-arch=gfx950", "-I" + os.path.join(root, "omm_amd", "csrc"), os.path.join(root, "tests", "native", "bird_check.hip"), "-o", exe],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "22369600 indices, 0 mismatches" in r.stdout, r.stdout + r.stderr
