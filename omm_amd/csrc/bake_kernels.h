@@ -19,7 +19,9 @@ void launch_triage(const ClassifyParams& P, const float* uv, const SetupCounters
 void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
                    uint64_t* digests, hipStream_t stream);
 // summed-area table of (alpha > cutoff)
-void launch_sat_build(const void* texels, int fp32, uint32_t* sat, int w, int h, float cutoff, hipStream_t stream);
+// (scratch: sat_scratch_bytes(w, h) bytes of device memory, free again once the stream has passed the build)
+size_t sat_scratch_bytes(int w, int h);
+void launch_sat_build(const void* texels, int fp32, uint32_t* sat, uint32_t* scratch, int w, int h, float cutoff, hipStream_t stream);
 // active[item] == 0: the item has no stored states (settled by triage); its block is the constant pattern of its single state
 void launch_gather_omms(const uint8_t* states, const uint64_t* stateOfs, const uint8_t* active, const uint32_t* stateMask, const uint8_t* level, int bits,
                         const uint32_t* order, const uint32_t* dstOfs, const uint32_t* sizes, uint32_t numOmms, uint8_t* arrayData, hipStream_t stream);

@@ -426,7 +426,11 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 const uint32_t q = q0 + tid;
                 if (q < qn2) {
                     const uint32_t i = s_queue[q];
+#ifdef OMMX_DEBUG_NO_GENERIC   // register-pressure experiment only (never shipped): wrong states for the left-over micro-triangles
+                    s_state[i] = 3;
+#else
                     s_state[i] = (uint8_t)fine_state<FP32, MD>(P, tile_micro_triangle(i), uDegenerate, W);
+#endif
                 }
             }
         } else
@@ -779,19 +783,47 @@ __global__ __launch_bounds__(256) void sat_rows(const void* __restrict__ texels,
     }
 }
 
-__global__ __launch_bounds__(256) void sat_cols(uint32_t* __restrict__ sat, int w, int h)
+// column pass in three steps so that all of the chip works on it (a thread per column alone is 4096 threads walking 4096 rows: 1 ms at 4K):
+//   sat_cols_block    thread = (column, block of SAT_ROWS rows): running sum inside the block, block total -> partial[block][column]
+//   sat_cols_carry    thread = column: exclusive scan of that column's block totals (h / SAT_ROWS values)
+//   sat_cols_add      thread = (column, block): add the carried total of the blocks above
+constexpr int SAT_ROWS = 64;
+__global__ __launch_bounds__(256) void sat_cols_block(uint32_t* __restrict__ sat, uint32_t* __restrict__ partial, int w, int h)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (x >= w) return;
+    const int y0 = k * SAT_ROWS, y1 = y0 + SAT_ROWS < h ? y0 + SAT_ROWS : h;
+    uint32_t run = 0;
+    for (int y = y0; y < y1; ++y) { const size_t i = (size_t)x + (size_t)y * (size_t)w; run += sat[i]; sat[i] = run; }
+    partial[(size_t)k * (size_t)w + (size_t)x] = run;
+}
+__global__ __launch_bounds__(256) void sat_cols_carry(uint32_t* __restrict__ partial, int w, int blocks)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= w) return;
     uint32_t run = 0;
-    for (int y = 0; y < h; ++y) { const size_t i = (size_t)x + (size_t)y * (size_t)w; run += sat[i]; sat[i] = run; }
+    for (int k = 0; k < blocks; ++k) { const size_t i = (size_t)k * (size_t)w + (size_t)x; const uint32_t v = partial[i]; partial[i] = run; run += v; }
+}
+__global__ __launch_bounds__(256) void sat_cols_add(uint32_t* __restrict__ sat, const uint32_t* __restrict__ partial, int w, int h)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (x >= w || k == 0) return;
+    const uint32_t carry = partial[(size_t)k * (size_t)w + (size_t)x];
+    const int y0 = k * SAT_ROWS, y1 = y0 + SAT_ROWS < h ? y0 + SAT_ROWS : h;
+    for (int y = y0; y < y1; ++y) sat[(size_t)x + (size_t)y * (size_t)w] += carry;
 }
 
-void launch_sat_build(const void* texels, int fp32, uint32_t* sat, int w, int h, float cutoff, hipStream_t stream)
+size_t sat_scratch_bytes(int w, int h) { return sizeof(uint32_t) * (size_t)w * (size_t)((h + SAT_ROWS - 1) / SAT_ROWS); }
+
+void launch_sat_build(const void* texels, int fp32, uint32_t* sat, uint32_t* scratch, int w, int h, float cutoff, hipStream_t stream)
 {
     if (fp32) hipLaunchKernelGGL(sat_rows<true>, dim3((h + 3) / 4), dim3(256), 0, stream, texels, sat, w, h, cutoff);
     else      hipLaunchKernelGGL(sat_rows<false>, dim3((h + 3) / 4), dim3(256), 0, stream, texels, sat, w, h, cutoff);
-    hipLaunchKernelGGL(sat_cols, dim3((w + 255) / 256), dim3(256), 0, stream, sat, w, h);
+    const int blocks = (h + SAT_ROWS - 1) / SAT_ROWS;
+    const dim3 grid((w + 255) / 256, blocks);
+    hipLaunchKernelGGL(sat_cols_block, grid, dim3(256), 0, stream, sat, scratch, w, h);
+    hipLaunchKernelGGL(sat_cols_carry, dim3((w + 255) / 256), dim3(256), 0, stream, scratch, w, blocks);
+    hipLaunchKernelGGL(sat_cols_add, grid, dim3(256), 0, stream, sat, (const uint32_t*)scratch, w, h);
 }
 
 // ------------------------------------------------------------------------------------------------

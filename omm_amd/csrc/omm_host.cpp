@@ -1058,7 +1058,7 @@ ommResult create_texture_impl(Baker* b, const ommCpuTextureDesc* desc, ommCpuTex
     const size_t px = desc->format == ommCpuTextureFormat_FP32 ? 4 : 1;
     const bool enableSAT = desc->alphaCutoff >= 0; // texture_impl.cpp:91
     bool ok = true;
-    std::vector<uint8_t> staging;
+    std::vector<uint8_t> staging; std::vector<void*> satScratch;
     for (uint32_t mi = 0; mi < desc->mipCount && ok; ++mi) {
         const ommCpuTextureMipDesc& md = desc->mips[mi];
         TexMip m; m.w = (int)md.width; m.h = (int)md.height;
@@ -1074,11 +1074,16 @@ ommResult create_texture_impl(Baker* b, const ommCpuTextureDesc* desc, ommCpuTex
         ok = HIP_OK(hipMalloc(&m.texels, bytes)) && HIP_OK(hipMemcpy(m.texels, src, bytes, hipMemcpyHostToDevice));
         if (ok && enableSAT) {
             ok = HIP_OK(hipMalloc((void**)&m.sat, sizeof(uint32_t) * (size_t)m.w * (size_t)m.h));
-            if (ok) { launch_sat_build(m.texels, desc->format == ommCpuTextureFormat_FP32, m.sat, m.w, m.h, desc->alphaCutoff, nullptr); ok = HIP_OK(hipGetLastError()); }
+            if (ok) {   // (null stream; the pooled scratch block goes back after the device synchronisation below)
+                uint32_t* scratch = (uint32_t*)b->devPool->acquire(sat_scratch_bytes(m.w, m.h));
+                ok = scratch != nullptr;
+                if (ok) { satScratch.push_back(scratch); launch_sat_build(m.texels, desc->format == ommCpuTextureFormat_FP32, m.sat, scratch, m.w, m.h, desc->alphaCutoff, nullptr); ok = HIP_OK(hipGetLastError()); }
+            }
         }
         t->mips.push_back(m);
     }
-    if (ok) ok = HIP_OK(hipDeviceSynchronize());
+    if (ok) ok = HIP_OK(hipDeviceSynchronize()); else (void)hipDeviceSynchronize();
+    for (void* p : satScratch) b->devPool->release(p);
     if (!ok) { (void)hipGetLastError(); b->mem.destroy(t); return L.failure("[Failure] - could not create the texture on the HIP device (no CPU fallback)"); }
     *outTexture = (ommCpuTexture)((uintptr_t)t | kTexture);
     return ommResult_SUCCESS;
