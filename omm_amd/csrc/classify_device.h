@@ -377,7 +377,11 @@ __device__ __forceinline__ bool root_rejected(const RootFilter& f, float n, floa
 
 // bake_kernels_cpu.h:144-238 -- does segment (a0,a1) cross the level curve
 // h.x + h.y*x + h.z*y + h.w*x*y = 0 inside the unit texel?
+#ifdef OMMX_EDGE_NOINLINE
+__device__ __attribute__((noinline)) bool edge_crosses_level_curve(V2 a0, V2 a1, float ha, float hb, float hc, float hd)
+#else
 __device__ __forceinline__ bool edge_crosses_level_curve(V2 a0, V2 a1, float ha, float hb, float hc, float hd)
+#endif
 {
     if (a0.x > a1.x) { V2 t = a0; a0 = a1; a1 = t; }
     // Edge::_length (bake_kernels_cpu.h:115-133) is only consumed by IsPointOnEdge: evaluated lazily, same value

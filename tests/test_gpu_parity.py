@@ -424,6 +424,16 @@ def test_hierarchy_levels_all_paths(product, oracle):
             both(product, oracle, [tex], uv, ix, level, addr=ot.CLAMP, promo=ot.PROMO_NEAREST, flags=ot.FLAG_THREADS | ot.FLAG_NO_SPECIAL)
 
 
+@pytest.mark.parametrize("level,extent,count", [(10, 0.02, 24), (10, 0.4, 6), (11, 0.03, 10), (11, 0.5, 3), (12, 0.05, 5), (12, 0.7, 2)])
+def test_highest_levels(product, oracle, level, extent, count):
+    """levels 10..12 (up to 16.7 M micro-triangles and 4096 tiles per work item): tile queue records, split bird decode with 9 high bits,
+    tiny and texture-sized triangles, both formats"""
+    tex = ot.foliage_texture(91, 2048, 2048, feature=80)
+    uv, ix = ot.random_triangles(7000 + level, count, extent)
+    both(product, oracle, [tex], uv, ix, level, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+    both(product, oracle, [tex], uv, ix, level, fmt=ot.FMT_2STATE, addr=ot.MIRROR, promo=ot.PROMO_NEAREST, flags=ot.FLAG_THREADS | ot.FLAG_NO_SPECIAL | ot.FLAG_NO_DEDUP)
+
+
 def test_device_resident_entry_point(product, oracle):
     """ommxBakeDevice: inputs and outputs stay in HBM; results must equal ommCpuBake's and the oracle's."""
     hip = ot.Hip()
