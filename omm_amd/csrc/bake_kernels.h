@@ -9,7 +9,8 @@ namespace ommx {
 struct SetupCounters;
 
 // classification of the active items of ALL levels: level l = activeIds[first[l] .. first[l] + count[l]).  Items of level >= 5 are cut into
-// tiles; `queue` holds classify_queue_records(count) 16-byte tile records, `queueCtl` 4 words (zeroed here).  numCUs sizes the persistent grid.
+// tiles; `queue` holds classify_queue_records(count) tile records of kTileRecordBytes, `queueCtl` 4 words (zeroed here).  numCUs sizes the persistent grid.
+constexpr size_t kTileRecordBytes = 48;
 uint64_t classify_queue_records(const uint32_t count[kNumLevels]);
 hipError_t launch_classify(const ClassifyParams& P, const ItemArrays& A, const uint32_t* activeIds, const uint32_t first[kNumLevels], const uint32_t count[kNumLevels],
                            void* queue, uint32_t* queueCtl, uint32_t numCUs, hipStream_t stream);

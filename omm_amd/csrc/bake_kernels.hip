@@ -107,7 +107,10 @@ struct TileLevels {                 // the sliced levels of one tile size, highe
     uint32_t n;
     uint32_t level[kNumLevels], first[kNumLevels], tileStart[kNumLevels + 1]; // items activeIds[first .. ), tiles [tileStart[k], tileStart[k+1])
 };
-// record: x = item | rectOk << 31, y = tile in item | level << 24, z = sx | sy << 16, w = ex | ey << 16 (addressed texel rectangle of the tile)
+// record = 3 x uint4 (everything a tile's workgroup needs, in ONE memory round trip):
+//   [0] x = item | degenerate << 30 | rectOk << 31, y = tile in item | level << 24, z = sx | sy << 16, w = ex | ey << 16 (addressed texel rectangle)
+//   [1] the item's uv[0..3]      [2] uv[4], uv[5], address of the tile's packed states (lo, hi)
+constexpr uint32_t kTileRecordWords = 3;   // uint4 per record (bake_kernels.h: kTileRecordBytes)
 template <int TILE>
 __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays A, const uint32_t* __restrict__ activeIds, TileLevels L,
                                                     uint4* __restrict__ queue, uint32_t* __restrict__ queueTail)
@@ -117,6 +120,8 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
     const uint32_t lane = threadIdx.x & 63u;
     const bool live = t < L.tileStart[L.n];
     int st = -1; uint32_t item = 0, tileInItem = 0, level = TILE_LOG4; TexRect r; r.sx = r.sy = r.ex = r.ey = 0; r.ok = false;
+    float uvv[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    const uint32_t bits = (uint32_t)P.format, tileBytes = (uint32_t)TILE * bits / 8u;
     if (live) {
         uint32_t k = 0;
         while (k + 1 < L.n && t >= L.tileStart[k + 1]) ++k;
@@ -124,6 +129,8 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
         const uint32_t shift = 2u * (level - TILE_LOG4), rel = t - L.tileStart[k];   // tiles per item = 4^(level - log4 TILE)
         item = activeIds[L.first[k] + (rel >> shift)]; tileInItem = rel & ((1u << shift) - 1u);
         const float* uv = A.uv + 6ull * item;
+        #pragma unroll
+        for (int q = 0; q < 6; ++q) uvv[q] = uv[q];
         const float maxAbs = item_max_abs(uv);
         const MicroTri sub = micro_triangle(uv, tileInItem, level - TILE_LOG4);
         r = region_rect<ModeDynamic>(P, sub, maxAbs);
@@ -136,11 +143,16 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
         uint32_t wbase = 0;
         if (lane == (uint32_t)__ffsll((long long)ob) - 1u) wbase = atomicAdd(queueTail, (uint32_t)__popcll(ob));
         wbase = __shfl(wbase, __ffsll((long long)ob) - 1);
-        if (open) queue[wbase + __popcll(ob & ((1ull << lane) - 1ull))] =
-            make_uint4(item | (r.ok ? 0x80000000u : 0u), tileInItem | (level << 24), (uint32_t)r.sx | ((uint32_t)r.sy << 16), (uint32_t)r.ex | ((uint32_t)r.ey << 16));
+        if (open) {
+            uint4* rec = queue + (size_t)kTileRecordWords * (wbase + __popcll(ob & ((1ull << lane) - 1ull)));
+            const unsigned long long dst = (unsigned long long)(A.states + A.stateOfs[item] + (size_t)tileInItem * tileBytes);
+            rec[0] = make_uint4(item | (A.degenerate[item] ? 0x40000000u : 0u) | (r.ok ? 0x80000000u : 0u), tileInItem | (level << 24),
+                                (uint32_t)r.sx | ((uint32_t)r.sy << 16), (uint32_t)r.ex | ((uint32_t)r.ey << 16));
+            rec[1] = make_uint4(__float_as_uint(uvv[0]), __float_as_uint(uvv[1]), __float_as_uint(uvv[2]), __float_as_uint(uvv[3]));
+            rec[2] = make_uint4(__float_as_uint(uvv[4]), __float_as_uint(uvv[5]), (uint32_t)dst, (uint32_t)(dst >> 32));
+        }
     }
     // ---- settled tiles: constant states, written by the whole wave ----
-    const uint32_t bits = (uint32_t)P.format, tileBytes = (uint32_t)TILE * bits / 8u;
     if (live && st >= 0) {
         atomicOr(&A.stateMask[item], 1u << st);
         if (P.wantKnownCount && st < 2) atomicAdd(&A.knownCount[item], (uint32_t)TILE);
@@ -202,11 +214,12 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     }
   for (;;) {
     uint32_t level = levelArg, tile = 0;
-    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u), rec1 = rec, rec2 = rec;
     uint32_t nextPos = 0;
     if (SLICED) {
         if (qpos >= qtotal) return;
-        rec = tileQueue[qpos];
+        const uint4* rp = tileQueue + (size_t)kTileRecordWords * qpos;
+        rec = rp[0]; rec1 = rp[1]; rec2 = rp[2];   // three independent loads: one round trip for item, rectangle, UVs and output address
         rec.x = uniform_u32(rec.x); rec.y = uniform_u32(rec.y); rec.z = uniform_u32(rec.z); rec.w = uniform_u32(rec.w);
         if (tid == 0) nextPos = atomicAdd(queueHead, 1u);   // consumed at the end of this tile
         level = rec.y >> 24;
@@ -240,21 +253,25 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         return micro_triangle_grouped(uUv, bg, (uint32_t)s_btab[SLICED ? ((bg.word >> 24) & 3u) * 64u + (i & 63u) : 0u], level);
     };
     if (SLICED) {
-        uItem = rec.x & 0x7FFFFFFFu;
-        #pragma unroll
-        for (int k = 0; k < 6; ++k) uUv[k] = uniform_f32(A.uv[6ull * uItem + k]);
+        uItem = rec.x & 0x3FFFFFFFu;
+        uUv[0] = uniform_f32(__uint_as_float(rec1.x)); uUv[1] = uniform_f32(__uint_as_float(rec1.y)); uUv[2] = uniform_f32(__uint_as_float(rec1.z));
+        uUv[3] = uniform_f32(__uint_as_float(rec1.w)); uUv[4] = uniform_f32(__uint_as_float(rec2.x)); uUv[5] = uniform_f32(__uint_as_float(rec2.y));
         uMaxAbs = uniform_f32(item_max_abs(uUv));
-        uDegenerate = uniform_u32(A.degenerate[uItem]) != 0;
+        uDegenerate = ((rec.x >> 30) & 1u) != 0u;
         {
             // ---- phase 0b: LDS window = every texel / SAT entry this tile can touch ----
             // (the tile's texel rectangle was computed by triage_tiles: region_rect of its sub-triangle)
             TexRect r; r.sx = (int)(rec.z & 0xFFFFu); r.sy = (int)(rec.z >> 16); r.ex = (int)(rec.w & 0xFFFFu); r.ey = (int)(rec.w >> 16); r.ok = (rec.x >> 31) != 0u;
             const int ww = r.ex - r.sx + 1, wh = r.ey - r.sy + 1;
+            bool windowOk = false;
             if (r.ok && ww <= WIN && wh <= WIN) {
                 const DevMip& m0 = P.mips[0];
-                // 64 x 4 thread grid over the window (no integer division by the run-time width): column = lane, 4 rows per pass
+                // 64 x 3 thread grid over the window (no integer division by the run-time width): column = lane, one row per wave and pass;
+                // wave 1 is busy with the group queries below, waves 0, 2, 3 load
                 const int cx = (int)(tid & 63u);
-                for (int cy = (int)(tid >> 6); cy <= wh; cy += BLOCK / 64) {
+                const uint32_t wv = tid >> 6;
+                if (wv != 1u || !coarse)
+                for (int cy = coarse ? (int)(wv == 0u ? 0u : wv - 1u) : (int)wv; cy <= wh; cy += coarse ? 3 : 4) {
                     const int x = r.sx + cx, y = r.sy + cy;
                     if (cx < ww && cy < wh) {
                         const size_t idx = (size_t)x + (size_t)y * (size_t)m0.w;
@@ -263,14 +280,13 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                     if (m0.sat && cx <= ww) // SAT entry (x-1, y-1); row / column -1 of the table is zero
                         s_wsat[cx + cy * (ww + 1)] = (x >= 1 && y >= 1) ? m0.sat[(size_t)(x - 1) + (size_t)(y - 1) * (size_t)m0.w] : 0u;
                 }
-                W.tex = (lds_float*)s_wtex; W.sat = (lds_u32*)s_wsat; W.base = m0.texels; W.sx = r.sx; W.sy = r.sy; W.w = ww; W.h = wh; // (SAT part is only read when coarse is on)
+                windowOk = true;
             }
-            __syncthreads();
-            // ---- phase 0c: one query per 64-micro-triangle group (wave 1) ----
+            // ---- phase 0c: one query per 64-micro-triangle group (wave 1), straight from the global SAT while the other waves fill the window ----
             if (coarse) {
                 if (tid >= 64 && tid < 64 + TILE / GROUP) { // (4096-tile: 64 groups = all of wave 1; 1024-tile: 16 of its lanes)
                     const uint32_t g = tid - 64;
-                    const int gs = region_state_ex<MD>(P, micro_triangle(uUv, (base >> 6) + g, level - 3), uMaxAbs, W);
+                    const int gs = region_state_ex<MD>(P, micro_triangle(uUv, (base >> 6) + g, level - 3), uMaxAbs, no_window());
                     s_group[g] = gs;
                     s_gdec[g] = bird_group((base >> 6) + g, level - 3).word;
                     const unsigned long long open = __ballot(gs < 0), allOpen = __ballot(gs == kRegionAllOpen);
@@ -280,6 +296,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 }
             } else if (tid < (uint32_t)(TILE / GROUP)) { s_group[tid] = -1; s_glist[tid] = (uint16_t)tid; s_gdec[tid] = bird_group((base >> 6) + tid, level - 3).word; if (tid == 0) { s_gcount = (uint32_t)(TILE / GROUP); s_ocount = 0; } }
             __syncthreads();
+            if (windowOk) { const DevMip& m0 = P.mips[0]; W.tex = (lds_float*)s_wtex; W.sat = (lds_u32*)s_wsat; W.base = m0.texels; W.sx = r.sx; W.sy = r.sy; W.w = ww; W.h = wh; } // (SAT part is only read when coarse is on)
         }
     } else {
         __syncthreads();
@@ -454,7 +471,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     const uint32_t bits = (uint32_t)P.format;          // 1 or 2 bits per micro-triangle
     const uint32_t perWord = 32u / bits;               // micro-triangles per 32-bit word
     if (SLICED) {
-        uint32_t* dst = (uint32_t*)(A.states + A.stateOfs[uItem]) + base / perWord;
+        uint32_t* dst = (uint32_t*)(((unsigned long long)uniform_u32(rec2.w) << 32) | uniform_u32(rec2.z));   // (from the tile record)
         uint32_t localMask = 0, localKnown = 0;   // (tiles settled as a whole never get here: triage_tiles wrote them)
         for (uint32_t w = tid; w < (uint32_t)TILE / perWord; w += BLOCK) {
             uint32_t v = 0;
@@ -475,11 +492,15 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         }
         if (localMask) atomicOr(&s_mask, localMask);
         if (P.wantKnownCount && localKnown) atomicAdd(&s_known, localKnown);
+        if (tid == 0) s_next = nextPos;   // next tile of this workgroup (requested at the top of the loop); published with the barrier below
         __syncthreads();
         if (tid == 0) {
             atomicOr(&A.stateMask[uItem], s_mask);
             if (P.wantKnownCount) atomicAdd(&A.knownCount[uItem], s_known);
         }
+        // Every LDS array of this tile was last read before that barrier, so the next tile starts right here: no further synchronisation.
+        qpos = uniform_u32(s_next);
+        continue;
     } else if (M >= perWord) {
         const uint32_t words = count / perWord;
         for (uint32_t w = tid; w < words; w += BLOCK) {
@@ -514,12 +535,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
             if (P.wantKnownCount) A.knownCount[item] = known;
         }
     }
-    if (!SLICED) return;
-    // next tile of this workgroup (its queue position was requested at the top of the loop)
-    __syncthreads();
-    if (tid == 0) s_next = nextPos;
-    __syncthreads();
-    qpos = uniform_u32(s_next);
+    return;   // (!SLICED: one tile per workgroup)
   }
 }
 
@@ -562,7 +578,7 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
         }
         if (!total || total > 0xFFFFFFFFull) continue;   // (more than 2^32 tiles cannot happen: their packed states would not fit in HBM)
         L.tileStart[L.n] = (uint32_t)total;
-        uint4* q = queue + recOfs; recOfs += total;
+        uint4* q = queue + recOfs * kTileRecordWords; recOfs += total;
         uint32_t* tail = queueCtl + 2 * cls; uint32_t* head = tail + 1;
         const dim3 tg((uint32_t)((total + 255u) / 256u)), tb(256);
         // persistent grid: every CU holds OMMX_CLASSIFY_WAVES workgroups of 4 waves (one per SIMD)

@@ -691,8 +691,8 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         for (uint32_t r = 0; r <= bounds.world; ++r) bounds.b[l][r] = (uint32_t)(a + cnt * r / bounds.world);
         lvlFirst[l] = bounds.b[l][bounds.rank]; lvlCount[l] = bounds.b[l][bounds.rank + 1] - bounds.b[l][bounds.rank];
     }
-    // packed states of the active items + the queue of open tiles (16-byte records, bake_kernels.hip) + its 4 control words
-    const size_t stateBytes = pad256(hc.stateBytes ? (size_t)hc.stateBytes : 256), queueBytes = pad256((size_t)classify_queue_records(lvlCount) * 16 + 16);
+    // packed states of the active items + the queue of open tiles (48-byte records, bake_kernels.hip) + its 4 control words
+    const size_t stateBytes = pad256(hc.stateBytes ? (size_t)hc.stateBytes : 256), queueBytes = pad256((size_t)classify_queue_records(lvlCount) * kTileRecordBytes + 16);
     if (!statesArena->reserve(stateBytes + queueBytes + 256)) return L.failure("[Failure] - out of device memory for the packed micro-triangle states");
     uint8_t* dStates = statesArena->base;
     void* dTileQueue = statesArena->base + stateBytes; uint32_t* dQueueCtl = (uint32_t*)(statesArena->base + stateBytes + queueBytes);
