@@ -377,11 +377,7 @@ __device__ __forceinline__ bool root_rejected(const RootFilter& f, float n, floa
 
 // bake_kernels_cpu.h:144-238 -- does segment (a0,a1) cross the level curve
 // h.x + h.y*x + h.z*y + h.w*x*y = 0 inside the unit texel?
-#ifdef OMMX_EDGE_NOINLINE
-__device__ __attribute__((noinline)) bool edge_crosses_level_curve(V2 a0, V2 a1, float ha, float hb, float hc, float hd)
-#else
 __device__ __forceinline__ bool edge_crosses_level_curve(V2 a0, V2 a1, float ha, float hb, float hc, float hd)
-#endif
 {
     if (a0.x > a1.x) { V2 t = a0; a0 = a1; a1 = t; }
     // Edge::_length (bake_kernels_cpu.h:115-133) is only consumed by IsPointOnEdge: evaluated lazily, same value
@@ -779,18 +775,7 @@ __device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const 
                 const V2 r0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy);
                 const V2 r1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy);
                 const V2 r2 = mk2(m.fw * t.p2.x - pfx, m.fh * t.p2.y - pfy);
-#if defined(OMMX_EDGE_LOOP)
-                // one inlined copy of the edge test, walked three times (the reference breaks at the first crossing edge)
-                bool crossing = false;
-                V2 ea = r0, eb = r1;
-                #pragma nounroll
-                for (int k = 0; k < 3; ++k) {
-                    if (!crossing) crossing = edge_crosses_level_curve(ea, eb, ha, sb, sc, sd);
-                    const V2 nb = k == 0 ? r2 : r0;
-                    ea = eb; eb = nb;
-                }
-                if (crossing) { above += 1; below += 1; }
-#elif defined(OMMX_EDGE_SHORT_CIRCUIT)
+#if defined(OMMX_EDGE_SHORT_CIRCUIT)   // (A/B switch: the reference's order of evaluation)
                 if (edge_crosses_level_curve(r0, r1, ha, sb, sc, sd) || edge_crosses_level_curve(r1, r2, ha, sb, sc, sd) ||
                     edge_crosses_level_curve(r2, r0, ha, sb, sc, sd)) { above += 1; below += 1; }
 #else
