@@ -23,3 +23,9 @@ cd $R
 python profiles/summarize_rocprof.py $(find $O/trace -name "*.db" | head -1) > $O/kernel_stats.md 2> $O/kernel_stats.err
 python profiles/summarize_pmc.py $tag $O "python bench.py $PM" > $O/pmc_summary.json 2> $O/pmc_summary.err
 tail -c 700 $O/bench.json; echo; cat $O/pmc_summary.json; head -14 $O/kernel_stats.md
+# optional: the full-size BASELINE configs[4] bake (4 M triangles, levels 4-10 + dynamic, 8K alpha) under the kernel trace
+if [ "$2" = "c4" ]; then
+  cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_c4 -o trace -- python $R/tests/scripts/c4_full.py > $O/c4.log 2>&1; cd $R
+  python profiles/summarize_rocprof.py $(find $O/trace_c4 -name "*.db" | head -1) > $O/c4_kernel_stats.md 2>> $O/kernel_stats.err
+  tail -4 $O/c4.log; head -8 $O/c4_kernel_stats.md
+fi
