@@ -154,7 +154,14 @@ def main():
     # N > 1: the library's one-call sharded bake, RCCL collectives issued from C++ (ommxShardedBakeRccl); OMM_BENCH_COLLECTIVES=torch keeps
     # the caller-driven path (collectives through torch.distributed) for the gloo self-tests
     native = world > 1 and os.environ.get("OMM_BENCH_COLLECTIVES", "native") == "native" and os.environ.get("OMM_BENCH_BACKEND", "nccl") == "nccl"
-    comm = shard.rccl_comm(prod.dll, torch, dist, rank, world) if native else None
+    comm = None
+    if native:
+        try:
+            comm = shard.rccl_comm(prod.dll, torch, dist, rank, world)   # raises on every rank or on none
+        except RuntimeError as e:
+            if rank == 0:
+                print("bench: native RCCL communicator unavailable (%s): collectives through torch.distributed instead" % e, file=sys.stderr)
+            native = False
 
     def step():
         if native:

@@ -52,20 +52,34 @@ def rccl_comm(dll, torch, dist, rank, world):
     dll.ommxRcclCommInitRank.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     dll.ommxRcclCommDestroy.argtypes = [C.c_void_p]
     buf = (C.c_uint8 * 128)()
+    ok = 1
     if rank == 0:
-        r = dll.ommxRcclGetUniqueId(buf, 128)
-        if r != 0:
-            raise RuntimeError("ommxRcclGetUniqueId failed: %d (is librccl.so.1 loadable?)" % r)
+        ok = 1 if dll.ommxRcclGetUniqueId(buf, 128) == 0 else 0
+    dev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu"
     if world > 1:
-        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        t = torch.tensor(list(buf), dtype=torch.uint8, device=dev)
+        # the id travels with rank 0's status byte, so that a failure there is an exception on EVERY rank instead of a hang in the broadcast
+        t = torch.tensor(list(buf) + [ok], dtype=torch.uint8, device=dev)
         dist.broadcast(t, 0)
-        for i, v in enumerate(t.cpu().tolist()):
-            buf[i] = v
+        vals = t.cpu().tolist()
+        ok = vals[128]
+        for i in range(128):
+            buf[i] = vals[i]
+    if not ok:
+        raise RuntimeError("ommxRcclGetUniqueId failed on rank 0 (is librccl.so.1 loadable?)")
     comm = C.c_void_p()
     r = dll.ommxRcclCommInitRank(buf, 128, rank, world, C.byref(comm))
-    if r != 0:
-        raise RuntimeError("ommxRcclCommInitRank failed: %d" % r)
+    joined = 1 if r == 0 else 0
+    if world > 1:
+        # every rank learns whether ALL joined: a caller can fall back to its own transport collectively
+        t = torch.tensor([joined], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        joined_all = int(t.item())
+    else:
+        joined_all = joined
+    if not joined_all:
+        if joined:
+            dll.ommxRcclCommDestroy(comm)
+        raise RuntimeError("ommxRcclCommInitRank failed (this rank: %d)" % r)
     return comm
 
 

@@ -85,3 +85,34 @@ def test_two_rank_exchange_protocol(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert open(os.path.join(str(tmp_path), "rank%d" % r)).read() == "1 1"
+
+
+def _bootstrap_worker(rank, world, port, result_dir):
+    import sys, ctypes as C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import omm_amd.sharded as sh
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dll = C.CDLL(os.path.join(root, "omm_amd", "lib", "libomm-lib.so"))
+    try:
+        comm = sh.rccl_comm(dll, torch, dist, rank, world)
+        outcome = "joined"
+        dll.ommxRcclCommDestroy(comm)
+    except RuntimeError as e:
+        outcome = "raised"
+    open(os.path.join(result_dir, "boot%d" % rank), "w").write(outcome)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_communicator_bootstrap_fails_on_every_rank_or_on_none(tmp_path):
+    """rccl_comm() on a box without GPUs: the RCCL communicator cannot be created, and that must surface as the same exception on BOTH
+    ranks (bench.py then falls back to torch.distributed collectively) -- never as one rank raising while the other waits in a collective"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_bootstrap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [open(os.path.join(str(tmp_path), "boot%d" % r)).read() for r in range(2)]
+    assert got[0] == got[1], got
+    if not torch.cuda.is_available():
+        assert got == ["raised", "raised"], got
