@@ -242,7 +242,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     const bool coarse = P.useCoarse != 0;
 
     // block-uniform item data of a sliced tile
-    uint32_t uItem = 0; float uUv[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }; float uMaxAbs = 0.f; bool uDegenerate = false;
+    uint32_t uItem = 0; float uUv[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }; float uMaxAbs = 0.f; bool uDegenerate = false, uFast = false;
     TexWindow W = no_window();
     if (tid == 0) { s_qcount = 0; s_mask = 0; s_known = 0; s_pending = 0; s_fine = 0; }
     // the single-texel fast pass (fine_single_texel) covers Linear filtering of one mip on non-degenerate items; everything else is generic
@@ -258,6 +258,9 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         uUv[3] = uniform_f32(__uint_as_float(rec1.w)); uUv[4] = uniform_f32(__uint_as_float(rec2.x)); uUv[5] = uniform_f32(__uint_as_float(rec2.y));
         uMaxAbs = uniform_f32(item_max_abs(uUv));
         uDegenerate = ((rec.x >> 30) & 1u) != 0u;
+        // fine_single_texel's FINITE precondition: |uv| <= 16384 bounds every pixel coordinate by 2^30 (size <= 65536) and excludes NaN;
+        // items outside it (and degenerate ones) take the generic path
+        uFast = fastFine && !uDegenerate && uMaxAbs <= 16384.f;
         {
             // ---- phase 0b: LDS window = every texel / SAT entry this tile can touch ----
             // (the tile's texel rectangle was computed by triage_tiles: region_rect of its sub-triangle)
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         auto phase1_group = [&](uint32_t i, int gs) {
             bool unresolved = false;
             if (gs == kRegionAllOpen) { // the whole group is unresolved by construction: no per-micro-triangle SAT test
-                if (fastFine && !uDegenerate) return;   // phase 2a takes the group as a whole, it needs no queue entries
+                if (uFast) return;   // phase 2a takes the group as a whole, it needs no queue entries
                 unresolved = i < count;   // (phase 2 writes the state of every queued micro-triangle)
             } else
             if (i < count) {
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
             for (uint32_t q = tid; q < qn; q += BLOCK) s_state[s_queue[q]] = 3;
         } else
 #endif
-        if (fastFine && !uDegenerate) {
+        if (uFast) {
             // ---- phase 2a: straight-line single-texel pass.  Work units of 64 lanes: first the all-open groups (one wave = one group, no
             //      queue entries), then the queued micro-triangles of the other open groups, 64 at a time ----
             uint32_t pend = 0;

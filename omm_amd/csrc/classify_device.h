@@ -717,17 +717,18 @@ __device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const 
     }
     V2 a = mk2(q0x, q0y); const V2 b = mk2(q1x, q1y); V2 c = mk2(q2x, q2y);
     if (!ccw) { V2 s = a; a = c; c = s; }
-    const float lox = std_min(std_min(a.x, b.x), c.x), loy = std_min(std_min(a.y, b.y), c.y);
-    const float hix = std_max(std_max(a.x, b.x), c.x), hiy = std_max(std_max(a.y, b.y), c.y);
-    // all six float -> int conversions below take values of [lo, hi]: with that box inside +-2^30 none of them can leave the int range, so the
-    // x86 "integer indefinite" rule of cvt_trunc_x86() cannot apply and the plain conversion gives the same integers (NaN fails the test)
-    const bool inRange = lox >= -1073741824.f && hix <= 1073741824.f && loy >= -1073741824.f && hiy <= 1073741824.f;
+    // FINITE (the caller's guarantee: every |uv| of the item <= 16384, so |Q| <= 16384 * 65536 + 0.5 < 2^31 and nothing is NaN): the
+    // min(min(a, b), c) chains of the reference reduce to three-operand minima / maxima (v_min3_f32 / v_max3_f32) -- the two differ only for
+    // NaN operands and in the sign of a zero, which floor / ceil -> int erases -- and none of the six float -> int conversions below can
+    // leave the int range, so the x86 "integer indefinite" rule of cvt_trunc_x86() cannot apply and the plain conversion gives the same integers
+    const float lox = __builtin_fminf(__builtin_fminf(a.x, b.x), c.x), loy = __builtin_fminf(__builtin_fminf(a.y, b.y), c.y);
+    const float hix = __builtin_fmaxf(__builtin_fmaxf(a.x, b.x), c.x), hiy = __builtin_fmaxf(__builtin_fmaxf(a.y, b.y), c.y);
     const int minx = (int)__builtin_floorf(lox), miny = (int)__builtin_floorf(loy);
     const int maxx = (int)__builtin_ceilf(hix), maxy = (int)__builtin_ceilf(hiy);
     const float fx = __builtin_floorf(q0x), fy = __builtin_floorf(q0y);
     const int ix = (int)fx, iy = (int)fy;
     // one texel, which is also the centre-vote cell
-    if (!(inRange && maxx - minx == 1 && maxy - miny == 1 && ix == minx && iy == miny)) return -1;
+    if (!(maxx - minx == 1 && maxy - miny == 1 && ix == minx && iy == miny)) return -1;
 
 #ifdef OMMX_DEBUG_ELIG_ONLY   // timing attribution only (never shipped)
     if (minx != 123456789) return 3;

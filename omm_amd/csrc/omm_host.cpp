@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <memory>
@@ -187,8 +188,28 @@ struct HostPool {
     }
 };
 
+// A baker works on ONE HIP device: the device that is current on the calling thread when its first texture is created.  HIP's current
+// device is per thread (default 0), so every later entry point switches to the baker's device for the duration of the call and restores
+// the caller's -- a worker thread of a multi-GPU host can bake without calling hipSetDevice itself, and a texture is never sampled from
+// the wrong GPU.  One process driving several GPUs uses one baker per device.
+struct DeviceScope {
+    int prev = -1; bool changed = false;
+    explicit DeviceScope(int dev) { if (dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != dev) changed = hipSetDevice(dev) == hipSuccess; }
+    ~DeviceScope() { if (changed) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope&) = delete; DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 struct Baker {
     Allocator mem; Logger log; ommBakerType type;
+    std::atomic<int> device{ -1 };   // bound by the first ommCpuCreateTexture / deserialised texture
+    int bind_device() {
+        int d = device.load();
+        if (d >= 0) return d;
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) return -1;
+        int expected = -1;
+        return device.compare_exchange_strong(expected, cur) ? cur : expected;
+    }
     std::shared_ptr<HostPool> hostPool = std::make_shared<HostPool>();
     std::shared_ptr<DevPool> devPool = std::make_shared<DevPool>();
     std::shared_ptr<ArenaPool> arenas = std::make_shared<ArenaPool>();   // device working sets, one per bake in flight
@@ -879,6 +900,7 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     const ommResult fr = scope_fences(baker, d, true);
     if (fr != ommResult_SUCCESS) return fr;
     const uint32_t T = d.indexCount / 3u;
+    const DeviceScope onBakersDevice(baker.bind_device());
     BakeSession ses(baker);
     if (!ses.open()) return L.failure("[Failure] - no usable HIP device (the MI355X baker has no CPU fallback)");
     hipStream_t stream = ses.stream;
@@ -1040,6 +1062,7 @@ namespace {
 ommResult create_texture_impl(Baker* b, const ommCpuTextureDesc* desc, ommCpuTexture* outTexture)
 {
     const Logger& L = b->log;
+    const DeviceScope onBakersDevice(b->bind_device());
     // texture_impl.cpp:44-65
     if (desc->mipCount == 0) return L.invalid("[Invalid Arg] - mipCount must be non-zero");
     if (desc->format == ommCpuTextureFormat_MAX_NUM) return L.invalid("[Invalid Arg] - format is not set");
@@ -1316,6 +1339,7 @@ OMM_MI355X_API ommResult ommxBakeDevice(ommBaker baker, const ommCpuBakeInputDes
     if (r != ommResult_SUCCESS) return r;
     return guarded(&b->log, [&]() -> ommResult {
     const double t0 = now_ms();
+    const DeviceScope onBakersDevice(b->bind_device());
     BakeSession ses(*b);
     if (!ses.open()) return b->log.failure("[Failure] - no usable HIP device (the MI355X baker has no CPU fallback)");
     DeviceBakeResult* res = b->mem.make<DeviceBakeResult>();
@@ -1535,6 +1559,7 @@ OMM_MI355X_API ommResult ommxShardedBegin(ommBaker baker, const ommCpuBakeInputD
     if (r != ommResult_SUCCESS) return r;
     if (worldSize == 0 || worldSize > (uint32_t)kMaxRanks || rank >= worldSize) return b->log.invalid("[Invalid Argument] - rank / worldSize out of range (at most 16 ranks)");
     return guarded(&b->log, [&]() -> ommResult {
+        const DeviceScope onBakersDevice(b->bind_device());
         ShardedBake* sb = nullptr;
         const ommResult rr = sharded_begin(b, desc, rank, worldSize, false, &sb);
         if (rr == ommResult_SUCCESS) *out = (ommxShardedBake)sb;
@@ -1555,6 +1580,7 @@ OMM_MI355X_API ommResult ommxShardedTail(ommxShardedBake h, void** contribution,
     if (h == 0 || contribution == nullptr || contributionBytes == nullptr || strideBytes == nullptr) return ommResult_INVALID_ARGUMENT;
     ShardedBake* sb = (ShardedBake*)h; ShardCtx& c = sb->ctx;
     return guarded(&sb->baker->log, [&]() -> ommResult {
+        const DeviceScope onBakersDevice(sb->baker->bind_device());
         const double t1 = now_ms();
         const ommResult r = sharded_tail(sb);   // (a second call re-uses the same exchange block: nothing leaks)
         if (r != ommResult_SUCCESS) return r;
@@ -1571,6 +1597,7 @@ OMM_MI355X_API ommResult ommxShardedFinish(ommxShardedBake h, const void* gather
     ShardedBake* sb = (ShardedBake*)h; ShardCtx& c = sb->ctx;
     if (c.counts.numOmms && gathered == nullptr) return sb->baker->log.invalid("[Invalid Argument] - gathered contributions missing");
     return guarded(&sb->baker->log, [&]() -> ommResult {
+        const DeviceScope onBakersDevice(sb->baker->bind_device());
         const double t1 = now_ms();
         const ommResult r = sharded_finish(sb, [&](uint8_t* arrayData) {
             // same chunk walk as the RCCL path (there each chunk arrives separately): a block that straddles a chunk boundary is placed in pieces
@@ -1648,6 +1675,7 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
     if (!rccl().ok()) return L.failure(("[Failure] - RCCL is not available: " + rccl().error).c_str());
     RcclComm* rc = (RcclComm*)comm;
     return guarded(&L, [&]() -> ommResult {
+        const DeviceScope onBakersDevice(b->bind_device());   // (the communicator must have been created on this device)
         auto nccl_fail = [&](int code, const char* what) {
             char buf[256]; snprintf(buf, sizeof buf, "[Failure] - %s: %s", what, rccl().getErrorString ? rccl().getErrorString(code) : "RCCL error");
             return L.failure(buf);

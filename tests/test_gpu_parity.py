@@ -414,6 +414,17 @@ def test_large_uv_offsets(product, oracle, offset, addr):
     both(product, oracle, [noise_u8()], uv, ix, 5, addr=addr, promo=ot.PROMO_FORCE_OPAQUE)
 
 
+@pytest.mark.parametrize("offset", [16382.0, 16383.9, 16384.5, -16383.5, -16386.0])
+def test_uv_magnitude_threshold_of_the_single_texel_pass(product, oracle, offset):
+    """work items on either side of |uv| = 16384: below it the straight-line single-texel pass runs (three-operand min / max, plain float -> int
+    conversions under its FINITE precondition), above it the generic path -- the result is the oracle's either way; 4096^2 texture, so the pixel
+    coordinates reach 2^26"""
+    uv, ix = ot.random_triangles(321, 60, 0.8)
+    uv = (uv + np.float32(offset)).astype(np.float32)
+    tex = ot.foliage_texture(11, 4096, 4096, feature=64)
+    both(product, oracle, [tex], uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+
+
 def test_hierarchy_levels_all_paths(product, oracle):
     """big triangles (many tiles per item, most of them uniform) and tiny ones, every level 0..9, SAT on"""
     tex = ot.foliage_texture(77, 1024, 1024, feature=96)
