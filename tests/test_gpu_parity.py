@@ -947,6 +947,58 @@ def test_concurrent_bakes_on_one_baker(product):
     product.destroy_baker(b)
 
 
+def test_no_memory_growth_over_baker_lifecycles(product):
+    """30 complete lifecycles (baker, texture, host-array bake, device-resident bake, sharded bake with one rank, blob round trip, destroy
+    everything): the free HBM reported by hipMemGetInfo and the resident set of the process return to where they were after the first
+    (warm-up) cycle -- the baker's pools, arenas, streams and events are released with it"""
+    import ctypes as C, resource
+    hip = ot.Hip()
+    hip.rt.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    hip.rt.hipDeviceSynchronize.argtypes = []
+    import omm_amd.sharded as sh
+
+    def free_hbm():
+        assert hip.rt.hipDeviceSynchronize() == 0
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.rt.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    def rss():
+        with open("/proc/self/statm") as fh:
+            return int(fh.read().split()[1]) * resource.getpagesize()
+
+    tex = ot.foliage_texture(33, 1024, 1024, feature=24)
+    uv, ix = ot.random_triangles(4242, 3000, 10.0 / 1024)
+    d_uv, d_ix = hip.upload(uv), hip.upload(ix.astype(np.int32))
+
+    def cycle():
+        b = product.create_baker()
+        t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+        d = ot.make_desc(t, uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+        r = product.bake(b, d, want_stats=False)
+        dd = ot.BakeInputDesc.from_buffer_copy(d); dd.texCoords, dd.indexBuffer = d_uv.value, d_ix.value
+        out = C.c_void_p()
+        product.dll.ommxBakeDevice.argtypes = [C.c_void_p, C.POINTER(ot.BakeInputDesc), C.POINTER(C.c_void_p)]
+        assert product.dll.ommxBakeDevice(b, C.byref(dd), C.byref(out)) == ot.SUCCESS
+        product.dll.ommxDestroyDeviceBakeResult.argtypes = [C.c_void_p]
+        assert product.dll.ommxDestroyDeviceBakeResult(out) == ot.SUCCESS
+        out2 = sh.sharded_bake(product.dll, b, C.byref(dd), 0, 1, None, None)
+        assert product.dll.ommxDestroyDeviceBakeResult(out2) == ot.SUCCESS
+        product.destroy_texture(b, t)
+        product.destroy_baker(b)
+        return r
+
+    first = cycle()
+    cycle()
+    f0, r0 = free_hbm(), rss()
+    for _ in range(30):
+        assert cycle().same_as(first)
+    f1, r1 = free_hbm(), rss()
+    hip.rt.hipFree(d_uv); hip.rt.hipFree(d_ix)
+    assert f0 - f1 < (32 << 20), "free HBM shrank by %d bytes over 30 lifecycles" % (f0 - f1)
+    assert r1 - r0 < (96 << 20), "resident set grew by %d bytes over 30 lifecycles" % (r1 - r0)
+
+
 def test_log_cases(product):
     """support/tests/test_omm_log.cpp:146-209 through the HIP library: same messages, same order, same results"""
     import log_cases
