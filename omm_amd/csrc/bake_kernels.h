@@ -73,6 +73,7 @@ void launch_shard_scatter(const uint8_t* gathered, uint64_t rankPitch, uint64_t 
 // ---- device tail (tail_kernels.hip) ----
 struct TailInputs {
     uint32_t numItems, numTris;
+    uint32_t maxDistinctDigests; // upper bound of the number of different digests (0 = unknown: numItems); sizes the dedup hash table
     const float*    uv;         // 6 per item
     const uint8_t*  level;      // per item
     const uint32_t* stateMask;  // per item

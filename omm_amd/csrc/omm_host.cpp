@@ -756,6 +756,8 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     TailInputs ti; memset(&ti, 0, sizeof ti);
     ti.numItems = U; ti.numTris = T; ti.uv = dUv; ti.level = dLevel; ti.stateMask = dMask; ti.knownCount = dKnown; ti.digests = dDigests;
     ti.uniformDigest = dUniformDigest; ti.triToItem = dTriToItem; ti.format = bits;
+    // every work item outside the active lists is uniform, and uniform items of one level and state share a digest: at most 13 x 4 of those
+    ti.maxDistinctDigests = hc.activeStart[kNumLevels] + 64u;
     ti.disableSpecial = (flags & (1u << 1)) != 0; ti.disableDedup = (flags & (1u << 3)) != 0;
     ti.rejectionThreshold = d.rejectionThreshold; ti.unresolved = (int32_t)d.unresolvedTriState; ti.errorFlag = dErr;
     TailOutputs to; memset(&to, 0, sizeof to);

@@ -28,8 +28,7 @@ __device__ __forceinline__ uint32_t spread16(uint32_t x)
 }
 
 // promote (bake_cpu_impl.cpp:1432-1472) + digest of uniform items from the table
-__global__ __launch_bounds__(256) void tail_summarize(TailInputs in, int32_t* __restrict__ special, uint64_t* __restrict__ digestKeys,
-                                                      uint32_t* __restrict__ itemIdx)
+__global__ __launch_bounds__(256) void tail_summarize(TailInputs in, int32_t* __restrict__ special)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= in.numItems) return;
@@ -47,8 +46,6 @@ __global__ __launch_bounds__(256) void tail_summarize(TailInputs in, int32_t* __
         if (frac < in.rejectionThreshold) { allEqual = true; common = 2; }
     }
     special[i] = (allEqual && !in.disableSpecial) ? (-(int32_t)common - 1) : 0;
-    digestKeys[i] = in.digests[i];
-    itemIdx[i] = i;
 }
 
 __global__ __launch_bounds__(256) void tail_iota(uint32_t* __restrict__ v, uint32_t n)
@@ -57,30 +54,101 @@ __global__ __launch_bounds__(256) void tail_iota(uint32_t* __restrict__ v, uint3
     if (i < n) v[i] = i;
 }
 
-// segment heads of the digest-sorted list -> position of the head (for the running-max scan)
-__global__ __launch_bounds__(256) void tail_head_pos(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ headPos)
+// ---- exact-duplicate detection as a hash build (DeduplicateExact, bake_cpu_impl.cpp:1031-1066: equality of the XXH64 digest only, the
+//      FIRST work item with a digest keeps its block) ----
+// Open addressing over 64-bit digests, linear probing, slot value = smallest item index seen (atomicMin): rep[i] = value of the slot that
+// holds digest[i].  The build is wave-cooperative: most work items are uniform and share a few dozen digests (one per level and state), so a
+// wave first groups its lanes by digest and only the lowest lane of each group touches the table -- one CAS + one atomicMin per distinct
+// digest per wave instead of ~870 000 atomics on the same few addresses.  Empty = all ones (also the initial value, one memset fills keys
+// and values); a digest that IS all ones lives in a dedicated slot past the table.
+constexpr uint64_t kEmptyDigest = ~0ull;
+__device__ __forceinline__ uint32_t digest_slot(uint64_t k, uint32_t mask) { return (uint32_t)(k >> 17) & mask; }   // (XXH64 output: any bits will do)
+
+// probe for `kk` (claiming an empty slot if it is not in the table yet) and lower the slot's value to `i`.  Plain (L2-coherent) loads
+// first: a slot's value only ever decreases, so a value <= i read here -- however stale -- proves that item i is not the first occurrence
+// and no atomic is needed.
+__device__ __forceinline__ void dedup_put(uint64_t kk, uint32_t i, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t mask)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    headPos[p] = (p == 0 || keys[p] != keys[p - 1]) ? p : 0u;
+    uint32_t slot = kk == kEmptyDigest ? mask + 1u : digest_slot(kk, mask);
+    if (kk != kEmptyDigest)
+        for (;;) {
+            unsigned long long cur = __atomic_load_n(keys + slot, __ATOMIC_RELAXED);
+            if (cur == kEmptyDigest) cur = atomicCAS(keys + slot, (unsigned long long)kEmptyDigest, (unsigned long long)kk);
+            if (cur == kEmptyDigest || cur == kk) break;
+            slot = (slot + 1u) & mask;
+        }
+    if (__atomic_load_n(vals + slot, __ATOMIC_RELAXED) > i) atomicMin(vals + slot, i);
 }
 
-__global__ __launch_bounds__(256) void tail_assign_rep(const uint32_t* __restrict__ sortedItems, const uint32_t* __restrict__ headPos, uint32_t n,
-                                                       uint32_t* __restrict__ rep)
+// Uniform work items (87 % of the bench workload) carry one of 13 x 4 table digests (tail_summarize): their first occurrence per (level, state)
+// is a min-reduction -- LDS bins per workgroup, then at most one gated global atomic per bin and workgroup -- not 870 000 operations on three
+// table slots (same-address atomics cost ~9 ns each on this chip).  The bins enter the table afterwards (dedup_insert_bins), so a
+// non-uniform item whose digest happens to equal a table digest still merges with it, as digest-only equality demands.
+constexpr uint32_t kUniformBins = kNumLevels * 4u;
+__global__ __launch_bounds__(256) void dedup_insert(const uint64_t* __restrict__ digests, const uint32_t* __restrict__ stateMask, const uint8_t* __restrict__ level,
+                                                    int haveUniformTable, uint32_t n, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                    uint32_t mask, uint32_t* __restrict__ firstUniform)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    rep[sortedItems[p]] = sortedItems[headPos[p]];
+    __shared__ uint32_t bins[kUniformBins];
+    if (threadIdx.x < kUniformBins) bins[threadIdx.x] = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = i < n;
+    if (live && haveUniformTable) {
+        const uint32_t m = stateMask[i];
+        if ((m & (m - 1u)) == 0u) {   // same test and same bin as tail_summarize
+            const int common = 31 - __clz((int)m);
+            atomicMin(&bins[(uint32_t)level[i] * 4u + (uint32_t)(common == 2 ? 3 : common)], i);
+            live = false;
+        }
+    }
+    const uint64_t k = live ? digests[i] : 0ull;
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long todo = __ballot(live);
+    while (todo) {   // (wave-uniform loop: one round per distinct digest among the wave's remaining items)
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, leader), khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k >> 32), leader);
+        const uint64_t kk = ((uint64_t)khi << 32) | klo;
+        const unsigned long long same = __ballot(live && k == kk);
+        // items ascend with the lane: the leader (lowest lane of the group) carries the group's smallest index
+        if ((int)lane == leader) dedup_put(kk, i, keys, vals, mask);
+        todo &= ~same;
+    }
+    __syncthreads();
+    if (threadIdx.x < kUniformBins) {
+        const uint32_t b = bins[threadIdx.x];
+        if (b != 0xFFFFFFFFu && __atomic_load_n(firstUniform + threadIdx.x, __ATOMIC_RELAXED) > b) atomicMin(firstUniform + threadIdx.x, b);
+    }
+}
+
+__global__ __launch_bounds__(64) void dedup_insert_bins(const uint64_t* __restrict__ uniformDigest, const uint32_t* __restrict__ firstUniform,
+                                                        unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t mask)
+{
+    const uint32_t t = threadIdx.x;
+    if (t < kUniformBins && firstUniform[t] != 0xFFFFFFFFu) dedup_put(uniformDigest[t], firstUniform[t], keys, vals, mask);
+}
+
+__global__ __launch_bounds__(256) void dedup_lookup(const uint64_t* __restrict__ digests, uint32_t n, const unsigned long long* __restrict__ keys,
+                                                    const uint32_t* __restrict__ vals, uint32_t mask, uint32_t* __restrict__ rep)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = digests[i];
+    uint32_t slot = mask + 1u;
+    if (k != kEmptyDigest) { slot = digest_slot(k, mask); while (keys[slot] != k) slot = (slot + 1u) & mask; }
+    rep[i] = vals[slot];
 }
 
 // spatial sort key (bake_cpu_impl.cpp:1722-1748); non-emitted items sort to the far end
 __global__ __launch_bounds__(256) void tail_sort_keys(TailInputs in, const int32_t* __restrict__ special, const uint32_t* __restrict__ rep,
-                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ emittedFlag)
+                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ emittedFlag)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= in.numItems) return;
     const bool emitted = rep[i] == i && special[i] == 0;
-    uint64_t key = ~0ull;
+    // the reference's 64-bit key is level << 60 | 26 Morton bits: the same order in 30 bits (level << 26 | Morton), so the sort moves half the
+    // bytes and a radix sort needs 4 digit passes instead of 8
+    uint32_t key = ~0u;
     if (emitted) {
         const float* p = in.uv + 6ull * i;
         const float cx = (p[0] + p[2] + p[4]) / 3.f, cy = (p[1] + p[3] + p[5]) / 3.f;
@@ -88,7 +156,7 @@ __global__ __launch_bounds__(256) void tail_sort_keys(TailInputs in, const int32
         // GetTexCoord<MirrorOnce, non-pow2> on an 8192^2 grid (util/texture.h:84-87)
         const int mx = clampi_t(cvt_trunc_x86_t(__builtin_fabsf((float)qx + 0.5f)), 0, 8191);
         const int my = clampi_t(cvt_trunc_x86_t(__builtin_fabsf((float)qy + 0.5f)), 0, 8191);
-        key = ((uint64_t)in.level[i] << 60) | (uint64_t)(spread16((uint32_t)mx) | (spread16((uint32_t)my) << 1));
+        key = ((uint32_t)in.level[i] << 26) | (spread16((uint32_t)mx) | (spread16((uint32_t)my) << 1));   // (mx, my < 8192: 26 Morton bits)
     }
     keys[i] = key;
     emittedFlag[i] = emitted ? 1u : 0u;
@@ -407,22 +475,24 @@ void launch_shard_scatter(const uint8_t* gathered, uint64_t rankPitch, uint64_t 
 
 // ---- scratch layout ----
 struct Scratch {
-    uint64_t *keysA, *keysB, *sizes64, *ofs64;
-    uint32_t *valsA, *valsB, *headPos, *headScan, *emitted, *numEmitted;
+    uint32_t *keysA, *keysB;   // spatial sort keys (level << 26 | Morton)
+    uint64_t *sizes64, *ofs64;
+    uint32_t *valsA, *valsB, *emitted, *numEmitted;
     uint64_t* total;
+    unsigned long long* hashKeys; uint32_t* hashVals; uint32_t hashMask;   // digest table: hashMask + 1 slots (+ 1 dedicated slot in hashVals)
     void* tmp; size_t tmpBytes;
 };
+static uint32_t hash_slots(uint32_t n) { uint32_t s = 1024; while (s < 2u * n && s < 0x80000000u) s <<= 1; return s; }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static size_t prim_temp_bytes(uint32_t n)
 {
-    size_t a = 0, b = 0, c = 0, d = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n);
-    (void)rocprim::inclusive_scan(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, rocprim::maximum<uint32_t>());
+    size_t a = 0, c = 0, d = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n);
     (void)rocprim::exclusive_scan(nullptr, c, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>());
     (void)rocprim::reduce(nullptr, d, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>());
-    size_t m = a; if (b > m) m = b; if (c > m) m = c; if (d > m) m = d;
+    size_t m = a; if (c > m) m = c; if (d > m) m = d;
     return align_up(m, 256) + 256;
 }
 
@@ -430,10 +500,14 @@ static Scratch carve(void* base, uint32_t n)
 {
     Scratch s; uint8_t* p = (uint8_t*)base;
     const size_t n64 = align_up((size_t)n * 8, 256), n32 = align_up((size_t)n * 4, 256);
-    s.keysA = (uint64_t*)p; p += n64; s.keysB = (uint64_t*)p; p += n64; s.sizes64 = (uint64_t*)p; p += n64; s.ofs64 = (uint64_t*)p; p += n64;
-    s.valsA = (uint32_t*)p; p += n32; s.valsB = (uint32_t*)p; p += n32; s.headPos = (uint32_t*)p; p += n32; s.headScan = (uint32_t*)p; p += n32;
+    s.sizes64 = (uint64_t*)p; p += n64; s.ofs64 = (uint64_t*)p; p += n64;
+    s.keysA = (uint32_t*)p; p += n32; s.keysB = (uint32_t*)p; p += n32;
+    s.valsA = (uint32_t*)p; p += n32; s.valsB = (uint32_t*)p; p += n32;
     s.emitted = (uint32_t*)p; p += n32;
     s.numEmitted = (uint32_t*)p; p += 256; s.total = (uint64_t*)p; p += 256;
+    const uint32_t slots = hash_slots(n);
+    s.hashMask = slots - 1u;
+    s.hashKeys = (unsigned long long*)p; p += align_up((size_t)slots * 8, 256); s.hashVals = (uint32_t*)p; p += align_up(((size_t)slots + 1 + kUniformBins) * 4, 256);
     s.tmp = p; s.tmpBytes = prim_temp_bytes(n);
     return s;
 }
@@ -442,7 +516,8 @@ size_t tail_scratch_bytes(uint32_t numItems, uint32_t numTris)
 {
     (void)numTris;
     const uint32_t n = numItems ? numItems : 1;
-    return 4 * align_up((size_t)n * 8, 256) + 5 * align_up((size_t)n * 4, 256) + 512 + prim_temp_bytes(n);
+    const size_t slots = hash_slots(n);
+    return 2 * align_up((size_t)n * 8, 256) + 5 * align_up((size_t)n * 4, 256) + 512 + align_up(slots * 8, 256) + align_up((slots + 1 + kUniformBins) * 4, 256) + prim_temp_bytes(n);
 }
 
 hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch, size_t scratchBytes, TailCounts* counts, hipStream_t stream)
@@ -456,23 +531,27 @@ hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch,
         if (scratchBytes < tail_scratch_bytes(n, in.numTris)) return hipErrorInvalidValue;
         Scratch s = carve(scratch, n);
         const dim3 grid((n + 255u) / 256u), block(256);
-        hipLaunchKernelGGL(tail_summarize, grid, block, 0, stream, in, out.special, s.keysA, s.valsA);
+        hipLaunchKernelGGL(tail_summarize, grid, block, 0, stream, in, out.special);
         if (in.disableDedup) {
             hipLaunchKernelGGL(tail_iota, grid, block, 0, stream, out.rep, n);
         } else {
-            size_t tb = s.tmpBytes;
-            TAIL_CHECK(rocprim::radix_sort_pairs(s.tmp, tb, s.keysA, s.keysB, s.valsA, s.valsB, (size_t)n, (unsigned)0, (unsigned)64, stream));
-            hipLaunchKernelGGL(tail_head_pos, grid, block, 0, stream, s.keysB, n, s.headPos);
-            tb = s.tmpBytes;
-            TAIL_CHECK(rocprim::inclusive_scan(s.tmp, tb, s.headPos, s.headScan, (size_t)n, rocprim::maximum<uint32_t>(), stream));
-            hipLaunchKernelGGL(tail_assign_rep, grid, block, 0, stream, s.valsB, s.headScan, n, out.rep);
+            // (the scratch block is sized for numItems distinct digests; the table only needs twice the number that can occur)
+            const uint32_t distinct = in.maxDistinctDigests && in.maxDistinctDigests < n ? in.maxDistinctDigests : n;
+            s.hashMask = hash_slots(distinct) - 1u;
+            s.hashVals = (uint32_t*)((uint8_t*)s.hashKeys + align_up(((size_t)s.hashMask + 1) * 8, 256));
+            // keys, values and the uniform bins are adjacent in the scratch block: one fill sets them all to all ones
+            uint32_t* firstUniform = s.hashVals + s.hashMask + 2u;
+            TAIL_CHECK(hipMemsetAsync(s.hashKeys, 0xFF, (size_t)((uint8_t*)(firstUniform + kUniformBins) - (uint8_t*)s.hashKeys), stream));
+            hipLaunchKernelGGL(dedup_insert, grid, block, 0, stream, in.digests, in.stateMask, in.level, in.uniformDigest ? 1 : 0, n, s.hashKeys, s.hashVals, s.hashMask, firstUniform);
+            if (in.uniformDigest) hipLaunchKernelGGL(dedup_insert_bins, dim3(1), dim3(64), 0, stream, in.uniformDigest, firstUniform, s.hashKeys, s.hashVals, s.hashMask);
+            hipLaunchKernelGGL(dedup_lookup, grid, block, 0, stream, in.digests, n, s.hashKeys, s.hashVals, s.hashMask, out.rep);
         }
         hipLaunchKernelGGL(tail_sort_keys, grid, block, 0, stream, in, out.special, out.rep, s.keysA, s.emitted);
         hipLaunchKernelGGL(tail_iota, grid, block, 0, stream, s.valsA, n);
         size_t tb = s.tmpBytes;
         TAIL_CHECK(rocprim::reduce(s.tmp, tb, s.emitted, s.numEmitted, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>(), stream));
         tb = s.tmpBytes;
-        TAIL_CHECK(rocprim::radix_sort_pairs(s.tmp, tb, s.keysA, s.keysB, s.valsA, s.valsB, (size_t)n, (unsigned)0, (unsigned)64, stream));
+        TAIL_CHECK(rocprim::radix_sort_pairs(s.tmp, tb, s.keysA, s.keysB, s.valsA, s.valsB, (size_t)n, (unsigned)0, (unsigned)32, stream));
         TAIL_CHECK(hipMemsetAsync(s.sizes64, 0, (size_t)n * 8, stream));
         hipLaunchKernelGGL(tail_order_sizes, grid, block, 0, stream, s.valsB, s.numEmitted, in.level, in.format, out.order, s.sizes64, out.sizes, out.arrayHist);
         tb = s.tmpBytes;
