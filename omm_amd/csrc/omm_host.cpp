@@ -609,6 +609,8 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     S.globalLevel = d.maxSubdivisionLevel; S.dynScale = d.dynamicSubdivisionScale; S.edgeHeuristic = 0;
     S.texW = tex.mips[0].w; S.texH = tex.mips[0].h; S.disableDedup = (flags & (1u << 3)) != 0;
     S.wantWorkload = ((flags & (1u << 5)) != 0) || d.maxWorkloadSize != 0xFFFFFFFFFFFFFFFFull;
+    S.keyMask = ~0ull;
+    if (const char* kb = getenv("OMMX_TEST_SETUP_KEY_BITS")) { const int bits = atoi(kb); if (bits > 0 && bits < 63) S.keyMask = (1ull << bits) - 1ull; }   // test hook
     bool ok = HIP_OK(hipMemcpyAsync(dUniformDigest, uniform_digests().v, sizeof(uint64_t) * kNumLevels * 4, hipMemcpyHostToDevice, stream));
     ok = ok && HIP_OK(hipMemsetAsync(dKnown, 0, (size_t)maxItems * 4, stream));
     ok = ok && HIP_OK(run_setup_fetch(S, dScratch, scratchBytes, dCounters, stream));

@@ -2,17 +2,18 @@
 //
 // The reference walks the triangles serially: fetch UVs, pick the subdivision level, drop invalid (NaN/Inf) triangles,
 // and merge triangles with an identical (UV triangle, level, format) into one work item owned by the FIRST occurrence.
-// Device form: one lane per triangle + a stable radix sort by a 64-bit key hash:
-//   * segment heads of the sorted (hash, triangle) list  = first occurrences (stable => lowest triangle index)
+// Device form: one lane per triangle + a hash build over a 64-bit key hash (hash_build.h):
+//   * slot value = smallest triangle index with the key  = first occurrence
 //   * exclusive scan over "is first occurrence" in triangle order = work-item numbering in the reference's order
-//   * stable sort of the items by level = the per-level launch lists
+//   * stable counting split of the items by level = the per-level launch lists
 // The reference itself keys its map by a 64-bit hash and trusts it; here every merged triangle is additionally compared
-// against its predecessor's full key and a mismatch raises `collision` (the host then redoes the setup serially).
+// against its first occurrence's full key and a mismatch raises `collision` (the host then redoes the setup serially).
 // The one libm-dependent piece -- log2f in the edge heuristic for degenerate triangles under dynamic subdivision
 // (bake_cpu_impl.cpp:511-528) -- is not evaluated here: such triangles are reported in `pending` for the host.
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <rocprim/rocprim.hpp>
+#include "hash_build.h"
 #include <stdint.h>
 #include "bake_types.h"
 #include "bake_kernels.h"
@@ -47,7 +48,7 @@ __device__ __forceinline__ uint32_t cvt_u32_x86(float f)
 }
 
 __global__ __launch_bounds__(256) void setup_fetch(SetupParams S, float* __restrict__ triUv, uint8_t* __restrict__ triLevel,
-                                                   uint8_t* __restrict__ triFlags, uint64_t* __restrict__ hashKeys, uint32_t* __restrict__ triIdx,
+                                                   uint8_t* __restrict__ triFlags, uint64_t* __restrict__ hashKeys,
                                                    SetupCounters* __restrict__ counters, uint32_t* __restrict__ pendingList)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,7 +105,6 @@ __global__ __launch_bounds__(256) void setup_fetch(SetupParams S, float* __restr
     for (int k = 0; k < 6; ++k) triUv[6ull * t + k] = p[k];
     triLevel[t] = (uint8_t)level;
     triFlags[t] = (uint8_t)((invalid ? 1u : 0u) | (degenerate ? 2u : 0u) | (pending ? 4u : 0u));
-    triIdx[t] = t;
     if (invalid) atomicAdd(&counters->numDisabled, 1u);
     if (pending) { const uint32_t slot = atomicAdd(&counters->numPending, 1u); pendingList[slot] = t; }
     uint64_t h;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void setup_fetch(SetupParams S, float* __restr
         #pragma unroll
         for (int k = 0; k < 6; ++k) h = mix64(h, __float_as_uint(p[k] == 0.f ? 0.f : p[k])); // +0 == -0 (std::hash<float>)
         h = mix64(h, level);
-        h &= 0x7FFFFFFFFFFFFFFFULL; // keep clear of the invalid-triangle key range
+        h &= 0x7FFFFFFFFFFFFFFFULL & S.keyMask; // keep clear of the invalid-triangle key range
     }
     hashKeys[t] = h;
 }
@@ -130,41 +130,46 @@ __global__ __launch_bounds__(256) void setup_rehash_pending(SetupParams S, const
     uint64_t h = 0x9E3779B97F4A7C15ULL;
     for (int q = 0; q < 6; ++q) { const float f = triUv[6ull * t + q]; h = mix64(h, __float_as_uint(f == 0.f ? 0.f : f)); }
     h = mix64(h, triLevel[t]);
-    hashKeys[t] = h & 0x7FFFFFFFFFFFFFFFULL;
+    hashKeys[t] = h & 0x7FFFFFFFFFFFFFFFULL & S.keyMask;
 }
 
-__global__ __launch_bounds__(256) void setup_heads(const uint64_t* __restrict__ sortedKeys, const uint32_t* __restrict__ sortedTris, uint32_t n,
-                                                   const float* __restrict__ triUv, const uint8_t* __restrict__ triLevel,
-                                                   uint32_t* __restrict__ headPos, SetupCounters* __restrict__ counters)
+// ---- UV-triangle dedup as a hash build (hash_build.h): firstTri[t] = smallest triangle index with triangle t's 64-bit key ----
+// (keys: setup_fetch; invalid triangles and disableDedup bakes have unique keys by construction and skip the table)
+__global__ __launch_bounds__(256) void setup_dedup_insert(const uint64_t* __restrict__ hashKeys, const uint8_t* __restrict__ triFlags, uint32_t n, HashTable table)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const bool head = p == 0 || sortedKeys[p] != sortedKeys[p - 1];
-    headPos[p] = head ? p : 0u;
-    if (!head) { // equal hash: the full keys must be equal too, else the hash collided
-        const uint32_t a = sortedTris[p], b = sortedTris[p - 1];
-        bool same = triLevel[a] == triLevel[b];
-        for (int q = 0; q < 6; ++q) { const float x = triUv[6ull * a + q], y = triUv[6ull * b + q]; same &= (x == y); }
-        if (!same) atomicOr(&counters->collision, 1u);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t buckets[256];
+    const bool live = t < n && !(triFlags[t] & 1u);
+    hash_put_min_block(table, live, live ? hashKeys[t] : 0ull, t, buckets);
+}
+
+// first occurrence, item flag, and the collision check: a triangle whose key equals the first occurrence's must have the same (UV, level)
+// tuple, else the 64-bit hash collided and the host redoes the dedup exactly
+__global__ __launch_bounds__(256) void setup_dedup_lookup(const uint64_t* __restrict__ hashKeys, const uint8_t* __restrict__ triFlags, uint32_t n, HashTable table,
+                                                          int disableDedup, const float* __restrict__ triUv, const uint8_t* __restrict__ triLevel,
+                                                          uint32_t* __restrict__ firstTri, uint32_t* __restrict__ isItem, SetupCounters* __restrict__ counters)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const bool invalid = (triFlags[t] & 1u) != 0;
+    uint32_t f = t;
+    if (!invalid && !disableDedup) {
+        f = hash_get(table, hashKeys[t]);
+        if (f != t) {
+            bool same = triLevel[t] == triLevel[f];
+            for (int q = 0; q < 6; ++q) { const float x = triUv[6ull * t + q], y = triUv[6ull * f + q]; same &= (x == y); }
+            if (!same) atomicOr(&counters->collision, 1u);
+        }
     }
-}
-
-__global__ __launch_bounds__(256) void setup_first_tri(const uint32_t* __restrict__ sortedTris, const uint32_t* __restrict__ headScan, uint32_t n,
-                                                       const uint8_t* __restrict__ triFlags, uint32_t* __restrict__ firstTri, uint32_t* __restrict__ isItem)
-{
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const uint32_t t = sortedTris[p], f = sortedTris[headScan[p]];
     firstTri[t] = f;
-    isItem[t] = (f == t && !(triFlags[t] & 1u)) ? 1u : 0u;
+    isItem[t] = (f == t && !invalid) ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void setup_emit_items(SetupParams S, const float* __restrict__ triUv, const uint8_t* __restrict__ triLevel,
                                                         const uint8_t* __restrict__ triFlags, const uint32_t* __restrict__ firstTri,
                                                         const uint32_t* __restrict__ isItem, const uint32_t* __restrict__ itemOfTri,
                                                         float* __restrict__ itemUv, uint8_t* __restrict__ itemLevel, uint8_t* __restrict__ itemDegenerate,
-                                                        int32_t* __restrict__ triToItem, uint32_t* __restrict__ sortKeys, uint32_t* __restrict__ sortVals,
-                                                        SetupCounters* __restrict__ counters)
+                                                        int32_t* __restrict__ triToItem, SetupCounters* __restrict__ counters)
 {
     __shared__ uint32_t s_hist[kNumLevels];
     __shared__ unsigned long long s_work;
@@ -173,7 +178,6 @@ __global__ __launch_bounds__(256) void setup_emit_items(SetupParams S, const flo
     __syncthreads();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < S.numTris) {
-        sortKeys[t] = 15u; sortVals[t] = 0u; // slots past the item count sort to the end
         if (t == S.numTris - 1) counters->numItems = itemOfTri[t] + isItem[t];
         triToItem[t] = (triFlags[t] & 1u) ? -1 : (int32_t)itemOfTri[firstTri[t]];
         if (isItem[t]) {
@@ -199,21 +203,94 @@ __global__ __launch_bounds__(256) void setup_emit_items(SetupParams S, const flo
     if (threadIdx.x == 0 && s_work) atomicAdd((unsigned long long*)&counters->workload, s_work);
 }
 
-// items are numbered in triangle order; their level keys are written in a second pass once the numbering exists
-__global__ __launch_bounds__(256) void setup_level_keys(const uint8_t* __restrict__ itemLevel, const SetupCounters* __restrict__ counters, uint32_t n,
-                                                        uint32_t* __restrict__ sortKeys, uint32_t* __restrict__ sortVals)
+// ---- items grouped by level (stable): a counting split over the 13 levels instead of a sort ----
+// Items are numbered in triangle order; itemIds lists them level by level, ascending inside a level.  Chunks of kSplitChunk consecutive
+// items: (1) per-chunk counts per level, (2) one small scan gives every chunk its write position per level (behind levelStart[l]),
+// (3) the chunks scatter their items, ranked inside the chunk with wave ballots in item order.
+constexpr uint32_t kSplitChunk = 4096;
+__device__ __forceinline__ uint32_t level_of_slot(const uint8_t* __restrict__ itemLevel, uint32_t i, uint32_t numItems) { return i < numItems ? (uint32_t)itemLevel[i] : 0xFFu; }
+
+__global__ __launch_bounds__(256) void setup_split_count(const uint8_t* __restrict__ itemLevel, const SetupCounters* __restrict__ counters, uint32_t* __restrict__ chunkCount)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || i >= counters->numItems) return;
-    sortKeys[i] = itemLevel[i]; sortVals[i] = i;
+    __shared__ uint32_t h[kNumLevels];
+    if (threadIdx.x < kNumLevels) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t numItems = counters->numItems, base = blockIdx.x * kSplitChunk;
+    if (base < numItems) {
+        for (uint32_t j = 0; j < kSplitChunk; j += 256) {
+            const uint32_t lvl = level_of_slot(itemLevel, base + j + threadIdx.x, numItems);
+            unsigned long long todo = __ballot(lvl != 0xFFu);
+            while (todo) {   // one LDS atomic per (wave, level)
+                const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+                const uint32_t l0 = (uint32_t)__shfl((int)lvl, (int)leader);
+                const unsigned long long same = __ballot(lvl == l0);
+                if ((threadIdx.x & 63u) == leader) atomicAdd(&h[l0], (uint32_t)__popcll(same));
+                todo &= ~same;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumLevels) chunkCount[blockIdx.x * kNumLevels + threadIdx.x] = h[threadIdx.x];
 }
 
-__global__ void setup_level_starts(SetupCounters* __restrict__ counters)
+// levelStart[] from the level histogram, then chunkCount[c][l] -> first write position of chunk c in level l.  One wave per level, 64
+// chunks per step (wave prefix sum).
+__global__ __launch_bounds__(1024) void setup_split_scan(SetupCounters* __restrict__ counters, uint32_t* __restrict__ chunkCount, uint32_t numChunks)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    __shared__ uint32_t start[kNumLevels + 1];
+    if (threadIdx.x == 0) {
         uint32_t run = 0;
-        for (int l = 0; l < kNumLevels; ++l) { counters->levelStart[l] = run; run += counters->levelCount[l]; }
-        counters->levelStart[kNumLevels] = run;
+        for (int l = 0; l < kNumLevels; ++l) { start[l] = run; counters->levelStart[l] = run; run += counters->levelCount[l]; }
+        start[kNumLevels] = run; counters->levelStart[kNumLevels] = run;
+    }
+    __syncthreads();
+    const uint32_t l = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (l >= (uint32_t)kNumLevels) return;
+    uint32_t run = start[l];
+    for (uint32_t c0 = 0; c0 < numChunks; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        const uint32_t v = c < numChunks ? chunkCount[c * kNumLevels + l] : 0u;
+        uint32_t incl = v;
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d); if ((int)lane >= d) incl += o; }
+        if (c < numChunks) chunkCount[c * kNumLevels + l] = run + incl - v;
+        run += (uint32_t)__shfl((int)incl, 63);
+    }
+}
+
+__global__ __launch_bounds__(256) void setup_split_scatter(const uint8_t* __restrict__ itemLevel, const SetupCounters* __restrict__ counters,
+                                                           const uint32_t* __restrict__ chunkStart, uint32_t* __restrict__ itemIds)
+{
+    __shared__ uint32_t pos[kNumLevels];            // next write position of this chunk per level
+    __shared__ uint32_t waveCount[4][kNumLevels];   // items of each level held by each wave in the current round
+    const uint32_t numItems = counters->numItems, base = blockIdx.x * kSplitChunk;
+    if (base >= numItems) return;   // (block-uniform)
+    if (threadIdx.x < kNumLevels) pos[threadIdx.x] = chunkStart[blockIdx.x * kNumLevels + threadIdx.x];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t j = 0; j < kSplitChunk; j += 256) {
+        if (threadIdx.x < 4 * kNumLevels) (&waveCount[0][0])[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t i = base + j + threadIdx.x;
+        const uint32_t lvl = level_of_slot(itemLevel, i, numItems);
+        uint32_t rank = 0;
+        unsigned long long todo = __ballot(lvl != 0xFFu);
+        while (todo) {
+            const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+            const uint32_t l0 = (uint32_t)__shfl((int)lvl, (int)leader);
+            const unsigned long long same = __ballot(lvl == l0);
+            if (lvl == l0) rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            if (lane == leader) waveCount[wave][l0] = (uint32_t)__popcll(same);
+            todo &= ~same;
+        }
+        __syncthreads();
+        if (lvl != 0xFFu) {
+            uint32_t before = 0;
+            for (uint32_t w = 0; w < wave; ++w) before += waveCount[w][lvl];
+            itemIds[pos[lvl] + before + rank] = i;
+        }
+        __syncthreads();
+        if (threadIdx.x < kNumLevels) pos[threadIdx.x] += waveCount[0][threadIdx.x] + waveCount[1][threadIdx.x] + waveCount[2][threadIdx.x] + waveCount[3][threadIdx.x];
+        __syncthreads();
     }
 }
 
@@ -237,23 +314,19 @@ __global__ __launch_bounds__(256) void setup_tri_areas(const float* __restrict__
 size_t setup_scratch_bytes(uint32_t numTris)
 {
     const size_t n = numTris ? numTris : 1;
-    size_t a = 0, b = 0, c = 0, d = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n);
-    (void)rocprim::inclusive_scan(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, rocprim::maximum<uint32_t>());
-    (void)rocprim::exclusive_scan(nullptr, c, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>());
-    (void)rocprim::radix_sort_pairs(nullptr, d, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n);
-    size_t m = a; if (b > m) m = b; if (c > m) m = c; if (d > m) m = d;
+    size_t m = 0;
+    (void)rocprim::exclusive_scan(nullptr, m, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>());
     const size_t p256 = 256;
     auto pad = [&](size_t v) { return (v + p256 - 1) / p256 * p256; };
-    //           triUv        keys x2          tri/sorted idx x2  headPos,headScan,firstTri,isItem,itemOfTri  level,flags      pending
-    return pad(n * 24) + 2 * pad(n * 8) + 2 * pad(n * 4) + 5 * pad(n * 4) + 2 * pad(n) + pad(n * 4) + 2 * pad(n * 4) + pad(m) + 1024;
+    //           triUv        keys         firstTri,isItem,itemOfTri  level,flags   pending      chunk counts  hash table
+    return pad(n * 24) + pad(n * 8) + 3 * pad(n * 4) + 2 * pad(n) + pad(n * 4) + pad(n * 4) + pad(hash_table_bytes(hash_table_slots(n))) + pad(m) + 1024;
 }
 
 // phase A: fetch + levels + hash keys.  The caller then looks at counters->numPending (after its sync) and, if non-zero,
 // fixes those levels and calls setup_rehash().  phase B: dedup + item emission + level grouping.
 struct SetupScratch {
-    float* triUv; uint64_t *keysA, *keysB; uint32_t *trisA, *trisB, *headPos, *headScan, *firstTri, *isItem, *itemOfTri, *pending, *lkeysA, *lkeysB;
-    uint8_t *triLevel, *triFlags; void* tmp; size_t tmpBytes;
+    float* triUv; uint64_t* keysA; uint32_t *firstTri, *isItem, *itemOfTri, *pending, *lkeysA;
+    uint8_t *triLevel, *triFlags; void* hash; void* tmp; size_t tmpBytes;
 };
 static SetupScratch carve_setup(void* base, size_t bytes, uint32_t numTris)
 {
@@ -261,13 +334,13 @@ static SetupScratch carve_setup(void* base, size_t bytes, uint32_t numTris)
     auto pad = [](size_t v) { return (v + 255) / 256 * 256; };
     SetupScratch s; uint8_t* p = (uint8_t*)base;
     s.triUv = (float*)p; p += pad(n * 24);
-    s.keysA = (uint64_t*)p; p += pad(n * 8); s.keysB = (uint64_t*)p; p += pad(n * 8);
-    s.trisA = (uint32_t*)p; p += pad(n * 4); s.trisB = (uint32_t*)p; p += pad(n * 4);
-    s.headPos = (uint32_t*)p; p += pad(n * 4); s.headScan = (uint32_t*)p; p += pad(n * 4); s.firstTri = (uint32_t*)p; p += pad(n * 4);
+    s.keysA = (uint64_t*)p; p += pad(n * 8);
+    s.firstTri = (uint32_t*)p; p += pad(n * 4);
     s.isItem = (uint32_t*)p; p += pad(n * 4); s.itemOfTri = (uint32_t*)p; p += pad(n * 4);
     s.triLevel = p; p += pad(n); s.triFlags = p; p += pad(n);
     s.pending = (uint32_t*)p; p += pad(n * 4);
-    s.lkeysA = (uint32_t*)p; p += pad(n * 4); s.lkeysB = (uint32_t*)p; p += pad(n * 4);
+    s.lkeysA = (uint32_t*)p; p += pad(n * 4);
+    s.hash = p; p += pad(hash_table_bytes(hash_table_slots(n)));
     s.tmp = p; s.tmpBytes = bytes - (size_t)(p - (uint8_t*)base);
     return s;
 }
@@ -278,7 +351,7 @@ hipError_t run_setup_fetch(const SetupParams& S, void* scratch, size_t scratchBy
     if (S.numTris == 0) return hipSuccess;
     if (scratchBytes < setup_scratch_bytes(S.numTris)) return hipErrorInvalidValue;
     SetupScratch s = carve_setup(scratch, scratchBytes, S.numTris);
-    hipLaunchKernelGGL(setup_fetch, dim3((S.numTris + 255u) / 256u), dim3(256), 0, stream, S, s.triUv, s.triLevel, s.triFlags, s.keysA, s.trisA, counters, s.pending);
+    hipLaunchKernelGGL(setup_fetch, dim3((S.numTris + 255u) / 256u), dim3(256), 0, stream, S, s.triUv, s.triLevel, s.triFlags, s.keysA, counters, s.pending);
     return hipGetLastError();
 }
 
@@ -343,20 +416,22 @@ hipError_t run_setup_items(const SetupParams& S, void* scratch, size_t scratchBy
     SetupScratch s = carve_setup(scratch, scratchBytes, n);
     const dim3 grid((n + 255u) / 256u), block(256);
     if (triArea) hipLaunchKernelGGL(setup_tri_areas, grid, block, 0, stream, s.triUv, s.triFlags, n, triArea);
-    size_t tb = s.tmpBytes;
-    SETUP_CHECK(rocprim::radix_sort_pairs(s.tmp, tb, s.keysA, s.keysB, s.trisA, s.trisB, (size_t)n, (unsigned)0, (unsigned)64, stream));
-    hipLaunchKernelGGL(setup_heads, grid, block, 0, stream, s.keysB, s.trisB, n, s.triUv, s.triLevel, s.headPos, counters);
-    tb = s.tmpBytes;
-    SETUP_CHECK(rocprim::inclusive_scan(s.tmp, tb, s.headPos, s.headScan, (size_t)n, rocprim::maximum<uint32_t>(), stream));
-    hipLaunchKernelGGL(setup_first_tri, grid, block, 0, stream, s.trisB, s.headScan, n, s.triFlags, s.firstTri, s.isItem);
+    const uint32_t slots = hash_table_slots(n);
+    const HashTable table = hash_table_at(s.hash, slots);
+    if (!S.disableDedup) {
+        SETUP_CHECK(hipMemsetAsync(s.hash, 0xFF, hash_table_bytes(slots), stream));
+        hipLaunchKernelGGL(setup_dedup_insert, grid, block, 0, stream, s.keysA, s.triFlags, n, table);
+    }
+    hipLaunchKernelGGL(setup_dedup_lookup, grid, block, 0, stream, s.keysA, s.triFlags, n, table, S.disableDedup ? 1 : 0, s.triUv, s.triLevel, s.firstTri, s.isItem, counters);
+    size_t tb;
     tb = s.tmpBytes;
     SETUP_CHECK(rocprim::exclusive_scan(s.tmp, tb, s.isItem, s.itemOfTri, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>(), stream));
     hipLaunchKernelGGL(setup_emit_items, grid, block, 0, stream, S, s.triUv, s.triLevel, s.triFlags, s.firstTri, s.isItem, s.itemOfTri, itemUv, itemLevel,
-                       itemDegenerate, triToItem, s.lkeysA, s.trisA, counters);
-    hipLaunchKernelGGL(setup_level_keys, grid, block, 0, stream, itemLevel, counters, n, s.lkeysA, s.trisA);
-    tb = s.tmpBytes;
-    SETUP_CHECK(rocprim::radix_sort_pairs(s.tmp, tb, s.lkeysA, s.lkeysB, s.trisA, itemIds, (size_t)n, (unsigned)0, (unsigned)4, stream));
-    hipLaunchKernelGGL(setup_level_starts, dim3(1), dim3(64), 0, stream, counters);
+                       itemDegenerate, triToItem, counters);
+    const uint32_t numChunks = (n + kSplitChunk - 1u) / kSplitChunk;   // (n bounds the item count, which only the device knows here)
+    hipLaunchKernelGGL(setup_split_count, dim3(numChunks), block, 0, stream, itemLevel, counters, s.lkeysA);
+    hipLaunchKernelGGL(setup_split_scan, dim3(1), dim3(1024), 0, stream, counters, s.lkeysA, numChunks);
+    hipLaunchKernelGGL(setup_split_scatter, dim3(numChunks), block, 0, stream, itemLevel, counters, s.lkeysA, itemIds);
     return hipGetLastError();
 }
 

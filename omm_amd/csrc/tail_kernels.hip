@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <rocprim/rocprim.hpp>
+#include "hash_build.h"
 #include <stdint.h>
 #include "bake_types.h"
 #include "bake_kernels.h"
@@ -55,41 +56,17 @@ __global__ __launch_bounds__(256) void tail_iota(uint32_t* __restrict__ v, uint3
 }
 
 // ---- exact-duplicate detection as a hash build (DeduplicateExact, bake_cpu_impl.cpp:1031-1066: equality of the XXH64 digest only, the
-//      FIRST work item with a digest keeps its block) ----
-// Open addressing over 64-bit digests, linear probing, slot value = smallest item index seen (atomicMin): rep[i] = value of the slot that
-// holds digest[i].  The build is wave-cooperative: most work items are uniform and share a few dozen digests (one per level and state), so a
-// wave first groups its lanes by digest and only the lowest lane of each group touches the table -- one CAS + one atomicMin per distinct
-// digest per wave instead of ~870 000 atomics on the same few addresses.  Empty = all ones (also the initial value, one memset fills keys
-// and values); a digest that IS all ones lives in a dedicated slot past the table.
-constexpr uint64_t kEmptyDigest = ~0ull;
-__device__ __forceinline__ uint32_t digest_slot(uint64_t k, uint32_t mask) { return (uint32_t)(k >> 17) & mask; }   // (XXH64 output: any bits will do)
-
-// probe for `kk` (claiming an empty slot if it is not in the table yet) and lower the slot's value to `i`.  Plain (L2-coherent) loads
-// first: a slot's value only ever decreases, so a value <= i read here -- however stale -- proves that item i is not the first occurrence
-// and no atomic is needed.
-__device__ __forceinline__ void dedup_put(uint64_t kk, uint32_t i, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t mask)
-{
-    uint32_t slot = kk == kEmptyDigest ? mask + 1u : digest_slot(kk, mask);
-    if (kk != kEmptyDigest)
-        for (;;) {
-            unsigned long long cur = __atomic_load_n(keys + slot, __ATOMIC_RELAXED);
-            if (cur == kEmptyDigest) cur = atomicCAS(keys + slot, (unsigned long long)kEmptyDigest, (unsigned long long)kk);
-            if (cur == kEmptyDigest || cur == kk) break;
-            slot = (slot + 1u) & mask;
-        }
-    if (__atomic_load_n(vals + slot, __ATOMIC_RELAXED) > i) atomicMin(vals + slot, i);
-}
-
+//      FIRST work item with a digest keeps its block): rep[i] = smallest item index with digest[i] (hash_build.h) ----
 // Uniform work items (87 % of the bench workload) carry one of 13 x 4 table digests (tail_summarize): their first occurrence per (level, state)
 // is a min-reduction -- LDS bins per workgroup, then at most one gated global atomic per bin and workgroup -- not 870 000 operations on three
-// table slots (same-address atomics cost ~9 ns each on this chip).  The bins enter the table afterwards (dedup_insert_bins), so a
-// non-uniform item whose digest happens to equal a table digest still merges with it, as digest-only equality demands.
+// table slots.  The bins enter the table afterwards (dedup_insert_bins), so a non-uniform item whose digest happens to equal a table digest
+// still merges with it, as digest-only equality demands.
 constexpr uint32_t kUniformBins = kNumLevels * 4u;
 __global__ __launch_bounds__(256) void dedup_insert(const uint64_t* __restrict__ digests, const uint32_t* __restrict__ stateMask, const uint8_t* __restrict__ level,
-                                                    int haveUniformTable, uint32_t n, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                    uint32_t mask, uint32_t* __restrict__ firstUniform)
+                                                    int haveUniformTable, uint32_t n, HashTable table, uint32_t* __restrict__ firstUniform)
 {
     __shared__ uint32_t bins[kUniformBins];
+    __shared__ uint32_t buckets[256];
     if (threadIdx.x < kUniformBins) bins[threadIdx.x] = 0xFFFFFFFFu;
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -102,18 +79,7 @@ __global__ __launch_bounds__(256) void dedup_insert(const uint64_t* __restrict__
             live = false;
         }
     }
-    const uint64_t k = live ? digests[i] : 0ull;
-    const uint32_t lane = threadIdx.x & 63u;
-    unsigned long long todo = __ballot(live);
-    while (todo) {   // (wave-uniform loop: one round per distinct digest among the wave's remaining items)
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, leader), khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k >> 32), leader);
-        const uint64_t kk = ((uint64_t)khi << 32) | klo;
-        const unsigned long long same = __ballot(live && k == kk);
-        // items ascend with the lane: the leader (lowest lane of the group) carries the group's smallest index
-        if ((int)lane == leader) dedup_put(kk, i, keys, vals, mask);
-        todo &= ~same;
-    }
+    hash_put_min_block(table, live, live ? digests[i] : 0ull, i, buckets);
     __syncthreads();
     if (threadIdx.x < kUniformBins) {
         const uint32_t b = bins[threadIdx.x];
@@ -121,22 +87,16 @@ __global__ __launch_bounds__(256) void dedup_insert(const uint64_t* __restrict__
     }
 }
 
-__global__ __launch_bounds__(64) void dedup_insert_bins(const uint64_t* __restrict__ uniformDigest, const uint32_t* __restrict__ firstUniform,
-                                                        unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t mask)
+__global__ __launch_bounds__(64) void dedup_insert_bins(const uint64_t* __restrict__ uniformDigest, const uint32_t* __restrict__ firstUniform, HashTable table)
 {
     const uint32_t t = threadIdx.x;
-    if (t < kUniformBins && firstUniform[t] != 0xFFFFFFFFu) dedup_put(uniformDigest[t], firstUniform[t], keys, vals, mask);
+    if (t < kUniformBins && firstUniform[t] != 0xFFFFFFFFu) hash_put_min(table, uniformDigest[t], firstUniform[t]);
 }
 
-__global__ __launch_bounds__(256) void dedup_lookup(const uint64_t* __restrict__ digests, uint32_t n, const unsigned long long* __restrict__ keys,
-                                                    const uint32_t* __restrict__ vals, uint32_t mask, uint32_t* __restrict__ rep)
+__global__ __launch_bounds__(256) void dedup_lookup(const uint64_t* __restrict__ digests, uint32_t n, HashTable table, uint32_t* __restrict__ rep)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t k = digests[i];
-    uint32_t slot = mask + 1u;
-    if (k != kEmptyDigest) { slot = digest_slot(k, mask); while (keys[slot] != k) slot = (slot + 1u) & mask; }
-    rep[i] = vals[slot];
+    if (i < n) rep[i] = hash_get(table, digests[i]);
 }
 
 // spatial sort key (bake_cpu_impl.cpp:1722-1748); non-emitted items sort to the far end
@@ -479,10 +439,9 @@ struct Scratch {
     uint64_t *sizes64, *ofs64;
     uint32_t *valsA, *valsB, *emitted, *numEmitted;
     uint64_t* total;
-    unsigned long long* hashKeys; uint32_t* hashVals; uint32_t hashMask;   // digest table: hashMask + 1 slots (+ 1 dedicated slot in hashVals)
+    void* hashBase;   // digest table (hash_build.h) + kUniformBins words
     void* tmp; size_t tmpBytes;
 };
-static uint32_t hash_slots(uint32_t n) { uint32_t s = 1024; while (s < 2u * n && s < 0x80000000u) s <<= 1; return s; }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -505,9 +464,7 @@ static Scratch carve(void* base, uint32_t n)
     s.valsA = (uint32_t*)p; p += n32; s.valsB = (uint32_t*)p; p += n32;
     s.emitted = (uint32_t*)p; p += n32;
     s.numEmitted = (uint32_t*)p; p += 256; s.total = (uint64_t*)p; p += 256;
-    const uint32_t slots = hash_slots(n);
-    s.hashMask = slots - 1u;
-    s.hashKeys = (unsigned long long*)p; p += align_up((size_t)slots * 8, 256); s.hashVals = (uint32_t*)p; p += align_up(((size_t)slots + 1 + kUniformBins) * 4, 256);
+    s.hashBase = p; p += align_up(hash_table_bytes(hash_table_slots(n), kUniformBins), 256);
     s.tmp = p; s.tmpBytes = prim_temp_bytes(n);
     return s;
 }
@@ -516,8 +473,7 @@ size_t tail_scratch_bytes(uint32_t numItems, uint32_t numTris)
 {
     (void)numTris;
     const uint32_t n = numItems ? numItems : 1;
-    const size_t slots = hash_slots(n);
-    return 2 * align_up((size_t)n * 8, 256) + 5 * align_up((size_t)n * 4, 256) + 512 + align_up(slots * 8, 256) + align_up((slots + 1 + kUniformBins) * 4, 256) + prim_temp_bytes(n);
+    return 2 * align_up((size_t)n * 8, 256) + 5 * align_up((size_t)n * 4, 256) + 512 + align_up(hash_table_bytes(hash_table_slots(n), kUniformBins), 256) + prim_temp_bytes(n);
 }
 
 hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch, size_t scratchBytes, TailCounts* counts, hipStream_t stream)
@@ -537,14 +493,13 @@ hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch,
         } else {
             // (the scratch block is sized for numItems distinct digests; the table only needs twice the number that can occur)
             const uint32_t distinct = in.maxDistinctDigests && in.maxDistinctDigests < n ? in.maxDistinctDigests : n;
-            s.hashMask = hash_slots(distinct) - 1u;
-            s.hashVals = (uint32_t*)((uint8_t*)s.hashKeys + align_up(((size_t)s.hashMask + 1) * 8, 256));
-            // keys, values and the uniform bins are adjacent in the scratch block: one fill sets them all to all ones
-            uint32_t* firstUniform = s.hashVals + s.hashMask + 2u;
-            TAIL_CHECK(hipMemsetAsync(s.hashKeys, 0xFF, (size_t)((uint8_t*)(firstUniform + kUniformBins) - (uint8_t*)s.hashKeys), stream));
-            hipLaunchKernelGGL(dedup_insert, grid, block, 0, stream, in.digests, in.stateMask, in.level, in.uniformDigest ? 1 : 0, n, s.hashKeys, s.hashVals, s.hashMask, firstUniform);
-            if (in.uniformDigest) hipLaunchKernelGGL(dedup_insert_bins, dim3(1), dim3(64), 0, stream, in.uniformDigest, firstUniform, s.hashKeys, s.hashVals, s.hashMask);
-            hipLaunchKernelGGL(dedup_lookup, grid, block, 0, stream, in.digests, n, s.hashKeys, s.hashVals, s.hashMask, out.rep);
+            const uint32_t slots = hash_table_slots(distinct);
+            const HashTable table = hash_table_at(s.hashBase, slots);
+            uint32_t* firstUniform = table.vals + slots + 1u;   // keys, values and the uniform bins are adjacent: one fill sets them all to all ones
+            TAIL_CHECK(hipMemsetAsync(s.hashBase, 0xFF, hash_table_bytes(slots, kUniformBins), stream));
+            hipLaunchKernelGGL(dedup_insert, grid, block, 0, stream, in.digests, in.stateMask, in.level, in.uniformDigest ? 1 : 0, n, table, firstUniform);
+            if (in.uniformDigest) hipLaunchKernelGGL(dedup_insert_bins, dim3(1), dim3(64), 0, stream, in.uniformDigest, firstUniform, table);
+            hipLaunchKernelGGL(dedup_lookup, grid, block, 0, stream, in.digests, n, table, out.rep);
         }
         hipLaunchKernelGGL(tail_sort_keys, grid, block, 0, stream, in, out.special, out.rep, s.keysA, s.emitted);
         hipLaunchKernelGGL(tail_iota, grid, block, 0, stream, s.valsA, n);

@@ -1,5 +1,6 @@
 """GPU parity: the HIP library behind the C ABI must reproduce the reference's known answers and be bit-exact
 (arrayData, descArray, indexBuffer, histograms, indexFormat) with the oracle on seeded workloads."""
+import os
 import numpy as np
 import pytest
 import kat_runner as kr
@@ -945,6 +946,22 @@ def test_concurrent_bakes_on_one_baker(product):
     assert not errors, errors
     product.destroy_texture(b, t)
     product.destroy_baker(b)
+
+
+def test_work_item_key_collisions_take_the_exact_host_path(product, oracle):
+    """the device dedup of UV triangles keys a hash table by a 64-bit hash and verifies every merge against the first occurrence's full
+    (UV, level) tuple; a mismatch makes the host redo SetupWorkItems exactly.  OMMX_TEST_SETUP_KEY_BITS=6 leaves 64 distinct keys for 3000
+    triangles, so nearly every triangle collides: the result must still be the oracle's (with real duplicates and per-triangle levels in the mix)"""
+    uv, ix = ot.random_triangles(77, 3000, 0.03)
+    uv[3 * 100:3 * 103] = uv[3 * 10:3 * 13]; uv[3 * 2000:3 * 2003] = uv[3 * 10:3 * 13]   # real duplicates of triangle 10..12
+    lv = (3 + ot.hash_u32(np.arange(3000) + 5) % 4).astype(np.uint8); lv[100:103] = lv[10:13]; lv[2000:2003] = lv[10:13]
+    tex = ot.foliage_texture(8, 512, 512, feature=24)
+    os.environ["OMMX_TEST_SETUP_KEY_BITS"] = "6"
+    try:
+        both(product, oracle, [tex], uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv)
+    finally:
+        del os.environ["OMMX_TEST_SETUP_KEY_BITS"]
+    both(product, oracle, [tex], uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv)
 
 
 def test_no_memory_growth_over_baker_lifecycles(product):
