@@ -801,14 +801,18 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     R.index = R.dev_alloc((size_t)(T ? T : 1) * 4); // the reference narrows in place inside an int32 vector (:1882-1900)
     ok = ok && R.index != nullptr;
     if (ok) launch_narrow_indices(dIndex, T, idxBytes, R.index, stream);
-    ok = ok && HIP_OK(hipMemcpyAsync(R.hist, dArrayHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
-    ok = ok && HIP_OK(hipMemcpyAsync(R.hist + kNumLevels, dIndexHist, sizeof(uint32_t) * kNumLevels, hipMemcpyDeviceToHost, stream));
+    // the two histograms, the consistency word and the striped statistic counters were taken from the arena back to back: ONE read-back
     unsigned long long fineCount = 0;
     std::vector<unsigned long long> fineSlots((size_t)kFineSlots * kFineStride, 0ull);
-    ok = ok && HIP_OK(hipMemcpyAsync(fineSlots.data(), dFine, sizeof(unsigned long long) * fineSlots.size(), hipMemcpyDeviceToHost, stream));
+    const size_t spanBytes = (size_t)((const uint8_t*)(dFine + fineSlots.size()) - (const uint8_t*)dArrayHist);
+    std::vector<uint8_t> span(spanBytes);
+    ok = ok && HIP_OK(hipMemcpyAsync(span.data(), dArrayHist, spanBytes, hipMemcpyDeviceToHost, stream));
     const int e5 = et.mark();
     ok = ok && HIP_OK(hipStreamSynchronize(stream));
     if (!ok) return L.failure("[Failure] - could not materialise the bake result on the device");
+    memcpy(R.hist, span.data(), sizeof(uint32_t) * kNumLevels);
+    memcpy(R.hist + kNumLevels, span.data() + ((const uint8_t*)dIndexHist - (const uint8_t*)dArrayHist), sizeof(uint32_t) * kNumLevels);
+    memcpy(fineSlots.data(), span.data() + ((const uint8_t*)dFine - (const uint8_t*)dArrayHist), sizeof(unsigned long long) * fineSlots.size());
 
     tm.uploadMs = 0.f; tm.hostSetupMs = 0.f; tm.setupMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.digestMs = et.ms(e2, e3);
     tm.tailMs = et.ms(e3, e4); tm.gatherMs = et.ms(e4, e5);

@@ -155,10 +155,14 @@ __global__ __launch_bounds__(256) void tail_order_sizes(const uint32_t* __restri
 
 __global__ __launch_bounds__(256) void tail_item_values(const uint32_t* __restrict__ order, const uint32_t* __restrict__ numEmitted,
                                                         const uint64_t* __restrict__ ofs64, uint32_t* __restrict__ dstOfs,
-                                                        const int32_t* __restrict__ special, uint32_t numItems, int32_t* __restrict__ itemValue)
+                                                        const int32_t* __restrict__ special, uint32_t numItems, int32_t* __restrict__ itemValue,
+                                                        const uint64_t* __restrict__ sizes64, const uint32_t* __restrict__ errorFlag, uint64_t* __restrict__ summary)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t E = *numEmitted;
+    // what the host needs to continue, in one place for ONE read-back: OMM count, consistency flag, arrayData size
+    // (= ofs[n-1] + sizes[n-1]: entries past numEmitted are zero-sized)
+    if (i == 0) { summary[0] = (uint64_t)E | ((uint64_t)*errorFlag << 32); summary[1] = ofs64[numItems - 1u] + sizes64[numItems - 1u]; }
     if (i < numItems && special[i] != 0) itemValue[i] = special[i];
     if (i < E) { itemValue[order[i]] = (int32_t)i; dstOfs[i] = (uint32_t)ofs64[i]; }
 }
@@ -480,9 +484,13 @@ hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch,
 {
     const uint32_t n = in.numItems;
     counts->numOmms = 0; counts->arrayDataSize = 0;
-    TAIL_CHECK(hipMemsetAsync(out.arrayHist, 0, sizeof(uint32_t) * kNumLevels, stream));
-    TAIL_CHECK(hipMemsetAsync(out.indexHist, 0, sizeof(uint32_t) * kNumLevels, stream));
-    TAIL_CHECK(hipMemsetAsync(in.errorFlag, 0, sizeof(uint32_t), stream));
+    if (out.indexHist == out.arrayHist + 64 && in.errorFlag == out.arrayHist + 128)   // (the bake takes the three from its arena back to back: one fill)
+        TAIL_CHECK(hipMemsetAsync(out.arrayHist, 0, sizeof(uint32_t) * 129, stream));
+    else {
+        TAIL_CHECK(hipMemsetAsync(out.arrayHist, 0, sizeof(uint32_t) * kNumLevels, stream));
+        TAIL_CHECK(hipMemsetAsync(out.indexHist, 0, sizeof(uint32_t) * kNumLevels, stream));
+        TAIL_CHECK(hipMemsetAsync(in.errorFlag, 0, sizeof(uint32_t), stream));
+    }
     if (n != 0) {
         if (scratchBytes < tail_scratch_bytes(n, in.numTris)) return hipErrorInvalidValue;
         Scratch s = carve(scratch, n);
@@ -511,15 +519,13 @@ hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch,
         hipLaunchKernelGGL(tail_order_sizes, grid, block, 0, stream, s.valsB, s.numEmitted, in.level, in.format, out.order, s.sizes64, out.sizes, out.arrayHist);
         tb = s.tmpBytes;
         TAIL_CHECK(rocprim::exclusive_scan(s.tmp, tb, s.sizes64, s.ofs64, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), stream));
-        hipLaunchKernelGGL(tail_item_values, grid, block, 0, stream, out.order, s.numEmitted, s.ofs64, out.dstOfs, out.special, n, out.itemValue);
-        // total = ofs[n-1] + sizes[n-1] (entries past numEmitted are zero-sized)
-        uint32_t E = 0, err = 0; uint64_t lastOfs = 0, lastSize = 0;
-        TAIL_CHECK(hipMemcpyAsync(&err, in.errorFlag, 4, hipMemcpyDeviceToHost, stream));
-        TAIL_CHECK(hipMemcpyAsync(&E, s.numEmitted, 4, hipMemcpyDeviceToHost, stream));
-        TAIL_CHECK(hipMemcpyAsync(&lastOfs, s.ofs64 + (n - 1), 8, hipMemcpyDeviceToHost, stream));
-        TAIL_CHECK(hipMemcpyAsync(&lastSize, s.sizes64 + (n - 1), 8, hipMemcpyDeviceToHost, stream));
+        hipLaunchKernelGGL(tail_item_values, grid, block, 0, stream, out.order, s.numEmitted, s.ofs64, out.dstOfs, out.special, n, out.itemValue,
+                           s.sizes64, in.errorFlag, s.total);
+        uint64_t summary[2] = { 0, 0 };
+        TAIL_CHECK(hipMemcpyAsync(summary, s.total, sizeof summary, hipMemcpyDeviceToHost, stream));
         TAIL_CHECK(hipStreamSynchronize(stream));
-        counts->numOmms = E; counts->arrayDataSize = lastOfs + lastSize;
+        const uint32_t E = (uint32_t)summary[0], err = (uint32_t)(summary[0] >> 32);
+        counts->numOmms = E; counts->arrayDataSize = summary[1];
         if (err) return hipErrorAssert;
     }
     if (in.numTris != 0)
