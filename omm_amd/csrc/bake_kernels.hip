@@ -330,7 +330,8 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 else
 #endif
                 if (coarse) {
-                    if (SLICED) st = coarse_state<MD>(P, tile_micro_triangle(i), W);
+                    // (items under the single-texel pass's FINITE precondition take the straight-line form of the same test: 28.2 -> 27.1 ms)
+                    if (SLICED) st = uFast ? coarse_state_finite<MD>(P, tile_micro_triangle(i), W) : coarse_state<MD>(P, tile_micro_triangle(i), W);
                     else st = coarse_state<MD>(P, micro_triangle(A.uv + 6ull * itemIds[firstItem + (i >> (2 * level))], i & (M - 1u), level), W);
                 }
                 // the reference's fine pass re-classifies everything still "UnknownOpaque" (bake_cpu_impl.cpp:861)

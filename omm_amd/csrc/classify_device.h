@@ -634,6 +634,34 @@ __device__ __forceinline__ int coarse_state(const ClassifyParams& P, const Micro
     return -1;
 }
 
+// coarse_state() for items under the FINITE precondition of the single-texel pass (every |uv| <= 16384: nothing is NaN, every value
+// converted to int is below 2^31 in magnitude): the box comes from three-operand minima / maxima of the vertices (they differ from the
+// reference's min / max chains only in the sign of a zero, which the truncation and the "* size - 0.5" erase), the conversions are
+// plain, and the reference's four early exits are ONE predicate in front of the summed-area look-up.
+template <class MD>
+__device__ __forceinline__ int coarse_state_finite(const ClassifyParams& P, const MicroTri& t, const TexWindow& W)
+{
+    const DevMip& m = P.mips[0];
+    const float lox = __builtin_fminf(__builtin_fminf(t.p0.x, t.p1.x), t.p2.x), loy = __builtin_fminf(__builtin_fminf(t.p0.y, t.p1.y), t.p2.y);
+    const float hix = __builtin_fmaxf(__builtin_fmaxf(t.p0.x, t.p1.x), t.p2.x), hiy = __builtin_fmaxf(__builtin_fmaxf(t.p0.y, t.p1.y), t.p2.y);
+    const bool sameTile = ((int)lox == (int)hix) & ((int)loy == (int)hiy);
+    const float fsx = lox * m.fw - 0.5f, fsy = loy * m.fh - 0.5f;
+    const float fex = hix * m.fw - 0.5f, fey = hiy * m.fh - 0.5f;
+    const int sx = tex_coord(MD::addr(P), MD::pow2(P), (int)__builtin_floorf(fsx), m.w, m.log2w);
+    const int sy = tex_coord(MD::addr(P), MD::pow2(P), (int)__builtin_floorf(fsy), m.h, m.log2h);
+    const int ex = tex_coord(MD::addr(P), MD::pow2(P), (int)__builtin_floorf(fex) + 1, m.w, m.log2w);
+    const int ey = tex_coord(MD::addr(P), MD::pow2(P), (int)__builtin_floorf(fey) + 1, m.h, m.log2h);
+    // unsigned compares fold "0 <= v" and "v < size" into one test each
+    const bool ok = sameTile & !(ex < sx) & !(ey < sy) & ((uint32_t)sx < (uint32_t)m.w) & ((uint32_t)sy < (uint32_t)m.h) & ((uint32_t)ex < (uint32_t)m.w) & ((uint32_t)ey < (uint32_t)m.h);
+    int st = -1;
+    if (ok) {
+        const uint32_t area = (uint32_t)((ex - sx + 1) * (ey - sy + 1));
+        const uint32_t sa = sat_sum(m, sx, sy, ex, ey, W);
+        st = sa == 0 ? P.stateLE : (sa == area ? P.stateGT : -1);
+    }
+    return st;
+}
+
 // ---- hierarchical shortcut: is a whole bird-curve sub-triangle provably resolved by the coarse pass? ----
 // `sub` is an ancestor (level k <= N) of micro-triangles of one work item; `maxAbs` = largest |coordinate| of the item's
 // vertices.  Returns the state every descendant micro-triangle gets from coarse_state(), or -1 when that cannot be
