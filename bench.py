@@ -321,6 +321,9 @@ def main():
                 line["sat_off"] = {"entry": "ommCpuBake (host arrays, PCIe inclusive), texture without alphaCutoff", "gpu_micro_triangles_per_s": ks * 4.0 ** args.level / gpu_dt,
                                    "gpu_sample": "first %d triangles, %.1f ms" % (ks, gpu_dt * 1e3), "cpu_baseline": cb2, "parity": "bit-exact on the CPU sample"}
         print(json.dumps(line))
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()   # rank 0 has done more (host-API bakes, the JSON line): all ranks tear their communicators down together
     prod.destroy_texture(baker, th)
     prod.destroy_baker(baker)
     if comm is not None:
