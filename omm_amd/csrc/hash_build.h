@@ -37,7 +37,7 @@ __device__ __forceinline__ void hash_put_min(const HashTable& t, uint64_t k, uin
 {
     uint32_t slot = k == kEmptyKey ? t.mask + 1u : hash_slot_of(t, k);
     if (k != kEmptyKey)
-        for (;;) {
+        for (uint32_t probes = 0; probes <= t.mask; ++probes) {   // (the table is at most half full: the bound only guards against a hang)
             unsigned long long cur = __atomic_load_n(t.keys + slot, __ATOMIC_RELAXED);
             if (cur == kEmptyKey) cur = atomicCAS(t.keys + slot, (unsigned long long)kEmptyKey, (unsigned long long)k);
             if (cur == kEmptyKey || cur == k) break;
@@ -65,12 +65,17 @@ __device__ __forceinline__ void hash_put_min_block(const HashTable& t, bool live
     if (live && !(w < lane && kw == k)) hash_put_min(t, k, i);
 }
 
-// value of the slot that holds `k` (which must have been put)
-__device__ __forceinline__ uint32_t hash_get(const HashTable& t, uint64_t k)
+// value of the slot that holds `k`; `self` if the key was never put (cannot happen in the two users: the bound only guards against a hang)
+__device__ __forceinline__ uint32_t hash_get(const HashTable& t, uint64_t k, uint32_t self)
 {
     uint32_t slot = t.mask + 1u;
-    if (k != kEmptyKey) { slot = hash_slot_of(t, k); while (t.keys[slot] != k) slot = (slot + 1u) & t.mask; }
-    return t.vals[slot];
+    if (k != kEmptyKey) {
+        slot = hash_slot_of(t, k);
+        uint32_t probes = 0;
+        while (t.keys[slot] != k) { if (t.keys[slot] == kEmptyKey || ++probes > t.mask) return self; slot = (slot + 1u) & t.mask; }
+    }
+    const uint32_t v = t.vals[slot];
+    return v == 0xFFFFFFFFu ? self : v;
 }
 
 } // namespace ommx

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void setup_dedup_lookup(const uint64_t* __rest
     const bool invalid = (triFlags[t] & 1u) != 0;
     uint32_t f = t;
     if (!invalid && !disableDedup) {
-        f = hash_get(table, hashKeys[t]);
+        f = hash_get(table, hashKeys[t], t);
         if (f != t) {
             bool same = triLevel[t] == triLevel[f];
             for (int q = 0; q < 6; ++q) { const float x = triUv[6ull * t + q], y = triUv[6ull * f + q]; same &= (x == y); }

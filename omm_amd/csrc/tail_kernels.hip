@@ -35,8 +35,9 @@ __global__ __launch_bounds__(256) void tail_summarize(TailInputs in, int32_t* __
     if (i >= in.numItems) return;
     const uint32_t mask = in.stateMask[i];
     const uint32_t level = in.level[i];
-    if (mask == 0u || mask > 15u) atomicOr(in.errorFlag, 1u); // every work item must have been classified
-    bool allEqual = (mask & (mask - 1u)) == 0u;
+    const bool classified = mask != 0u && mask <= 15u;
+    if (!classified) atomicOr(in.errorFlag, 1u); // every work item must have been classified (the bake then fails; nothing below may fault on the way)
+    bool allEqual = classified && (mask & (mask - 1u)) == 0u;
     int common = 31 - __clz((int)mask);
     if (allEqual && in.uniformDigest) {
         const int s3 = common == 2 ? 3 : common;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void dedup_insert(const uint64_t* __restrict__
     bool live = i < n;
     if (live && haveUniformTable) {
         const uint32_t m = stateMask[i];
-        if ((m & (m - 1u)) == 0u) {   // same test and same bin as tail_summarize
+        if (m != 0u && m <= 15u && (m & (m - 1u)) == 0u) {   // same test and same bin as tail_summarize
             const int common = 31 - __clz((int)m);
             atomicMin(&bins[(uint32_t)level[i] * 4u + (uint32_t)(common == 2 ? 3 : common)], i);
             live = false;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(64) void dedup_insert_bins(const uint64_t* __restri
 __global__ __launch_bounds__(256) void dedup_lookup(const uint64_t* __restrict__ digests, uint32_t n, HashTable table, uint32_t* __restrict__ rep)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) rep[i] = hash_get(table, digests[i]);
+    if (i < n) rep[i] = hash_get(table, digests[i], i);
 }
 
 // spatial sort key (bake_cpu_impl.cpp:1722-1748); non-emitted items sort to the far end
