@@ -32,6 +32,21 @@ typedef struct ommxBakeTimings {
 
 OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings* out);
 
+/* ---- per-baker knobs ----
+ * Tuning and test switches are state of ONE baker, set explicitly through this call; the library reads no environment variables.
+ * A value of 0 restores the default.  Unknown knobs -> INVALID_ARGUMENT. */
+typedef enum ommxBakerKnob {
+    ommxBakerKnob_SetupKeyBits     = 0, /* TEST ONLY: work-item dedup keys are cut to this many bits (1..62), which forces 64-bit key collisions and with
+                                           them the exact host form of SetupWorkItems; 0 = full 64-bit keys */
+    ommxBakerKnob_ShardChunkBytes  = 1, /* sharded bake: bytes per rank and chunk of the block all-gather (>= 256; default 64 MiB, at most 8 chunks) */
+    ommxBakerKnob_StreamChunks     = 2, /* ommCpuBake: number of classification chunks whose finished OMM blocks are copied to the host while the next
+                                           chunk is being classified (1 = no overlap: classify, then one copy; default 12) */
+    ommxBakerKnob_GatherThreads    = 3, /* ommCpuBake: host threads that place the streamed blocks in arrayData order (default min(32, hardware threads);
+                                           always 1 without ommCpuBakeFlags_EnableInternalThreads) */
+    ommxBakerKnob_MAX_NUM          = 4
+} ommxBakerKnob;
+OMM_MI355X_API ommResult ommxSetBakerKnob(ommBaker baker, ommxBakerKnob knob, uint64_t value);
+
 /* ---- device-resident bake ----
  * Same contract as ommCpuBake (include/omm_mi355x.h; reference omm.h:574) except for where the bulk data lives:
  *   in : desc->texCoords, desc->indexBuffer and desc->subdivisionLevels are DEVICE pointers (HBM of the current HIP device);

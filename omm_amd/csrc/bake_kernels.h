@@ -36,7 +36,7 @@ struct SetupParams {
     const uint8_t* perTriLevels;                               // or null
     int globalLevel; float dynScale; int edgeHeuristic;
     int texW, texH; int disableDedup; int wantWorkload;
-    uint64_t keyMask;   // all ones; the test-suite narrows it (OMMX_TEST_SETUP_KEY_BITS) to force key collisions and exercise the exact host redo
+    uint64_t keyMask;   // all ones; tests narrow it (ommxBakerKnob_SetupKeyBits) to force key collisions and exercise the exact host redo
 };
 struct SetupCounters {                                         // one device-resident block, read back in a single copy
     uint32_t numItems, numDisabled, numPending, collision;

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     TexWindow W = no_window();
     if (tid == 0) { s_qcount = 0; s_mask = 0; s_known = 0; s_pending = 0; s_fine = 0; }
     // the single-texel fast pass (fine_single_texel) covers Linear filtering of one mip on non-degenerate items; everything else is generic
-    const bool fastFine = SLICED && P.filterLinear != 0 && P.mipCount == 1;
+    const bool fastFine = SLICED && P.filterLinear != 0 && P.mipCount == 1 && !P.noFine;
     // micro-triangle i (0 .. TILE) of a sliced tile through the split bird decode: group word + table entry instead of the full decode
     auto tile_micro_triangle = [&](uint32_t i) {
         BirdGroup bg; bg.word = s_gdec[SLICED ? i >> 6 : 0u];
@@ -322,13 +322,10 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
             if (gs == kRegionAllOpen) { // the whole group is unresolved by construction: no per-micro-triangle SAT test
                 if (uFast) return;   // phase 2a takes the group as a whole, it needs no queue entries
                 unresolved = i < count;   // (phase 2 writes the state of every queued micro-triangle)
+                if (P.noFine && i < count) s_state[i] = 3;
             } else
             if (i < count) {
                 int st = -1;
-#ifdef OMMX_DEBUG_SKIP_PHASE1  // timing attribution only (never shipped)
-                if (coarse) st = 0;
-                else
-#endif
                 if (coarse) {
                     // (items under the single-texel pass's FINITE precondition take the straight-line form of the same test: 28.2 -> 27.1 ms)
                     if (SLICED) st = uFast ? coarse_state_finite<MD>(P, tile_micro_triangle(i), W) : coarse_state<MD>(P, tile_micro_triangle(i), W);
@@ -338,6 +335,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 unresolved = (st < 0) || (st == 3) || !P.filterLinear;
                 s_state[i] = (uint8_t)(st < 0 ? 3 : st);
             }
+            if (P.noFine) unresolved = false;   // (DisableFineClassification: nothing is queued, unresolved micro-triangles stay UnknownOpaque)
             const unsigned long long vote = __ballot(unresolved);
             if (vote) {
                 const uint32_t lane = tid & 63u;
@@ -363,47 +361,8 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         __syncthreads();
 
         // ---- phase 2: fine, dense over the queue ----
-#ifdef OMMX_DEBUG_SKIP_FINE   // timing experiments only (never shipped): how long do phases 0/1/3 take on their own?
-        const uint32_t qn = 0;
-#else
         const uint32_t qn = s_qcount;
-#endif
         if (tid == 0 && qn) atomicAdd(A.fineCount + (size_t)((blockIdx.x + 7u * blockIdx.y) & (kFineSlots - 1)) * kFineStride, (unsigned long long)qn);
-#ifdef OMMX_STATS   // distribution counters for tuning (never shipped): entries 1.. of the tile's stripe
-        {
-            unsigned long long* st = A.fineCount + (size_t)((blockIdx.x + 7u * blockIdx.y) & (kFineSlots - 1)) * kFineStride;
-            if (tid == 0) {
-                atomicAdd(st + 1, 1ull);
-                if (SLICED) {
-                    unsigned long long ns = 0, no = 0, nu = 0;
-                    for (int g = 0; g < TILE / GROUP; ++g) { const int v = s_group[g]; ns += v >= 0; no += v == kRegionAllOpen; nu += v == kRegionUnknown; }
-                    atomicAdd(st + 2, ns); atomicAdd(st + 3, no); atomicAdd(st + 4, nu);
-                }
-            }
-            for (uint32_t q0 = 0; q0 < qn; q0 += BLOCK) {
-                const uint32_t q = q0 + tid;
-                int cat = -1;
-                if (q < qn && SLICED) {
-                    const uint32_t i = s_queue[q];
-                    const MicroTri t = micro_triangle(uUv, base + i, level);
-                    const DevMip& m = P.mips[0];
-                    const float ax = t.p0.x * m.fw - 0.5f, ay = t.p0.y * m.fh - 0.5f, bx = t.p1.x * m.fw - 0.5f, by = t.p1.y * m.fh - 0.5f, cx = t.p2.x * m.fw - 0.5f, cy = t.p2.y * m.fh - 0.5f;
-                    const float lox = std_min(std_min(ax, bx), cx), loy = std_min(std_min(ay, by), cy), hix = std_max(std_max(ax, bx), cx), hiy = std_max(std_max(ay, by), cy);
-                    const int w = cvt_trunc_x86(__builtin_ceilf(hix)) - cvt_trunc_x86(__builtin_floorf(lox)), h = cvt_trunc_x86(__builtin_ceilf(hiy)) - cvt_trunc_x86(__builtin_floorf(loy));
-                    const int area = w * h;
-                    cat = area <= 1 ? 0 : (area == 2 ? 1 : (area <= 4 ? 2 : 3));
-                    if (s_group[i >> 6] == kRegionAllOpen) cat += 4;
-                }
-                for (int c = 0; c < 8; ++c) { const unsigned long long b = __ballot(cat == c); if ((tid & 63u) == 0 && b) atomicAdd(st + 5 + c, (unsigned long long)__popcll(b)); }
-            }
-        }
-#endif
-#ifdef OMMX_DEBUG_SKIP_PHASE2   // timing attribution only (never shipped)
-        if (fastFine) {
-            for (uint32_t k = tid >> 6; k < s_gcount; k += BLOCK / 64) { const uint32_t g = s_glist[k]; if (s_group[g] == kRegionAllOpen) s_state[g * 64u + (tid & 63u)] = 3; }
-            for (uint32_t q = tid; q < qn; q += BLOCK) s_state[s_queue[q]] = 3;
-        } else
-#endif
         if (uFast) {
             // ---- phase 2a: straight-line single-texel pass.  Work units of 64 lanes: first the all-open groups (one wave = one group, no
             //      queue entries), then the queued micro-triangles of the other open groups, 64 at a time ----
@@ -447,11 +406,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 const uint32_t q = q0 + tid;
                 if (q < qn2) {
                     const uint32_t i = s_queue[q];
-#ifdef OMMX_DEBUG_NO_GENERIC   // register-pressure experiment only (never shipped): wrong states for the left-over micro-triangles
-                    s_state[i] = 3;
-#else
                     s_state[i] = (uint8_t)fine_state<FP32, MD>(P, tile_micro_triangle(i), uDegenerate, W);
-#endif
                 }
             }
         } else

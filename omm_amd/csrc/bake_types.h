@@ -33,6 +33,8 @@ struct ClassifyParams {
     int   useCoarse;          // texture has SAT && 1 mip && linear (bake_cpu_impl.cpp:723-727,746)
     float cutoff, borderAlpha;
     int   wantKnownCount;     // rejectionThreshold > 0
+    int   noFine;             // internal flag DisableFineClassification (bake_cpu_impl.cpp:45,822-823): ResampleFine is skipped, whatever the coarse pass
+                              // left unresolved keeps the initial state UnknownOpaque (:427)
     int   pow2Dispatch;       // SizeIsPow2() of mip 0: the template flag of the reference's kernels (bake_cpu_impl.cpp:299);
                               // TextureImpl::Bilinear alone uses the per-mip flag (texture_impl.cpp:266)
 };

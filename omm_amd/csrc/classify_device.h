@@ -487,13 +487,9 @@ __device__ __forceinline__ void level_line_texel(const ClassifyParams& P, const 
     const V2 q0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy);
     const V2 q1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy);
     const V2 q2 = mk2(m.fw * t.p2.x - pfx, m.fh * t.p2.y - pfy);
-#ifdef OMMX_DEBUG_NO_EDGES      // timing attribution only (never shipped)
-    if (q0.x + q1.x + q2.x == 12345.f) {
-#else
     // (all three edges, no short-circuit: as in the single-texel pass, the divergent regions cost more than the tests they skip: 29.3 -> 28.5 ms)
     const bool x0 = edge_crosses_level_curve(q0, q1, ha, b, c, d), x1 = edge_crosses_level_curve(q1, q2, ha, b, c, d), x2 = edge_crosses_level_curve(q2, q0, ha, b, c, d);
     if (x0 | x1 | x2) {
-#endif
         above += 1; below += 1;
     }
 }
@@ -549,9 +545,6 @@ __device__ __forceinline__ void raster_micro_triangle(const ClassifyParams& P, c
     // Only the Nearest promotion looks at the counts (bake_kernels_cpu.h:38,49); for the forced promotions the state is
     // final as soon as both counters are non-zero, so the remaining texels cannot change the result.
     const bool countsMatter = P.promotion == 0;
-#ifdef OMMX_DEBUG_NO_TEXELS     // timing attribution only (never shipped)
-    if (minx != -123456789) return;
-#endif
     for (int y = miny; y < maxy; ++y) {
         bool wasInside = false;
         for (int x = minx; x < maxx; ++x) {
@@ -772,9 +765,6 @@ __device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const 
     // one texel, which is also the centre-vote cell
     if (!(maxx - minx == 1 && maxy - miny == 1 && ix == minx && iy == miny)) return -1;
 
-#ifdef OMMX_DEBUG_ELIG_ONLY   // timing attribution only (never shipped)
-    if (minx != 123456789) return 3;
-#endif
     float g00, g01, g11, g10;
     fetch_cell<FP32, MD>(P, m, MD::pow2(P), minx, miny, W, g00, g01, g11, g10);
     // (TextureImpl::Bilinear addresses with the per-mip pow2 flag, the level-line kernel with the dispatch flag = mip 0's: the same here)
@@ -794,15 +784,11 @@ __device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const 
         const float pfx = sx + 0.5f, pfy = sy + 0.5f;
         const float ipx = pfx * m.rw, ipy = pfy * m.rh;
         const bool o0 = P.cutoff < g00, o1 = P.cutoff < g01, o2 = P.cutoff < g11, o3 = P.cutoff < g10;
-#ifdef OMMX_DEBUG_NO_CORNERS   // timing attribution only (never shipped)
-        const bool in0 = ipx == 12345.f, in1 = in0, in2 = in0, in3 = in0;
-#else
         // (ipx is never a zero, so the reference's "+ 0.f" on the unchanged coordinate of each corner is the identity)
         const bool in0 = point_in_triangle_flat(t, ipx, ipy);
         const bool in1 = point_in_triangle_flat(t, ipx, ipy + m.rh);
         const bool in2 = point_in_triangle_flat(t, ipx + m.rw, ipy + m.rh);
         const bool in3 = point_in_triangle_flat(t, ipx + m.rw, ipy);
-#endif
         const bool isO = (in0 && o0) || (in1 && o1) || (in2 && o2) || (in3 && o3);
         const bool isT = (in0 && !o0) || (in1 && !o1) || (in2 && !o2) || (in3 && !o3);
         if (isO) above += 1;
@@ -810,24 +796,15 @@ __device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const 
         if (!(isO && isT)) {
             const float sa = g00, sb = g10 - g00, sc = g01 - g00, sd = g00 + g11 - g01 - g10;
             if (near_zero(sb, 1e-6f) && near_zero(sc, 1e-6f) && near_zero(sd, 1e-6f)) vote(P.cutoff < sa, above, below);
-#ifdef OMMX_DEBUG_NO_EDGES_FAST   // timing attribution only (never shipped)
-            else if (sa == 12345.f) {
-#else
             else {
-#endif
                 const float ha = sa - P.cutoff;
                 const V2 r0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy);
                 const V2 r1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy);
                 const V2 r2 = mk2(m.fw * t.p2.x - pfx, m.fh * t.p2.y - pfy);
-#if defined(OMMX_EDGE_SHORT_CIRCUIT)   // (A/B switch: the reference's order of evaluation)
-                if (edge_crosses_level_curve(r0, r1, ha, sb, sc, sd) || edge_crosses_level_curve(r1, r2, ha, sb, sc, sd) ||
-                    edge_crosses_level_curve(r2, r0, ha, sb, sc, sd)) { above += 1; below += 1; }
-#else
                 // all three edges are evaluated by all lanes: the reference stops at the first crossing edge, but crossings are rare (0.4 % of
                 // the edge tests) and the lanes of a wave do not agree on them, so the short-circuit only adds divergent regions (33.1 -> 32.1 ms)
                 const bool x0 = edge_crosses_level_curve(r0, r1, ha, sb, sc, sd), x1 = edge_crosses_level_curve(r1, r2, ha, sb, sc, sd), x2 = edge_crosses_level_curve(r2, r0, ha, sb, sc, sd);
                 if (x0 | x1 | x2) { above += 1; below += 1; }
-#endif
             }
         }
     }

@@ -36,14 +36,16 @@ __device__ __forceinline__ uint32_t hash_slot_of(const HashTable& t, uint64_t k)
 __device__ __forceinline__ void hash_put_min(const HashTable& t, uint64_t k, uint32_t i)
 {
     uint32_t slot = k == kEmptyKey ? t.mask + 1u : hash_slot_of(t, k);
+    bool found = k == kEmptyKey;
     if (k != kEmptyKey)
         for (uint32_t probes = 0; probes <= t.mask; ++probes) {   // (the table is at most half full: the bound only guards against a hang)
             unsigned long long cur = __atomic_load_n(t.keys + slot, __ATOMIC_RELAXED);
             if (cur == kEmptyKey) cur = atomicCAS(t.keys + slot, (unsigned long long)kEmptyKey, (unsigned long long)k);
-            if (cur == kEmptyKey || cur == k) break;
+            if (cur == kEmptyKey || cur == k) { found = true; break; }
             slot = (slot + 1u) & t.mask;
         }
-    if (__atomic_load_n(t.vals + slot, __ATOMIC_RELAXED) > i) atomicMin(t.vals + slot, i);
+    // a full table (only reachable on the bake's error path) leaves the key out: hash_get() then answers `self`, never another key's slot
+    if (found && __atomic_load_n(t.vals + slot, __ATOMIC_RELAXED) > i) atomicMin(t.vals + slot, i);
 }
 
 // One call per workgroup (every thread, uniformly): all lanes put in parallel, except lanes that can see a lower lane of their own wave

@@ -214,6 +214,9 @@ struct Baker {
     std::shared_ptr<DevPool> devPool = std::make_shared<DevPool>();
     std::shared_ptr<ArenaPool> arenas = std::make_shared<ArenaPool>();   // device working sets, one per bake in flight
     std::mutex timingsMu; ommxBakeTimings timings; bool haveTimings = false;
+    std::atomic<uint64_t> knobs[ommxBakerKnob_MAX_NUM];   // ommxSetBakerKnob: 0 = default
+    Baker() { for (auto& k : knobs) k.store(0); }
+    uint64_t knob(ommxBakerKnob k) const { return knobs[k].load(std::memory_order_relaxed); }
 };
 
 // HIP events on the bake's own stream (torch / the caller never see this stream)
@@ -606,11 +609,11 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     S.texCoords = din.texCoords; S.indices = din.indices; S.perTriLevels = din.perTriLevels;
     S.stride = d.texCoordStrideInBytes ? d.texCoordStrideInBytes : (d.texCoordFormat == ommTexCoordFormat_UV32_FLOAT ? 8u : 4u);
     S.uvFormat = d.texCoordFormat; S.indexFormat = d.indexFormat; S.numTris = T;
-    S.globalLevel = d.maxSubdivisionLevel; S.dynScale = d.dynamicSubdivisionScale; S.edgeHeuristic = 0;
+    S.globalLevel = d.maxSubdivisionLevel; S.dynScale = d.dynamicSubdivisionScale; S.edgeHeuristic = (flags & (1u << 11)) != 0;   // (EnableEdgeHeuristic, bake_cpu_impl.cpp:48,547)
     S.texW = tex.mips[0].w; S.texH = tex.mips[0].h; S.disableDedup = (flags & (1u << 3)) != 0;
     S.wantWorkload = ((flags & (1u << 5)) != 0) || d.maxWorkloadSize != 0xFFFFFFFFFFFFFFFFull;
     S.keyMask = ~0ull;
-    if (const char* kb = getenv("OMMX_TEST_SETUP_KEY_BITS")) { const int bits = atoi(kb); if (bits > 0 && bits < 63) S.keyMask = (1ull << bits) - 1ull; }   // test hook
+    if (const uint64_t kb = baker.knob(ommxBakerKnob_SetupKeyBits)) S.keyMask = (1ull << kb) - 1ull;   // (tests: forced key collisions)
     bool ok = HIP_OK(hipMemcpyAsync(dUniformDigest, uniform_digests().v, sizeof(uint64_t) * kNumLevels * 4, hipMemcpyHostToDevice, stream));
     ok = ok && HIP_OK(hipMemsetAsync(dKnown, 0, (size_t)maxItems * 4, stream));
     ok = ok && HIP_OK(run_setup_fetch(S, dScratch, scratchBytes, dCounters, stream));
@@ -652,6 +655,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     P.useCoarse = tex.mips[0].sat != nullptr && P.mipCount == 1 && P.filterLinear;
     P.cutoff = d.alphaCutoff; P.borderAlpha = d.runtimeSamplerDesc.borderAlpha;
     P.wantKnownCount = d.rejectionThreshold > 0.f;
+    P.noFine = (flags & (1u << 9)) != 0;   // DisableFineClassification (bake_cpu_impl.cpp:45,822-823)
 
     // ---- level-0 hierarchical query per item + compaction of the items that need per-micro-triangle work; ONE sync ----
     launch_triage(P, dUv, dCounters, maxItems, dMask, dActive, stream);
@@ -661,7 +665,26 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
 
     uint32_t U = hc.numItems;
     if (hc.collision) { // two different (UV, level) tuples shared a 64-bit hash: redo the setup serially with exact keys
-        if (!hostDesc) return L.failure("[Failure] - work-item hash collision on a device-resident bake (retry through ommCpuBake)");
+        // (a device-resident caller has no host arrays: its index / UV / level arrays are read back for this 2^-64-class event)
+        ommCpuBakeInputDesc readBack = d; std::vector<uint8_t> hIdx, hUvRaw, hLv;
+        if (!hostDesc) {
+            const size_t idxSize = d.indexFormat == ommIndexFormat_UINT_8 ? 1 : (d.indexFormat == ommIndexFormat_UINT_16 ? 2 : 4);
+            hIdx.resize(idxSize * 3ull * T + 1);
+            if (!HIP_OK(hipMemcpyAsync(hIdx.data(), din.indices, idxSize * 3ull * T, hipMemcpyDeviceToHost, stream)) || !HIP_OK(hipStreamSynchronize(stream)))
+                return L.failure("[Failure] - device to host transfer of the index buffer failed");
+            uint32_t maxIndex = 0;
+            for (size_t i = 0; i < 3ull * T; ++i) {
+                const uint32_t v = idxSize == 1 ? hIdx[i] : (idxSize == 2 ? ((const uint16_t*)hIdx.data())[i] : ((const uint32_t*)hIdx.data())[i]);
+                maxIndex = v > maxIndex ? v : maxIndex;
+            }
+            const size_t elem = d.texCoordFormat == ommTexCoordFormat_UV32_FLOAT ? 8 : 4;
+            hUvRaw.resize((size_t)S.stride * maxIndex + elem); hLv.resize(din.perTriLevels ? T : 0);
+            bool okb = HIP_OK(hipMemcpyAsync(hUvRaw.data(), din.texCoords, hUvRaw.size(), hipMemcpyDeviceToHost, stream));
+            if (okb && !hLv.empty()) okb = HIP_OK(hipMemcpyAsync(hLv.data(), din.perTriLevels, hLv.size(), hipMemcpyDeviceToHost, stream));
+            if (!okb || !HIP_OK(hipStreamSynchronize(stream))) return L.failure("[Failure] - device to host transfer of the triangle data failed");
+            readBack.indexBuffer = hIdx.data(); readBack.texCoords = hUvRaw.data(); readBack.subdivisionLevels = hLv.empty() ? nullptr : hLv.data();
+            hostDesc = &readBack;
+        }
         std::vector<HostTri> itemUv; std::vector<uint8_t> itemLevel, itemDegenerate; std::vector<int32_t> triToItem(T ? T : 1, -1);
         setup_on_host(*hostDesc, flags, tex, itemUv, itemLevel, itemDegenerate, triToItem, hc.numDisabled);
         U = (uint32_t)itemUv.size();
@@ -817,13 +840,6 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     tm.uploadMs = 0.f; tm.hostSetupMs = 0.f; tm.setupMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.digestMs = et.ms(e2, e3);
     tm.tailMs = et.ms(e3, e4); tm.gatherMs = et.ms(e4, e5);
     for (int k = 0; k < kFineSlots; ++k) fineCount += fineSlots[(size_t)k * kFineStride];
-#ifdef OMMX_STATS   // tuning builds only: distribution counters of classify_tiles (bake_kernels.hip), printed per bake
-    {
-        unsigned long long v[kFineStride]; for (int j = 0; j < kFineStride; ++j) { v[j] = 0; for (int k = 0; k < kFineSlots; ++k) v[j] += fineSlots[(size_t)k * kFineStride + j]; }
-        fprintf(stderr, "OMMX_STATS fine=%llu openTiles=%llu groups{settled=%llu allOpen=%llu unknown=%llu} footprint{1=%llu 2=%llu 4=%llu more=%llu} allOpenFootprint{1=%llu 2=%llu 4=%llu more=%llu}\n",
-                v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12]);
-    }
-#endif
     tm.fineMicroTriangles = fineCount; tm.uniqueItems = U; tm.activeItems = hc.activeStart[kNumLevels]; tm.stateBytes = hc.stateBytes; tm.microTriangles = 0;
     for (int l = 0; l < kNumLevels; ++l) tm.microTriangles += (uint64_t)hc.levelCount[l] << (2 * l);
     {   // classify_tiles launches: one per level below 5, one for level 5, ONE for all levels >= 6 (bake_kernels.hip)
@@ -842,8 +858,10 @@ ommResult scope_fences(const Baker& baker, const ommCpuBakeInputDesc& d, bool fo
     const uint32_t flags = (uint32_t)d.bakeFlags;
     if (wants_host_tail(d) && !hostTailOk) // the serial reducers run on the host over the merged states: not in the caller-driven four-phase protocol
         { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - near-duplicate merging / maxArrayDataSize budgets are available through ommCpuBake, ommxBakeDevice and ommxShardedBakeRccl, not through ommxShardedBegin/Tail/Finish"); return ommResult_NOT_IMPLEMENTED; }
-    if ((flags & ((1u << 7) | (1u << 8) | (1u << 9) | (1u << 11))) != 0)
-        { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - internal bake flags (bits 7-11) are not supported"); return ommResult_NOT_IMPLEMENTED; }
+    // internal flags (bake_cpu_impl.cpp:43-48): DisableFineClassification (9), the brute-force near-duplicate search (10) and EnableEdgeHeuristic (11)
+    // are honoured; the two switches of the reference's alternative ConservativeBilinearKernel (7, 8) are not built
+    if ((flags & ((1u << 7) | (1u << 8))) != 0)
+        { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - internal bake flags EnableAABBTesting / DisableLevelLineIntersection (bits 7, 8) are not supported"); return ommResult_NOT_IMPLEMENTED; }
     if (d.formats) { // the reference sizes its arrays from the global format only (bake_cpu_impl.cpp:1763-1772): mixed formats corrupt its heap
         if (!formatsOnHost) return L.failure("[Failure] - per-triangle formats are not supported on the device-resident entry point");
         for (uint32_t i = 0; i < d.indexCount / 3u; ++i)
@@ -1437,12 +1455,12 @@ const RcclApi& rccl()
 struct RcclComm { rcclComm_t comm = nullptr; bool owned = false; int rank = 0, world = 1; };
 
 // The all-gather of the block contributions moves in chunks of <= 64 MiB per rank (at most 8 chunks, multiples of 256 bytes), so that the
-// scatter of one chunk overlaps the transfer of the next.  OMMX_SHARD_CHUNK_BYTES overrides the chunk size (tests use tiny chunks to force
-// blocks across chunk boundaries).
-uint64_t shard_chunk_bytes(uint64_t strideBytes)
+// scatter of one chunk overlaps the transfer of the next.  ommxBakerKnob_ShardChunkBytes overrides the chunk size (tests use tiny chunks to
+// force blocks across chunk boundaries).
+uint64_t shard_chunk_bytes(const Baker& b, uint64_t strideBytes)
 {
     uint64_t want = 64ull << 20;
-    if (const char* e = getenv("OMMX_SHARD_CHUNK_BYTES")) { const unsigned long long v = strtoull(e, nullptr, 10); if (v >= 256) want = v; }
+    if (const uint64_t v = b.knob(ommxBakerKnob_ShardChunkBytes)) want = v;
     uint64_t chunks = (strideBytes + want - 1) / want; if (chunks > 8) chunks = 8; if (chunks < 1) chunks = 1;
     return ((((strideBytes + chunks - 1) / chunks) + 255) & ~255ull);
 }
@@ -1609,7 +1627,7 @@ OMM_MI355X_API ommResult ommxShardedFinish(ommxShardedBake h, const void* gather
         const double t1 = now_ms();
         const ommResult r = sharded_finish(sb, [&](uint8_t* arrayData) {
             // same chunk walk as the RCCL path (there each chunk arrives separately): a block that straddles a chunk boundary is placed in pieces
-            const uint64_t chunkBytes = shard_chunk_bytes(c.strideBytes);
+            const uint64_t chunkBytes = shard_chunk_bytes(*sb->baker, c.strideBytes);
             for (uint64_t lo = 0; lo < c.strideBytes; lo += chunkBytes) {
                 const uint64_t hi = lo + chunkBytes < c.strideBytes ? lo + chunkBytes : c.strideBytes;
                 launch_shard_scatter((const uint8_t*)gathered + lo, c.strideBytes, lo, hi, c.dActive, c.dOwner, c.dMask, c.dLevel, c.bits, c.to.order, c.dCofs, c.to.dstOfs, c.to.sizes,
@@ -1731,7 +1749,7 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
             // (a one-rank communicator takes the same route: the collectives degenerate to copies, the plumbing is the same)
             if (!sb->ses.open_comm()) return false;
             hipStream_t cs = sb->ses.commStream;
-            const uint64_t chunkBytes = shard_chunk_bytes(c.strideBytes);              // per rank and chunk; at most 8 chunks
+            const uint64_t chunkBytes = shard_chunk_bytes(*sb->baker, c.strideBytes);              // per rank and chunk; at most 8 chunks
             uint64_t chunks = (c.strideBytes + chunkBytes - 1) / chunkBytes;
             hipEvent_t ready = nullptr, done[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
             bool ok = HIP_OK(hipEventCreateWithFlags(&ready, hipEventDisableTiming)) && HIP_OK(hipEventRecord(ready, stream)) && HIP_OK(hipStreamWaitEvent(cs, ready, 0));
@@ -1770,6 +1788,17 @@ OMM_MI355X_API ommResult ommxDestroyDeviceBakeResult(ommxDeviceBakeResult result
     DeviceBakeResult* r = (DeviceBakeResult*)result;
     const Allocator mem = r->mem;
     mem.destroy(r);
+    return ommResult_SUCCESS;
+}
+
+OMM_MI355X_API ommResult ommxSetBakerKnob(ommBaker baker, ommxBakerKnob knob, uint64_t value)
+{
+    if (baker == 0 || tag_of(baker) != kCpuBaker || (unsigned)knob >= (unsigned)ommxBakerKnob_MAX_NUM) return ommResult_INVALID_ARGUMENT;
+    if (knob == ommxBakerKnob_SetupKeyBits && value > 62) return ommResult_INVALID_ARGUMENT;
+    if (knob == ommxBakerKnob_ShardChunkBytes && value != 0 && value < 256) return ommResult_INVALID_ARGUMENT;
+    if (knob == ommxBakerKnob_StreamChunks && value > 64) return ommResult_INVALID_ARGUMENT;
+    if (knob == ommxBakerKnob_GatherThreads && value > 256) return ommResult_INVALID_ARGUMENT;
+    untag<Baker>(baker)->knobs[knob].store(value);
     return ommResult_SUCCESS;
 }
 

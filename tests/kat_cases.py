@@ -68,6 +68,7 @@ CASES = [
     case("SineUNORM8", 1001, "sine_u8", 4, S(O=128, T=256, UT=48, UO=80)),
     case("Sine", 1021, "sine", 4, S(O=224, T=128, UT=96, UO=64)),
     case("SineOC2", 1043, "sine", 4, S(O=288, T=224), fmt=1),
+    case("SineOC2Neg", 1063, "sine", 4, S(O=288, T=224), fmt=1),   # (the reference test body equals SineOC2's)
     case("Mandelbrot", 1083, "mandelbrot", 5, S(O=1212, T=484, UT=124, UO=228)),
     case("Mandelbrot2", 1124, "mandelbrot", 5, S(O=521, T=286, UT=82, UO=135), uv=TRI_A, ix=[0, 1, 2]),
     case("Mandelbrot3", 1169, "mandelbrot", 9, S(O=164040, T=91320, UT=3039, UO=3745), uv=TRI_A, ix=[0, 1, 2]),

@@ -25,6 +25,7 @@ TEX_UNORM8, TEX_FP32 = 0, 1
 FLAG_THREADS, FLAG_NO_SPECIAL, FLAG_FORCE32, FLAG_NO_DEDUP, FLAG_NEAR_DUP, FLAG_VALIDATION, FLAG_ALLOW8 = (1 << i for i in range(7))
 TEXFLAG_DISABLE_ZORDER = 1
 SPECIAL_FT, SPECIAL_FO, SPECIAL_FUT, SPECIAL_FUO = -1, -2, -3, -4
+KNOB_SETUP_KEY_BITS, KNOB_SHARD_CHUNK_BYTES, KNOB_STREAM_CHUNKS, KNOB_GATHER_THREADS = range(4)   # ommxBakerKnob
 
 
 class SamplerDesc(C.Structure):
@@ -288,6 +289,12 @@ class Lib:
 
     def destroy_baker(self, baker):
         return self.fn("ommDestroyBaker")(baker)
+
+    def set_knob(self, baker, knob, value):
+        """ommxSetBakerKnob (include/omm_mi355x_ext.h): product library only"""
+        self.dll.ommxSetBakerKnob.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+        r = self.dll.ommxSetBakerKnob(baker, knob, value)
+        assert r == SUCCESS, r
 
     def create_texture(self, baker, mips, alpha_cutoff=-1.0, disable_zorder=False, expect=SUCCESS, row_pitch=0):
         """mips: list of 2-D float32 / uint8 arrays (mip 0 first)."""

@@ -249,3 +249,25 @@ int main() {
                         "-Wl,-rpath," + lib_dir], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert subprocess.run([exe2]).returncode == 0      # baker create/destroy and the argument checks need no GPU
+
+
+def test_baker_knobs_are_per_baker_state_not_environment():
+    """ommxSetBakerKnob (include/omm_mi355x_ext.h) replaces the getenv() hooks of earlier rounds: switches belong to ONE baker, out-of-range values and
+    unknown knobs are refused, and the library never looks at the process environment (no getenv among its undefined symbols)."""
+    import subprocess
+    path = ot.product_path()
+    dll = C.CDLL(path)
+    dll.ommxSetBakerKnob.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+    lib = ot.Lib("product")
+    b = lib.create_baker()          # (no GPU needed: a baker is host state until its first texture)
+    assert dll.ommxSetBakerKnob(b, ot.KNOB_SETUP_KEY_BITS, 6) == ot.SUCCESS
+    assert dll.ommxSetBakerKnob(b, ot.KNOB_SETUP_KEY_BITS, 63) == ot.INVALID_ARGUMENT
+    assert dll.ommxSetBakerKnob(b, ot.KNOB_SHARD_CHUNK_BYTES, 100) == ot.INVALID_ARGUMENT
+    assert dll.ommxSetBakerKnob(b, ot.KNOB_SHARD_CHUNK_BYTES, 4352) == ot.SUCCESS
+    assert dll.ommxSetBakerKnob(b, ot.KNOB_STREAM_CHUNKS, 3) == ot.SUCCESS
+    assert dll.ommxSetBakerKnob(b, ot.KNOB_GATHER_THREADS, 0) == ot.SUCCESS
+    assert dll.ommxSetBakerKnob(b, 99, 1) == ot.INVALID_ARGUMENT
+    assert dll.ommxSetBakerKnob(None, ot.KNOB_STREAM_CHUNKS, 3) == ot.INVALID_ARGUMENT
+    lib.destroy_baker(b)
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", path], text=True)
+    assert "getenv" not in undefined.split()

@@ -56,10 +56,13 @@ def test_golden_blob_bit_exact(product, iname, oname):
 # ---------------------------------------------------------------------------------------------
 # oracle <-> product, full result arrays
 # ---------------------------------------------------------------------------------------------
-def both(product, oracle, mips, uv, ix, level, sat=True, zorder=False, cutoff=0.5, expect=ot.SUCCESS, **kw):
+def both(product, oracle, mips, uv, ix, level, sat=True, zorder=False, cutoff=0.5, expect=ot.SUCCESS, knobs=(), **kw):
     out = []
     for lib in (product, oracle):
         b = lib.create_baker()
+        if lib is product:
+            for k, v in knobs:
+                lib.set_knob(b, k, v)
         t = lib.create_texture(b, mips, alpha_cutoff=cutoff if sat else -1.0, disable_zorder=zorder)
         d = ot.make_desc(t, uv, ix, level, alpha_cutoff=cutoff, **kw)
         out.append(lib.bake(b, d, expect=expect))
@@ -497,10 +500,9 @@ def test_sharded_bake_equals_single_gpu(product, oracle, world):
             assert res.same_as(ref), "rank %d/%d: %s" % (r, world, res.diff(ref))
 
 
-def test_sharded_scatter_in_small_chunks(product, oracle, monkeypatch):
+def test_sharded_scatter_in_small_chunks(product, oracle):
     """The gathered contributions are scattered chunk by chunk (the RCCL path receives them that way).  With 4 KiB chunks every block of a
     level >= 7 item (4 KiB and more) straddles chunk boundaries and is placed in pieces: 3 simulated ranks must still reproduce the oracle."""
-    monkeypatch.setenv("OMMX_SHARD_CHUNK_BYTES", "4352")
     hip = ot.Hip()
     tex = ot.foliage_texture(9, 1024, 1024, feature=40)
     n = 1500
@@ -513,6 +515,7 @@ def test_sharded_scatter_in_small_chunks(product, oracle, monkeypatch):
     oracle.destroy_texture(ob, otx)
     oracle.destroy_baker(ob)
     b = product.create_baker()
+    product.set_knob(b, ot.KNOB_SHARD_CHUNK_BYTES, 4352)
     t = product.create_texture(b, [tex], alpha_cutoff=0.5)
     d = ot.make_desc(t, uv, ix, 8, levels=lv, **kwargs)
     per_rank = ot.bake_sharded_simulated(product, hip, b, d, uv, ix, 3, levels=lv)
@@ -950,18 +953,25 @@ def test_concurrent_bakes_on_one_baker(product):
 
 def test_work_item_key_collisions_take_the_exact_host_path(product, oracle):
     """the device dedup of UV triangles keys a hash table by a 64-bit hash and verifies every merge against the first occurrence's full
-    (UV, level) tuple; a mismatch makes the host redo SetupWorkItems exactly.  OMMX_TEST_SETUP_KEY_BITS=6 leaves 64 distinct keys for 3000
+    (UV, level) tuple; a mismatch makes the host redo SetupWorkItems exactly.  ommxBakerKnob_SetupKeyBits = 6 leaves 64 distinct keys for 3000
     triangles, so nearly every triangle collides: the result must still be the oracle's (with real duplicates and per-triangle levels in the mix)"""
     uv, ix = ot.random_triangles(77, 3000, 0.03)
     uv[3 * 100:3 * 103] = uv[3 * 10:3 * 13]; uv[3 * 2000:3 * 2003] = uv[3 * 10:3 * 13]   # real duplicates of triangle 10..12
     lv = (3 + ot.hash_u32(np.arange(3000) + 5) % 4).astype(np.uint8); lv[100:103] = lv[10:13]; lv[2000:2003] = lv[10:13]
     tex = ot.foliage_texture(8, 512, 512, feature=24)
-    os.environ["OMMX_TEST_SETUP_KEY_BITS"] = "6"
-    try:
-        both(product, oracle, [tex], uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv)
-    finally:
-        del os.environ["OMMX_TEST_SETUP_KEY_BITS"]
+    both(product, oracle, [tex], uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv, knobs=[(ot.KNOB_SETUP_KEY_BITS, 6)])
     both(product, oracle, [tex], uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv)
+    # the device-resident entry point has no host arrays: on a collision it reads the caller's device arrays back and takes the same exact path
+    hip = ot.Hip()
+    ob = oracle.create_baker(); otx = oracle.create_texture(ob, [tex], alpha_cutoff=0.5)
+    ref = oracle.bake(ob, ot.make_desc(otx, uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv))
+    oracle.destroy_texture(ob, otx); oracle.destroy_baker(ob)
+    b = product.create_baker(); product.set_knob(b, ot.KNOB_SETUP_KEY_BITS, 6)
+    t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+    dev = ot.bake_device(product, hip, b, ot.make_desc(t, uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv), uv, ix, levels=lv)
+    product.destroy_texture(b, t); product.destroy_baker(b)
+    dev.stats2 = None
+    assert dev.same_as(ref), dev.diff(ref)
 
 
 def test_no_memory_growth_over_baker_lifecycles(product):
@@ -1143,3 +1153,27 @@ def test_c_example_program(product, tmp_path):
         want.append((int(lvl), int(off), int(bits.sum()), n))
     assert got == want and len(got) == 4, (got, want)
     product.destroy_texture(b, t); product.destroy_baker(b)
+
+
+def test_internal_flags_no_fine_pass_and_edge_heuristic(product, oracle):
+    """Internal bake flags (bake_cpu_impl.cpp:43-48).  Bit 9 (DisableFineClassification) skips ResampleFine: what the summed-area pass leaves
+    unresolved keeps the initial UnknownOpaque -- the reference's own "everything but the fine pass" timing switch; bit 11 (EnableEdgeHeuristic)
+    selects the edge-length level heuristic for every triangle (glibc log2f on the host).  Bits 7 / 8 (the alternative conservative-bilinear
+    kernel) stay NOT_IMPLEMENTED."""
+    tex = ot.foliage_texture(3, 512, 512, feature=24)
+    uv, ix = ot.random_triangles(31, 600, 0.05)
+    lv = (2 + ot.hash_u32(np.arange(600) + 3) % 7).astype(np.uint8)          # levels 2..8: both tile sizes and the small-item launches
+    for sat in (True, False):
+        for filt in (ot.LINEAR, ot.NEAREST):
+            both(product, oracle, [tex], uv, ix, 8, sat=sat, addr=ot.WRAP, filt=filt, promo=ot.PROMO_FORCE_OPAQUE, levels=lv, flags=ot.FLAG_THREADS | (1 << 9))
+    both(product, oracle, [noise_u8()], uv, ix, 7, addr=ot.CLAMP, promo=ot.PROMO_NEAREST, flags=ot.FLAG_THREADS | (1 << 9), fmt=ot.FMT_2STATE)
+    # edge heuristic: dynamic levels for every triangle, with and without per-triangle overrides
+    lv2 = np.where(ot.hash_u32(np.arange(600) + 9) % 3 == 0, 0xF, lv).astype(np.uint8)
+    both(product, oracle, [tex], uv, ix, 9, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, dyn_scale=2.0, flags=ot.FLAG_THREADS | (1 << 11))
+    both(product, oracle, [tex], uv, ix, 9, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, dyn_scale=0.7, levels=lv2, flags=ot.FLAG_THREADS | (1 << 11) | (1 << 9))
+    b = product.create_baker()
+    t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+    for bit in (7, 8):
+        product.bake(b, ot.make_desc(t, uv, ix, 4, addr=ot.WRAP, flags=ot.FLAG_THREADS | (1 << bit)), expect=ot.NOT_IMPLEMENTED)
+    product.destroy_texture(b, t)
+    product.destroy_baker(b)
