@@ -1,11 +1,19 @@
 #!/usr/bin/env python3
-"""bench.py -- micro-triangles classified per second by ommCpuBake() on MI355X.
+"""bench.py -- micro-triangles classified per second + bake wall time of the MI355X opacity-micromap baker.
 
-A "step" is one complete bake (the whole hot path: work-item setup, SAT coarse pass, level-line fine pass, special-index
-promotion, XXH64 dedup, spatial sort, pack, index buffer) of BASELINE.json's metric configuration:
-    1 M random-UV triangles, 4096^2 foliage-style UNORM8 alpha (texture alphaCutoff = 0.5 => SAT on),
-    subdivision level 8, 4-state, Wrap / Linear, ForceOpaque promotion                       (configs[2] / [3])
-Prints ONE JSON line (rank 0).  `value` = micro-triangles of all unique work items / wall time of the step.
+A "step" is one complete bake (the whole hot path: work-item setup, SAT coarse pass, level-line fine pass, special-index promotion,
+XXH64 dedup, spatial sort, pack, index buffer).  Default workload = BASELINE.json's metric configuration (configs[2] / [3]):
+    1 M random-UV triangles, 4096^2 foliage-style UNORM8 alpha (texture alphaCutoff = 0.5 => SAT on), level 8, 4-state, Wrap / Linear
+`--config c1 | c2 | c4 | cards` selects another of tests/workloads.py (configs[1], configs[4] on one GPU, and an asset-shaped bake whose
+micro-triangles span several texels); the driver's line is the default, c2.
+
+Prints ONE JSON line (rank 0):
+  value / ms_per_step   micro-triangles of all unique work items / wall time of a step through ommxBakeDevice -- the ommCpuBake contract with
+                        the UV / index inputs and the result arrays resident in HBM (the bench contract: inputs resident when the clock starts)
+  bake_wall_time_ms     the SAME bake through the SDK entry point proper, ommCpuBake: host arrays in, host arrays out, PCIe inclusive
+                        (SURVEY.md section 8d metric 2), averaged over the same --steps after the same --warmup; details under host_api
+  roofline              what limits the dominant kernel (classify_tiles): VALU issue slots; roofline_hbm = the HBM view on the units the
+                        launch really processes; cpu_baseline = the oracle (port of the reference CPU baker) on the host cores, same run
 """
 import argparse
 import ctypes as C
@@ -20,15 +28,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ommtest as ot  # noqa: E402
+import workloads as wl  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_ISSUE_PEAK = 0.5      # one wave64 VALU instruction per SIMD every 2 cycles (SIMD-32 lanes), the plain-fp32 issue limit of gfx950
+NUM_SIMDS = 256 * 4
+
+# per config: triangles, CPU-baseline sample (triangles), description
+CONFIGS = {
+    "c1": dict(tris=100000, cpu_sample=20000, what="BASELINE configs[1]: %d random-UV triangles (10 texels), 2048x2048 value-noise UNORM8 alpha + SAT, subdiv level 6, 4-state, Wrap/Linear"),
+    "c2": dict(tris=1000000, cpu_sample=20000, what="%d random-UV triangles (8.0 texels), 4096x4096 foliage-style UNORM8 alpha + SAT, subdiv level 8, 4-state, Wrap/Linear"),
+    "c4": dict(tris=4000000, cpu_sample=3000, what="BASELINE configs[4] on ONE GPU: %d random-UV triangles (3 texels), per-triangle levels 4..10 (75 %%) + dynamic heuristic (25 %%, scale 2, max 10), 8192x8192 foliage UNORM8 alpha + SAT, 4-state, Wrap/Linear, dedup on"),
+    "cards": dict(tris=40000, cpu_sample=600, what="asset-shaped: %d triangles = axis-aligned quads covering 256..1024 texels of a 4096x4096 foliage UNORM8 alpha + SAT, per-quad levels 6..8 (micro-triangles of 1..16 texels: the generic texel-loop path), 4-state, Clamp/Linear"),
+}
 
 
 class BakeTimings(C.Structure):
     _fields_ = [("hostSetupMs", C.c_float), ("uploadMs", C.c_float), ("classifyMs", C.c_float), ("digestMs", C.c_float),
                 ("tailMs", C.c_float), ("gatherMs", C.c_float), ("downloadMs", C.c_float), ("totalMs", C.c_float),
                 ("microTriangles", C.c_uint64), ("uniqueItems", C.c_uint32), ("classifyLaunches", C.c_uint32),
-                ("stateBytes", C.c_uint64), ("triageMs", C.c_float), ("activeItems", C.c_uint32), ("fineMicroTriangles", C.c_uint64), ("setupMs", C.c_float)]
+                ("stateBytes", C.c_uint64), ("triageMs", C.c_float), ("activeItems", C.c_uint32), ("fineMicroTriangles", C.c_uint64), ("setupMs", C.c_float),
+                ("streamChunks", C.c_uint32), ("streamedBytes", C.c_uint64), ("streamTailMs", C.c_float),
+                ("openTiles", C.c_uint32), ("openTileMicroTriangles", C.c_uint64), ("streamEarlyItems", C.c_uint32), ("persistentMs", C.c_float)]
 
 
 def source_hash():
@@ -56,35 +77,8 @@ def create_texture_ms(prod, baker, size, seed):
     return best
 
 
-def make_workload(args):
-    """Seeded synthetic inputs (identical on every rank and for the CPU baseline)."""
-    tex = ot.foliage_texture(args.seed, args.tex, args.tex, feature=args.feature)
-    uv, ix = ot.random_triangles(args.seed + 1, args.tris, args.extent_texels / args.tex)
-    return tex, uv, ix
-
-
-def bake_desc(tex_handle, uv, ix, args, lo, hi):
-    return ot.make_desc(tex_handle, uv[3 * lo:3 * hi], ix[:3 * (hi - lo)], args.level, addr=ot.WRAP, filt=ot.LINEAR,
-                        promo=ot.PROMO_FORCE_OPAQUE, fmt=ot.FMT_4STATE, flags=ot.FLAG_THREADS)
-
-
-def cpu_baseline(args, tex, uv, ix, sat=True, sample=None):
-    """The oracle (bit-exact restatement of the reference CPU baker, OpenMP over work items like the reference) timed on a
-    bounded sample of the same triangle stream: the reference needs 2 * 4^N bytes per work item (131 GB at full size)."""
+def host_info():
     import multiprocessing
-    cores = multiprocessing.cpu_count()
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    orc = ot.Lib("oracle")
-    b = orc.create_baker()
-    t = orc.create_texture(b, [tex], alpha_cutoff=0.5 if sat else -1.0)
-    k = min(sample if sample is not None else args.cpu_sample, args.tris)
-    d = bake_desc(t, uv, ix, args, 0, k)
-    t0 = time.time()
-    res = orc.bake(b, d, want_stats=False)
-    dt = time.time() - t0
-    orc.destroy_texture(b, t)
-    orc.destroy_baker(b)
-    mt = k * 4 ** args.level
     model, sockets = "unknown", set()
     try:
         for ln in open("/proc/cpuinfo"):
@@ -94,10 +88,50 @@ def cpu_baseline(args, tex, uv, ix, sat=True, sample=None):
                 sockets.add(ln.split(":", 1)[1].strip())
     except OSError:
         pass
-    return {"value": mt / dt, "unit": "micro-triangles/s", "cores": cores, "kind": "port",
-            "note": "same loop structure as the reference (static-schedule OpenMP over work items, serial tail): with many threads the sample is dominated by the serial tail, "
-                    "so value / this mostly measures that tail plus the hierarchical SAT shortcut; sat_off below is the kernel-vs-kernel pair", "host": "%s, %d socket(s), %d hardware threads" % (model, max(1, len(sockets)), cores),
-            "sample": "first %d triangles of the same seeded stream (%.3g micro-triangles), SAT %s, %.1f s" % (k, mt, "on" if sat else "off", dt)}, res
+    cores = multiprocessing.cpu_count()
+    return cores, "%s, %d socket(s), %d hardware threads" % (model, max(1, len(sockets)), cores)
+
+
+def desc_for(tex_handle, uv, ix, lv, kw, extra_flags=0):
+    k = dict(kw)
+    level = k.pop("level")
+    return ot.make_desc(tex_handle, uv, ix, level, levels=lv, filt=ot.LINEAR, flags=ot.FLAG_THREADS | extra_flags, **k)
+
+
+def micro_triangles_of(lib, baker, desc):
+    """sum of 4^level over the unique work items of a bake (product library: from its timings)"""
+    tm = BakeTimings()
+    lib.dll.ommxGetLastBakeTimings(baker, C.byref(tm))
+    return int(tm.microTriangles)
+
+
+def cpu_baseline(tex, uv, ix, lv, kw, sample, sat=True, micro_tris=None):
+    """The oracle (bit-exact restatement of the reference CPU baker, OpenMP over work items like the reference) timed on a bounded sample
+    of the same triangle stream: the reference needs 2 * 4^N bytes per work item (131 GB at the full metric configuration).
+    Two runs: the whole bake, and the same bake with the reference's own DisableFineClassification switch (internal flag bit 9,
+    bake_cpu_impl.cpp:45) = everything except ResampleFine; the difference is the fine pass alone, the kernel-vs-kernel figure."""
+    cores, host = host_info()
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    orc = ot.Lib("oracle")
+    b = orc.create_baker()
+    t = orc.create_texture(b, [tex], alpha_cutoff=0.5 if sat else -1.0)
+    n = min(sample, ix.size // 3)
+    suv, six, slv = wl.subset(uv, ix, lv, 0, n)
+    d = desc_for(t, suv, six, slv, kw)
+    t0 = time.time()
+    res = orc.bake(b, d, want_stats=False)
+    dt = time.time() - t0
+    d9 = desc_for(t, suv, six, slv, kw, extra_flags=1 << 9)
+    t0 = time.time()
+    orc.bake(b, d9, want_stats=False)
+    dt9 = time.time() - t0
+    orc.destroy_texture(b, t)
+    orc.destroy_baker(b)
+    out = {"unit": "micro-triangles/s", "cores": cores, "kind": "port", "host": host,
+           "sample_triangles": n, "seconds": dt, "seconds_without_fine_pass": dt9,
+           "note": "same loop structure as the reference (static-schedule OpenMP over work items, serial tail): with many threads the whole-bake figure is dominated by the serial "
+                   "tail; `fine_pass_only` = micro-triangles / (whole bake - the same bake with the reference's DisableFineClassification flag) isolates ResampleFine"}
+    return out, res, (suv, six, slv), dt, dt9
 
 
 def main():
@@ -105,17 +139,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--tris", type=int, default=1000000)
-    ap.add_argument("--level", type=int, default=8)
-    ap.add_argument("--tex", type=int, default=4096)
-    ap.add_argument("--feature", type=int, default=64, help="foliage blob size in texels")
-    ap.add_argument("--extent-texels", type=float, default=8.0, help="triangle size in texels")
-    ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--host-api-steps", type=int, default=2, help="extra untimed-for-value bakes through ommCpuBake (host arrays)")
-    ap.add_argument("--cpu-sample", type=int, default=20000, help="triangles baked by the CPU baseline (0 = skip)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--tris", type=int, default=0, help="override the configuration's triangle count")
+    ap.add_argument("--host-api-steps", type=int, default=-1, help="timed bakes through ommCpuBake (host arrays in / out); -1 = --steps, 0 = skip")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="triangles baked by the CPU baseline (-1 = the configuration's default, 0 = skip)")
     ap.add_argument("--create-texture", type=int, default=1, help="time ommCpuCreateTexture at 4K and 8K (0 = skip)")
-    ap.add_argument("--sat-off-sample", type=int, default=50000, help="triangles of the SAT-off (no coarse pass) GPU measurement; CPU uses 1/20 of it (0 = skip)")
+    ap.add_argument("--sat-off-sample", type=int, default=50000, help="c2 only: triangles of the SAT-off (no coarse pass) GPU measurement; CPU uses 1/20 of it (0 = skip)")
+    ap.add_argument("--stream-chunks", type=int, default=0, help="ommxBakerKnob_StreamChunks for the ommCpuBake measurement (0 = library default)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    tris = args.tris or cfg["tris"]
+    host_steps = args.steps if args.host_api_steps < 0 else args.host_api_steps
+    cpu_sample = cfg["cpu_sample"] if args.cpu_sample < 0 else args.cpu_sample
 
     import torch
     import torch.distributed as dist
@@ -130,10 +165,8 @@ def main():
     if world > 1:
         dist.init_process_group(os.environ.get("OMM_BENCH_BACKEND", "nccl"))
 
-    tex, uv, ix = make_workload(args)
-    # strong scaling: every rank sees the whole (fixed) triangle stream; the library partitions the ACTIVE work items over the
-    # ranks (ommxSharded*), metadata are merged by an RCCL all-reduce and the surviving OMM blocks by an RCCL all-gather
-    lo, hi = 0, args.tris
+    tex, uv, ix, lv, kw = wl.workload(args.config, tris)
+    tris = ix.size // 3
 
     prod = ot.Lib("product")
     prod.dll.ommxGetLastBakeTimings.argtypes = [C.c_void_p, C.POINTER(BakeTimings)]
@@ -141,13 +174,17 @@ def main():
     prod.dll.ommxGetDeviceBakeResultDesc.argtypes = [C.c_void_p, C.POINTER(C.POINTER(ot.BakeResultDesc))]
     prod.dll.ommxDestroyDeviceBakeResult.argtypes = [C.c_void_p]
     baker = prod.create_baker()
+    if args.stream_chunks:
+        prod.set_knob(baker, ot.KNOB_STREAM_CHUNKS, args.stream_chunks)
     th = prod.create_texture(baker, [tex], alpha_cutoff=0.5)
-    host_desc = bake_desc(th, uv, ix, args, lo, hi)
+    host_desc = desc_for(th, uv, ix, lv, kw)
     # inputs resident in HBM before the timed region: torch owns the device buffers, the library gets raw pointers
-    d_uv = torch.from_numpy(np.ascontiguousarray(uv[3 * lo:3 * hi])).cuda()
-    d_ix = torch.from_numpy(ix[:3 * (hi - lo)].astype(np.int32)).cuda()
+    d_uv = torch.from_numpy(np.ascontiguousarray(uv)).cuda()
+    d_ix = torch.from_numpy(ix.astype(np.int32)).cuda()
+    d_lv = torch.from_numpy(np.ascontiguousarray(lv)).cuda() if lv is not None else None
     desc = ot.BakeInputDesc.from_buffer_copy(host_desc)
     desc.texCoords, desc.indexBuffer = d_uv.data_ptr(), d_ix.data_ptr()
+    desc.subdivisionLevels = d_lv.data_ptr() if d_lv is not None else None
 
     import omm_amd.sharded as shard
 
@@ -215,111 +252,148 @@ def main():
     result_info = {"arrayDataBytes": int(rd.arrayDataSize), "descs": int(rd.descArrayCount), "triangles": int(rd.indexCount)}
     prod.dll.ommxDestroyDeviceBakeResult(last)
 
-    # the SDK entry point proper (host arrays in, host arrays out) -- reported next to `value`, never as `value`
-    host_ms, host_tm = None, None
-    if rank == 0 and args.host_api_steps > 0:
+    # ---- the SDK entry point proper: host arrays in, host arrays out (metric 2) ----
+    host_ms, host_first_ms, host_tms = None, None, []
+    if rank == 0 and host_steps > 0:
         t1 = time.perf_counter()
         r, out = prod.bake_raw(baker, host_desc)
         assert r == ot.SUCCESS
         prod.fn("ommCpuDestroyBakeResult")(out)
-        host_first_ms = (time.perf_counter() - t1) * 1e3   # cold: fresh result pages are faulted in
-        t1 = time.perf_counter()
-        for _ in range(args.host_api_steps):
+        host_first_ms = (time.perf_counter() - t1) * 1e3   # cold: the pinned staging buffer and the result pages are set up
+        for _ in range(max(0, args.warmup - 1)):
             r, out = prod.bake_raw(baker, host_desc)
             assert r == ot.SUCCESS
-            host_tm = BakeTimings()
-            prod.dll.ommxGetLastBakeTimings(baker, C.byref(host_tm))
             prod.fn("ommCpuDestroyBakeResult")(out)
-        host_ms = (time.perf_counter() - t1) / args.host_api_steps * 1e3
+        t1 = time.perf_counter()
+        for _ in range(host_steps):
+            r, out = prod.bake_raw(baker, host_desc)
+            assert r == ot.SUCCESS
+            htm = BakeTimings()
+            prod.dll.ommxGetLastBakeTimings(baker, C.byref(htm))
+            host_tms.append(htm)
+            prod.fn("ommCpuDestroyBakeResult")(out)
+        host_ms = (time.perf_counter() - t1) / host_steps * 1e3
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        avg = lambda f: float(np.mean([getattr(t, f) for t in tms]))
+        avg = lambda f, ts=tms: float(np.mean([getattr(t, f) for t in ts]))
         classify_ms = avg("classifyMs")
-        launches = max(1, tms[-1].classifyLaunches)
-        # algorithmic bytes of the classification launch (DESIGN.md "Roofline"): 0.25 B written per 4-state micro-triangle,
-        # 24 B of UV read per work item, one pass over the texture and its summed-area table
-        alg_bytes = 0.25 * tms[-1].microTriangles + 24.0 * tms[-1].uniqueItems + args.tex * args.tex * (1 + 4)
-        achieved = alg_bytes / (classify_ms * 1e-3) / 1e9 if classify_ms > 0 else 0.0
+        persistent_ms = avg("persistentMs") or classify_ms
+        t_last = tms[-1]
+        bits = 2
         line = {
             "metric": "micro-triangles classified/sec (whole node)", "value": micro_tris / (elapsed / args.steps),
             "unit": "micro-triangles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%d random-UV triangles (%.1f texels), %dx%d foliage-style UNORM8 alpha + SAT, subdiv level %d, 4-state, Wrap/Linear"
-                                   % (args.tris, args.extent_texels, args.tex, args.tex, args.level),
-                       "entry": (("ommxShardedBakeRccl (collectives issued by the library)" if native else "ommxSharded* + torch.distributed") if world > 1 else "ommxBakeDevice") + " (ommCpuBake contract, UV/index inputs and result arrays resident in HBM)", "sharding": "active work items partitioned over ranks; RCCL all-reduce of item metadata + chunked all-gather of OMM blocks" if world > 1 else "none",
-                       "result": result_info, "unique_items": int(tms[-1].uniqueItems), "active_items": int(tms[-1].activeItems),
-                       "fine_micro_triangles": int(tms[-1].fineMicroTriangles)},
-            "bake_wall_time_ms": ms_per_step,
-            # `value` is measured on the device-resident entry point (inputs and result arrays in HBM, the bench contract); its peer below
-            # is the SDK call proper, host arrays in and out, i.e. the same bake plus one PCIe copy of the result
+            "config": {"workload": cfg["what"] % tris, "name": args.config,
+                       "entry": (("ommxShardedBakeRccl (collectives issued by the library)" if native else "ommxSharded* + torch.distributed") if world > 1 else "ommxBakeDevice") + " (ommCpuBake contract, UV/index inputs and result arrays resident in HBM)",
+                       "sharding": "active work items partitioned over ranks; RCCL all-reduce of item metadata + chunked all-gather of OMM blocks" if world > 1 else "none",
+                       "result": result_info, "unique_items": int(t_last.uniqueItems), "active_items": int(t_last.activeItems),
+                       "open_tiles": int(t_last.openTiles), "fine_micro_triangles": int(t_last.fineMicroTriangles)},
+            # `value` / `ms_per_step`: device-resident entry (the bench contract: inputs resident in HBM when the clock starts).
+            # `bake_wall_time_ms`: the SDK call a drop-in user makes, ommCpuBake, host arrays in and out, PCIe inclusive -- same steps, same warm-up.
             "value_entry": "ommxBakeDevice" if world == 1 else ("ommxShardedBakeRccl" if native else "ommxSharded* + torch.distributed"),
+            "bake_wall_time_ms": host_ms if host_ms is not None else ms_per_step,
+            "bake_wall_time_entry": "ommCpuBake (host arrays in/out, PCIe inclusive)" if host_ms is not None else "ommxBakeDevice (ommCpuBake was not timed in this run)",
             "rates": {"all_work_items": micro_tris / (elapsed / args.steps),
-                      "active_items_only": float(tms[-1].activeItems) * 4.0 ** args.level / (classify_ms * 1e-3) if classify_ms > 0 else None,
-                      "fine_pass_only": float(tms[-1].fineMicroTriangles) / (classify_ms * 1e-3) if classify_ms > 0 else None,
+                      "open_tiles_only": float(t_last.openTileMicroTriangles) / (persistent_ms * 1e-3) if persistent_ms > 0 else None,
+                      "fine_pass_only": float(t_last.fineMicroTriangles) / (classify_ms * 1e-3) if classify_ms > 0 else None,
                       "note": "`value` counts 4^level micro-triangles for every unique work item like the reference's loop does; most items are settled by one summed-area-table "
-                              "query (hierarchical culling), so the rate over the items that reach classify_tiles and over the micro-triangles that reach the level-line pass are given too"},
-            "host_api": None if host_ms is None else {"entry": "ommCpuBake (host arrays in/out, PCIe inclusive)", "ms_per_bake": host_ms, "first_call_ms": host_first_ms,
-                                                       "uploadMs": host_tm.uploadMs, "downloadMs": host_tm.downloadMs,
-                                                       "micro_triangles_per_s": micro_tris / (host_ms * 1e-3)},
-            "phases_ms": {k: avg(k) for k in ("uploadMs", "setupMs", "triageMs", "classifyMs", "digestMs", "tailMs", "gatherMs", "downloadMs", "totalMs")},
-            "roofline": {"bound": "hbm", "kernel": "classify_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": classify_ms / launches,
-                         "algorithmic_bytes_per_launch": alg_bytes / launches,
-                         "note": "classification is fp32-VALU/sqrt/div bound, not HBM bound (SURVEY.md section 8d)"},
+                              "query (hierarchical culling), so the rate over the micro-triangles of the tiles that reach classify_tiles and over those that reach the level-line pass are given too"},
+            "phases_ms": {k: avg(k) for k in ("uploadMs", "setupMs", "triageMs", "classifyMs", "persistentMs", "digestMs", "tailMs", "gatherMs", "downloadMs", "totalMs")},
         }
-        # HBM bytes per launch from the PMC counters cannot be read from inside this process: they come from the separate
-        # rocprofv3 --pmc passes of profiles/collect.sh (FETCH_SIZE x2 on gfx950, WRITE_SIZE x1), committed under profiles/, and
-        # apply only to the workload AND the library sources they were collected on: the summary carries a hash of omm_amd/csrc,
-        # and a summary older than the sources is not printed.
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
-        default_workload = (args.tris, args.level, args.tex, args.feature, args.extent_texels, args.seed) == (1000000, 8, 4096, 64, 8.0, 1234)
+        if host_ms is not None:
+            havg = lambda f: avg(f, host_tms)
+            line["host_api"] = {"entry": "ommCpuBake (host arrays in/out, PCIe inclusive)", "ms_per_bake": host_ms, "bakes": host_steps, "first_call_ms": host_first_ms,
+                                "micro_triangles_per_s": micro_tris / (host_ms * 1e-3),
+                                "stream": {"chunks": int(host_tms[-1].streamChunks), "streamed_bytes": int(host_tms[-1].streamedBytes), "exposed_copy_ms": havg("streamTailMs"),
+                                           "early_items": int(host_tms[-1].streamEarlyItems),
+                                           "note": "finished OMM blocks cross PCIe, straight to their final arrayData offsets, while the classification runs (one copy per classification "
+                                                   "launch); exposed = from the end of the classification to the last byte on the host"},
+                                "phases_ms": {k: havg(k) for k in ("uploadMs", "setupMs", "triageMs", "classifyMs", "digestMs", "tailMs", "gatherMs", "downloadMs", "totalMs")}}
+
+        # ---- roofline of the dominant kernel, classify_tiles (the persistent launch of the levels >= 6) ----
+        # The kernel is bound by VALU issue slots, not by HBM and not by MFMA.  Instruction counts per launch come from the separate
+        # rocprofv3 --pmc passes of profiles/collect.sh (they cannot be read from inside this process) and apply only to the workload AND the library
+        # sources they were collected on: the summary carries a hash of omm_amd/csrc, and a summary of other sources is not used.
+        launches = 1
+        # HBM view on the units the launch really processes: packed states of the OPEN tiles (0.25 B per 4-state micro-triangle), their 48-byte records,
+        # one pass over the texture and its summed-area table (5 B per texel)
+        tw, thh = tex.shape[1], tex.shape[0]
+        alg_bytes = bits / 8.0 * float(t_last.openTileMicroTriangles) + 48.0 * t_last.openTiles + tw * thh * 5.0
+        hbm_achieved = alg_bytes / (persistent_ms * 1e-3) / 1e9 if persistent_ms > 0 else 0.0
+        roof_hbm = {"bound": "hbm", "kernel": "classify_tiles", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_ms": persistent_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                    "formula": "(0.25 B x micro-triangles of the open tiles + 48 B x open tiles + 5 B x texels) / HIP-event duration of the launch",
+                    "all_work_items_view": {"note": "SURVEY.md section 8d per-unit figure (0.25 B per micro-triangle of EVERY unique work item + 24 B per item + 5 B per texel) over the same duration; "
+                                                    "95 % of those micro-triangles are settled by hierarchical SAT queries and never reach this launch",
+                                            "achieved": (bits / 8.0 * micro_tris + 24.0 * t_last.uniqueItems + tw * thh * 5.0) / (persistent_ms * 1e-3) / 1e9 if persistent_ms > 0 else None}}
+        roof_hbm["all_work_items_view"]["frac"] = (roof_hbm["all_work_items_view"]["achieved"] or 0.0) / HBM_PEAK_GBS
+        line["roofline"] = roof_hbm
+        tpath = os.path.join(ROOT, "profiles", "pmc_latest_%s.json" % args.config)
+        default_workload = tris == cfg["tris"]
         if world == 1 and default_workload and os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("source_sha256_16") == source_hash():
-                line["roofline"]["traffic"] = tj.get("traffic_bytes_per_launch")
-                line["roofline"]["traffic_source"] = "profiles/%s_pmc.md (separate rocprofv3 --pmc passes of `%s`; %s; sources %s)" % (
-                    tj.get("tag"), tj.get("command"), tj.get("corrections"), tj.get("source_sha256_16"))
-                # issue-slot view of the same profile (profiles/summarize_pmc.py: SQ instruction classes x measured cycles per class)
-                line["roofline"]["issue"] = {"valu_issue_utilisation": tj.get("valu_issue_utilisation"), "scalar_issue_utilisation": tj.get("scalar_issue_utilisation"),
-                                             "valu_lane_utilisation": tj.get("valu_lane_util"), "valu_instr_per_cycle_per_simd": tj.get("valu_instr_per_cycle_per_simd")}
+                src = "profiles/%s_pmc.md (separate rocprofv3 --pmc passes of `%s`; %s; sources %s)" % (tj.get("tag"), tj.get("command"), tj.get("corrections"), tj.get("source_sha256_16"))
+                roof_hbm["traffic"] = tj.get("traffic_bytes_per_launch")
+                roof_hbm["traffic_source"] = src
+                valu = tj.get("valu_wave_instructions_per_launch"); hz = tj.get("shader_clock_hz")
+                if valu and hz and persistent_ms > 0:
+                    ipc = valu / (persistent_ms * 1e-3 * hz * NUM_SIMDS)
+                    line["roofline"] = {"bound": "valu_issue", "kernel": "classify_tiles", "achieved": ipc, "peak": VALU_ISSUE_PEAK, "unit": "VALU wave-instructions / cycle / SIMD",
+                                        "frac": ipc / VALU_ISSUE_PEAK, "avg_launch_ms": persistent_ms,
+                                        "formula": "SQ_INSTS_VALU per launch (%.4g, PMC pass) / (HIP-event duration of the launch x %.4g Hz shader clock (GRBM_GUI_ACTIVE / 8 / duration of the counter pass) x 1024 SIMDs) / 0.5" % (valu, hz),
+                                        "calibrated_issue_utilisation": tj.get("valu_issue_utilisation"), "scalar_issue_utilisation": tj.get("scalar_issue_utilisation"),
+                                        "valu_lane_utilisation": tj.get("valu_lane_util"), "scalar_per_valu": tj.get("scalar_per_valu"),
+                                        "note": "calibrated = every instruction class priced with its measured issue cost (profiles/valu_rates_mi355x.json) instead of 2 cycles",
+                                        "source": src}
+                    line["roofline_hbm"] = roof_hbm
             else:
-                line["roofline"]["traffic_source"] = "none: profiles/hbm_traffic_latest.json was collected on other sources (%s, tree is %s)" % (tj.get("source_sha256_16"), source_hash())
+                roof_hbm["traffic_source"] = "none: %s was collected on other sources (%s, tree is %s)" % (os.path.basename(tpath), tj.get("source_sha256_16"), source_hash())
         # the streaming part of the path for comparison: final gather of the surviving OMM blocks into arrayData order
-        # (read + write of arrayData, HIP events around gather + index narrowing)
         gather_ms = avg("gatherMs")
         if gather_ms > 0 and world == 1:
             gb = 2.0 * result_info["arrayDataBytes"] + 8.0 * result_info["descs"] + 8.0 * result_info["triangles"]
             line["roofline_streaming"] = {"bound": "hbm", "kernel": "tail_gather_omms (+ narrow_indices)", "achieved": gb / (gather_ms * 1e-3) / 1e9,
                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / (gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        if world == 1 and args.create_texture:
-            line["create_texture_ms"] = {"entry": "ommCpuCreateTexture, UNORM8 + alphaCutoff (H2D + device summed-area table)", "4096": create_texture_ms(prod, baker, 4096, args.seed),
-                                         "8192": create_texture_ms(prod, baker, 8192, args.seed)}
-        if args.cpu_sample > 0 and world == 1:
-            cb, cpu_res = cpu_baseline(args, tex, uv, ix)
-            line["cpu_baseline"] = cb
-            line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"]
+        if world == 1 and args.create_texture and args.config == "c2":
+            line["create_texture_ms"] = {"entry": "ommCpuCreateTexture, UNORM8 + alphaCutoff (H2D + device summed-area table)", "4096": create_texture_ms(prod, baker, 4096, 1234),
+                                         "8192": create_texture_ms(prod, baker, 8192, 1234)}
+        if cpu_sample > 0 and world == 1:
+            cb, cpu_res, (suv, six, slv), dt, dt9 = cpu_baseline(tex, uv, ix, lv, kw, cpu_sample)
             # correctness gate of the same run: the HIP library bakes the CPU sample, byte-for-byte comparison
-            k = min(args.cpu_sample, args.tris)
-            gpu_res = prod.bake(baker, bake_desc(th, uv, ix, args, 0, k), want_stats=False)
+            gpu_res = prod.bake(baker, desc_for(th, suv, six, slv, kw), want_stats=False)
             assert gpu_res.same_as(cpu_res), "GPU result differs from the CPU baseline on its sample: " + gpu_res.diff(cpu_res)
+            mt = micro_triangles_of(prod, baker, None)
+            cb["value"] = mt / dt
+            cb["fine_pass_only"] = mt / max(dt - dt9, 1e-9)
+            cb["sample"] = "first %d triangles of the same seeded stream (%.3g micro-triangles), SAT on, %.1f s (%.1f s without the fine pass)" % (cb["sample_triangles"], mt, dt, dt9)
+            line["cpu_baseline"] = cb
+            line["speedup_vs_cpu_baseline"] = {"whole_bake_device_entry": line["value"] / cb["value"],
+                                               "whole_bake_ommCpuBake": (micro_tris / (host_ms * 1e-3)) / cb["value"] if host_ms else None,
+                                               "note": "whole-bake ratios include the hierarchical SAT shortcut and the baseline's serial tail; sat_off (c2) is the kernel-vs-kernel pair"}
             line["parity_vs_cpu_baseline"] = "bit-exact on the CPU sample (arrayData %d B, %d descs, index buffer, histograms, index format)" % (gpu_res.array_data.size, len(gpu_res.descs))
             # second texture mode (no summed-area table: every micro-triangle takes the level-line pass), bounded samples on both sides
-            if args.sat_off_sample > 0:
-                ks = min(args.sat_off_sample, args.tris)
+            if args.sat_off_sample > 0 and args.config == "c2":
+                ks = min(args.sat_off_sample, tris)
                 th2 = prod.create_texture(baker, [tex], alpha_cutoff=-1.0)
-                d2 = bake_desc(th2, uv, ix, args, 0, ks)
+                guv, gix, glv = wl.subset(uv, ix, lv, 0, ks)
+                d2 = desc_for(th2, guv, gix, glv, kw)
                 prod.bake(baker, d2, want_stats=False)
                 t2 = time.perf_counter()
                 prod.bake(baker, d2, want_stats=False)
                 gpu_dt = time.perf_counter() - t2
+                gmt = micro_triangles_of(prod, baker, None)
                 kc = min(max(args.sat_off_sample // 20, 200), ks)
-                cb2, cpu_res2 = cpu_baseline(args, tex, uv, ix, sat=False, sample=kc)
-                gpu_res2 = prod.bake(baker, bake_desc(th2, uv, ix, args, 0, kc), want_stats=False)
+                cb2, cpu_res2, (cuv, cix, clv), dt2, _ = cpu_baseline(tex, uv, ix, lv, kw, kc, sat=False)
+                gpu_res2 = prod.bake(baker, desc_for(th2, cuv, cix, clv, kw), want_stats=False)
                 assert gpu_res2.same_as(cpu_res2), "SAT-off GPU result differs from the CPU baseline: " + gpu_res2.diff(cpu_res2)
+                cb2["value"] = micro_triangles_of(prod, baker, None) / dt2
+                cb2["sample"] = "first %d triangles, SAT off, %.1f s" % (kc, dt2)
                 prod.destroy_texture(baker, th2)
-                line["sat_off"] = {"entry": "ommCpuBake (host arrays, PCIe inclusive), texture without alphaCutoff", "gpu_micro_triangles_per_s": ks * 4.0 ** args.level / gpu_dt,
-                                   "gpu_sample": "first %d triangles, %.1f ms" % (ks, gpu_dt * 1e3), "cpu_baseline": cb2, "parity": "bit-exact on the CPU sample"}
+                line["sat_off"] = {"entry": "ommCpuBake (host arrays, PCIe inclusive), texture without alphaCutoff", "gpu_micro_triangles_per_s": gmt / gpu_dt,
+                                   "gpu_sample": "first %d triangles, %.1f ms" % (ks, gpu_dt * 1e3), "cpu_baseline": cb2, "speedup": (gmt / gpu_dt) / cb2["value"], "parity": "bit-exact on the CPU sample"}
         print(json.dumps(line))
     if world > 1:
         torch.cuda.synchronize()

@@ -11,14 +11,33 @@ struct SetupCounters;
 // classification of the active items of ALL levels: level l = activeIds[first[l] .. first[l] + count[l]).  Items of level >= 5 are cut into
 // tiles; `queue` holds classify_queue_records(count) tile records of kTileRecordBytes, `queueCtl` 4 words (zeroed here).  numCUs sizes the persistent grid.
 constexpr size_t kTileRecordBytes = 48;
-uint64_t classify_queue_records(const uint32_t count[kNumLevels]);
+uint64_t classify_queue_records(const uint32_t count[kNumLevels], bool sections = false);   // sections: a streamed bake (chunks.count > 1), whose queue holds a second copy of the levels >= 6
+// `queueCtl`: kClassifyCtlWords words (zeroed here): tail / head of the 1024-tile queue, tail and head per section of the 4096-tile queue.
+// `chunks` (optional, streamed bakes): the work items of the levels >= 6 are cut into `count` ranges of about equal tile counts -- in the order of the final
+// result: highest level first, then the position in that level's active list -- and every range gets its own tile-triage and persistent launch;
+// after(user, k, segments, n, false) is called behind launch k with the range as segments of the active lists, after(user, count, ..., true) once more with
+// the lower levels (which come last in the result).  mark(user) is called right before the first persistent launch of the levels >= 6.  The hooks enqueue
+// their own work on the same stream.
+constexpr uint32_t kMaxClassifyChunks = 64, kClassifyCtlWords = 2 + 2 * kMaxClassifyChunks;
+struct ClassifySegment { uint32_t level, first, count; };   // activeIds[first .. first + count), all of one level
+struct ClassifyChunks {
+    uint32_t count;
+    void (*after)(void* user, uint32_t chunk, const ClassifySegment* segs, uint32_t numSegs, bool last);
+    void (*mark)(void* user);
+    void* user;
+    const uint8_t* early;   // or null.  Per item: 1 = classify it in a launch of its own class BEFORE the first range (streamed bakes: possible duplicates)
+    void (*afterEarly)(void* user, const ClassifySegment* segs, uint32_t numSegs);   // behind that launch: one segment per level >= 6 (all its items)
+};
+// the whole-item kernel at `level` over a plain item list (used for the level-2 preview of a streamed bake)
+hipError_t launch_classify_items(const ClassifyParams& P, const ItemArrays& A, const uint32_t* ids, uint32_t count, uint32_t level, hipStream_t stream);
 hipError_t launch_classify(const ClassifyParams& P, const ItemArrays& A, const uint32_t* activeIds, const uint32_t first[kNumLevels], const uint32_t count[kNumLevels],
-                           void* queue, uint32_t* queueCtl, uint32_t numCUs, hipStream_t stream);
+                           void* queue, uint32_t* queueCtl, uint32_t numCUs, hipStream_t stream, const ClassifyChunks* chunks = nullptr);
 // level-0 hierarchical query per work item: uniform items get stateMask = 1 << state and active = 0
 void launch_triage(const ClassifyParams& P, const float* uv, const SetupCounters* counters, uint32_t maxItems, uint32_t* stateMask, uint8_t* active, hipStream_t stream);
 // XXH64(seed 42) of the 3-state byte stream of each listed item -> digests[item]
+// (only != null: the listed items with (only[item] != 0) == (want != 0))
 void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
-                   uint64_t* digests, hipStream_t stream);
+                   uint64_t* digests, hipStream_t stream, const uint8_t* only = nullptr, int want = 0);
 // summed-area table of (alpha > cutoff)
 // (scratch: sat_scratch_bytes(w, h) bytes of device memory, free again once the stream has passed the build)
 size_t sat_scratch_bytes(int w, int h);
@@ -70,6 +89,28 @@ void launch_shard_gather(const uint8_t* states, const uint64_t* stateOfs, const 
 void launch_shard_scatter(const uint8_t* gathered, uint64_t rankPitch, uint64_t lo, uint64_t hi, const uint8_t* active, const uint8_t* owner, const uint32_t* stateMask,
                           const uint8_t* level, int bits, const uint32_t* order, const uint64_t* cofs, const uint32_t* dstOfs, const uint32_t* sizes,
                           uint32_t numOmms, uint8_t* arrayData, hipStream_t stream);
+
+// ---- streamed result of ommCpuBake (tail_kernels.hip: "Streamed result") ----
+struct StreamSegment {
+    const uint32_t* ids; uint32_t count, level, range;        // items activeIds[..] of ONE level, consecutive in the sorted list; range = index of the classification launch
+    const uint32_t* stateMask; const uint32_t* knownCount; const uint64_t* digests; const uint8_t* states; const uint64_t* stateOfs;
+    float rejectionThreshold; int bits, disableDedup;
+    const uint8_t* early;   // or null: per item, 1 = classified (and its digest entered into the table) before the first range
+};
+// the early items of a segment: their digests enter the table before anything is placed (run after their classification + launch_digest(.., early, 1))
+void launch_stream_insert_early(const StreamSegment& g, uint32_t numActive, void* scratch, size_t scratchBytes, hipStream_t stream);
+size_t stream_scratch_bytes(uint32_t numActive);
+hipError_t run_stream_begin(uint32_t* activeIds, uint32_t numActive, const float* uv, const uint8_t* level, void* scratch, size_t scratchBytes, hipStream_t stream);
+// placed[item] <- final arrayData offset of the item's block (~0: no block); *cursor advances by the bytes placed; ctl: 3 words {blocks placed, violation, mismatch}
+hipError_t run_stream_segment(const StreamSegment& g, uint32_t numActive, void* scratch, size_t scratchBytes, unsigned long long* cursor, uint8_t* stage,
+                              uint64_t* placed, uint32_t* ctl, hipStream_t stream);
+void launch_stream_publish(const unsigned long long* cursor, unsigned long long* hostSlot, hipStream_t stream);
+// preview of the items of level >= 6 (tail_kernels.hip "preview"): prepare -> launch_classify_items(kPreviewLevel, preview buffers) -> flags
+constexpr uint32_t kPreviewLevel = 5, kPreviewSlotBytes = 256;   // 1024 micro-triangles x 2 bits
+void launch_stream_preview_prepare(const uint32_t* ids, uint32_t n, const float* uv, float texW, float texH, float* uv2, uint64_t* ofs2, uint8_t* early, hipStream_t stream);
+hipError_t run_stream_preview_flags(const uint32_t* ids, uint32_t n, uint32_t numActive, const uint8_t* states2, const uint8_t* level, uint8_t* early, uint32_t* ctl,
+                                    void* scratch, size_t scratchBytes, hipStream_t stream);   // ctl[3] += number of early items
+void launch_stream_verify(const uint32_t* order, const uint32_t* dstOfs, uint32_t numOmms, const uint64_t* placed, uint32_t* ctl, hipStream_t stream);
 
 // ---- device tail (tail_kernels.hip) ----
 struct TailInputs {

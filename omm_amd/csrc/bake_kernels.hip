@@ -107,18 +107,28 @@ struct TileLevels {                 // the sliced levels of one tile size, highe
     uint32_t n;
     uint32_t level[kNumLevels], first[kNumLevels], tileStart[kNumLevels + 1]; // items activeIds[first .. ), tiles [tileStart[k], tileStart[k+1])
 };
+// The queue of one tile size is cut into sections, each drained by a persistent launch of its own.  Ordinary bakes: one section.  Streamed bakes
+// (ommCpuBake): section 0 = the items classified early (all ranges) + range 0, section k = range k; a section's records start at base[k], its fill
+// count is queueCtl word tails[k]; capacity = every tile that can land there.
+struct TileSections {
+    uint32_t n;                                   // sections in use
+    uint32_t cut[kMaxClassifyChunks + 1];         // range k = tiles [cut[k], cut[k + 1]) of the tile enumeration (section k; range 0 -> section 0)
+    uint32_t base[kMaxClassifyChunks];            // first record of section k
+};
 // record = 3 x uint4 (everything a tile's workgroup needs, in ONE memory round trip):
 //   [0] x = item | degenerate << 30 | rectOk << 31, y = tile in item | level << 24, z = sx | sy << 16, w = ex | ey << 16 (addressed texel rectangle)
 //   [1] the item's uv[0..3]      [2] uv[4], uv[5], address of the tile's packed states (lo, hi)
 constexpr uint32_t kTileRecordWords = 3;   // uint4 per record (bake_kernels.h: kTileRecordBytes)
 template <int TILE>
 __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays A, const uint32_t* __restrict__ activeIds, TileLevels L,
-                                                    uint4* __restrict__ queue, uint32_t* __restrict__ queueTail)
+                                                    uint4* __restrict__ queue, uint32_t* __restrict__ sectionTails, TileSections S,
+                                                    const uint8_t* __restrict__ early)
 {
     constexpr uint32_t TILE_LOG4 = TILE == 4096 ? 6u : 5u;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const bool live = t < L.tileStart[L.n];
+    uint32_t sec = 0;
     int st = -1; uint32_t item = 0, tileInItem = 0, level = TILE_LOG4; TexRect r; r.sx = r.sy = r.ex = r.ey = 0; r.ok = false;
     float uvv[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
     const uint32_t bits = (uint32_t)P.format, tileBytes = (uint32_t)TILE * bits / 8u;
@@ -128,6 +138,7 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
         level = L.level[k];
         const uint32_t shift = 2u * (level - TILE_LOG4), rel = t - L.tileStart[k];   // tiles per item = 4^(level - log4 TILE)
         item = activeIds[L.first[k] + (rel >> shift)]; tileInItem = rel & ((1u << shift) - 1u);
+        if (S.n > 1u && !(early && early[item])) while (sec + 1u < S.n && t >= S.cut[sec + 1u]) ++sec;   // (early items: section 0, whatever their range)
         const float* uv = A.uv + 6ull * item;
         #pragma unroll
         for (int q = 0; q < 6; ++q) uvv[q] = uv[q];
@@ -136,14 +147,18 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
         r = region_rect<ModeDynamic>(P, sub, maxAbs);
         if (P.useCoarse) st = region_state<ModeDynamic>(P, sub, maxAbs, no_window());
     }
-    // ---- open tiles: wave-compacted append ----
+    // ---- open tiles: wave-compacted append, section by section (a wave sees one section, two at a range boundary, early items apart) ----
     const bool open = live && st < 0;
-    const unsigned long long ob = __ballot(open);
-    if (ob) {
+    unsigned long long todo = __ballot(open);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t s0 = (uint32_t)__shfl((int)sec, leader);
+        const unsigned long long ob = __ballot(open && sec == s0) & todo;
+        todo &= ~ob;
         uint32_t wbase = 0;
-        if (lane == (uint32_t)__ffsll((long long)ob) - 1u) wbase = atomicAdd(queueTail, (uint32_t)__popcll(ob));
-        wbase = __shfl(wbase, __ffsll((long long)ob) - 1);
-        if (open) {
+        if ((int)lane == leader) wbase = S.base[s0] + atomicAdd(sectionTails + s0, (uint32_t)__popcll(ob));
+        wbase = __shfl(wbase, leader);
+        if (open && sec == s0) {
             uint4* rec = queue + (size_t)kTileRecordWords * (wbase + __popcll(ob & ((1ull << lane) - 1ull)));
             const unsigned long long dst = (unsigned long long)(A.states + A.stateOfs[item] + (size_t)tileInItem * tileBytes);
             rec[0] = make_uint4(item | (A.degenerate[item] ? 0x40000000u : 0u) | (r.ok ? 0x80000000u : 0u), tileInItem | (level << 24),
@@ -184,7 +199,8 @@ constexpr int WIN = 32; // largest LDS texel window edge
 template <bool FP32, bool SLICED, int TILE, class MD>
 __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(ClassifyParams P, ItemArrays A, const uint32_t* __restrict__ itemIds,
                                                         uint32_t numItems, uint32_t levelArg, uint64_t numTiles,
-                                                        const uint4* __restrict__ tileQueue, const uint32_t* __restrict__ queueCount, uint32_t* __restrict__ queueHead)
+                                                        const uint4* __restrict__ tileQueue, const uint32_t* __restrict__ queueCount, uint32_t* __restrict__ queueHead,
+                                                        uint32_t sectionBase)
 {
     __shared__ uint8_t  s_state[TILE];
     __shared__ uint16_t s_queue[TILE];
@@ -204,11 +220,13 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     const uint32_t tid = threadIdx.x;
     // SLICED: persistent workgroups drain the queue of open tiles that triage_tiles filled (all levels >= log4 TILE in one launch);
     // the position of the NEXT tile is fetched while the current one is being classified.
-    uint32_t qpos = 0, qtotal = 0;
+    // One launch drains ONE section of the queue (TileSections): records [sectionBase, sectionBase + *queueCount).  A streamed bake (ommCpuBake) has a
+    // section per range of work items, so that the finished blocks of one range travel to the host while the next range is classified.
+    uint32_t qpos = 0, qtotal = 0, qfirst = 0;
     if (SLICED) {
-        qtotal = *queueCount;
+        qfirst = sectionBase; qtotal = sectionBase + *queueCount;
         s_btab[tid] = (uint8_t)bird_table_entry(tid >> 6, tid & 63u);   // (BLOCK == 256 entries)
-        if (tid == 0) s_next = atomicAdd(queueHead, 1u);
+        if (tid == 0) s_next = qfirst + atomicAdd(queueHead, 1u);
         __syncthreads();
         qpos = uniform_u32(s_next);
     }
@@ -221,7 +239,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         const uint4* rp = tileQueue + (size_t)kTileRecordWords * qpos;
         rec = rp[0]; rec1 = rp[1]; rec2 = rp[2];   // three independent loads: one round trip for item, rectangle, UVs and output address
         rec.x = uniform_u32(rec.x); rec.y = uniform_u32(rec.y); rec.z = uniform_u32(rec.z); rec.w = uniform_u32(rec.w);
-        if (tid == 0) nextPos = atomicAdd(queueHead, 1u);   // consumed at the end of this tile
+        if (tid == 0) nextPos = qfirst + atomicAdd(queueHead, 1u);   // consumed at the end of this tile
         level = rec.y >> 24;
         // a sliced tile implies 4^level >= TILE; without the hint clang hoists micro_triangle()'s level-0 branch (three loop-invariant
         // vertices) out of the phase-1/2 loops and keeps them in VGPRs for the whole kernel
@@ -504,17 +522,60 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
 // packed several to a 1024-tile and keep a plain grid launch per level (their total cost is negligible: <= 256 micro-triangles each).
 static uint32_t tiles_per_item(uint32_t level, uint32_t tileLog4) { return 1u << (2u * (level - tileLog4)); }
 
-uint64_t classify_queue_records(const uint32_t count[kNumLevels])
+uint64_t classify_queue_records(const uint32_t count[kNumLevels], bool sections)
 {
     uint64_t n = 0;
-    for (uint32_t l = 5; l < (uint32_t)kNumLevels; ++l) n += (uint64_t)count[l] * tiles_per_item(l, l >= 6 ? 6u : 5u);
+    for (uint32_t l = 5; l < (uint32_t)kNumLevels; ++l) n += (uint64_t)count[l] * tiles_per_item(l, l >= 6 ? 6u : 5u) * (sections && l >= 6 ? 2u : 1u);
     return n;
 }
 
 template <bool FP32, class MD>
 static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, const uint32_t* activeIds, const uint32_t first[kNumLevels],
-                               const uint32_t count[kNumLevels], uint4* queue, uint32_t* queueCtl, uint32_t numCUs, hipStream_t stream)
+                               const uint32_t count[kNumLevels], uint4* queue, uint32_t* queueCtl, uint32_t numCUs, const ClassifyChunks& chunks, hipStream_t stream)
 {
+    // queueCtl: [0] tail and [1] head of the 1024-tile queue, then per section of the 4096-tile queue its tail [2 + k] and its head [2 + kMaxClassifyChunks + k]
+    uint32_t* tail1024 = queueCtl; uint32_t* head1024 = queueCtl + 1; uint32_t* secTails = queueCtl + 2; uint32_t* secHeads = queueCtl + 2 + kMaxClassifyChunks;
+    struct Cls { TileLevels L; uint64_t total; } cls[2];
+    for (int c = 0; c < 2; ++c) {   // 0: 4096-tiles (levels 6..12, highest first), 1: 1024-tiles (level 5)
+        TileLevels& L = cls[c].L; memset(&L, 0, sizeof L);
+        uint64_t total = 0;
+        for (int level = c == 0 ? kMaxLevel : 5; level >= (c == 0 ? 6 : 5); --level) {
+            if (!count[level]) continue;
+            L.level[L.n] = (uint32_t)level; L.first[L.n] = first[level]; L.tileStart[L.n] = (uint32_t)total;
+            total += (uint64_t)count[level] * tiles_per_item((uint32_t)level, c == 0 ? 6u : 5u);
+            L.n++;
+        }
+        if (total > 0x7FFFFFFFull) total = 0;   // (that many tiles cannot happen: their packed states would not fit in HBM)
+        L.tileStart[L.n] = (uint32_t)total;
+        cls[c].total = total;
+    }
+    // sections of the 4096-tile queue (TileSections): K ranges of (about) equal tile counts, cut at work-item boundaries, in the order of the tile
+    // enumeration = the order of the final result (highest level first, then the position in that level's active list)
+    const uint32_t K = cls[0].total ? (chunks.count ? chunks.count : 1u) : 0u;
+    TileSections S; memset(&S, 0, sizeof S); S.n = K;
+    // (equal ranges: measured against growing and bell-shaped splits, which leave the copy engine idle early or a large last range exposed -- the PCIe copy
+    //  is the slower pipe from the first range on, so it wants a steady supply of small pieces; a launch boundary costs ~0.25 ms of drain and refill)
+    for (uint32_t k = 1; k <= K; ++k) {
+        uint64_t t = cls[0].total * k / K;
+        if (k < K) {
+            const TileLevels& L = cls[0].L; uint32_t g = 0;
+            while (g + 1 < L.n && t >= L.tileStart[g + 1]) ++g;
+            const uint32_t per = tiles_per_item(L.level[g], 6u);
+            t = L.tileStart[g] + (t - L.tileStart[g]) / per * per;
+        }
+        S.cut[k] = (uint32_t)t;
+    }
+    // section 0 can receive every tile (the early items of all ranges); section k >= 1 the tiles of its range
+    uint64_t recOfs = K > 1 ? cls[0].total : 0;
+    for (uint32_t k = 1; k < K; ++k) { S.base[k] = (uint32_t)(recOfs + S.cut[k]); }
+    recOfs += cls[0].total;
+    uint4* q1024 = queue + recOfs * kTileRecordWords;
+    TileSections one; memset(&one, 0, sizeof one); one.n = 1;
+    // ---- sliced items, step 1: tile triage of both tile sizes (settled tiles are final after it, open ones are queued) ----
+    if (cls[0].total)
+        hipLaunchKernelGGL((triage_tiles<4096>), dim3((uint32_t)((cls[0].total + 255u) / 256u)), dim3(256), 0, stream, P, A, activeIds, cls[0].L, queue, secTails, S, chunks.early);
+    if (cls[1].total)
+        hipLaunchKernelGGL((triage_tiles<1024>), dim3((uint32_t)((cls[1].total + 255u) / 256u)), dim3(256), 0, stream, P, A, activeIds, cls[1].L, q1024, tail1024, one, (const uint8_t*)nullptr);
     // ---- small items: one launch per level ----
     for (uint32_t level = 0; level < 5u; ++level) {
         if (!count[level]) continue;
@@ -522,56 +583,88 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
         const uint64_t tiles = ((uint64_t)count[level] * M + 1023u) / 1024u;
         const uint32_t gx = tiles < (1u << 20) ? (uint32_t)tiles : (1u << 20), gy = (uint32_t)((tiles + gx - 1) / gx);
         hipLaunchKernelGGL((classify_tiles<FP32, false, 1024, MD>), dim3(gx, gy), dim3(BLOCK), 0, stream, P, A, activeIds + first[level], count[level], level, tiles,
-                           (const uint4*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                           (const uint4*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
     }
-    // ---- sliced items: triage -> queue -> persistent launch, per tile size ----
-    uint64_t recOfs = 0;
-    for (int cls = 0; cls < 2; ++cls) {   // 0: 4096-tiles (levels 6..12, highest first), 1: 1024-tiles (level 5)
-        TileLevels L; memset(&L, 0, sizeof L);
-        uint64_t total = 0;
-        for (int level = cls == 0 ? kMaxLevel : 5; level >= (cls == 0 ? 6 : 5); --level) {
-            if (!count[level]) continue;
-            L.level[L.n] = (uint32_t)level; L.first[L.n] = first[level]; L.tileStart[L.n] = (uint32_t)total;
-            total += (uint64_t)count[level] * tiles_per_item((uint32_t)level, cls == 0 ? 6u : 5u);
-            L.n++;
+    // ---- sliced items, step 2: persistent launches drain the queues; every CU holds OMMX_CLASSIFY_WAVES workgroups of 4 waves (one per SIMD) ----
+    // (streamed bakes leave one workgroup slot per CU to the placement kernels that run next to the persistent launches)
+    const uint64_t want = (uint64_t)numCUs * (chunks.after ? OMMX_CLASSIFY_WAVES - 1 : OMMX_CLASSIFY_WAVES);
+    if (cls[1].total) {
+        const dim3 cg((uint32_t)(cls[1].total < want ? cls[1].total : want)), cb(BLOCK);
+        hipLaunchKernelGGL((classify_tiles<FP32, true, 1024, MD>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)q1024,
+                           (const uint32_t*)tail1024, head1024, 0u);
+    }
+    if (chunks.mark) chunks.mark(chunks.user);   // (everything but the persistent launches of the levels >= 6 is enqueued)
+    for (uint32_t k = 0; k < K; ++k) {
+        const uint64_t tiles = k == 0 && K > 1 ? cls[0].total : (uint64_t)(S.cut[k + 1] - S.cut[k]);   // (upper bound of the section's open tiles)
+        if (tiles) {
+            const dim3 cg((uint32_t)(tiles < want ? tiles : want)), cb(BLOCK);
+            hipLaunchKernelGGL((classify_tiles<FP32, true, 4096, MD>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)queue,
+                               (const uint32_t*)(secTails + k), secHeads + k, S.base[k]);
         }
-        if (!total || total > 0xFFFFFFFFull) continue;   // (more than 2^32 tiles cannot happen: their packed states would not fit in HBM)
-        L.tileStart[L.n] = (uint32_t)total;
-        uint4* q = queue + recOfs * kTileRecordWords; recOfs += total;
-        uint32_t* tail = queueCtl + 2 * cls; uint32_t* head = tail + 1;
-        const dim3 tg((uint32_t)((total + 255u) / 256u)), tb(256);
-        // persistent grid: every CU holds OMMX_CLASSIFY_WAVES workgroups of 4 waves (one per SIMD)
-        const uint64_t want = (uint64_t)numCUs * OMMX_CLASSIFY_WAVES;
-        const dim3 cg((uint32_t)(total < want ? total : want)), cb(BLOCK);
-        if (cls == 0) {
-            hipLaunchKernelGGL((triage_tiles<4096>), tg, tb, 0, stream, P, A, activeIds, L, q, tail);
-            hipLaunchKernelGGL((classify_tiles<FP32, true, 4096, MD>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)q, (const uint32_t*)tail, head);
-        } else {
-            hipLaunchKernelGGL((triage_tiles<1024>), tg, tb, 0, stream, P, A, activeIds, L, q, tail);
-            hipLaunchKernelGGL((classify_tiles<FP32, true, 1024, MD>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)q, (const uint32_t*)tail, head);
+        if (k == 0 && chunks.afterEarly && chunks.early) {   // every level >= 6 as one segment: the hook looks at the early items in it
+            ClassifySegment segs[kNumLevels]; uint32_t ns = 0;
+            for (uint32_t g = 0; g < cls[0].L.n; ++g) { segs[ns].level = cls[0].L.level[g]; segs[ns].first = cls[0].L.first[g]; segs[ns].count = count[cls[0].L.level[g]]; ns++; }
+            chunks.afterEarly(chunks.user, segs, ns);
         }
+        if (chunks.after) {   // the work items of this range, as segments of the per-level active lists, in the order of the final result
+            ClassifySegment segs[kNumLevels]; uint32_t ns = 0;
+            const TileLevels& L = cls[0].L;
+            for (uint32_t g = 0; g < L.n; ++g) {
+                const uint32_t lo = S.cut[k] > L.tileStart[g] ? S.cut[k] : L.tileStart[g], hi = S.cut[k + 1] < L.tileStart[g + 1] ? S.cut[k + 1] : L.tileStart[g + 1];
+                if (lo >= hi) continue;
+                const uint32_t per = tiles_per_item(L.level[g], 6u);
+                segs[ns].level = L.level[g]; segs[ns].first = L.first[g] + (lo - L.tileStart[g]) / per; segs[ns].count = (hi - lo) / per; ns++;
+            }
+            chunks.after(chunks.user, k, segs, ns, false);
+        }
+    }
+    if (chunks.after) {   // the lower levels come last in the result (descending level): one more call, after the last big range
+        ClassifySegment segs[kNumLevels]; uint32_t ns = 0;
+        for (int level = 5; level >= 0; --level) if (count[level]) { segs[ns].level = (uint32_t)level; segs[ns].first = first[level]; segs[ns].count = count[level]; ns++; }
+        chunks.after(chunks.user, K, segs, ns, true);
     }
 }
 
 hipError_t launch_classify(const ClassifyParams& P, const ItemArrays& A, const uint32_t* activeIds, const uint32_t first[kNumLevels], const uint32_t count[kNumLevels],
-                           void* queue, uint32_t* queueCtl, uint32_t numCUs, hipStream_t stream)
+                           void* queue, uint32_t* queueCtl, uint32_t numCUs, hipStream_t stream, const ClassifyChunks* chunksIn)
 {
+    ClassifyChunks chunks; chunks.count = 1; chunks.after = nullptr; chunks.mark = nullptr; chunks.user = nullptr; chunks.early = nullptr; chunks.afterEarly = nullptr;
+    if (chunksIn) chunks = *chunksIn;
+    if (chunks.count > kMaxClassifyChunks - 1) chunks.count = kMaxClassifyChunks - 1;
     uint64_t any = 0; for (int l = 0; l < kNumLevels; ++l) any += count[l];
     if (!any) return hipSuccess;
-    hipError_t e = hipMemsetAsync(queueCtl, 0, 4 * sizeof(uint32_t), stream);
+    hipError_t e = hipMemsetAsync(queueCtl, 0, kClassifyCtlWords * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     // the two address-mode/pow2 pairs that real assets use get their own instantiation (the reference has one per pair); the rest is dynamic
     const bool wrapP2 = P.addrMode == 0 && P.pow2Dispatch, clampP2 = P.addrMode == 2 && P.pow2Dispatch;
     uint4* q = (uint4*)queue;
     if (P.texIsFp32) {
-        if (wrapP2) launch_classify_md<true, ModeStatic<0, 1>>(P, A, activeIds, first, count, q, queueCtl, numCUs, stream);
-        else if (clampP2) launch_classify_md<true, ModeStatic<2, 1>>(P, A, activeIds, first, count, q, queueCtl, numCUs, stream);
-        else launch_classify_md<true, ModeDynamic>(P, A, activeIds, first, count, q, queueCtl, numCUs, stream);
+        if (wrapP2) launch_classify_md<true, ModeStatic<0, 1>>(P, A, activeIds, first, count, q, queueCtl, numCUs, chunks, stream);
+        else if (clampP2) launch_classify_md<true, ModeStatic<2, 1>>(P, A, activeIds, first, count, q, queueCtl, numCUs, chunks, stream);
+        else launch_classify_md<true, ModeDynamic>(P, A, activeIds, first, count, q, queueCtl, numCUs, chunks, stream);
     } else {
-        if (wrapP2) launch_classify_md<false, ModeStatic<0, 1>>(P, A, activeIds, first, count, q, queueCtl, numCUs, stream);
-        else if (clampP2) launch_classify_md<false, ModeStatic<2, 1>>(P, A, activeIds, first, count, q, queueCtl, numCUs, stream);
-        else launch_classify_md<false, ModeDynamic>(P, A, activeIds, first, count, q, queueCtl, numCUs, stream);
+        if (wrapP2) launch_classify_md<false, ModeStatic<0, 1>>(P, A, activeIds, first, count, q, queueCtl, numCUs, chunks, stream);
+        else if (clampP2) launch_classify_md<false, ModeStatic<2, 1>>(P, A, activeIds, first, count, q, queueCtl, numCUs, chunks, stream);
+        else launch_classify_md<false, ModeDynamic>(P, A, activeIds, first, count, q, queueCtl, numCUs, chunks, stream);
     }
+    return hipGetLastError();
+}
+
+// Plain grid launch of the whole-item kernel at an arbitrary level (streamed bakes: a level-2 preview of every active item, 16 micro-triangles =
+// its sixteenths, written to preview buffers of their own).
+hipError_t launch_classify_items(const ClassifyParams& P, const ItemArrays& A, const uint32_t* ids, uint32_t count, uint32_t level, hipStream_t stream)
+{
+    if (!count) return hipSuccess;
+    const uint64_t M = 1ull << (2 * level);
+    const uint64_t tiles = ((uint64_t)count * M + 1023u) / 1024u;
+    const uint32_t gx = tiles < (1u << 20) ? (uint32_t)tiles : (1u << 20), gy = (uint32_t)((tiles + gx - 1) / gx);
+#define OMMX_ITEMS(FP, MD) hipLaunchKernelGGL((classify_tiles<FP, false, 1024, MD>), dim3(gx, gy), dim3(BLOCK), 0, stream, P, A, ids, count, level, tiles, \
+                                              (const uint4*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u)
+    const bool wrapP2 = P.addrMode == 0 && P.pow2Dispatch, clampP2 = P.addrMode == 2 && P.pow2Dispatch;
+    typedef ModeStatic<0, 1> WrapP2; typedef ModeStatic<2, 1> ClampP2;
+    if (P.texIsFp32) { if (wrapP2) OMMX_ITEMS(true, WrapP2); else if (clampP2) OMMX_ITEMS(true, ClampP2); else OMMX_ITEMS(true, ModeDynamic); }
+    else             { if (wrapP2) OMMX_ITEMS(false, WrapP2); else if (clampP2) OMMX_ITEMS(false, ClampP2); else OMMX_ITEMS(false, ModeDynamic); }
+#undef OMMX_ITEMS
     return hipGetLastError();
 }
 
@@ -616,12 +709,13 @@ __device__ __forceinline__ uint32_t state_at(const uint8_t* p, uint32_t u, uint3
 
 __global__ __launch_bounds__(256) void digest_items(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs,
                                                     const uint32_t* __restrict__ itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
-                                                    uint64_t* __restrict__ digests)
+                                                    uint64_t* __restrict__ digests, const uint8_t* __restrict__ only, int want)
 {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t it = gid >> 2, acc = gid & 3u;
-    const bool live = it < numItems;
+    bool live = it < numItems;
     const uint32_t item = live ? itemIds[it] : 0u;
+    if (live && only && (only[item] != 0) != (want != 0)) live = false;   // (streamed bakes: the items of one class only)
     const uint8_t* p = states + (live ? stateOfs[item] : 0ull);
     const uint32_t M = 1u << (2 * level);     // stream length in bytes
     const uint64_t seed = 42;
@@ -670,17 +764,27 @@ __global__ __launch_bounds__(256) void digest_items(const uint8_t* __restrict__ 
 // pieces of 16 items that lie 16 KiB apart, and rocprofv3 counted 4.6x the states' bytes in HBM fetches.  Here a workgroup
 // (64 items x 4 accumulators) stages 256 packed bytes per item through LDS with 16-byte coalesced loads (row stride 65 words:
 // the 64 rows start in different banks), then every lane walks its accumulator's pieces out of LDS.
-constexpr int DG_ITEMS = 64, DG_CHUNK = 256, DG_STRIDE = DG_CHUNK / 4 + 1;
+// The walk over an item is sequential (XXH64's accumulators are chains), so a workgroup's run time is (bytes per item / chunk) round trips to HBM,
+// however few items a launch has: with 256-byte chunks a 16 KiB item took 64 round trips (0.7 ms even for a handful of items, and the streamed bake
+// digests range by range); items of >= 1 KiB are staged in 1 KiB chunks (65.8 KB of LDS per workgroup), 16 round trips.
+constexpr int DG_ITEMS = 64;
+template <int DG_CHUNK>
 __global__ __launch_bounds__(256) void digest_items_lds(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs,
                                                         const uint32_t* __restrict__ itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
-                                                        uint64_t* __restrict__ digests)
+                                                        uint64_t* __restrict__ digests, const uint8_t* __restrict__ only, int want)
 {
+    constexpr int DG_STRIDE = DG_CHUNK / 4 + 1;
     __shared__ uint32_t s_buf[DG_ITEMS * DG_STRIDE];
     __shared__ const uint8_t* s_ptr[DG_ITEMS];
     const uint32_t tid = threadIdx.x, first = blockIdx.x * DG_ITEMS;
     const uint32_t il = tid >> 2, acc = tid & 3u, it = first + il;
-    const bool live = it < numItems;
-    if (tid < DG_ITEMS) { const uint32_t j = first + tid; s_ptr[tid] = j < numItems ? states + stateOfs[itemIds[j]] : nullptr; }
+    bool live = it < numItems;
+    if (live && only && (only[itemIds[it]] != 0) != (want != 0)) live = false;   // (streamed bakes: the items of one class only)
+    if (tid < DG_ITEMS) {
+        const uint32_t j = first + tid;
+        const bool take = j < numItems && !(only && (only[itemIds[j]] != 0) != (want != 0));
+        s_ptr[tid] = take ? states + stateOfs[itemIds[j]] : nullptr;
+    }
     const uint32_t M = 1u << (2 * level);
     const uint32_t bytesPerItem = (M * bits) >> 3;            // multiple of DG_CHUNK (launch_digest)
     const uint32_t stripesPerChunk = DG_CHUNK / (4u * bits);  // a 32-byte stripe of the byte stream = 4*bits packed bytes
@@ -688,8 +792,9 @@ __global__ __launch_bounds__(256) void digest_items_lds(const uint8_t* __restric
     uint64_t v = acc == 0 ? seed + XP1 + XP2 : (acc == 1 ? seed + XP2 : (acc == 2 ? seed : seed - XP1));
     __syncthreads();
     for (uint32_t chunk = 0; chunk < bytesPerItem; chunk += DG_CHUNK) {
+        #pragma unroll 4
         for (uint32_t k = tid; k < DG_ITEMS * (DG_CHUNK / 16); k += 256) {
-            const uint32_t row = k >> 4, part = k & 15u;
+            const uint32_t row = k / (DG_CHUNK / 16), part = k % (DG_CHUNK / 16);
             const uint8_t* src = s_ptr[row];
             uint4 w = make_uint4(0u, 0u, 0u, 0u);
             if (src) w = *(const uint4*)(src + chunk + part * 16u);
@@ -718,16 +823,22 @@ __global__ __launch_bounds__(256) void digest_items_lds(const uint8_t* __restric
 }
 
 void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
-                   uint64_t* digests, hipStream_t stream)
+                   uint64_t* digests, hipStream_t stream, const uint8_t* only, int want)
 {
     if (numItems == 0) return;
     const uint32_t bytesPerItem = ((1u << (2 * level)) * bits) >> 3;
-    if (bytesPerItem >= (uint32_t)DG_CHUNK) { // (powers of two: a multiple of DG_CHUNK)
-        hipLaunchKernelGGL(digest_items_lds, dim3((numItems + DG_ITEMS - 1) / DG_ITEMS), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests);
+    // (measured: a full-size launch is faster with the small chunks -- 0.77 vs 1.12 ms for 127 k items, more workgroups per CU hide the latency --, a
+    //  range of a streamed bake, a few thousand items, with the large ones)
+    if (bytesPerItem >= 1024u && numItems <= 32768u) { // (powers of two: a multiple of the chunk size)
+        hipLaunchKernelGGL(digest_items_lds<1024>, dim3((numItems + DG_ITEMS - 1) / DG_ITEMS), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests, only, want);
+        return;
+    }
+    if (bytesPerItem >= 256u) {
+        hipLaunchKernelGGL(digest_items_lds<256>, dim3((numItems + DG_ITEMS - 1) / DG_ITEMS), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests, only, want);
         return;
     }
     const uint32_t threads = numItems * 4u;
-    hipLaunchKernelGGL(digest_items, dim3((threads + 255u) / 256u), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests);
+    hipLaunchKernelGGL(digest_items, dim3((threads + 255u) / 256u), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests, only, want);
 }
 
 // ------------------------------------------------------------------------------------------------

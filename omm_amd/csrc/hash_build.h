@@ -67,6 +67,15 @@ __device__ __forceinline__ void hash_put_min_block(const HashTable& t, bool live
     if (live && !(w < lane && kw == k)) hash_put_min(t, k, i);
 }
 
+// index of the slot that holds `k`, or 0xFFFFFFFF if the key was never put
+__device__ __forceinline__ uint32_t hash_find_slot(const HashTable& t, uint64_t k)
+{
+    if (k == kEmptyKey) return t.mask + 1u;
+    uint32_t slot = hash_slot_of(t, k), probes = 0;
+    while (t.keys[slot] != k) { if (t.keys[slot] == kEmptyKey || ++probes > t.mask) return 0xFFFFFFFFu; slot = (slot + 1u) & t.mask; }
+    return slot;
+}
+
 // value of the slot that holds `k`; `self` if the key was never put (cannot happen in the two users: the bound only guards against a hang)
 __device__ __forceinline__ uint32_t hash_get(const HashTable& t, uint64_t k, uint32_t self)
 {

@@ -10,6 +10,8 @@
 #include "host_tail.h"
 
 #include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 #include <malloc.h>
 #include <math.h>
 #include <dlfcn.h>
@@ -17,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <mutex>
@@ -104,7 +107,19 @@ inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 // The device working set of one bake in flight: per-item tables + scratch, packed states + tile queue, and (sharded bakes) the exchange
 // buffers.  A baker keeps a small pool of these sets: a bake takes one for its duration -- concurrent bakes on one baker get different
 // sets, a sharded bake keeps its set from Begin to Destroy without holding any lock in between -- and steady-state bakes never hipMalloc.
-struct ArenaSet { DeviceArena tables, states, xchg; };
+// pinned host memory of a working set (grow-only like the device arenas): staging of the blocks that ommCpuBake streams out during classification
+struct HostArena {
+    uint8_t* base = nullptr; size_t cap = 0;
+    ~HostArena() { if (base) (void)hipHostFree(base); }
+    bool reserve(size_t bytes) {
+        if (bytes <= cap) return true;
+        if (base) { (void)hipHostFree(base); base = nullptr; cap = 0; }
+        const size_t want = (bytes + (bytes >> 3) + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);   // 12 % head room: bakes of similar size do not re-pin
+        if (hipHostMalloc((void**)&base, want, hipHostMallocDefault) != hipSuccess) { base = nullptr; (void)hipGetLastError(); return false; }
+        cap = want; return true;
+    }
+};
+struct ArenaSet { DeviceArena tables, states, xchg; HostArena pinned; };
 struct ArenaPool {
     std::mutex mu; std::vector<std::unique_ptr<ArenaSet>> idle;
     std::unique_ptr<ArenaSet> acquire() {
@@ -149,22 +164,35 @@ struct DevPool {
     }
 };
 
-// ---- warm host memory for the (large) result array -------------------------------------------------
+// ---- warm, pinned host memory for the (large) result array -------------------------------------------------
 // A fresh 1.3 GB malloc costs more in page faults (70-100 ms) and munmap (95 ms) than the PCIe copy itself (24 ms at 57 GB/s), so
-// with the DEFAULT allocator the arrayData block of a destroyed result is kept by its baker and handed to the next bake; a new block
-// is 2 MiB aligned (transparent huge pages) and pre-faulted by a few threads.  User-supplied allocators are always honoured as given.
+// with the DEFAULT allocator the arrayData block of a destroyed result is kept by its baker and handed to the next bake.  The blocks are
+// page-locked (hipHostMalloc): device-to-host copies into them run on the SDMA engines, truly asynchronous and without occupying compute
+// units -- a copy into pageable memory is a blit KERNEL that competes with the classification it is supposed to overlap (measured: the
+// streamed bake's classification 37 ms instead of 28).  If pinning fails the block is ordinary memory, 2 MiB aligned (transparent huge
+// pages) and pre-faulted by a few threads.  User-supplied allocators are always honoured as given.
 struct HostPool {
-    struct Blk { void* p; size_t cap; bool used; };
+    struct Blk { void* p; size_t cap; bool used; bool pinned; };
     std::mutex mu; std::vector<Blk> blks;
     static constexpr size_t kMinBytes = 8u << 20, kHuge = 2u << 20;
-    ~HostPool() { for (auto& b : blks) free(b.p); }
-    void* acquire(size_t bytes) {
+    static void drop(const Blk& b) { if (b.pinned) (void)hipHostFree(b.p); else free(b.p); }
+    ~HostPool() { for (auto& b : blks) drop(b); }
+    void* acquire(size_t bytes, bool* pinned = nullptr) {
+        if (pinned) *pinned = false;
         {
             std::lock_guard<std::mutex> g(mu);
-            for (auto& b : blks) if (!b.used && b.cap >= bytes && b.cap / 2 <= bytes + kHuge) { b.used = true; return b.p; }
+            for (auto& b : blks) if (!b.used && b.cap >= bytes && b.cap / 2 <= bytes + kHuge) { b.used = true; if (pinned) *pinned = b.pinned; return b.p; }
         }
         const size_t cap = (bytes + kHuge - 1) & ~(kHuge - 1);
-        void* p = aligned_alloc(kHuge, cap);
+        void* p = nullptr;
+        if (hipHostMalloc(&p, cap, hipHostMallocDefault) == hipSuccess && p) {   // (pinning touches every page: no pre-fault pass needed)
+            std::lock_guard<std::mutex> g(mu);
+            blks.push_back({ p, cap, true, true });
+            if (pinned) *pinned = true;
+            return p;
+        }
+        (void)hipGetLastError();
+        p = aligned_alloc(kHuge, cap);
         if (!p) return nullptr;
         (void)madvise(p, cap, MADV_HUGEPAGE);
         unsigned nt = std::thread::hardware_concurrency(); nt = nt > 8 ? 8 : (nt ? nt : 1);
@@ -176,7 +204,7 @@ struct HostPool {
         touch(0, per < cap ? per : cap);
         for (auto& t : th) t.join();
         std::lock_guard<std::mutex> g(mu);
-        blks.push_back({ p, cap, true });
+        blks.push_back({ p, cap, true, false });
         return p;
     }
     void release(void* p) {
@@ -184,7 +212,53 @@ struct HostPool {
         size_t freeBlocks = 0;
         for (auto& b : blks) { if (b.p == p) b.used = false; if (!b.used) freeBlocks++; }
         for (size_t i = 0; i < blks.size() && freeBlocks > 2; ) // keep at most two idle blocks
-            if (!blks[i].used && blks[i].p != p) { free(blks[i].p); blks.erase(blks.begin() + (long)i); freeBlocks--; } else ++i;
+            if (!blks[i].used && blks[i].p != p) { drop(blks[i]); blks.erase(blks.begin() + (long)i); freeBlocks--; } else ++i;
+    }
+};
+
+// ---- device-to-host copies on the SDMA engines ------------------------------------------------------------------------------------
+// hipMemcpyAsync moves device -> host data with a blit KERNEL (__amd_rocclr_copyBuffer, also into pinned memory): a kernel that sits on
+// compute-unit slots waiting for PCIe, next to the persistent classification launch it is meant to overlap -- measured: the classification
+// launches that ran beside such a copy took 2.5x as long.  The streamed result therefore goes through the HSA runtime that HIP itself
+// sits on: hsa_amd_memory_async_copy runs on one of the chip's DMA engines and needs no compute unit.  Destination must be pinned
+// (the baker's result pool); anything else keeps to hipMemcpyAsync.
+struct SdmaCopier {
+    hsa_agent_t gpu{ 0 }, cpu{ 0 }; hsa_signal_t sig{ 0 }; bool ok = false; int64_t pending = 0;
+    struct Find { int wantOrdinal, seen; uint32_t wantBdf; bool haveBdf; hsa_agent_t gpu, cpu; bool gotGpu, gotCpu; };
+    static hsa_status_t visit(hsa_agent_t a, void* u) {
+        Find& f = *(Find*)u; hsa_device_type_t t;
+        if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+        if (t == HSA_DEVICE_TYPE_CPU && !f.gotCpu) { f.cpu = a; f.gotCpu = true; }
+        if (t == HSA_DEVICE_TYPE_GPU) {
+            uint32_t bdf = 0; const bool hb = hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) == HSA_STATUS_SUCCESS;
+            const bool match = f.haveBdf && hb ? (bdf & 0xFFFFu) == f.wantBdf : f.seen == f.wantOrdinal;
+            if (match && !f.gotGpu) { f.gpu = a; f.gotGpu = true; }
+            f.seen++;
+        }
+        return HSA_STATUS_SUCCESS;
+    }
+    bool open(int hipDevice) {
+        if (hsa_init() != HSA_STATUS_SUCCESS) return false;   // (reference counted: HIP holds the runtime open already)
+        Find f; memset(&f, 0, sizeof f); f.wantOrdinal = hipDevice;
+        char bus[32] = { 0 };
+        if (hipDeviceGetPCIBusId(bus, sizeof bus, hipDevice) == hipSuccess) { unsigned dom = 0, b = 0, d = 0, fn = 0; if (sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &fn) == 4) { f.wantBdf = (b << 8) | (d << 3) | fn; f.haveBdf = true; } }
+        if (hsa_iterate_agents(visit, &f) != HSA_STATUS_SUCCESS || !f.gotGpu || !f.gotCpu) { (void)hsa_shut_down(); return false; }
+        gpu = f.gpu; cpu = f.cpu;
+        if (hsa_signal_create(0, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) { (void)hsa_shut_down(); return false; }
+        ok = true; return true;
+    }
+    ~SdmaCopier() { if (ok) { (void)wait(); (void)hsa_signal_destroy(sig); (void)hsa_shut_down(); } }
+    bool copy_to_host(void* dstHostPinned, const void* srcDevice, size_t bytes) {   // asynchronous; wait() before the data is read
+        hsa_signal_add_relaxed(sig, 1); pending++;
+        if (hsa_amd_memory_async_copy(dstHostPinned, cpu, srcDevice, gpu, bytes, 0, nullptr, sig) != HSA_STATUS_SUCCESS) { hsa_signal_subtract_relaxed(sig, 1); pending--; return false; }
+        return true;
+    }
+    bool wait() {
+        if (!ok || pending == 0) return true;
+        const hsa_signal_value_t v = hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
+        pending = 0;
+        if (v != 0) { hsa_signal_store_relaxed(sig, 0); return false; }   // (negative: a copy failed)
+        return true;
     }
 };
 
@@ -482,6 +556,59 @@ struct ShardCtx {
 // opt-in lossy reducers (near-duplicate merge, maxArrayDataSize): classification on the device, serial tail on the host
 struct HostTailRequest { std::vector<HostItem> items; };
 
+// ommCpuBake: the result has to end up in host memory, and the 1.3 GB of arrayData of the metric configuration need 23 ms of PCIe time -- nearly
+// as long as the classification itself.  The final ORDER of the blocks is known up front (descending level / spatial key / item index over the items
+// that are emitted), so the classification of the levels >= 6 runs as `chunks` launches over consecutive ranges of that order; behind each launch the
+// blocks of its range are packed behind those of the earlier ranges -- a contiguous piece of the final arrayData -- and ONE asynchronous copy on a second
+// stream moves that piece to its final place in the caller's array while the next launch classifies (tail_kernels.hip: "Streamed result").  The
+// placement is verified against the ordinary tail at the end; on a mismatch (a duplicate block whose first occurrence was classified later) the bake
+// falls back to the ordinary gather + copy.
+struct StreamOut {
+    // in
+    uint32_t chunksWanted = 0;        // 0 = decide from the size of the bake
+    bool forced = false;              // (knob set: stream whatever the size)
+    ArenaSet* set = nullptr; hipStream_t copyStream = nullptr, placeStream = nullptr;
+    void* allocUser = nullptr; uint8_t* (*alloc)(void* user, uint64_t upperBoundBytes, bool* pinned) = nullptr;   // the host arrayData, before the first block leaves
+    int device = 0;
+    // out
+    bool used = false, fellBack = false; uint32_t chunks = 0; uint64_t streamedBytes = 0;
+    double classifyEndMs = 0, lastByteMs = 0;
+};
+struct StreamCtx {   // what the hook behind a classification launch needs
+    hipStream_t stream, place; hipEvent_t* fences; const uint32_t* activeIds; uint32_t numActive; StreamSegment proto; void* scratch; size_t scratchBytes;
+    uint64_t* digests; unsigned long long* cursor; uint8_t* stage; uint64_t* placed; uint32_t* ctl; unsigned long long* hostCursor; hipEvent_t* events; uint32_t numEvents, recorded; bool ok;
+};
+void stream_hook(void* user, uint32_t chunk, const ClassifySegment* segs, uint32_t numSegs, bool /*last*/)
+{
+    // The placement runs on a second, high-priority stream behind a fence on the classification launch: the next classification launch starts at
+    // once, and the digest kernel of a range (a latency-bound ~1 ms for a few thousand items) hides behind it instead of standing between two launches.
+    StreamCtx& c = *(StreamCtx*)user;
+    if (chunk >= c.numEvents) { c.ok = false; return; }
+    c.ok = c.ok && hipEventRecord(c.fences[chunk], c.stream) == hipSuccess && hipStreamWaitEvent(c.place, c.fences[chunk], 0) == hipSuccess;
+    for (uint32_t k = 0; k < numSegs && c.ok; ++k) {
+        StreamSegment g = c.proto; g.ids = c.activeIds + segs[k].first; g.count = segs[k].count; g.level = segs[k].level; g.range = chunk;
+        if (!g.disableDedup) launch_digest(g.states, g.stateOfs, g.ids, g.count, g.level, (uint32_t)g.bits, c.digests, c.place, g.early, 0);   // CalcDigest (bake_cpu_impl.cpp:1038-1040); early items have theirs
+        c.ok = run_stream_segment(g, c.numActive, c.scratch, c.scratchBytes, c.cursor, c.stage, c.placed, c.ctl, c.place) == hipSuccess;
+    }
+    launch_stream_publish(c.cursor, c.hostCursor + chunk, c.place);
+    c.ok = c.ok && hipEventRecord(c.events[chunk], c.place) == hipSuccess;
+    if (c.ok) c.recorded = chunk + 1u;
+}
+// behind the launch of the early class: digests of the early items, entered into the table before the first range is placed
+void stream_early_hook(void* user, const ClassifySegment* segs, uint32_t numSegs)
+{
+    StreamCtx& c = *(StreamCtx*)user;
+    c.ok = c.ok && hipEventRecord(c.fences[c.numEvents], c.stream) == hipSuccess && hipStreamWaitEvent(c.place, c.fences[c.numEvents], 0) == hipSuccess;   // (the extra fence of the early launch)
+    for (uint32_t k = 0; k < numSegs && c.ok; ++k) {
+        StreamSegment g = c.proto; g.ids = c.activeIds + segs[k].first; g.count = segs[k].count; g.level = segs[k].level; g.range = 0;
+        if (g.disableDedup || !g.early) continue;
+        launch_digest(g.states, g.stateOfs, g.ids, g.count, g.level, (uint32_t)g.bits, c.digests, c.place, g.early, 1);
+        launch_stream_insert_early(g, c.numActive, c.scratch, c.scratchBytes, c.place);
+    }
+}
+struct MarkCtx { EventTimer* et; int mark; };
+void mark_hook(void* user) { MarkCtx& c = *(MarkCtx*)user; c.mark = c.et->mark(); }
+
 // host form of SetupWorkItems, used when the device setup reports a hash collision (never observed; 2^-64 class event)
 void setup_on_host(const ommCpuBakeInputDesc& d, uint32_t flags, const Texture& tex, std::vector<HostTri>& itemUv, std::vector<uint8_t>& itemLevel,
                    std::vector<uint8_t>& itemDegenerate, std::vector<int32_t>& triToItem, uint32_t& numDisabled)
@@ -569,7 +696,7 @@ ommResult run_host_tail_for(const ommCpuBakeInputDesc& d, uint32_t T, std::vecto
 // same desc with host pointers, needed only by the serial fallbacks.
 ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInputs& din, const ommCpuBakeInputDesc* hostDesc,
                     DeviceArena* arena, DeviceArena* statesArena, hipStream_t stream, EventTimer& et, DeviceResult& R, ommxBakeTimings& tm,
-                    ShardCtx* sh = nullptr, HostTailRequest* ht = nullptr)
+                    ShardCtx* sh = nullptr, HostTailRequest* ht = nullptr, StreamOut* so = nullptr)
 {
     const Logger& L = baker.log;
     const uint32_t flags = (uint32_t)d.bakeFlags;
@@ -580,11 +707,13 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     const uint32_t maxItems = T ? T : 1;
 
     // ---- device layout (worst case: every triangle is its own work item) ----
-    const size_t setupBytes = setup_scratch_bytes(T), tailBytes = tail_scratch_bytes(maxItems, T);
-    const size_t scratchBytes = setupBytes > tailBytes ? setupBytes : tailBytes;
+    const size_t setupBytes = setup_scratch_bytes(T), tailBytes = tail_scratch_bytes(maxItems, T), streamScratch = so ? stream_scratch_bytes(maxItems) : 0;
+    const size_t scratchBytes = std::max(std::max(setupBytes, tailBytes), streamScratch);
     const size_t i32 = pad256((size_t)maxItems * 4), i64 = pad256((size_t)maxItems * 8);
     const size_t shardBytes = sh ? pad256((size_t)maxItems * 16) + pad256(maxItems) + i64 + pad256(sizeof(uint64_t) * kMaxRanks) : 0;
-    const size_t need = pad256((size_t)maxItems * 24) + 3 * pad256(maxItems) + i64 * 2 + i32 * 13 + pad256(sizeof(SetupCounters)) + 4096 + pad256(sizeof(unsigned long long) * kFineSlots * kFineStride) + pad256(scratchBytes) + shardBytes;
+    // streamed result: placed offset per item, cursor + control words; preview: collapsed UVs, 16-byte state slots, offsets, masks, early flags
+    const size_t streamBytes = so ? i64 + 512 + pad256((size_t)maxItems * 24) + pad256((size_t)maxItems * kPreviewSlotBytes) + i64 + i32 + pad256(maxItems) + pad256(sizeof(unsigned long long) * kFineSlots * kFineStride) : 0;
+    const size_t need = pad256((size_t)maxItems * 24) + 3 * pad256(maxItems) + i64 * 2 + i32 * 13 + pad256(sizeof(SetupCounters)) + 4096 + pad256(sizeof(unsigned long long) * kFineSlots * kFineStride) + pad256(scratchBytes) + shardBytes + streamBytes;
     if (!arena->reserve(need)) return L.failure("[Failure] - out of device memory for the bake working set");
     float* dUv = arena->take<float>((size_t)maxItems * 6);
     uint8_t* dLevel = arena->take<uint8_t>(maxItems); uint8_t* dDegen = arena->take<uint8_t>(maxItems); uint8_t* dActive = arena->take<uint8_t>(maxItems);
@@ -602,6 +731,13 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     unsigned long long* dFine = arena->take<unsigned long long>(kFineSlots * kFineStride); // striped statistic counter (bake_types.h)
     uint8_t* dScratch = arena->take<uint8_t>(scratchBytes);
     if (sh) { sh->dMeta = arena->take<uint32_t>((size_t)maxItems * 4); sh->dOwner = arena->take<uint8_t>(maxItems); sh->dCofs = arena->take<uint64_t>(maxItems); sh->dTotals = arena->take<uint64_t>(kMaxRanks); }
+    uint64_t* dPlaced = nullptr; unsigned long long* dCursor = nullptr; uint32_t* dStreamCtl = nullptr;
+    float* dUv2 = nullptr; uint8_t *dStates2 = nullptr, *dEarly = nullptr; uint64_t* dOfs2 = nullptr; uint32_t* dMask2 = nullptr; unsigned long long* dFine2 = nullptr;
+    if (so) {
+        dPlaced = arena->take<uint64_t>(maxItems); dCursor = arena->take<unsigned long long>(1); dStreamCtl = arena->take<uint32_t>(4);
+        dUv2 = arena->take<float>((size_t)maxItems * 6); dStates2 = arena->take<uint8_t>((size_t)maxItems * kPreviewSlotBytes); dOfs2 = arena->take<uint64_t>(maxItems);
+        dMask2 = arena->take<uint32_t>(maxItems); dEarly = arena->take<uint8_t>(maxItems); dFine2 = arena->take<unsigned long long>(kFineSlots * kFineStride);
+    }
 
     // ---- SetupWorkItems (bake_cpu_impl.cpp:589-660) on the device ----
     const int e0 = et.mark();
@@ -738,10 +874,21 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         lvlFirst[l] = bounds.b[l][bounds.rank]; lvlCount[l] = bounds.b[l][bounds.rank + 1] - bounds.b[l][bounds.rank];
     }
     // packed states of the active items + the queue of open tiles (48-byte records, bake_kernels.hip) + its 4 control words
-    const size_t stateBytes = pad256(hc.stateBytes ? (size_t)hc.stateBytes : 256), queueBytes = pad256((size_t)classify_queue_records(lvlCount) * kTileRecordBytes + 16);
-    if (!statesArena->reserve(stateBytes + queueBytes + 256)) return L.failure("[Failure] - out of device memory for the packed micro-triangle states");
+    const size_t stateBytes = pad256(hc.stateBytes ? (size_t)hc.stateBytes : 256), ctlBytes = pad256(sizeof(uint32_t) * kClassifyCtlWords);
+    // ---- streamed result (ommCpuBake)?  Worth it when the packed states are large enough for the copy to matter ----
+    uint32_t streamChunks = 0; const uint32_t numActiveAll = hc.activeStart[kNumLevels];
+    uint8_t* hostArray = nullptr; unsigned long long* hCursor = nullptr; bool hostPinned = false;
+    if (so && numActiveAll && !(flags & (1u << 1)) && !hc.collision) {   // (with special indices disabled every uniform item is a block too: the plain path handles that)
+        uint32_t k = so->chunksWanted;
+        if (!so->forced) { k = hc.stateBytes >= (64ull << 20) ? (uint32_t)(hc.stateBytes >> 25) : 0u; if (k > 16u) k = 16u; }   // >= 64 MiB of packed states: one range per 32 MiB, at most 16
+        if (k > kMaxClassifyChunks) k = kMaxClassifyChunks;
+        if (k && so->set->pinned.reserve(4096) && (hostArray = so->alloc(so->allocUser, hc.stateBytes, &hostPinned)) != nullptr) { streamChunks = k; hCursor = (unsigned long long*)so->set->pinned.base; }
+    }
+    const size_t queueBytes = pad256((size_t)classify_queue_records(lvlCount, streamChunks > 1) * kTileRecordBytes + 16);
+    if (!statesArena->reserve(stateBytes + queueBytes + ctlBytes + (streamChunks ? stateBytes : 0))) return L.failure("[Failure] - out of device memory for the packed micro-triangle states");
     uint8_t* dStates = statesArena->base;
     void* dTileQueue = statesArena->base + stateBytes; uint32_t* dQueueCtl = (uint32_t*)(statesArena->base + stateBytes + queueBytes);
+    uint8_t* dStage = streamChunks ? statesArena->base + stateBytes + queueBytes + ctlBytes : nullptr;
     const int e1b = et.mark();
 
     // ---- ResampleCoarse + ResampleFine (bake_cpu_impl.cpp:715-1029) on the active items ----
@@ -763,7 +910,37 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         }
         if (!okp) return L.failure("[Failure] - shard permutation failed");
     }
-    if (!HIP_OK(launch_classify(P, A, dActiveIds, lvlFirst, lvlCount, dTileQueue, dQueueCtl, device_cu_count(), stream))) return L.failure("[Failure] - kernel launch failed");
+    // streamed: the active lists in the order of the final result, events behind the classification launches, the cursor published to a pinned word after each
+    struct EventList { hipEvent_t ev[2 * kMaxClassifyChunks + 3]; uint32_t n = 0; ~EventList() { for (uint32_t k = 0; k < n; ++k) (void)hipEventDestroy(ev[k]); } } chunkEvents;   // placement done [K + 1] | fences [K + 2]
+    StreamCtx sc; ClassifyChunks cc; cc.count = 1; cc.after = nullptr; cc.mark = nullptr; cc.user = nullptr; cc.early = nullptr; cc.afterEarly = nullptr;
+    MarkCtx mk; mk.et = &et; mk.mark = -1;
+    const bool noDedup = (flags & (1u << 3)) != 0;
+    if (streamChunks) {
+        bool oks = HIP_OK(hipMemsetAsync(dPlaced, 0xFF, (size_t)maxItems * 8, stream)) && HIP_OK(hipMemsetAsync(dCursor, 0, 8, stream)) && HIP_OK(hipMemsetAsync(dStreamCtl, 0, 16, stream));
+        oks = oks && HIP_OK(run_stream_begin(dActiveIds, numActiveAll, dUv, dLevel, dScratch, scratchBytes, stream));
+        for (uint32_t k = 0; oks && k < 2u * streamChunks + 3u; ++k) { oks = HIP_OK(hipEventCreateWithFlags(&chunkEvents.ev[k], hipEventDisableTiming)); chunkEvents.n += oks ? 1u : 0u; }
+        if (!oks) return L.failure("[Failure] - could not set up the streamed result");
+        sc.stream = stream; sc.place = so->placeStream; sc.fences = chunkEvents.ev + streamChunks + 1u; sc.activeIds = dActiveIds; sc.numActive = numActiveAll; sc.scratch = dScratch; sc.scratchBytes = scratchBytes; sc.digests = dDigests;
+        sc.cursor = dCursor; sc.stage = dStage; sc.placed = dPlaced; sc.ctl = dStreamCtl; sc.hostCursor = hCursor; sc.events = chunkEvents.ev; sc.numEvents = streamChunks + 1u; sc.recorded = 0; sc.ok = true;
+        memset(&sc.proto, 0, sizeof sc.proto);
+        sc.proto.stateMask = dMask; sc.proto.knownCount = dKnown; sc.proto.digests = dDigests; sc.proto.states = dStates; sc.proto.stateOfs = dStateOfs;
+        sc.proto.rejectionThreshold = d.rejectionThreshold; sc.proto.bits = bits; sc.proto.disableDedup = noDedup ? 1 : 0;
+        cc.count = streamChunks; cc.after = stream_hook; cc.user = &sc; cc.early = nullptr;
+        // preview (tail_kernels.hip): level-5 classification of the items of level >= 6 into buffers of its own; items that share their preview are classified early
+        const uint32_t first6 = hc.activeStart[6], count6 = numActiveAll - hc.activeStart[6];
+        if (count6 && streamChunks > 1) {
+            ClassifyParams P2 = P; P2.format = 2; P2.promotion = 1; P2.wantKnownCount = 0; P2.noFine = 0;
+            ItemArrays A2 = A; A2.uv = dUv2; A2.stateOfs = dOfs2; A2.states = dStates2; A2.stateMask = dMask2; A2.fineCount = dFine2;   // (its level-line statistic goes nowhere)
+            bool okp = HIP_OK(hipMemsetAsync(dEarly, 0, maxItems, stream)) && HIP_OK(hipMemsetAsync(dMask2, 0, (size_t)maxItems * 4, stream));
+            launch_stream_preview_prepare(dActiveIds + first6, count6, dUv, P.mips[0].fw, P.mips[0].fh, dUv2, dOfs2, dEarly, stream);
+            okp = okp && HIP_OK(launch_classify_items(P2, A2, dActiveIds + first6, count6, kPreviewLevel, stream));
+            okp = okp && HIP_OK(run_stream_preview_flags(dActiveIds + first6, count6, numActiveAll, dStates2, dLevel, dEarly, dStreamCtl, dScratch, scratchBytes, stream));
+            if (!okp) return L.failure("[Failure] - could not set up the streamed result");
+            cc.early = dEarly; cc.afterEarly = stream_early_hook; sc.proto.early = dEarly;
+        }
+    } else { cc.mark = mark_hook; cc.user = &mk; cc.early = nullptr; }   // (HIP event in front of the persistent launch of the levels >= 6)
+    if (!HIP_OK(launch_classify(P, A, dActiveIds, lvlFirst, lvlCount, dTileQueue, dQueueCtl, device_cu_count(), stream, &cc))) return L.failure("[Failure] - kernel launch failed");
+    if (streamChunks && !sc.ok) return L.failure("[Failure] - kernel launch failed");
     const int e2 = et.mark();
     if (ht) { // bring the per-micro-triangle states to the host for the serial tail (host_tail.cpp)
         const ommResult gr = gather_host_items(L, stream, U, T, hc, dUv, dLevel, dActive, dMask, dStateOfs, dStates, dTriToItem, bits, ht->items);
@@ -771,12 +948,28 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         return gr;
     }
     // ---- CalcDigest (bake_cpu_impl.cpp:1038-1040): active items here, uniform ones from the table in the tail ----
-    if (!(flags & (1u << 3)))
+    if (!noDedup && !streamChunks)   // (a streamed bake computed them range by range)
         for (int l = 0; l < kNumLevels; ++l)
             launch_digest(dStates, dStateOfs, dActiveIds + bounds.b[l][bounds.rank], bounds.b[l][bounds.rank + 1] - bounds.b[l][bounds.rank], (uint32_t)l, (uint32_t)bits, dDigests, stream);
     if (!HIP_OK(hipGetLastError())) return L.failure("[Failure] - kernel launch failed");
     const int e3 = et.mark();
-
+    // ---- streamed result: everything is enqueued; follow the classification launches and send what each one placed ----
+    uint64_t sent = 0;
+    SdmaCopier sdma;   // (its destructor waits for copies in flight: error paths included)
+    if (streamChunks) {
+        const bool useSdma = hostPinned && sdma.open(so->device);
+        for (uint32_t k = 0; k < sc.recorded; ++k) {
+            if (!HIP_OK(hipEventSynchronize(chunkEvents.ev[k]))) return L.failure("[Failure] - the classification failed");
+            if (k + 1u == sc.recorded) so->classifyEndMs = now_ms();
+            const uint64_t cur = *(volatile unsigned long long*)(hCursor + k);
+            if (cur > sent) {
+                const bool okc = cur <= hc.stateBytes && (useSdma ? sdma.copy_to_host(hostArray + sent, dStage + sent, (size_t)(cur - sent))
+                                                                  : HIP_OK(hipMemcpyAsync(hostArray + sent, dStage + sent, (size_t)(cur - sent), hipMemcpyDeviceToHost, so->copyStream)));
+                if (!okc) return L.failure("[Failure] - device to host transfer of the bake result failed");
+                sent = cur;
+            }
+        }
+    }
     // ---- promote / dedup / sort / offsets on the device ----
     TailInputs ti; memset(&ti, 0, sizeof ti);
     ti.numItems = U; ti.numTris = T; ti.uv = dUv; ti.level = dLevel; ti.stateMask = dMask; ti.knownCount = dKnown; ti.digests = dDigests;
@@ -809,11 +1002,30 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     const uint32_t E = counts.numOmms;
     R.bits = bits; R.numDescs = E; R.arrayDataSize = E ? counts.arrayDataSize : 0; R.numTris = T;
     ok = true;
+    bool streamed = false;
+    if (streamChunks) {
+        // the blocks are (or will shortly be) at their final offsets in the caller's array, provided the speculative placement equals the exact layout the
+        // tail has just produced: compare, and fall back to the ordinary gather + copy otherwise
+        uint32_t hctl[4] = { 0u, 0u, 0u, 0u };
+        launch_stream_verify(dOrder, dDstOfs, E, dPlaced, dStreamCtl, stream);
+        if (!HIP_OK(hipMemcpyAsync(hctl, dStreamCtl, sizeof hctl, hipMemcpyDeviceToHost, stream)) || !HIP_OK(hipStreamSynchronize(stream)))
+            return L.failure("[Failure] - could not verify the streamed result");
+        streamed = hctl[2] == 0u && sent == R.arrayDataSize;
+        if (!streamed) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "[Perf Warning] - the streamed result was discarded (%u blocks placed / %u expected, %llu bytes / %llu expected, duplicate owned by a later range: %u): "
+                     "falling back to one copy after the bake", hctl[0], E, (unsigned long long)sent, (unsigned long long)R.arrayDataSize, hctl[1]);
+            L.msg(ommMessageSeverity_PerfWarning, buf);
+        }
+        so->chunks = streamChunks; so->streamedBytes = sent; so->used = streamed; so->fellBack = !streamed;
+        tm.streamChunks = streamed ? streamChunks : 0u; tm.streamedBytes = sent; tm.streamEarlyItems = hctl[3];
+    }
     if (E) {
-        R.arrayData = (uint8_t*)R.dev_alloc((size_t)counts.arrayDataSize); R.descs = (ommCpuOpacityMicromapDesc*)R.dev_alloc(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E);
-        ok = R.arrayData != nullptr && R.descs != nullptr;
+        R.descs = (ommCpuOpacityMicromapDesc*)R.dev_alloc(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E);
+        if (!streamed) R.arrayData = (uint8_t*)R.dev_alloc((size_t)counts.arrayDataSize);
+        ok = R.descs != nullptr && (streamed || R.arrayData != nullptr);
         if (ok) {
-            launch_gather_omms(dStates, dStateOfs, dActive, dMask, dLevel, bits, dOrder, dDstOfs, dSizes, E, R.arrayData, stream);
+            if (!streamed) launch_gather_omms(dStates, dStateOfs, dActive, dMask, dLevel, bits, dOrder, dDstOfs, dSizes, E, R.arrayData, stream);
             launch_write_descs(dOrder, dDstOfs, dLevel, bits, E, R.descs, stream);
         }
     }
@@ -830,16 +1042,22 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     const size_t spanBytes = (size_t)((const uint8_t*)(dFine + fineSlots.size()) - (const uint8_t*)dArrayHist);
     std::vector<uint8_t> span(spanBytes);
     ok = ok && HIP_OK(hipMemcpyAsync(span.data(), dArrayHist, spanBytes, hipMemcpyDeviceToHost, stream));
+    uint32_t queueTails[2] = { 0u, 0u };   // open tiles of the two tile sizes (statistics)
+    uint32_t hostCtl[kClassifyCtlWords]; memset(hostCtl, 0, sizeof hostCtl);
+    if (hc.activeStart[kNumLevels]) ok = ok && HIP_OK(hipMemcpyAsync(hostCtl, dQueueCtl, sizeof hostCtl, hipMemcpyDeviceToHost, stream));
     const int e5 = et.mark();
     ok = ok && HIP_OK(hipStreamSynchronize(stream));
+    if (streamChunks) { ok = HIP_OK(hipStreamSynchronize(so->copyStream)) && ok; ok = sdma.wait() && ok; so->lastByteMs = now_ms(); }
     if (!ok) return L.failure("[Failure] - could not materialise the bake result on the device");
     memcpy(R.hist, span.data(), sizeof(uint32_t) * kNumLevels);
     memcpy(R.hist + kNumLevels, span.data() + ((const uint8_t*)dIndexHist - (const uint8_t*)dArrayHist), sizeof(uint32_t) * kNumLevels);
     memcpy(fineSlots.data(), span.data() + ((const uint8_t*)dFine - (const uint8_t*)dArrayHist), sizeof(unsigned long long) * fineSlots.size());
 
     tm.uploadMs = 0.f; tm.hostSetupMs = 0.f; tm.setupMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.digestMs = et.ms(e2, e3);
-    tm.tailMs = et.ms(e3, e4); tm.gatherMs = et.ms(e4, e5);
+    tm.tailMs = et.ms(e3, e4); tm.gatherMs = et.ms(e4, e5); tm.persistentMs = mk.mark >= 0 ? et.ms(mk.mark, e2) : 0.f;
     for (int k = 0; k < kFineSlots; ++k) fineCount += fineSlots[(size_t)k * kFineStride];
+    queueTails[1] = hostCtl[0]; for (uint32_t k = 0; k < kMaxClassifyChunks; ++k) queueTails[0] += hostCtl[2 + k];   // (1024-tile queue; sections of the 4096-tile queue)
+    tm.openTiles = queueTails[0] + queueTails[1]; tm.openTileMicroTriangles = (uint64_t)queueTails[0] * 4096u + (uint64_t)queueTails[1] * 1024u;
     tm.fineMicroTriangles = fineCount; tm.uniqueItems = U; tm.activeItems = hc.activeStart[kNumLevels]; tm.stateBytes = hc.stateBytes; tm.microTriangles = 0;
     for (int l = 0; l < kNumLevels; ++l) tm.microTriangles += (uint64_t)hc.levelCount[l] << (2 * l);
     {   // classify_tiles launches: one per level below 5, one for level 5, ONE for all levels >= 6 (bake_kernels.hip)
@@ -862,6 +1080,10 @@ ommResult scope_fences(const Baker& baker, const ommCpuBakeInputDesc& d, bool fo
     // are honoured; the two switches of the reference's alternative ConservativeBilinearKernel (7, 8) are not built
     if ((flags & ((1u << 7) | (1u << 8))) != 0)
         { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - internal bake flags EnableAABBTesting / DisableLevelLineIntersection (bits 7, 8) are not supported"); return ommResult_NOT_IMPLEMENTED; }
+    // without the fine pass unresolved micro-triangles keep the state UnknownOpaque (3), which the reference ORs into ONE bit of a 2-state block together with
+    // its neighbour's (bake_cpu_impl.cpp:1811) while digesting the unpacked value: not reproducible from packed states
+    if ((flags & (1u << 9)) != 0 && d.format == ommFormat_OC1_2_State)
+        { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - internal bake flag DisableFineClassification (bit 9) is supported for OC1_4_State only"); return ommResult_NOT_IMPLEMENTED; }
     if (d.formats) { // the reference sizes its arrays from the global format only (bake_cpu_impl.cpp:1763-1772): mixed formats corrupt its heap
         if (!formatsOnHost) return L.failure("[Failure] - per-triangle formats are not supported on the device-resident entry point");
         for (uint32_t i = 0; i < d.indexCount / 3u; ++i)
@@ -906,16 +1128,23 @@ ommResult upload_host_tail(Baker& b, const HostTailResult& hres, ommIndexFormat 
 }
 
 struct BakeSession { // device working set + streams of one bake in flight
-    std::shared_ptr<ArenaPool> pool; std::unique_ptr<ArenaSet> set; DeviceArena* arena; DeviceArena* states; hipStream_t stream = nullptr, commStream = nullptr;
+    std::shared_ptr<ArenaPool> pool; std::unique_ptr<ArenaSet> set; DeviceArena* arena; DeviceArena* states; hipStream_t stream = nullptr, commStream = nullptr, placeStream = nullptr;
     explicit BakeSession(Baker& b) : pool(b.arenas), set(pool->acquire()) { arena = &set->tables; states = &set->states; }
     ~BakeSession() {
         // the set goes back to the pool only when nothing on the device can still touch it
+        if (placeStream) { (void)hipStreamSynchronize(placeStream); (void)hipStreamDestroy(placeStream); }
         if (commStream) { (void)hipStreamSynchronize(commStream); (void)hipStreamDestroy(commStream); }
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
         pool->release(std::move(set));
     }
     bool open() { return hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess; }
     bool open_comm() { return commStream || hipStreamCreateWithFlags(&commStream, hipStreamNonBlocking) == hipSuccess; }
+    // high priority: its (small) kernels are dispatched ahead of the next persistent classification launch instead of behind it
+    bool open_place() {
+        if (placeStream) return true;
+        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        return hipStreamCreateWithPriority(&placeStream, hipStreamNonBlocking, hi) == hipSuccess;
+    }
 };
 
 // ommCpuBake: host arrays in, host arrays out
@@ -992,25 +1221,47 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
         *out = (ommCpuBakeResult)res;
         return ommResult_SUCCESS;
     }
-    const ommResult br = bake_core(baker, d, din, &d, ses.arena, ses.states, stream, et, R, tm);
-    if (br != ommResult_SUCCESS) return br;
-
-    // ---- copy the result out through the user's allocator ----
+    // the finished blocks travel to their final place in the result array while the classification is still running (StreamOut): the array is allocated
+    // when the first block is about to leave, from an upper bound of its size (every active work item a block)
     BakeResult* res = baker.mem.make<BakeResult>();
     if (!res) return ommResult_FAILURE;
     res->mem = baker.mem;
+    // (error paths: nothing may still be copying into the result array when it is freed)
+    struct ResGuard { Baker& b; BakeResult*& r; BakeSession& s; ~ResGuard() { if (r) { if (s.commStream) (void)hipStreamSynchronize(s.commStream); (void)hipStreamSynchronize(s.stream); b.mem.destroy(r); } } } resGuard{ baker, res, ses };
+    struct ArrayAlloc {
+        Baker* b; BakeResult* res; uint64_t cap; bool pinned;
+        static uint8_t* get(void* u, uint64_t bytes, bool* pinned) {
+            ArrayAlloc& a = *(ArrayAlloc*)u;
+            if (pinned) *pinned = false;
+            if (a.res->arrayData && a.cap >= bytes) { if (pinned) *pinned = a.pinned; return (uint8_t*)a.res->arrayData; }
+            if (a.res->arrayData) { if (a.res->pool) { a.res->pool->release(a.res->arrayData); a.res->pool.reset(); } else a.b->mem.release(a.res->arrayData); a.res->arrayData = nullptr; a.cap = 0; }
+            if (a.b->mem.alloc == default_alloc && (size_t)bytes >= HostPool::kMinBytes) {
+                a.res->arrayData = a.b->hostPool->acquire((size_t)bytes, &a.pinned);
+                if (a.res->arrayData) a.res->pool = a.b->hostPool;
+            }
+            if (!a.res->arrayData) { a.res->arrayData = a.b->mem.allocate((size_t)bytes, 64); a.pinned = false; }
+            a.cap = a.res->arrayData ? bytes : 0;
+            if (pinned) *pinned = a.pinned;
+            return (uint8_t*)a.res->arrayData;
+        }
+    } arrayAlloc{ &baker, res, 0, false };
+    StreamOut so; so.set = ses.set.get(); so.allocUser = &arrayAlloc; so.alloc = &ArrayAlloc::get;
+    if (const uint64_t k = baker.knob(ommxBakerKnob_StreamChunks)) { so.chunksWanted = (uint32_t)k; so.forced = true; }
+    const bool canStream = ses.open_comm() && ses.open_place();
+    so.copyStream = ses.commStream; so.placeStream = ses.placeStream; so.device = baker.bind_device();
+    const ommResult br = bake_core(baker, d, din, &d, ses.arena, ses.states, stream, et, R, tm, nullptr, nullptr, canStream ? &so : nullptr);
+    if (br != ommResult_SUCCESS) return br;
+
+    // ---- copy the (rest of the) result out through the user's allocator ----
     const int d0 = et.mark();
     const uint32_t E = R.numDescs;
     if (E) {
-        if (baker.mem.alloc == default_alloc && (size_t)R.arrayDataSize >= HostPool::kMinBytes) {
-            res->arrayData = baker.hostPool->acquire((size_t)R.arrayDataSize);
-            if (res->arrayData) res->pool = baker.hostPool;
-        }
-        if (!res->arrayData) res->arrayData = baker.mem.allocate((size_t)R.arrayDataSize, 64);
+        ok = ArrayAlloc::get(&arrayAlloc, R.arrayDataSize, nullptr) != nullptr;   // (a streamed bake has it already)
         res->descs = (ommCpuOpacityMicromapDesc*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, 16);
-        ok = res->arrayData && res->descs;
-        ok = ok && HIP_OK(hipMemcpyAsync(res->arrayData, R.arrayData, (size_t)R.arrayDataSize, hipMemcpyDeviceToHost, stream));
+        ok = ok && res->descs;
+        if (!so.used) ok = ok && HIP_OK(hipMemcpyAsync(res->arrayData, R.arrayData, (size_t)R.arrayDataSize, hipMemcpyDeviceToHost, stream));
         ok = ok && HIP_OK(hipMemcpyAsync(res->descs, R.descs, sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, hipMemcpyDeviceToHost, stream));
+        if (so.used) tm.streamTailMs = (float)(so.lastByteMs - so.classifyEndMs);
     }
     res->index = (int32_t*)baker.mem.allocate(sizeof(int32_t) * (size_t)(T ? T : 1), 16);
     res->triArea = (float*)baker.mem.allocate(sizeof(float) * (size_t)(T ? T : 1), 16);
@@ -1020,12 +1271,12 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     if (ok && T) ok = HIP_OK(hipMemcpyAsync(res->triArea, R.triAreaScratch, sizeof(float) * (size_t)T, hipMemcpyDeviceToHost, stream));
     const int d1 = et.mark();
     ok = ok && HIP_OK(hipStreamSynchronize(stream));
-    if (!ok) { baker.mem.destroy(res); return L.failure("[Failure] - device to host transfer of the bake result failed"); }
+    if (!ok) { return L.failure("[Failure] - device to host transfer of the bake result failed"); }
 
     // histograms: format {2-state, 4-state} x level ascending, non-zero entries only (:1833-1850); one global format here
     res->arrayHist = (ommCpuOpacityMicromapUsageCount*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapUsageCount) * 2 * kNumLevels, 16);
     res->indexHist = (ommCpuOpacityMicromapUsageCount*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapUsageCount) * 2 * kNumLevels, 16);
-    if (!res->arrayHist || !res->indexHist) { baker.mem.destroy(res); return L.failure("[Failure] - the memory allocator returned null for the bake result"); }
+    if (!res->arrayHist || !res->indexHist) { return L.failure("[Failure] - the memory allocator returned null for the bake result"); }
     uint32_t nAH = 0, nIH = 0;
     for (uint32_t l = 0; l < (uint32_t)kNumLevels; ++l) {
         if (R.hist[l]) { res->arrayHist[nAH].count = R.hist[l]; res->arrayHist[nAH].subdivisionLevel = (uint16_t)l; res->arrayHist[nAH].format = (uint16_t)R.bits; nAH++; }
@@ -1039,6 +1290,7 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     tm.uploadMs = et.ms(u0, u1); tm.downloadMs = et.ms(d0, d1); tm.totalMs = (float)(now_ms() - t0);
     { std::lock_guard<std::mutex> g(baker.timingsMu); baker.timings = tm; baker.haveTimings = true; }
     *out = (ommCpuBakeResult)res;
+    res = nullptr;   // (handed over: the guard lets go)
     return ommResult_SUCCESS;
 }
 
@@ -1797,7 +2049,6 @@ OMM_MI355X_API ommResult ommxSetBakerKnob(ommBaker baker, ommxBakerKnob knob, ui
     if (knob == ommxBakerKnob_SetupKeyBits && value > 62) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_ShardChunkBytes && value != 0 && value < 256) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_StreamChunks && value > 64) return ommResult_INVALID_ARGUMENT;
-    if (knob == ommxBakerKnob_GatherThreads && value > 256) return ommResult_INVALID_ARGUMENT;
     untag<Baker>(baker)->knobs[knob].store(value);
     return ommResult_SUCCESS;
 }

@@ -100,6 +100,18 @@ __global__ __launch_bounds__(256) void dedup_lookup(const uint64_t* __restrict__
     if (i < n) rep[i] = hash_get(table, digests[i], i);
 }
 
+// 30-bit spatial key of a work item: level << 26 | 26 Morton bits of its centroid on the reference's 8192^2 grid (bake_cpu_impl.cpp:1722-1748; the
+// reference's 64-bit key is level << 60 | the same Morton bits: the same order)
+__device__ __forceinline__ uint32_t spatial_key30(const float* __restrict__ p, uint32_t level)
+{
+    const float cx = (p[0] + p[2] + p[4]) / 3.f, cy = (p[1] + p[3] + p[5]) / 3.f;
+    const int qx = cvt_trunc_x86_t(8192.f * cx), qy = cvt_trunc_x86_t(8192.f * cy);
+    // GetTexCoord<MirrorOnce, non-pow2> on an 8192^2 grid (util/texture.h:84-87)
+    const int mx = clampi_t(cvt_trunc_x86_t(__builtin_fabsf((float)qx + 0.5f)), 0, 8191);
+    const int my = clampi_t(cvt_trunc_x86_t(__builtin_fabsf((float)qy + 0.5f)), 0, 8191);
+    return (level << 26) | (spread16((uint32_t)mx) | (spread16((uint32_t)my) << 1));   // (mx, my < 8192: 26 Morton bits)
+}
+
 // spatial sort key (bake_cpu_impl.cpp:1722-1748); non-emitted items sort to the far end
 __global__ __launch_bounds__(256) void tail_sort_keys(TailInputs in, const int32_t* __restrict__ special, const uint32_t* __restrict__ rep,
                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ emittedFlag)
@@ -110,15 +122,7 @@ __global__ __launch_bounds__(256) void tail_sort_keys(TailInputs in, const int32
     // the reference's 64-bit key is level << 60 | 26 Morton bits: the same order in 30 bits (level << 26 | Morton), so the sort moves half the
     // bytes and a radix sort needs 4 digit passes instead of 8
     uint32_t key = ~0u;
-    if (emitted) {
-        const float* p = in.uv + 6ull * i;
-        const float cx = (p[0] + p[2] + p[4]) / 3.f, cy = (p[1] + p[3] + p[5]) / 3.f;
-        const int qx = cvt_trunc_x86_t(8192.f * cx), qy = cvt_trunc_x86_t(8192.f * cy);
-        // GetTexCoord<MirrorOnce, non-pow2> on an 8192^2 grid (util/texture.h:84-87)
-        const int mx = clampi_t(cvt_trunc_x86_t(__builtin_fabsf((float)qx + 0.5f)), 0, 8191);
-        const int my = clampi_t(cvt_trunc_x86_t(__builtin_fabsf((float)qy + 0.5f)), 0, 8191);
-        key = ((uint32_t)in.level[i] << 26) | (spread16((uint32_t)mx) | (spread16((uint32_t)my) << 1));   // (mx, my < 8192: 26 Morton bits)
-    }
+    if (emitted) key = spatial_key30(in.uv + 6ull * i, (uint32_t)in.level[i]);
     keys[i] = key;
     emittedFlag[i] = emitted ? 1u : 0u;
 }
@@ -436,6 +440,280 @@ void launch_shard_scatter(const uint8_t* gathered, uint64_t rankPitch, uint64_t 
     const uint32_t grid = numOmms < 262144u ? numOmms : 262144u;
     hipLaunchKernelGGL(shard_scatter_contributions, dim3(grid), dim3(256), 0, stream, gathered, rankPitch, lo, hi, active, owner, stateMask, level, bits, order, cofs,
                        dstOfs, sizes, numOmms, arrayData);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Streamed result (ommCpuBake): OMM blocks leave for the host WHILE the classification runs, straight to their final arrayData offsets.
+//
+// The final order of the blocks is known before anything is classified: descending (level, Morton key of the centroid, item index)
+// over the items that end up EMITTED (bake_cpu_impl.cpp:1707-1754).  So the per-level lists of active items are sorted into that order
+// first (run_stream_sort), the classification of the levels >= 6 proceeds range by range in it (launch_classify: chunks), and behind every
+// range run_stream_segment() decides which of its items are emitted -- non-uniform, not rejected, first occurrence of their digest --,
+// scans their sizes and packs their blocks behind the blocks of the earlier ranges: a contiguous piece of the final arrayData, which one
+// device-to-host copy on a second stream moves while the next range is classified.
+//
+// "First occurrence of the digest" (DeduplicateExact, bake_cpu_impl.cpp:1031-1066: the LOWEST work-item index keeps the block) is only known
+// for the ranges classified so far, so the placement is speculative in exactly one respect: if a later range brings a LOWER index for a
+// digest that an earlier range has already emitted, the earlier block should not have been there.  That event is detected (claimed[] below)
+// and, belt and braces, the complete result layout of the ordinary tail is compared with the streamed one at the end (stream_verify); on any
+// difference the bake falls back to the ordinary gather + copy.  Identical non-uniform blocks of DIFFERENT UV triangles at levels >= 6 are
+// rare (>= 4096 states each), and a bake full of them has a small arrayData anyway.
+// ------------------------------------------------------------------------------------------------------------------------------
+struct StreamScratch {
+    HashTable table; uint8_t* claimed;        // digest -> lowest emitted-candidate index; claimed[slot] = 1 + range that emitted a block for it
+    uint64_t *sizes64, *ofs64, *keysA, *keysB; void* tmp; size_t tmpBytes;
+};
+static size_t stream_prim_temp_bytes(uint32_t n)
+{
+    size_t a = 0, c = 0;
+    (void)rocprim::radix_sort_keys(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)n, 0u, 62u);
+    (void)rocprim::exclusive_scan(nullptr, c, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>());
+    return ((a > c ? a : c) + 255) / 256 * 256 + 256;
+}
+static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+size_t stream_scratch_bytes(uint32_t numActive)
+{
+    const uint32_t n = numActive ? numActive : 1, slots = hash_table_slots(n);
+    return align256(hash_table_bytes(slots)) + align256((size_t)slots + 1) + 4 * align256((size_t)n * 8) + stream_prim_temp_bytes(n);
+}
+static StreamScratch stream_carve(void* base, uint32_t numActive)
+{
+    const uint32_t n = numActive ? numActive : 1, slots = hash_table_slots(n);
+    StreamScratch s; uint8_t* p = (uint8_t*)base;
+    s.table = hash_table_at(p, slots); p += align256(hash_table_bytes(slots));
+    s.claimed = p; p += align256((size_t)slots + 1);
+    s.sizes64 = (uint64_t*)p; p += align256((size_t)n * 8); s.ofs64 = (uint64_t*)p; p += align256((size_t)n * 8);
+    s.keysA = (uint64_t*)p; p += align256((size_t)n * 8); s.keysB = (uint64_t*)p; p += align256((size_t)n * 8);
+    s.tmp = p; s.tmpBytes = stream_prim_temp_bytes(n);
+    return s;
+}
+
+// sort key of position p of the active list: level ascending (the list is already grouped that way), then Morton key DEscending, then item index DEscending
+__global__ __launch_bounds__(256) void stream_sort_keys(const uint32_t* __restrict__ activeIds, uint32_t n, const float* __restrict__ uv, const uint8_t* __restrict__ level, uint64_t* __restrict__ keys)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t item = activeIds[p], lvl = level[item];
+    const uint32_t morton = spatial_key30(uv + 6ull * item, lvl) & 0x3FFFFFFu;
+    keys[p] = ((uint64_t)lvl << 58) | ((uint64_t)(0x3FFFFFFu - morton) << 32) | (uint64_t)(0xFFFFFFFFu - item);
+}
+__global__ __launch_bounds__(256) void stream_sort_unpack(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ activeIds)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) activeIds[p] = 0xFFFFFFFFu - (uint32_t)keys[p];
+}
+
+// sorts every level's sub-list of activeIds into the order of the final result and clears the digest table of the streamed placement
+hipError_t run_stream_begin(uint32_t* activeIds, uint32_t numActive, const float* uv, const uint8_t* level, void* scratch, size_t scratchBytes, hipStream_t stream)
+{
+    if (numActive == 0) return hipSuccess;
+    if (scratchBytes < stream_scratch_bytes(numActive)) return hipErrorInvalidValue;
+    StreamScratch s = stream_carve(scratch, numActive);
+    const dim3 grid((numActive + 255u) / 256u), block(256);
+    hipLaunchKernelGGL(stream_sort_keys, grid, block, 0, stream, (const uint32_t*)activeIds, numActive, uv, level, s.keysA);
+    size_t tb = s.tmpBytes;
+    TAIL_CHECK(rocprim::radix_sort_keys(s.tmp, tb, s.keysA, s.keysB, (size_t)numActive, 0u, 62u, stream));
+    hipLaunchKernelGGL(stream_sort_unpack, grid, block, 0, stream, (const uint64_t*)s.keysB, numActive, activeIds);
+    const uint32_t slots = s.table.mask + 1u;
+    TAIL_CHECK(hipMemsetAsync(s.table.keys, 0xFF, hash_table_bytes(slots), stream));
+    TAIL_CHECK(hipMemsetAsync(s.claimed, 0, (size_t)slots + 1, stream));
+    return hipGetLastError();
+}
+
+// ---- preview: which work items could end up as duplicates of each other? ----
+// Identical blocks of DIFFERENT triangles are not rare: the patterns that a (locally straight) alpha edge cuts out of a triangle come from small
+// families -- a corner or edge point that is just touched (a handful of unknown micro-triangles, one state everywhere else), k complete rows of
+// micro-triangles parallel to an edge, ... -- measured on the bench workload: 959 of 77 627 blocks are shared by 2 .. 4 triangles.
+// Two items with the same block have the same block at every coarser level too (a coarse micro-triangle is T / O exactly when all of its
+// descendants are), so the preview classifies every active item of level >= 6 at level 5 (1024 micro-triangles, the whole-item kernel with
+// 4-state / ForceOpaque parameters, buffers of its own: < 2 % of the work of the bake), hashes the 256 bytes, and marks as `early` every item
+// whose preview (a) is not one single state -- those become special indices, not blocks -- and (b) is shared with another item.  The early
+// items are classified, digested and entered into the digest table before the first range is placed, so every first-occurrence relation that
+// can exist is exact when the placement starts.  Items whose preview micro-triangles would be large (> 256 texels each: asset-sized triangles)
+// are not previewed (a collapsed triangle stands in for them) and never early.  A wrong guess costs speed only: the placement is verified.
+__global__ __launch_bounds__(256) void stream_preview_prepare(const uint32_t* __restrict__ ids, uint32_t n, const float* __restrict__ uv, float texW, float texH,
+                                                              float* __restrict__ uv2, uint64_t* __restrict__ ofs2, uint8_t* __restrict__ early)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t item = ids[p];
+    const float* t = uv + 6ull * item; float* o = uv2 + 6ull * item;
+    const float lx = fminf(fminf(t[0], t[2]), t[4]), hx = fmaxf(fmaxf(t[0], t[2]), t[4]), ly = fminf(fminf(t[1], t[3]), t[5]), hy = fmaxf(fmaxf(t[1], t[3]), t[5]);
+    const bool large = !((hx - lx) * texW * (hy - ly) * texH <= 262144.f);   // (NaN-safe: anything odd counts as large)
+    for (int k = 0; k < 6; ++k) o[k] = large ? t[k & 1] : t[k];               // large: the three vertices collapse onto vertex 0
+    ofs2[item] = (uint64_t)item * kPreviewSlotBytes;
+    early[item] = large ? 2 : 0;                                              // 2 = not previewed
+}
+// signature of the preview: 64-bit hash of its 256 bytes (and the level); previews of one single state and items that were not previewed get none
+__global__ __launch_bounds__(256) void stream_preview_signature(const uint32_t* __restrict__ ids, uint32_t n, const uint8_t* __restrict__ states2, const uint8_t* __restrict__ level,
+                                                                uint8_t* __restrict__ early, uint64_t* __restrict__ sig, HashTable table)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t item = ids[p];
+    if (early[item] == 2) { early[item] = 0; sig[p] = kEmptyKey; return; }
+    const uint4* w = (const uint4*)(states2 + (size_t)item * kPreviewSlotBytes);
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)level[item]; bool uniform = true; const uint32_t w0 = w[0].x;
+    for (uint32_t k = 0; k < kPreviewSlotBytes / 16u; ++k) {
+        const uint4 v = w[k];
+        uniform = uniform && v.x == w0 && v.y == w0 && v.z == w0 && v.w == w0;
+        h = (h ^ (((uint64_t)v.y << 32) | v.x)) * 0xff51afd7ed558ccdull; h ^= h >> 32;
+        h = (h ^ (((uint64_t)v.w << 32) | v.z)) * 0xc4ceb9fe1a85ec53ull; h ^= h >> 29;
+    }
+    uniform = uniform && (w0 == 0u || w0 == 0x55555555u || w0 == 0xAAAAAAAAu || w0 == 0xFFFFFFFFu);
+    if (h == kEmptyKey) h = 0;
+    sig[p] = uniform ? kEmptyKey : h;
+    if (!uniform) hash_put_min(table, h, item);
+}
+// every member of a family of >= 2 items is early: the later members see another first occurrence, and tell it
+__global__ __launch_bounds__(256) void stream_preview_followers(const uint32_t* __restrict__ ids, uint32_t n, const uint64_t* __restrict__ sig, HashTable table,
+                                                                uint8_t* __restrict__ followed, uint8_t* __restrict__ early)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n || sig[p] == kEmptyKey) return;
+    const uint32_t item = ids[p], slot = hash_find_slot(table, sig[p]);
+    if (slot != 0xFFFFFFFFu && table.vals[slot] != item) { early[item] = 1; followed[slot] = 1; }
+}
+__global__ __launch_bounds__(256) void stream_preview_leaders(const uint32_t* __restrict__ ids, uint32_t n, const uint64_t* __restrict__ sig, HashTable table,
+                                                              const uint8_t* __restrict__ followed, uint8_t* __restrict__ early, uint32_t* __restrict__ ctl)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    bool e = false;
+    if (p < n && sig[p] != kEmptyKey) {
+        const uint32_t item = ids[p], slot = hash_find_slot(table, sig[p]);
+        if (slot != 0xFFFFFFFFu && table.vals[slot] == item && followed[slot]) early[item] = 1;
+        e = early[item] != 0;
+    }
+    const unsigned long long b = __ballot(e);
+    if ((threadIdx.x & 63u) == 0 && b) atomicAdd(ctl + 3, (uint32_t)__popcll(b));   // statistics: size of the early class
+}
+void launch_stream_preview_prepare(const uint32_t* ids, uint32_t n, const float* uv, float texW, float texH, float* uv2, uint64_t* ofs2, uint8_t* early, hipStream_t stream)
+{
+    if (n) hipLaunchKernelGGL(stream_preview_prepare, dim3((n + 255u) / 256u), dim3(256), 0, stream, ids, n, uv, texW, texH, uv2, ofs2, early);
+}
+// after the preview classification.  Uses the (still empty) digest table of the streamed placement for the signatures and clears it again.
+hipError_t run_stream_preview_flags(const uint32_t* ids, uint32_t n, uint32_t numActive, const uint8_t* states2, const uint8_t* level, uint8_t* early, uint32_t* ctl,
+                                    void* scratch, size_t scratchBytes, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    if (scratchBytes < stream_scratch_bytes(numActive)) return hipErrorInvalidValue;
+    StreamScratch s = stream_carve(scratch, numActive);
+    const dim3 grid((n + 255u) / 256u), block(256);
+    const uint32_t slots = s.table.mask + 1u;
+    hipLaunchKernelGGL(stream_preview_signature, grid, block, 0, stream, ids, n, states2, level, early, s.sizes64, s.table);   // (sizes64: free until the first segment)
+    hipLaunchKernelGGL(stream_preview_followers, grid, block, 0, stream, ids, n, (const uint64_t*)s.sizes64, s.table, s.claimed, early);
+    hipLaunchKernelGGL(stream_preview_leaders, grid, block, 0, stream, ids, n, (const uint64_t*)s.sizes64, s.table, (const uint8_t*)s.claimed, early, ctl);
+    TAIL_CHECK(hipMemsetAsync(s.table.keys, 0xFF, hash_table_bytes(slots), stream));
+    TAIL_CHECK(hipMemsetAsync(s.claimed, 0, (size_t)slots + 1, stream));
+    return hipGetLastError();
+}
+
+// can this item become a block?  non-uniform and not rejected (PromoteToSpecialIndices, bake_cpu_impl.cpp:1432-1472; special indices are enabled in streamed bakes)
+__device__ __forceinline__ bool stream_candidate(const StreamSegment& g, uint32_t item)
+{
+    const uint32_t mask = g.stateMask[item];
+    if ((mask & (mask - 1u)) == 0u) return false;
+    if (g.rejectionThreshold > 0.f) {
+        const float frac = (float)g.knownCount[item] / (float)(1u << (2u * g.level));
+        if (frac < g.rejectionThreshold) return false;
+    }
+    return true;
+}
+__global__ __launch_bounds__(256) void stream_insert(StreamSegment g, HashTable table, int earlyOnly)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.count) return;
+    const uint32_t item = g.ids[p];
+    if (earlyOnly && !(g.early && g.early[item])) return;
+    if (stream_candidate(g, item)) hash_put_min(table, g.digests[item], item);
+}
+void launch_stream_insert_early(const StreamSegment& g, uint32_t numActive, void* scratch, size_t scratchBytes, hipStream_t stream)
+{
+    if (g.count == 0 || g.disableDedup || scratchBytes < stream_scratch_bytes(numActive)) return;
+    StreamScratch s = stream_carve(scratch, numActive);
+    hipLaunchKernelGGL(stream_insert, dim3((g.count + 255u) / 256u), dim3(256), 0, stream, g, s.table, 1);
+}
+__global__ __launch_bounds__(256) void stream_flags(StreamSegment g, HashTable table, uint8_t* __restrict__ claimed, uint64_t* __restrict__ sizes64, uint32_t* __restrict__ ctl)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.count) return;
+    const uint32_t item = g.ids[p];
+    bool emit = stream_candidate(g, item);
+    if (emit && !g.disableDedup) {
+        const uint32_t slot = hash_find_slot(table, g.digests[item]);
+        if (slot == 0xFFFFFFFFu) { atomicOr(ctl + 1, 1u); emit = false; }
+        else if (table.vals[slot] != item) emit = false;                 // a lower index with this digest exists in this or an earlier range: that one keeps the block
+        else {
+            const uint8_t tag = (uint8_t)(g.range + 1u);
+            if (claimed[slot] != 0 && claimed[slot] != tag) atomicOr(ctl + 1, 1u);   // an EARLIER range emitted a block for this digest, and this index is lower: misplaced
+            claimed[slot] = tag;
+        }
+    }
+    uint64_t bytes = 0;
+    if (emit) { bytes = (((uint64_t)1 << (2u * g.level)) * (uint64_t)g.bits) >> 3; if (bytes < 1) bytes = 1; }   // Serialize: at least one byte per OMM (bake_cpu_impl.cpp:1768-1772)
+    sizes64[p] = bytes;
+    const unsigned long long b = __ballot(emit);
+    if ((threadIdx.x & 63u) == 0 && b) atomicAdd(ctl, (uint32_t)__popcll(b));   // number of blocks placed so far
+}
+// one wave per item: the block goes behind everything placed so far
+__global__ __launch_bounds__(256) void stream_copy(StreamSegment g, const uint64_t* __restrict__ sizes64, const uint64_t* __restrict__ ofs64,
+                                                   const unsigned long long* __restrict__ cursor, uint8_t* __restrict__ stage, uint64_t* __restrict__ placed)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
+    const unsigned long long base = *cursor;
+    for (uint32_t p = wave; p < g.count; p += waves) {
+        const uint32_t item = g.ids[p];
+        const uint64_t bytes = sizes64[p];
+        if (bytes == 0) { if (lane == 0) placed[item] = ~0ull; continue; }
+        const unsigned long long dstOfs = base + ofs64[p];
+        const uint8_t* src = g.states + g.stateOfs[item]; uint8_t* dst = stage + dstOfs;
+        if (((bytes | dstOfs) & 15ull) == 0) { const uint4* s4 = (const uint4*)src; uint4* d4 = (uint4*)dst; for (uint64_t k = lane; k < bytes / 16u; k += 64u) d4[k] = s4[k]; }
+        else for (uint64_t k = lane; k < bytes; k += 64u) dst[k] = src[k];
+        if (lane == 0) placed[item] = dstOfs;
+    }
+}
+__global__ void stream_advance(unsigned long long* __restrict__ cursor, const uint64_t* __restrict__ sizes64, const uint64_t* __restrict__ ofs64, uint32_t count)
+{
+    *cursor += ofs64[count - 1u] + sizes64[count - 1u];
+}
+__global__ void stream_publish(const unsigned long long* __restrict__ cursor, volatile unsigned long long* __restrict__ hostSlot) { *hostSlot = *cursor; }
+
+// one segment (items of ONE level, consecutive in the sorted active list) behind the classification launch that finished them.
+// Digests of the segment's items must have been computed (launch_digest) unless dedup is disabled.
+hipError_t run_stream_segment(const StreamSegment& g, uint32_t numActive, void* scratch, size_t scratchBytes, unsigned long long* cursor, uint8_t* stage,
+                              uint64_t* placed, uint32_t* ctl, hipStream_t stream)
+{
+    if (g.count == 0) return hipSuccess;
+    if (scratchBytes < stream_scratch_bytes(numActive)) return hipErrorInvalidValue;
+    StreamScratch s = stream_carve(scratch, numActive);
+    const dim3 grid((g.count + 255u) / 256u), block(256);
+    if (!g.disableDedup) hipLaunchKernelGGL(stream_insert, grid, block, 0, stream, g, s.table, 0);
+    hipLaunchKernelGGL(stream_flags, grid, block, 0, stream, g, s.table, s.claimed, s.sizes64, ctl);
+    size_t tb = s.tmpBytes;
+    TAIL_CHECK(rocprim::exclusive_scan(s.tmp, tb, s.sizes64, s.ofs64, (uint64_t)0, (size_t)g.count, rocprim::plus<uint64_t>(), stream));
+    const uint32_t blocks = (g.count + 3u) / 4u;
+    hipLaunchKernelGGL(stream_copy, dim3(blocks < 8192u ? blocks : 8192u), dim3(256), 0, stream, g, (const uint64_t*)s.sizes64, (const uint64_t*)s.ofs64,
+                       (const unsigned long long*)cursor, stage, placed);
+    hipLaunchKernelGGL(stream_advance, dim3(1), dim3(1), 0, stream, cursor, (const uint64_t*)s.sizes64, (const uint64_t*)s.ofs64, g.count);
+    return hipGetLastError();
+}
+void launch_stream_publish(const unsigned long long* cursor, unsigned long long* hostSlot, hipStream_t stream)
+{
+    hipLaunchKernelGGL(stream_publish, dim3(1), dim3(1), 0, stream, cursor, (volatile unsigned long long*)hostSlot);
+}
+
+// the ordinary tail has produced the exact layout: is the streamed placement the same?  ctl[0] = blocks placed, ctl[1] = violation seen, ctl[2] <- mismatch
+__global__ __launch_bounds__(256) void stream_verify(const uint32_t* __restrict__ order, const uint32_t* __restrict__ dstOfs, uint32_t numOmms, const uint64_t* __restrict__ placed,
+                                                     uint32_t* __restrict__ ctl)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0 && (ctl[0] != numOmms || ctl[1] != 0u)) atomicOr(ctl + 2, 1u);
+    if (j < numOmms && placed[order[j]] != (uint64_t)dstOfs[j]) atomicOr(ctl + 2, 1u);
+}
+void launch_stream_verify(const uint32_t* order, const uint32_t* dstOfs, uint32_t numOmms, const uint64_t* placed, uint32_t* ctl, hipStream_t stream)
+{
+    hipLaunchKernelGGL(stream_verify, dim3((numOmms + 256u) / 256u), dim3(256), 0, stream, order, dstOfs, numOmms, placed, ctl);
 }
 
 // ---- scratch layout ----

@@ -1,17 +1,18 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): the default bench, kernel-trace stats of the same command, then PMC passes (kernel-trace only, one
-# counter group per pass: HBM bytes, instruction classes, issue / wait cycles), all under gpurun_out/<tag>/.
-# usage: bash profiles/collect.sh <tag>      e.g.  gpurun -- 'bash profiles/collect.sh r02_v1'; then copy gpurun_out/<tag>/*.md|json -> profiles/
-tag=${1:-rXX}
+# Runs on the GPU box (via gpurun): the bench of one configuration, kernel-trace stats of the same command, then PMC passes (kernel-trace only,
+# one counter group per pass: HBM bytes, instruction classes, issue / wait cycles), all under gpurun_out/<tag>/.
+# usage: bash profiles/collect.sh <tag> [config]     e.g.  gpurun -- 'bash profiles/collect.sh r03_v1 c2'
+# then copy gpurun_out/<tag>/{bench.json -> profiles/<tag>_bench.json, kernel_stats.md, <tag>_pmc.md, <tag>_hbm_traffic.json -> profiles/pmc_latest_<config>.json}
+tag=${1:-rXX}; cfg=${2:-c2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd /tmp; export TMPDIR=/tmp
 O=$R/gpurun_out/$tag; mkdir -p $O
-BENCH="python $R/bench.py"
-[ -x $R/profiles/bin/valu_rates ] && $R/profiles/bin/valu_rates > $O/valu_rates.json 2> $O/valu_rates.err
-timeout 900 $BENCH > $O/bench.json 2> $O/bench.err
-# (the trace run skips the bench's small side bakes -- CPU-baseline parity samples, SAT-off sample -- so that every classify_tiles launch in the
-#  stats table is the full workload and its average is comparable with roofline.avg_launch_ms)
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- $BENCH --cpu-sample 0 --sat-off-sample 0 > $O/trace.log 2>&1
-PM="--steps 2 --warmup 1 --cpu-sample 0 --host-api-steps 0 --sat-off-sample 0"
+BENCH="python $R/bench.py --config $cfg"
+[ -x $R/profiles/bin/valu_rates ] && [ ! -s $O/valu_rates.json ] && $R/profiles/bin/valu_rates > $O/valu_rates.json 2> $O/valu_rates.err
+timeout 1200 $BENCH > $O/bench.json 2> $O/bench.err
+# (the trace run skips the bench's side bakes -- CPU-baseline parity samples, SAT-off sample, the ommCpuBake steps -- so that every classify_tiles launch in
+#  the stats table is the full workload through the device-resident entry and its average is comparable with roofline.avg_launch_ms)
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- $BENCH --cpu-sample 0 --sat-off-sample 0 --host-api-steps 0 --create-texture 0 > $O/trace.log 2>&1
+PM="--steps 2 --warmup 1 --cpu-sample 0 --host-api-steps 0 --sat-off-sample 0 --create-texture 0"
 pass() { n=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$n -o pmc -- $BENCH $PM > $O/pmc_$n.log 2>&1; }
 pass FETCH_SIZE FETCH_SIZE
 pass WRITE_SIZE WRITE_SIZE
@@ -21,11 +22,5 @@ pass C3 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_
 pass C4 SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_INSTS_VSKIPPED GRBM_GUI_ACTIVE
 cd $R
 python profiles/summarize_rocprof.py $(find $O/trace -name "*.db" | head -1) > $O/kernel_stats.md 2> $O/kernel_stats.err
-python profiles/summarize_pmc.py $tag $O "python bench.py $PM" > $O/pmc_summary.json 2> $O/pmc_summary.err
-tail -c 700 $O/bench.json; echo; cat $O/pmc_summary.json; head -14 $O/kernel_stats.md
-# optional: the full-size BASELINE configs[4] bake (4 M triangles, levels 4-10 + dynamic, 8K alpha) under the kernel trace
-if [ "$2" = "c4" ]; then
-  cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_c4 -o trace -- python $R/tests/scripts/c4_full.py > $O/c4.log 2>&1; cd $R
-  python profiles/summarize_rocprof.py $(find $O/trace_c4 -name "*.db" | head -1) > $O/c4_kernel_stats.md 2>> $O/kernel_stats.err
-  tail -4 $O/c4.log; head -8 $O/c4_kernel_stats.md
-fi
+python profiles/summarize_pmc.py $tag $O "python bench.py --config $cfg $PM" > $O/pmc_summary.json 2> $O/pmc_summary.err
+tail -c 900 $O/bench.json; echo; cat $O/pmc_summary.json; head -14 $O/kernel_stats.md

@@ -4,7 +4,8 @@
   <dir>/<tag>_hbm_traffic.json the figures bench.py reports as roofline.traffic (stamped with the library they were measured on)
 
 usage: python profiles/summarize_pmc.py <tag> <dir with pmc_*/ passes> "<bench command line>"
-The two outputs are then copied into profiles/ (tracked) by hand: gpurun merges only gpurun_out/.
+The two outputs are then copied into profiles/ (tracked) by hand: gpurun merges only gpurun_out/; the json also becomes
+profiles/pmc_latest_<config>.json, which bench.py reads for `roofline` (VALU wave-instructions per launch, shader clock, HBM traffic).
 
 Units and corrections (MI355X_MICROARCH.md, HBM section; calibrated here on kernels with a known byte count, sat_rows and
 sat_cols of the 4096^2 texture): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports HALF the bytes read
@@ -30,6 +31,8 @@ NUM_CU, SIMD_PER_CU = 256, 4
 
 
 def short(name):
+    if "classify_tiles<" in name:   # the persistent launch of the levels >= 6 is THE kernel of the roofline; the other instantiations are listed apart
+        return "ommx::classify_tiles" if re.search(r"classify_tiles<\w+, true, 4096", name) else "ommx::classify_tiles (levels < 6)"
     name = re.sub(r"rocprim::ROCPRIM_\d+_NS::detail::", "rocprim::", name)
     if "rocprim::" in name:
         m = re.search(r"rocprim::(?:trampoline_kernel<rocprim::)?(?:wrapped_)?(\w+)", name)
@@ -135,6 +138,12 @@ def main():
                            ("vector memory reads", "SQ_INSTS_VMEM_RD"), ("vector memory writes", "SQ_INSTS_VMEM_WR")):
             if ctr in c:
                 out.append("| %s | %s | %.4g | %.3f |" % (label, ctr, c[ctr], c[ctr] / valu if valu else 0))
+        summary["valu_wave_instructions_per_launch"] = valu
+        summary["scalar_wave_instructions_per_launch"] = scal
+        summary["scalar_per_valu"] = scal / valu if valu else None
+        summary["shader_cycles_per_launch"] = cyc
+        summary["kernel_ms_in_counter_pass"] = dur_ms
+        summary["shader_clock_hz"] = cyc / (dur_ms * 1e-3) if dur_ms else None   # effective clock of the launch: GRBM_GUI_ACTIVE / 8 XCDs / its duration in the same pass
         summary["valu_issue_utilisation"] = busy / simd_cycles if simd_cycles else None
         summary["valu_instr_per_cycle_per_simd"] = valu / simd_cycles if simd_cycles else None
         summary["scalar_issue_utilisation"] = scal * R["salu_per_cu"] / cu_cycles if cu_cycles else None

@@ -21,29 +21,9 @@ import ommtest as ot  # noqa: E402
 
 
 def workload(case):
-    k = case["kind"]
-    if k == "c0":
-        yy, xx = np.mgrid[0:256, 0:256]
-        tex = (((xx // 32) + (yy // 32)) & 1).astype(np.float32)
-        uv = np.array([[0, 0], [0, 1], [1, 0], [1, 1]], np.float32)       # the SDK tests' quad (test_omm_bake_cpu.cpp:594-595)
-        ix = np.array([0, 1, 2, 3, 1, 2], np.uint32)
-        return tex, uv, ix, None, dict(level=4, fmt=case["fmt"], addr=ot.CLAMP, promo=ot.PROMO_FORCE_OPAQUE)
-    if k == "c1":
-        tex = (ot.value_noise(77, 2048, 2048, octaves=5, base_cell=128) * 255).astype(np.uint8)
-        uv, ix = ot.random_triangles(78, case["tris"], 10.0 / 2048)
-        return tex, uv, ix, None, dict(level=6, fmt=ot.FMT_4STATE, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
-    if k == "c2":
-        tex = ot.foliage_texture(1234, 4096, 4096, feature=64)
-        uv, ix = ot.random_triangles(1235, case["tris"], 8.0 / 4096)
-        return tex, uv, ix, None, dict(level=8, fmt=ot.FMT_4STATE, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
-    if k == "c4":
-        n = case["tris"]
-        tex = ot.foliage_texture(4321, 8192, 8192, feature=96)
-        uv, ix = ot.random_triangles(9, n, 3.0 / 8192)
-        h = ot.hash_u32(np.arange(n) + 9000)
-        lv = (4 + (h >> 8) % 7).astype(np.uint8); lv[(h & 3) == 0] = 0xF
-        return tex, uv, ix, lv, dict(level=10, fmt=ot.FMT_4STATE, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, dyn_scale=2.0)
-    raise ValueError(k)
+    """the recipes live in tests/workloads.py (shared with bench.py and the full-size GPU tests)"""
+    import workloads as wl
+    return wl.workload(case["kind"], case.get("tris"), case.get("fmt", ot.FMT_4STATE))
 
 
 def bake(lib, case):

@@ -848,12 +848,20 @@ def test_bench_contract_small():
     """bench.py prints exactly one JSON line with the driver's keys (tiny workload)"""
     import json, subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--tris", "3000", "--level", "6", "--tex", "512", "--steps", "2", "--warmup", "1",
-                          "--cpu-sample", "300", "--sat-off-sample", "400", "--host-api-steps", "1"], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c2", "--tris", "3000", "--steps", "2", "--warmup", "1",
+                          "--cpu-sample", "300", "--sat-off-sample", "400", "--host-api-steps", "2", "--stream-chunks", "3", "--create-texture", "0"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
+    assert d["bake_wall_time_entry"].startswith("ommCpuBake") and d["bake_wall_time_ms"] > 0 and d["host_api"]["stream"]["chunks"] == 3 and d["value_entry"] == "ommxBakeDevice"
+    assert d["cpu_baseline"]["fine_pass_only"] > 0 and d["roofline"]["bound"] == "hbm"      # (the issue-slot roofline needs the PMC summary of the full-size workload)
+    for cfgname in ("c1", "c4", "cards"):
+        o2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", cfgname, "--tris", "1500", "--steps", "1", "--warmup", "1", "--cpu-sample", "200",
+                             "--host-api-steps", "1"], capture_output=True, text=True, timeout=600)
+        assert o2.returncode == 0, (cfgname, o2.stderr[-2000:])
+        d2 = json.loads([l for l in o2.stdout.splitlines() if l.startswith("{")][0])
+        assert d2["config"]["name"] == cfgname and d2["parity_vs_cpu_baseline"].startswith("bit-exact") and d2["value"] > 0
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None and d["value"] > 0
@@ -1115,7 +1123,7 @@ def test_bench_two_ranks_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, OMM_BENCH_ONE_GPU="1", OMM_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--tris", "20000", "--level", "7", "--tex", "1024"]
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--tris", "20000"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -1166,7 +1174,7 @@ def test_internal_flags_no_fine_pass_and_edge_heuristic(product, oracle):
     for sat in (True, False):
         for filt in (ot.LINEAR, ot.NEAREST):
             both(product, oracle, [tex], uv, ix, 8, sat=sat, addr=ot.WRAP, filt=filt, promo=ot.PROMO_FORCE_OPAQUE, levels=lv, flags=ot.FLAG_THREADS | (1 << 9))
-    both(product, oracle, [noise_u8()], uv, ix, 7, addr=ot.CLAMP, promo=ot.PROMO_NEAREST, flags=ot.FLAG_THREADS | (1 << 9), fmt=ot.FMT_2STATE)
+    both(product, oracle, [noise_u8()], uv, ix, 7, addr=ot.CLAMP, promo=ot.PROMO_NEAREST, flags=ot.FLAG_THREADS | (1 << 9))
     # edge heuristic: dynamic levels for every triangle, with and without per-triangle overrides
     lv2 = np.where(ot.hash_u32(np.arange(600) + 9) % 3 == 0, 0xF, lv).astype(np.uint8)
     both(product, oracle, [tex], uv, ix, 9, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, dyn_scale=2.0, flags=ot.FLAG_THREADS | (1 << 11))
@@ -1175,5 +1183,96 @@ def test_internal_flags_no_fine_pass_and_edge_heuristic(product, oracle):
     t = product.create_texture(b, [tex], alpha_cutoff=0.5)
     for bit in (7, 8):
         product.bake(b, ot.make_desc(t, uv, ix, 4, addr=ot.WRAP, flags=ot.FLAG_THREADS | (1 << bit)), expect=ot.NOT_IMPLEMENTED)
+    product.bake(b, ot.make_desc(t, uv, ix, 4, addr=ot.WRAP, flags=ot.FLAG_THREADS | (1 << 9), fmt=ot.FMT_2STATE), expect=ot.NOT_IMPLEMENTED)   # (state 3 has no 1-bit form)
     product.destroy_texture(b, t)
     product.destroy_baker(b)
+
+
+@pytest.mark.parametrize("chunks", [1, 3, 7])
+def test_streamed_result_of_ommCpuBake(product, oracle, chunks):
+    """ommCpuBake sends finished OMM blocks to the host while the classification is still running: the active items are sorted into the order of
+    the final result, the levels >= 6 are classified in `chunks` launches over consecutive ranges of it, the blocks of each range are packed behind
+    the earlier ones and copied to their final arrayData offsets on a second stream; the placement is verified against the ordinary tail at the end
+    (omm_host.cpp: StreamOut; tail_kernels.hip: "Streamed result").  Large bakes do that on their own; ommxBakerKnob_StreamChunks forces it
+    here on small ones: every level (small-item launches, 1024-tiles, 4096-tiles), duplicates, both formats, the rejection threshold -- all
+    byte-identical to the oracle."""
+    tex = ot.foliage_texture(21, 1024, 1024, feature=48)
+    n = 2500
+    uv, ix = ot.random_triangles(515, n, 0.04)
+    uv[3 * 700:3 * 730] = uv[3 * 20:3 * 50]                                   # exact duplicates (UV dedup)
+    lv = (1 + ot.hash_u32(np.arange(n) + 17) % 9).astype(np.uint8); lv[700:730] = lv[20:50]          # levels 1..9
+    knobs = [(ot.KNOB_STREAM_CHUNKS, chunks)]
+    both(product, oracle, [tex], uv, ix, 9, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv, knobs=knobs)
+    both(product, oracle, [tex], uv, ix, 7, addr=ot.CLAMP, promo=ot.PROMO_NEAREST, fmt=ot.FMT_2STATE, knobs=knobs)
+    both(product, oracle, [tex], uv, ix, 8, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv, rejection=0.7, knobs=knobs)
+    both(product, oracle, [tex], uv, ix, 8, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv, flags=0, knobs=knobs)
+    both(product, oracle, [tex], uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, flags=ot.FLAG_THREADS | ot.FLAG_NO_SPECIAL, knobs=knobs)   # (falls back to the plain copy)
+    both(product, oracle, [tex], uv, ix, 6, sat=False, addr=ot.MIRROR, promo=ot.PROMO_FORCE_TRANSPARENT, flags=ot.FLAG_THREADS | ot.FLAG_NO_DEDUP, knobs=knobs)
+    # nothing to stream: every item uniform
+    flat = np.full((64, 64), 255, np.uint8)
+    both(product, oracle, [flat], uv, ix, 6, addr=ot.WRAP, knobs=knobs)
+
+
+def test_streamed_result_repeated_and_concurrent(product, oracle):
+    """the working sets (staging buffer included) are reused across bakes, and concurrent bakes on one baker get their own working sets"""
+    import threading
+    tex = ot.foliage_texture(5, 1024, 1024, feature=32)
+    uv, ix = ot.random_triangles(99, 1500, 0.03)
+    ob = oracle.create_baker(); otx = oracle.create_texture(ob, [tex], alpha_cutoff=0.5)
+    ref = oracle.bake(ob, ot.make_desc(otx, uv, ix, 7, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE))
+    oracle.destroy_texture(ob, otx); oracle.destroy_baker(ob)
+    b = product.create_baker(); product.set_knob(b, ot.KNOB_STREAM_CHUNKS, 4)
+    t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+    d = ot.make_desc(t, uv, ix, 7, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+    for _ in range(3):
+        assert product.bake(b, d).same_as(ref)
+    errors = []
+    def worker():
+        try:
+            for _ in range(3):
+                r = product.bake(b, d)
+                if not r.same_as(ref):
+                    errors.append(r.diff(ref))
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+    ths = [threading.Thread(target=worker) for _ in range(3)]
+    for x in ths: x.start()
+    for x in ths: x.join()
+    assert not errors, errors
+    product.destroy_texture(b, t); product.destroy_baker(b)
+
+
+def test_streamed_result_falls_back_when_a_later_range_owns_the_block(product, oracle):
+    """The streamed placement is speculative in one respect (tail_kernels.hip "Streamed result"): a block is emitted for the lowest work-item index
+    with its digest SO FAR.  Copies of one triangle shifted by whole periods of a periodic texture classify identically, so their digests collide
+    across ranges in both index orders.  For ordinary triangles the level-5 preview sees that coming (the copies share their preview, are classified
+    early, and the bake streams); asset-sized triangles are not previewed, so there a later range brings the lower index, the bake must notice and
+    fall back to the ordinary gather + copy -- and the result is the oracle's either way."""
+    import bench
+    import ctypes
+    fell_back = []
+    for size, period, extent, lo, hi, n_base, level in ((512, 64, 0.02, 0.03, 0.09, 60, 7), (1024, 64, 0.7, 0.45, 0.55, 5, 7)):
+        yy, xx = np.mgrid[0:size, 0:size]
+        tile = ((((xx % period) - period // 2) ** 2 + ((yy % period) - period // 2) ** 2) < (period * 5 // 16) ** 2).astype(np.uint8) * 255   # a disc per period
+        step = np.float32(period / size)
+        base_uv, _ = ot.random_triangles(4, n_base, extent, lo=lo, hi=hi)
+        rng_k = ot.hash_u32(np.arange(n_base * 12) + 5)
+        shift = np.stack([(rng_k % 8).astype(np.float32) * step, ((rng_k >> 3) % 8).astype(np.float32) * step], 1).reshape(12, n_base, 1, 2)
+        uv = (base_uv.reshape(1, n_base, 3, 2) + shift).astype(np.float32).reshape(-1, 2)                 # 12 copies of every triangle, each in a period of its own
+        n = uv.shape[0] // 3
+        ix = np.arange(3 * n, dtype=np.uint32)
+        ob = oracle.create_baker(); otx = oracle.create_texture(ob, [tile], alpha_cutoff=0.5)
+        ref = oracle.bake(ob, ot.make_desc(otx, uv, ix, level, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE))
+        oracle.destroy_texture(ob, otx); oracle.destroy_baker(ob)
+        assert 0 < len(ref.descs) < n // 3        # the workload really is full of duplicate blocks
+        b = product.create_baker(); product.set_knob(b, ot.KNOB_STREAM_CHUNKS, 6)
+        t = product.create_texture(b, [tile], alpha_cutoff=0.5)
+        res = product.bake(b, ot.make_desc(t, uv, ix, level, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE))
+        tm = bench.BakeTimings()
+        product.dll.ommxGetLastBakeTimings.argtypes = [ctypes.c_void_p, ctypes.POINTER(bench.BakeTimings)]
+        product.dll.ommxGetLastBakeTimings(b, ctypes.byref(tm))
+        product.destroy_texture(b, t); product.destroy_baker(b)
+        assert res.same_as(ref), res.diff(ref)
+        assert tm.streamedBytes > 0
+        fell_back.append(tm.streamChunks == 0)
+    assert fell_back == [False, True], fell_back      # previewed copies stream; the asset-sized ones stream, notice, and take the ordinary path
