@@ -208,7 +208,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     __shared__ uint16_t s_glist[TILE / GROUP];   // sliced tiles: the groups that are not settled, compacted (phase 1 walks only these)
     __shared__ uint16_t s_olist[TILE / GROUP];   // ... and those of them that are all-open (taken as whole waves by the single-texel pass)
     __shared__ uint32_t s_gcount, s_ocount;
-    __shared__ uint32_t s_qcount;
+    __shared__ uint32_t s_qcount, s_ecount;      // queue fill counts (front / back of s_queue)
     __shared__ uint32_t s_mask, s_known;
     __shared__ uint32_t s_pending, s_fine;       // single-texel pass: micro-triangles left for the generic pass / level-line statistic
     __shared__ uint32_t s_next;                  // sliced: next tile-queue position of this (persistent) workgroup
@@ -382,43 +382,55 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         const uint32_t qn = s_qcount;
         if (tid == 0 && qn) atomicAdd(A.fineCount + (size_t)((blockIdx.x + 7u * blockIdx.y) & (kFineSlots - 1)) * kFineStride, (unsigned long long)qn);
         if (uFast) {
-            // ---- phase 2a: straight-line single-texel pass.  Work units of 64 lanes: first the all-open groups (one wave = one group, no
-            //      queue entries), then the queued micro-triangles of the other open groups, 64 at a time ----
-            uint32_t pend = 0;
-            const uint32_t gcount = s_gcount, ocount = s_ocount, units = ocount + ((qn + 63u) >> 6);
+            // ---- phase 2a: straight-line single-texel pass.  Work units of 64 lanes: the all-open groups (one wave = one group, no queue entries), then
+            //      the queued micro-triangles of the other open groups.  The three edge tests are replaced by curve_excluded() (classify_device.h), which
+            //      settles 88 % of the micro-triangles; what is left is compacted into s_queue: micro-triangles outside the single-texel pattern (0xFF)
+            //      from the front, for the generic pass 2c; those that need their edge tests (kNeedsEdges) from the back, for pass 2b ----
+            const uint32_t gcount = s_gcount, ocount = s_ocount;
+            uint32_t qn2 = 0, en = 0, pend = 0;
+            const uint32_t units = ocount + ((qn + 63u) >> 6);
             for (uint32_t k = tid >> 6; k < units; k += BLOCK / 64) {   // (k is wave-uniform)
                 uint32_t i; bool live = true;
                 if (k < ocount) i = (uint32_t)s_olist[k] * 64u + (tid & 63u);
                 else { const uint32_t q = (k - ocount) * 64u + (tid & 63u); live = q < qn; i = live ? (uint32_t)s_queue[q] : 0u; }
                 if (live) {
-                    const int st = fine_single_texel<FP32, MD>(P, tile_micro_triangle(i), W);
+                    const int st = fine_single_texel<FP32, MD>(P, tile_micro_triangle(i), W);   // state | kNeedsEdges + hints | -1
                     s_state[i] = (uint8_t)(st < 0 ? 0xFF : st);
-                    pend |= st < 0 ? 1u : 0u;
+                    pend |= st < 0 ? 1u : ((st & kNeedsEdges) ? 2u : 0u);
                 }
             }
             if (tid == 0 && ocount) s_fine = ocount * 64u;
-            if (__any(pend != 0) && (tid & 63u) == 0) s_pending = 1u;
+            const unsigned long long anyGeneric = __ballot((pend & 1u) != 0), anyEdges = __ballot((pend & 2u) != 0);
+            if ((tid & 63u) == 0 && (anyGeneric | anyEdges)) atomicOr(&s_pending, (anyGeneric ? 1u : 0u) | (anyEdges ? 2u : 0u));
             __syncthreads();
-            // ---- phase 2c: whatever did not fit the single-texel pattern (marked 0xFF) is compacted into the queue for the generic pass ----
-            uint32_t qn2 = 0;
             if (s_pending) {   // (block-uniform)
-                if (tid == 0) s_qcount = 0;
+                if (tid == 0) { s_qcount = 0; s_ecount = 0; }
                 __syncthreads();
                 for (uint32_t k = tid >> 6; k < gcount; k += BLOCK / 64) {
                     const uint32_t i = s_glist[k] * 64u + (tid & 63u);
-                    const bool open = s_state[i] == 0xFF;
-                    const unsigned long long vote = __ballot(open);
-                    if (vote) {
+                    const uint32_t code = s_state[i];
+                    const unsigned long long vg = __ballot(code == 0xFFu), ve = __ballot(code >= (uint32_t)kNeedsEdges && code != 0xFFu);
+                    if (vg | ve) {
                         const uint32_t lane = tid & 63u;
-                        uint32_t wbase = 0;
-                        if (lane == 0) wbase = atomicAdd(&s_qcount, (uint32_t)__popcll(vote));
-                        wbase = __shfl(wbase, 0);
-                        if (open) s_queue[wbase + __popcll(vote & ((1ull << lane) - 1ull))] = (uint16_t)i;
+                        uint32_t bg = 0, be = 0;
+                        if (lane == 0) { if (vg) bg = atomicAdd(&s_qcount, (uint32_t)__popcll(vg)); if (ve) be = atomicAdd(&s_ecount, (uint32_t)__popcll(ve)); }
+                        bg = __shfl(bg, 0); be = __shfl(be, 0);
+                        if (code == 0xFFu) s_queue[bg + __popcll(vg & ((1ull << lane) - 1ull))] = (uint16_t)i;
+                        else if (code >= (uint32_t)kNeedsEdges) s_queue[(uint32_t)TILE - 1u - (be + __popcll(ve & ((1ull << lane) - 1ull)))] = (uint16_t)i;
                     }
                 }
                 __syncthreads();
-                qn2 = s_qcount;
+                qn2 = s_qcount; en = s_ecount;
             }
+            // ---- phase 2b: the edge tests of the micro-triangles that curve_excluded() could not settle, densely ----
+            for (uint32_t q0 = 0; q0 < en; q0 += BLOCK) {
+                const uint32_t q = q0 + tid;
+                if (q < en) {
+                    const uint32_t i = s_queue[(uint32_t)TILE - 1u - q];
+                    s_state[i] = (uint8_t)single_texel_edges<FP32, MD>(P, tile_micro_triangle(i), W, (int)s_state[i]);
+                }
+            }
+            // ---- phase 2c: the generic pass for whatever did not fit the single-texel pattern ----
             if (tid == 0 && s_fine) atomicAdd(A.fineCount + (size_t)((blockIdx.x + 7u * blockIdx.y) & (kFineSlots - 1)) * kFineStride, (unsigned long long)s_fine);
             for (uint32_t q0 = 0; q0 < qn2; q0 += BLOCK) {
                 const uint32_t q = q0 + tid;

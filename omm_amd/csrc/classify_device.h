@@ -429,6 +429,50 @@ __device__ __forceinline__ bool edge_crosses_level_curve(V2 a0, V2 a1, float ha,
 #undef ON_EDGE
 }
 
+// ---- curve exclusion: can ANY of the three edge tests of a micro-triangle succeed in this texel?   ----
+// An edge test succeeds only if a computed root (x^, y^) lies in the unit texel and on the edge (IsPointOnEdge).  Whichever branch of
+// TestEdgeHyperbolaIntersection produced it, such a point (i) lies within 5e-3 of the edge's bounding box (the ellipse argument of the root
+// filter above, edges with |dx| + |dy| <= 2) and (ii) is an approximate zero of the bilinear patch f(x, y) = ha + hb x + hc y + hd x y: with
+// K >= |slope| of every edge, k^ / m^ the computed slope / intercept, c0..c2 the computed coefficients of f along the carrier line, forward
+// error analysis of the three branches gives |f(x^, y^)| <= R with
+//     vertical edge     R <= 5.2 e S                                              (S = |ha| + |hb| + |hc| + |hd|, e = 6e-8 >= 2^-24)
+//     |c0| < 1e-6       R <= 1.0001e-6 + e (|hd| K + 3 C1 + 3 C2 + 1.01 (|hc| + |hd|)(K + 1))
+//     quadratic         R <= e (1.01 C1^2 / |c0| + 6.1 C2 + 5.1 C1 + 5.1 |hd| K + 1.01 (|hc| + |hd|)(K + 1))
+// where C1 >= |c1|, C2 >= |c2| are bounds in terms of K and |coordinates| <= 2.5 (the residual of the quadratic formula is (rho^2 - D) / 4 c0 for
+// the computed root rho of the computed discriminant: no cancellation enters it; the 1 / |c0| term is the genuine ill-conditioning of a small
+// leading coefficient, and |c0| >= max(1e-6, |hd| K_min) in that branch).  f is bilinear, so over the bounding box of the micro-triangle fattened
+// by 6e-3 its extremes sit in the four corners: if they have one sign and the smallest |f| among them exceeds the sum of the three bounds plus the
+// fp32 evaluation error of the corners (66 e S), no edge test can succeed, and all three -- a division and usually a square root each -- are
+// skipped.  The two slopes bounds take one v_rcp_f32 each (1 ulp), widened by 2e-6.  Anything the test does not cover (micro-triangles wider than
+// a texel, a nearly vertical edge, NaN) answers false and is evaluated exactly.  Audited like the two filters above: the audit build of the oracle
+// evaluates this predicate (with reciprocals on the permissive side of anything v_rcp_f32 can return) next to the three edge tests for every
+// call: 5.5 M calls on the bench workloads, 88 % excluded, no disagreement (tests/test_edge_prefilter_audit.py).
+__device__ __forceinline__ bool curve_excluded(V2 r0, V2 r1, V2 r2, float ha, float hb, float hc, float hd)
+{
+    const float E = 6.0e-8f;
+    const float lx = __builtin_fminf(__builtin_fminf(r0.x, r1.x), r2.x), hx = __builtin_fmaxf(__builtin_fmaxf(r0.x, r1.x), r2.x);
+    const float ly = __builtin_fminf(__builtin_fminf(r0.y, r1.y), r2.y), hy = __builtin_fmaxf(__builtin_fmaxf(r0.y, r1.y), r2.y);
+    const float dxmax = hx - lx, dymax = hy - ly;
+    const float dxmin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(r1.x - r0.x), __builtin_fabsf(r2.x - r1.x)), __builtin_fabsf(r0.x - r2.x));
+    const float dymin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(r1.y - r0.y), __builtin_fabsf(r2.y - r1.y)), __builtin_fabsf(r0.y - r2.y));
+    const bool ok = (dxmax <= 1.f) & (dymax <= 1.f) & (lx >= -1.5f) & (hx <= 2.5f) & (ly >= -1.5f) & (hy <= 2.5f) & (dxmin >= 1e-4f);
+    const float Kub = (dymax * __builtin_amdgcn_rcpf(dxmin)) * 1.000002f, Klb = (dymin * __builtin_amdgcn_rcpf(dxmax)) * 0.999998f;
+    const float aa = __builtin_fabsf(ha), ab = __builtin_fabsf(hb), ac = __builtin_fabsf(hc), ad = __builtin_fabsf(hd);
+    const float S = aa + ab + ac + ad;
+    const float Mb = 2.5f * (1.f + Kub) * 1.000001f;
+    const float C1b = (ac * Kub + ad * Mb + ab) * 1.000001f;
+    const float C2b = (aa + ac * Mb) * 1.000001f;
+    const float c0lb = __builtin_fmaxf(ad * Klb * 0.999999f, 0.999999e-6f);
+    const float rest = 1.0001e-6f + E * (9.1f * C2b + 8.1f * C1b + 6.1f * ad * Kub + 2.02f * (ac + ad) * (Kub + 1.f)) + 66.f * E * S + 1e-30f;
+    const float rho = 6e-3f;
+    const float x0 = lx - rho, x1 = hx + rho, y0 = ly - rho, y1 = hy + rho;
+    const float g0 = ha + hc * y0, h0 = hb + hd * y0, g1 = ha + hc * y1, h1 = hb + hd * y1;
+    const float f00 = g0 + x0 * h0, f10 = g0 + x1 * h0, f01 = g1 + x0 * h1, f11 = g1 + x1 * h1;
+    const float fmn = __builtin_fminf(__builtin_fminf(f00, f10), __builtin_fminf(f01, f11)), fmx = __builtin_fmaxf(__builtin_fmaxf(f00, f10), __builtin_fmaxf(f01, f11));
+    const float F = __builtin_fmaxf(fmn, -fmx) - rest;
+    return ok & (F > 0.f) & (F * c0lb > 1.01f * E * C1b * C1b);
+}
+
 // bake_kernels_cpu.h:241-399 : one texel of the bilinear footprint grid.  Adds to (above, below).
 template <bool FP32, bool DEGENERATE, class MD>
 __device__ __forceinline__ void level_line_texel(const ClassifyParams& P, const DevMip& m, const MicroTri& tIn, int px, int py,
@@ -734,6 +778,9 @@ __device__ __forceinline__ int region_state_ex(const ClassifyParams& P, const Mi
 //   * winding: sign of the fp64 difference of two products of fp32 values (geometry.h:49-55).  The products are exact in fp64, and
 //     rounding to fp32 is monotone, so whenever the fp32-rounded products differ their order IS the exact order; fp64 is evaluated
 //     only when they round to the same float.
+// The three edge tests are NOT evaluated here: curve_excluded() settles 88 % of the micro-triangles that get that far; for the others the answer is
+// kNeedsEdges | (above >= below) << 2 | the state without a crossing, and single_texel_edges() below finishes them in a second, compacted pass.
+constexpr int kNeedsEdges = 0x80;
 template <bool FP32, class MD>
 __device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const MicroTri& t, const TexWindow& W)
 {
@@ -768,7 +815,7 @@ __device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const 
     float g00, g01, g11, g10;
     fetch_cell<FP32, MD>(P, m, MD::pow2(P), minx, miny, W, g00, g01, g11, g10);
     // (TextureImpl::Bilinear addresses with the per-mip pow2 flag, the level-line kernel with the dispatch flag = mip 0's: the same here)
-    uint32_t above = 0, below = 0;
+    uint32_t above = 0, below = 0; bool needsEdges = false;
     {   // centre vote: TextureImpl::Bilinear at p0 (texture_impl.cpp:261-278); a = 00, b = 01, c = 10, d = 11
         const float wx = q0x - fx, wy = q0y - fy;
         const float ac = g00 * (1.f - wx) + g10 * wx;
@@ -801,14 +848,34 @@ __device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const 
                 const V2 r0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy);
                 const V2 r1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy);
                 const V2 r2 = mk2(m.fw * t.p2.x - pfx, m.fh * t.p2.y - pfy);
-                // all three edges are evaluated by all lanes: the reference stops at the first crossing edge, but crossings are rare (0.4 % of
-                // the edge tests) and the lanes of a wave do not agree on them, so the short-circuit only adds divergent regions (33.1 -> 32.1 ms)
-                const bool x0 = edge_crosses_level_curve(r0, r1, ha, sb, sc, sd), x1 = edge_crosses_level_curve(r1, r2, ha, sb, sc, sd), x2 = edge_crosses_level_curve(r2, r0, ha, sb, sc, sd);
-                if (x0 | x1 | x2) { above += 1; below += 1; }
+                needsEdges = !curve_excluded(r0, r1, r2, ha, sb, sc, sd);   // (88 % of the micro-triangles are provably not touched by the level curve)
             }
         }
     }
-    return state_from_coverage(P, above, below);
+    const int st = state_from_coverage(P, above, below);
+    return needsEdges ? (kNeedsEdges | (above >= below ? 4 : 0) | st) : st;
+}
+
+// Second pass for the micro-triangles fine_single_texel() answered kNeedsEdges for (`code` = its answer): the three edge tests of
+// LevelLineIntersectionKernel::run (bake_kernels_cpu.h:376-396) in the single texel of the micro-triangle, from the same expressions as there.
+template <bool FP32, class MD>
+__device__ __forceinline__ int single_texel_edges(const ClassifyParams& P, const MicroTri& t, const TexWindow& W, int code)
+{
+    const DevMip& m = P.mips[0];
+    // the texel is the centre-vote cell (the first pass checked that): floor(p0 * size - 0.5)
+    const int minx = (int)__builtin_floorf(t.p0.x * m.fw - 0.5f), miny = (int)__builtin_floorf(t.p0.y * m.fh - 0.5f);
+    float g00, g01, g11, g10;
+    fetch_cell<FP32, MD>(P, m, MD::pow2(P), minx, miny, W, g00, g01, g11, g10);
+    const float pfx = (float)minx + 0.5f, pfy = (float)miny + 0.5f;
+    const float sb = g10 - g00, sc = g01 - g00, sd = g00 + g11 - g01 - g10, ha = g00 - P.cutoff;
+    const V2 r0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy);
+    const V2 r1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy);
+    const V2 r2 = mk2(m.fw * t.p2.x - pfx, m.fh * t.p2.y - pfy);
+    // all three edges are evaluated by all lanes: the reference stops at the first crossing edge, but crossings are rare and the lanes of a wave do not
+    // agree on them, so the short-circuit only adds divergent regions (33.1 -> 32.1 ms)
+    const bool x0 = edge_crosses_level_curve(r0, r1, ha, sb, sc, sd), x1 = edge_crosses_level_curve(r1, r2, ha, sb, sc, sd), x2 = edge_crosses_level_curve(r2, r0, ha, sb, sc, sd);
+    // a crossing adds one to both counters: both non-zero, and (above + 1 >= below + 1) == (above >= below)
+    return (x0 | x1 | x2) ? state_from_coverage(P, (code & 4) ? 2u : 1u, (code & 4) ? 1u : 2u) : (code & 3);
 }
 
 // ---- fine pass for one micro-triangle (bake_cpu_impl.cpp:859-914 linear, :983-1022 nearest) ----

@@ -1251,7 +1251,7 @@ def test_streamed_result_falls_back_when_a_later_range_owns_the_block(product, o
     import bench
     import ctypes
     fell_back = []
-    for size, period, extent, lo, hi, n_base, level in ((512, 64, 0.02, 0.03, 0.09, 60, 7), (1024, 64, 0.7, 0.45, 0.55, 5, 7)):
+    for size, period, extent, lo, hi, n_base, level in ((512, 64, 0.02, 0.03, 0.09, 60, 7), (2048, 64, 0.7, 0.45, 0.55, 5, 7)):
         yy, xx = np.mgrid[0:size, 0:size]
         tile = ((((xx % period) - period // 2) ** 2 + ((yy % period) - period // 2) ** 2) < (period * 5 // 16) ** 2).astype(np.uint8) * 255   # a disc per period
         step = np.float32(period / size)
