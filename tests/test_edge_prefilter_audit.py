@@ -1,6 +1,7 @@
-"""Audit of the two places where the HIP kernel does NOT evaluate the reference's expression for every input: point_on_edge() in
-omm_amd/csrc/classify_device.h discards points that a sqrt-free bound proves to be off the segment, and root_rejected()
-skips the division of a level-curve root that provably cannot be accepted (section 5.3b).
+"""Audit of the three places where the HIP kernel does NOT evaluate the reference's expression for every input: point_on_edge() in
+omm_amd/csrc/classify_device.h discards points that a sqrt-free bound proves to be off the segment, root_rejected()
+skips the division of a level-curve root that provably cannot be accepted (section 5.3b), and curve_excluded() skips all three edge tests of a
+micro-triangle whose fattened bounding box the level curve provably stays away from (section 5.3c).
 The audit build of the oracle evaluates the reference expression AND the bound for every call and counts disagreements."""
 import ctypes as C
 import os
@@ -24,11 +25,13 @@ def audit():
     lib.dll.orc_audit_counter.restype = C.c_longlong
     lib.dll.orc_audit_counter.argtypes = [C.c_int]
     lib.dll.orc_audit_min_discarded.restype = C.c_float
+    lib.dll.orc_audit_curve_counter.restype = C.c_longlong
+    lib.dll.orc_audit_curve_counter.argtypes = [C.c_int]
     return lib
 
 
 def test_bound_never_discards_a_point_the_reference_accepts(audit):
-    audit.dll.orc_audit_reset()
+    audit.dll.orc_audit_reset(); audit.dll.orc_audit_curve_reset()
     tex8 = (ot.value_noise(5, 512, 512, octaves=5, base_cell=32) * 255).astype(np.uint8)
     texf = ot.value_noise(6, 300, 200, octaves=3, base_cell=16).astype(np.float32)
     b = audit.create_baker()
@@ -52,3 +55,35 @@ def test_bound_never_discards_a_point_the_reference_accepts(audit):
     roots, rejected, bad_roots = (audit.dll.orc_audit_counter(i) for i in (4, 5, 6))
     assert roots > 1000000 and rejected > 1000000   # (large micro-triangles, M > 2, are not filtered: most of this sweep)
     assert bad_roots == 0
+    # curve exclusion (classify_device.h curve_excluded): never true when one of the three edge tests succeeds
+    calls3, excluded3, bad3, crossings3 = (audit.dll.orc_audit_curve_counter(i) for i in range(4))
+    assert calls3 > 1000000 and excluded3 > 100000 and crossings3 > 10000
+    assert bad3 == 0
+
+
+def test_curve_exclusion_on_adversarial_patches(audit):
+    """curve_excluded() against textures that stress its error bounds: tiny bilinear twist (|hd| around the 1e-6 branch threshold), alpha values
+    within a few ulp of the cutoff, steep two-level ramps, and micro-triangles with nearly horizontal / vertical edges, at sub-texel sizes"""
+    audit.dll.orc_audit_curve_reset()
+    rng = np.random.RandomState(7)
+    yy, xx = np.mgrid[0:256, 0:256].astype(np.float32)
+    texs = [
+        (0.5 + 1e-6 * (xx - 128) + 3e-7 * (yy - 128) + 1e-8 * (xx - 128) * (yy - 128)).astype(np.float32),        # nearly flat, twist ~1e-8
+        (0.5 + 1e-3 * np.sin(xx * 0.7) * np.cos(yy * 0.9) + 2e-6 * rng.rand(256, 256)).astype(np.float32),         # alpha hugging the cutoff
+        (rng.rand(256, 256) > 0.5).astype(np.float32),                                                                # 0 / 1 noise: steep patches, |hd| up to 2
+        (0.5 + 0.25 * np.sin(xx * 0.05) + 1e-5 * xx * yy / 256).astype(np.float32),
+    ]
+    b = audit.create_baker()
+    for tx in texs:
+        t = audit.create_texture(b, [tx], alpha_cutoff=-1.0)
+        for seed, (ext, level, n) in enumerate([(0.02, 6, 40), (0.006, 5, 60), (0.05, 8, 12)]):
+            uv, ix = ot.random_triangles(900 + seed, n, ext)
+            # a third of the triangles get an axis-aligned edge (nearly vertical / horizontal carrier lines at every micro-triangle)
+            tri = uv.reshape(-1, 3, 2); tri[::3, 1, 0] = tri[::3, 0, 0] + np.float32(1e-7); tri[1::3, 2, 1] = tri[1::3, 0, 1]
+            d = ot.make_desc(t, tri.reshape(-1, 2), ix, level, addr=ot.WRAP, promo=ot.PROMO_NEAREST, flags=ot.FLAG_THREADS | ot.FLAG_NO_DEDUP)
+            audit.bake(b, d, want_stats=False)
+        audit.destroy_texture(b, t)
+    audit.destroy_baker(b)
+    calls3, excluded3, bad3, crossings3 = (audit.dll.orc_audit_curve_counter(i) for i in range(4))
+    assert calls3 > 200000 and excluded3 > 1000 and crossings3 > 1000, (calls3, excluded3, crossings3)
+    assert bad3 == 0
