@@ -3,7 +3,8 @@
 //                              internal brute-force variant :1354-1430)
 //   * array-size budget       (maxArrayDataSize: greedy one-level down-sampling, :1474-1688)
 // Both are sequential greedy algorithms over whole OMMs (std::mt19937, std::sort, libm powf/logf) and stay on the host, as
-// in the reference; they run on the per-micro-triangle states the HIP kernels produced.
+// in the reference; they run on the per-micro-triangle states the HIP kernels produced, in the
+// device's own 2-bit packed form (Hamming distances by XOR + population count), uniform work items as (state, level).
 // The default bake never comes here: its tail is tail_kernels.hip.
 #include "host_tail.h"
 
@@ -51,17 +52,44 @@ uint64_t xxh64(const uint8_t* p, size_t len, uint64_t seed)
 }
 
 
+// ---- state storage of a work item (host_tail.h): uniform items are (state, level); the others hold 2 bits per micro-triangle, LSB first -- the layout of
+//      the device's packed states and of a 4-state arrayData block.  (The reference keeps one BYTE per micro-triangle of every item, bake_cpu_impl.cpp:401-411:
+//      65 GB at the metric configuration; this form needs 2 GB there.) ----
+inline size_t num_micro(const HostItem& it) { return (size_t)1 << (2 * it.level); }
+inline uint8_t get_state(const HostItem& it, size_t u) { return it.uniform >= 0 ? (uint8_t)it.uniform : (uint8_t)((it.packed[u >> 2] >> ((u & 3) << 1)) & 3u); }
+inline void set_state(HostItem& it, size_t u, uint8_t v) { uint8_t& b = it.packed[u >> 2]; const int sh = (int)((u & 3) << 1); b = (uint8_t)((b & ~(3u << sh)) | ((uint32_t)v << sh)); }
+void materialize(HostItem& it)   // uniform -> explicit states (before a merge writes into it)
+{
+    if (it.uniform < 0) return;
+    const size_t n = num_micro(it);
+    it.packed.assign(n >= 4 ? n / 4 : 1, (uint8_t)((0x55u * (uint32_t)it.uniform) & (n >= 4 ? 0xFFu : 0x03u)));   // (level 0: one field, the rest of the byte stays clear)
+    it.uniform = -1;
+}
+inline uint64_t load64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+inline uint64_t fold3(uint64_t w) { return w | ((w >> 1) & 0x5555555555555555ull); }   // per 2-bit field: UT (2) -> UO (3), as three()
+// number of micro-triangles of a (non-uniform) item whose state is T or O
+size_t count_known(const HostItem& it)
+{
+    const size_t n = num_micro(it);
+    if (n < 32) { size_t k = 0; for (size_t u = 0; u < n; ++u) k += is_known(get_state(it, u)); return k; }
+    size_t unknown = 0;
+    for (size_t o = 0; o < n / 4; o += 8) unknown += (size_t)__builtin_popcountll(load64(it.packed.data() + o) & 0xAAAAAAAAAAAAAAAAull);
+    return n - unknown;
+}
+
 // bake_cpu_impl.cpp:1432-1472
 void promote(const HostTailDesc& d, std::vector<HostItem>& items)
 {
     for (HostItem& it : items) {
         if (it.special != 0) continue;
-        const size_t n = it.st.size();
-        bool allEqual = true; uint8_t common = it.st[0];
-        for (size_t u = 1; u < n; ++u) allEqual &= common == it.st[u];
+        const size_t n = num_micro(it);
+        bool allEqual = true; uint8_t common = get_state(it, 0);
+        if (it.uniform < 0) {
+            if (n < 32) { for (size_t u = 1; u < n; ++u) allEqual &= common == get_state(it, u); }
+            else { const uint64_t pat = 0x5555555555555555ull * common; for (size_t o = 0; o < n / 4 && allEqual; o += 8) allEqual = load64(it.packed.data() + o) == pat; }
+        }
         if (!allEqual && d.rejectionThreshold > 0.f) {
-            uint32_t known = 0;
-            for (size_t u = 0; u < n; ++u) if (is_known(it.st[u])) known++;
+            const uint32_t known = (uint32_t)count_known(it);
             const float frac = known / (float)(uint32_t)n;
             if (frac < d.rejectionThreshold) { allEqual = true; common = 2; }
         }
@@ -76,11 +104,20 @@ void dedup_exact(const HostTailDesc& d, std::vector<HostItem>& items)
     std::unordered_map<uint64_t, uint32_t> seen;
     seen.reserve(items.size() * 2);
     std::vector<uint8_t> tmp;
+    uint64_t uniformDigest[13][4]; bool haveUniform[13][4]; memset(haveUniform, 0, sizeof haveUniform);
     for (uint32_t i = 0; i < items.size(); ++i) {
         HostItem& it = items[i];
-        tmp.resize(it.st.size());
-        for (size_t u = 0; u < tmp.size(); ++u) tmp[u] = three(it.st[u]);
-        const uint64_t dg = xxh64(tmp.data(), tmp.size(), 42);
+        const size_t n = num_micro(it);
+        uint64_t dg;
+        if (it.uniform >= 0) {   // XXH64 of 4^level equal bytes: once per (level, state)
+            const uint8_t s3 = three((uint8_t)it.uniform);
+            if (!haveUniform[it.level][s3]) { tmp.assign(n, s3); uniformDigest[it.level][s3] = xxh64(tmp.data(), n, 42); haveUniform[it.level][s3] = true; }
+            dg = uniformDigest[it.level][s3];
+        } else {
+            tmp.resize(n);
+            for (size_t u = 0; u < n; ++u) tmp[u] = three(get_state(it, u));
+            dg = xxh64(tmp.data(), n, 42);
+        }
         auto f = seen.find(dg);
         if (f == seen.end()) seen.emplace(dg, i);
         else {
@@ -91,10 +128,15 @@ void dedup_exact(const HostTailDesc& d, std::vector<HostItem>& items)
     }
 }
 
-float hamming3(const HostItem& a, const HostItem& b) // :1068-1083
+float hamming3(const HostItem& a, const HostItem& b) // :1068-1083 (XOR of the folded 2-bit fields, population count of the fields that differ)
 {
+    const size_t n = num_micro(a);
     uint32_t diff = 0;
-    for (size_t u = 0; u < a.st.size(); ++u) if (three(a.st[u]) != three(b.st[u])) diff++;
+    if (n < 32 || a.uniform >= 0 || b.uniform >= 0) { for (size_t u = 0; u < n; ++u) if (three(get_state(a, u)) != three(get_state(b, u))) diff++; return float(diff); }
+    for (size_t o = 0; o < n / 4; o += 8) {
+        const uint64_t x = fold3(load64(a.packed.data() + o)) ^ fold3(load64(b.packed.data() + o));
+        diff += (uint32_t)__builtin_popcountll((x | (x >> 1)) & 0x5555555555555555ull);
+    }
     return float(diff);
 }
 
@@ -102,11 +144,13 @@ void merge_items(HostItem& to, HostItem& from) // :1093-1132
 {
     to.prims.insert(to.prims.end(), from.prims.begin(), from.prims.end());
     from.prims.clear(); from.special = -1;
-    for (size_t u = 0; u < from.st.size(); ++u) {
-        const uint8_t ts = to.st[u], fs = from.st[u];
+    materialize(to);
+    const size_t n = num_micro(from);
+    for (size_t u = 0; u < n; ++u) {
+        const uint8_t ts = get_state(to, u), fs = get_state(from, u);
         if (ts != fs) {
-            if (is_known(fs) && is_known(ts)) to.st[u] = 3;
-            else if (is_known(ts) && is_unknown(fs)) to.st[u] = fs;
+            if (is_known(fs) && is_known(ts)) set_state(to, u, 3);
+            else if (is_known(ts) && is_unknown(fs)) set_state(to, u, fs);
         }
     }
 }
@@ -130,26 +174,29 @@ void dedup_lsh(const HostTailDesc& d, std::vector<HostItem>& items, uint32_t ite
             if (L == 0) continue;
             const uint32_t k = f2u(ceilf((logf((float)n) * dd) / (c * r)));
             if (k == 0) continue;
-            bits.resize((size_t)L * k); hashes.assign((size_t)L * N, 0); samples.resize(k);
+            // (hashes are indexed by position in the batch, not by item: the reference's L x N table would be 8 bytes x L x all items)
+            bits.resize((size_t)L * k); hashes.assign((size_t)L * n, 0); samples.resize(k);
             for (uint32_t l = 0; l < L; ++l) for (uint32_t j = 0; j < k; ++j) bits[(size_t)l * k + j] = (uint32_t)mt() & (numMicro - 1);
             // bucket lists keep insertion order (std::vector push_back in batch order)
             std::vector<std::unordered_map<uint64_t, std::vector<uint32_t>>> buckets(L);
-            for (uint32_t wi : batch) {
+            for (uint32_t bi = 0; bi < n; ++bi) {
+                const uint32_t wi = batch[bi];
                 const HostItem& it = items[wi];
                 for (uint32_t l = 0; l < L; ++l) {
-                    for (uint32_t j = 0; j < k; ++j) samples[j] = three(it.st[bits[(size_t)l * k + j]]);
+                    for (uint32_t j = 0; j < k; ++j) samples[j] = three(get_state(it, bits[(size_t)l * k + j]));
                     const uint64_t h = xxh64((const uint8_t*)samples.data(), sizeof(uint32_t) * k, 42);
-                    hashes[(size_t)l * N + wi] = h;
+                    hashes[(size_t)l * n + bi] = h;
                     buckets[l][h].push_back(wi);
                 }
             }
             std::set<uint32_t> potential;
-            for (uint32_t wi : batch) {
+            for (uint32_t bi = 0; bi < n; ++bi) {
+                const uint32_t wi = batch[bi];
                 HostItem& it = items[wi];
                 if (it.special != 0) continue;
                 potential.clear();
                 for (uint32_t l = 0; l < L; ++l) {
-                    const auto& lst = buckets[l][hashes[(size_t)l * N + wi]];
+                    const auto& lst = buckets[l][hashes[(size_t)l * n + bi]];
                     for (uint32_t cand : lst) {
                         if (cand == wi) continue;
                         if (items[cand].special != 0) continue;
@@ -181,7 +228,7 @@ void dedup_brute(const HostTailDesc& d, std::vector<HostItem>& items)
         for (uint32_t bI = start; bI < end; ++bI) {
             const HostItem& B = items[bI];
             if (B.special != 0 || B.format != 2 || B.prims.empty() || A.level != B.level || merged.count(bI)) continue;
-            const float dist = hamming3(A, B) / (uint32_t)A.st.size();
+            const float dist = hamming3(A, B) / (uint32_t)num_micro(A);
             if (dist < 0.1f && dist < minDist) { minDist = dist; nearest = (int32_t)bI; }
         }
         if (nearest >= 0) { merged.insert(a); merged.insert((uint32_t)nearest); merge_items(A, items[nearest]); }
@@ -196,27 +243,32 @@ float area2d(const float* p) // util/geometry.h:141-145
     const float nx = v0y * 0.f - v1y * 0.f, ny = 0.f * v1x - 0.f * v0x, nz = v0x * v1y - v1x * v0y;
     return 0.5f * sqrtf(nx * nx + ny * ny + nz * nz);
 }
+// the state of a parent micro-triangle from its four children (one byte of the packed states), :1499-1529
+inline uint8_t parent_state(uint8_t childByte)
+{
+    const uint8_t f = (uint8_t)(childByte | ((childByte >> 1) & 0x55u));   // three() per field
+    return f == 0x00u ? 0 : (f == 0x55u ? 1 : 3);
+}
 void downsample(HostItem& it) // :1499-1529
 {
     it.level -= 1;
-    const size_t n = (size_t)1 << (2 * it.level);
-    for (size_t i = 0; i < n; ++i) {
-        const uint8_t s0 = three(it.st[4 * i]), s1 = three(it.st[4 * i + 1]), s2 = three(it.st[4 * i + 2]), s3 = three(it.st[4 * i + 3]);
-        it.st[i] = (is_known(s0) && s0 == s1 && s0 == s2 && s0 == s3) ? s0 : 3;
-    }
-    it.st.resize(n);
+    if (it.uniform >= 0) { it.uniform = is_known(three((uint8_t)it.uniform)) ? three((uint8_t)it.uniform) : 3; return; }
+    const size_t n = num_micro(it);
+    std::vector<uint8_t> next(n >= 4 ? n / 4 : 1, 0);
+    for (size_t i = 0; i < n; ++i) next[i >> 2] = (uint8_t)(next[i >> 2] | (parent_state(it.packed[i]) << ((i & 3) << 1)));
+    it.packed.swap(next);
 }
 void compute_info(const HostItem& it, Info& o) // :1572-1595
 {
-    uint32_t known = 0; const uint32_t total = (uint32_t)it.st.size();
-    for (uint32_t i = 0; i < total; ++i) if (is_known(three(it.st[i]))) known++;
-    o.knownRatio = (float)known / total;
+    const uint32_t total = (uint32_t)num_micro(it);
     const size_t nd = (size_t)1 << (2 * (it.level - 1));
-    uint32_t kd = 0;
-    for (size_t i = 0; i < nd; ++i) {
-        const uint8_t s0 = three(it.st[4 * i]), s1 = three(it.st[4 * i + 1]), s2 = three(it.st[4 * i + 2]), s3 = three(it.st[4 * i + 3]);
-        if (is_known(s0) && s0 == s1 && s0 == s2 && s0 == s3) kd++;
+    uint32_t known, kd = 0;
+    if (it.uniform >= 0) { known = is_known((uint8_t)it.uniform) ? total : 0; kd = is_known((uint8_t)it.uniform) ? (uint32_t)nd : 0; }
+    else {
+        known = (uint32_t)count_known(it);
+        for (size_t i = 0; i < nd; ++i) kd += parent_state(it.packed[i]) != 3;
     }
+    o.knownRatio = (float)known / total;
     o.knownRatioDown = kd / (float)nd;
     o.totalArea = 0;
     for (size_t k = 0; k < it.prims.size(); ++k) o.totalArea += area2d(it.uv);
@@ -318,10 +370,11 @@ int run_host_tail(const HostTailDesc& d, std::vector<HostItem>& items, HostTailR
         if (off >= dataSize || di >= descCount) return 1;
         out.descs[di].offset = off; out.descs[di].subdivisionLevel = (uint16_t)it.level; out.descs[di].format = (uint16_t)it.format;
         descOffset[kv.second] = di++;
-        const uint32_t nM = (uint32_t)it.st.size(), is2 = it.format == 1;
+        const uint32_t nM = (uint32_t)num_micro(it), is2 = it.format == 1;
         uint8_t* dst = out.arrayData.data() + off;
-        for (uint32_t u = 0; u < nM; ++u) {
-            const uint32_t st = it.st[u];
+        if (!is2 && it.uniform < 0) memcpy(dst, it.packed.data(), nM >= 4 ? nM / 4 : 1);   // (4-state: the packed states ARE the block, :1806-1816)
+        else for (uint32_t u = 0; u < nM; ++u) {
+            const uint32_t st = get_state(it, u);
             dst[u >> (2 + is2)] |= is2 ? (uint8_t)(st << (u & 7)) : (uint8_t)(st << ((u & 3) << 1));
         }
         off += std::max((nM * bitCount) >> 3u, 1u);

@@ -10,7 +10,8 @@ struct HostItem {
     uint32_t level = 0; int format = 2; float uv[6];
     std::vector<uint32_t> prims;   // referencing triangles, ascending
     int32_t special = 0;           // 0 = none
-    std::vector<uint8_t> st;       // one state per micro-triangle (4^level)
+    int uniform = -1;              // >= 0: every micro-triangle has this state and `packed` is empty
+    std::vector<uint8_t> packed;   // else 2 bits per micro-triangle, LSB first (max(1, 4^level / 4) bytes), whatever the output format
 };
 struct HostTailDesc {
     int format; bool disableSpecial, disableDedup, nearDup, nearDupBrute;

@@ -642,9 +642,9 @@ ommResult gather_host_items(const Logger& L, hipStream_t stream, uint32_t U, uin
                             std::vector<HostItem>& items)
 {
     {   // refuse cleanly when that cannot fit in host memory instead of dying in std::bad_alloc half way
-        uint64_t bytes = hc.stateBytes; for (int l = 0; l < kNumLevels; ++l) bytes += (uint64_t)hc.levelCount[l] << (2 * l);
+        const uint64_t bytes = 2 * hc.stateBytes * (bits == 1 ? 2u : 1u);   // the packed states of the non-uniform items, once as read back and once per item
         const uint64_t phys = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGE_SIZE);
-        if (bytes > phys / 2) return L.failure("[Failure] - near-duplicate merging / maxArrayDataSize need one byte per micro-triangle of every work item on the host: not enough host memory for this bake");
+        if (bytes > phys / 2) return L.failure("[Failure] - near-duplicate merging / maxArrayDataSize need the packed states of every non-uniform work item on the host: not enough host memory for this bake");
     }
     std::vector<float> hUv((size_t)U * 6); std::vector<uint8_t> hLevel(U), hActive(U), hStates((size_t)hc.stateBytes);
     std::vector<uint32_t> hMask(U); std::vector<uint64_t> hOfs(U); std::vector<int32_t> hTri(T);
@@ -663,12 +663,13 @@ ommResult gather_host_items(const Logger& L, hipStream_t stream, uint32_t U, uin
         HostItem& it = items[i];
         it.level = hLevel[i]; it.format = bits; memcpy(it.uv, &hUv[(size_t)i * 6], 24);
         const size_t n = (size_t)1 << (2 * it.level);
-        it.st.resize(n);
-        if (!hActive[i]) { uint32_t st = 0; while (!((hMask[i] >> st) & 1u) && st < 3) ++st; memset(it.st.data(), (int)st, n); }
+        // uniform items stay (state, level); the others keep the device's 2-bit packing (1-bit states of a 2-state bake are widened to it)
+        if (!hActive[i]) { uint32_t st = 0; while (!((hMask[i] >> st) & 1u) && st < 3) ++st; it.uniform = (int)st; }
         else {
             const uint8_t* p = hStates.data() + hOfs[i];
-            if (bits == 2) for (size_t u = 0; u < n; ++u) it.st[u] = (p[u >> 2] >> ((u & 3) << 1)) & 3u;
-            else for (size_t u = 0; u < n; ++u) it.st[u] = (p[u >> 3] >> (u & 7)) & 1u;
+            it.uniform = -1; it.packed.assign(n >= 4 ? n / 4 : 1, 0);
+            if (bits == 2) memcpy(it.packed.data(), p, n >= 4 ? n / 4 : 1);
+            else for (size_t u = 0; u < n; ++u) it.packed[u >> 2] = (uint8_t)(it.packed[u >> 2] | (((p[u >> 3] >> (u & 7)) & 1u) << ((u & 3) << 1)));
         }
     }
     for (uint32_t t = 0; t < T; ++t) if (hTri[t] >= 0) items[(size_t)hTri[t]].prims.push_back(t);

@@ -1296,3 +1296,24 @@ def test_micro_triangles_of_several_texels(product, oracle):
     # random triangles of 20 .. 60 texels (no axis-aligned edges), level 6
     uv2, ix2 = ot.random_triangles(61, 300, 0.05)
     both(product, oracle, [tex8], uv2, ix2, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+
+
+def test_near_duplicate_merge_and_budget_at_scale(product, oracle):
+    """The serial reducers (near-duplicate LSH merge, maxArrayDataSize budget) work on the device's 2-bit packed states, uniform work items as
+    (state, level): a level-8 bake of 20 000 triangles needs 40 MB on the host for them, not the 2.6 GB of one byte x 2 per micro-triangle of every
+    item that the reference (and the oracle) hold.  Result = the oracle's."""
+    import workloads as wl
+    tex, uv, ix, lv, kw = wl.workload("c2", 20000)
+    kw = dict(kw); level = kw.pop("level")
+    for flags, extra in ((ot.FLAG_THREADS | ot.FLAG_NEAR_DUP, {}), (ot.FLAG_THREADS, {"max_array": 12 << 20})):
+        out = []
+        for lib in (product, oracle):
+            b = lib.create_baker()
+            t = lib.create_texture(b, [tex], alpha_cutoff=0.5)
+            d = ot.make_desc(t, uv, ix, level, flags=flags, **kw)
+            if "max_array" in extra:
+                d.maxArrayDataSize = extra["max_array"]
+            out.append(lib.bake(b, d))
+            lib.destroy_texture(b, t); lib.destroy_baker(b)
+        assert out[0].same_as(out[1]), out[0].diff(out[1])
+        assert len(out[0].descs) > 50
