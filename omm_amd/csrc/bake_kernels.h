@@ -9,16 +9,20 @@ namespace ommx {
 struct SetupCounters;
 
 // classification of the active items of ALL levels: level l = activeIds[first[l] .. first[l] + count[l]).  Items of level >= 5 are cut into
-// tiles; `queue` holds classify_queue_records(count) tile records of kTileRecordBytes, `queueCtl` 4 words (zeroed here).  numCUs sizes the persistent grid.
+// tiles; `queue` holds classify_queue_records(count) tile records of kTileRecordBytes, `queueCtl` kClassifyCtlWords words (zeroed here).  numCUs sizes the persistent grid.
 constexpr size_t kTileRecordBytes = 48;
 uint64_t classify_queue_records(const uint32_t count[kNumLevels], bool sections = false);   // sections: a streamed bake (chunks.count > 1), whose queue holds a second copy of the levels >= 6
-// `queueCtl`: kClassifyCtlWords words (zeroed here): tail / head of the 1024-tile queue, tail and head per section of the 4096-tile queue.
+// `queueCtl` (zeroed here): per section k of the 4096-tile queue the words [kSecTails + k] records appended, [kSecHeads + k] records handed out,
+// [kSecBases + k] first record, [kSecDone + k] records whose tiles are finished AND visible device-wide (== tail: the section is complete); the same four
+// words of the 1024-tile queue (one section) follow at kCtl1024.
 // `chunks` (optional, streamed bakes): the work items of the levels >= 6 are cut into `count` ranges of about equal tile counts -- in the order of the final
-// result: highest level first, then the position in that level's active list -- and every range gets its own tile-triage and persistent launch;
-// after(user, k, segments, n, false) is called behind launch k with the range as segments of the active lists, after(user, count, ..., true) once more with
-// the lower levels (which come last in the result).  mark(user) is called right before the first persistent launch of the levels >= 6.  The hooks enqueue
-// their own work on the same stream.
-constexpr uint32_t kMaxClassifyChunks = 64, kClassifyCtlWords = 2 + 2 * kMaxClassifyChunks;
+// result: highest level first, then the position in that level's active list -- and every range gets a section of the queue; ONE persistent launch drains the
+// sections in order.  after(user, k, segments, n, false) is called once per range (after that launch is enqueued) with the range as segments of the active
+// lists: its work must wait for section k (launch_stream_wait_section).  after(user, count, ..., true) follows with the lower levels (which come last in the
+// result).  mark(user) is called right before the persistent launch of the levels >= 6.
+constexpr uint32_t kMaxClassifyChunks = 64;
+constexpr uint32_t kSecTails = 0, kSecHeads = kMaxClassifyChunks, kSecBases = 2 * kMaxClassifyChunks, kSecDone = 3 * kMaxClassifyChunks, kCtl1024 = 4 * kMaxClassifyChunks;
+constexpr uint32_t kClassifyCtlWords = 8 * kMaxClassifyChunks;
 struct ClassifySegment { uint32_t level, first, count; };   // activeIds[first .. first + count), all of one level
 struct ClassifyChunks {
     uint32_t count;
@@ -35,9 +39,9 @@ hipError_t launch_classify(const ClassifyParams& P, const ItemArrays& A, const u
 // level-0 hierarchical query per work item: uniform items get stateMask = 1 << state and active = 0
 void launch_triage(const ClassifyParams& P, const float* uv, const SetupCounters* counters, uint32_t maxItems, uint32_t* stateMask, uint8_t* active, hipStream_t stream);
 // XXH64(seed 42) of the 3-state byte stream of each listed item -> digests[item]
-// (only != null: the listed items with (only[item] != 0) == (want != 0))
+// (only != null: the listed items with (only[item] != 0) == (want != 0); liveCount != null: a device word with the number of listed items, <= numItems)
 void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
-                   uint64_t* digests, hipStream_t stream, const uint8_t* only = nullptr, int want = 0);
+                   uint64_t* digests, hipStream_t stream, const uint8_t* only = nullptr, int want = 0, const uint32_t* liveCount = nullptr);
 // summed-area table of (alpha > cutoff)
 // (scratch: sat_scratch_bytes(w, h) bytes of device memory, free again once the stream has passed the build)
 size_t sat_scratch_bytes(int w, int h);
@@ -96,6 +100,7 @@ struct StreamSegment {
     const uint32_t* stateMask; const uint32_t* knownCount; const uint64_t* digests; const uint8_t* states; const uint64_t* stateOfs;
     float rejectionThreshold; int bits, disableDedup;
     const uint8_t* early;   // or null: per item, 1 = classified (and its digest entered into the table) before the first range
+    const uint32_t* liveCount;   // or null: device word with the number of ids in use (<= count; the early lists are filled on the device)
 };
 // the early items of a segment: their digests enter the table before anything is placed (run after their classification + launch_digest(.., early, 1))
 void launch_stream_insert_early(const StreamSegment& g, uint32_t numActive, void* scratch, size_t scratchBytes, hipStream_t stream);
@@ -105,11 +110,17 @@ hipError_t run_stream_begin(uint32_t* activeIds, uint32_t numActive, const float
 hipError_t run_stream_segment(const StreamSegment& g, uint32_t numActive, void* scratch, size_t scratchBytes, unsigned long long* cursor, uint8_t* stage,
                               uint64_t* placed, uint32_t* ctl, hipStream_t stream);
 void launch_stream_publish(const unsigned long long* cursor, unsigned long long* hostSlot, hipStream_t stream);
+// `stream` does not pass until section `section` of the 4096-tile queue is complete (every block of that range classified and visible); the stream must
+// already be ordered behind the tile triage.  ctl: the streamed result's control words (a wait that gives up sets the violation word)
+void launch_stream_wait_section(const uint32_t* queueCtl, uint32_t section, uint32_t* ctl, hipStream_t stream);
 // preview of the items of level >= 6 (tail_kernels.hip "preview"): prepare -> launch_classify_items(kPreviewLevel, preview buffers) -> flags
 constexpr uint32_t kPreviewLevel = 5, kPreviewSlotBytes = 256;   // 1024 micro-triangles x 2 bits
 void launch_stream_preview_prepare(const uint32_t* ids, uint32_t n, const float* uv, float texW, float texH, float* uv2, uint64_t* ofs2, uint8_t* early, hipStream_t stream);
+// ctl: kStreamCtlWords words {blocks placed, violation, mismatch, early items, early items per level [kStreamCtlEarly + level]}
+constexpr uint32_t kStreamCtlEarly = 4, kStreamCtlWords = 4 + 16;
+// early[item] <- 1 for the early class; the class also as per-level lists earlyList[levelStart[level] + k], k < ctl[kStreamCtlEarly + level]
 hipError_t run_stream_preview_flags(const uint32_t* ids, uint32_t n, uint32_t numActive, const uint8_t* states2, const uint8_t* level, uint8_t* early, uint32_t* ctl,
-                                    void* scratch, size_t scratchBytes, hipStream_t stream);   // ctl[3] += number of early items
+                                    void* scratch, size_t scratchBytes, uint32_t* earlyList, const uint32_t levelStart[kNumLevels], hipStream_t stream);
 void launch_stream_verify(const uint32_t* order, const uint32_t* dstOfs, uint32_t numOmms, const uint64_t* placed, uint32_t* ctl, hipStream_t stream);
 
 // ---- device tail (tail_kernels.hip) ----

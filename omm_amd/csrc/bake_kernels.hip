@@ -122,10 +122,11 @@ constexpr uint32_t kTileRecordWords = 3;   // uint4 per record (bake_kernels.h: 
 template <int TILE>
 __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays A, const uint32_t* __restrict__ activeIds, TileLevels L,
                                                     uint4* __restrict__ queue, uint32_t* __restrict__ sectionTails, TileSections S,
-                                                    const uint8_t* __restrict__ early)
+                                                    const uint8_t* __restrict__ early, uint32_t* __restrict__ sectionBases)
 {
     constexpr uint32_t TILE_LOG4 = TILE == 4096 ? 6u : 5u;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < S.n) sectionBases[t] = S.base[t];   // (the persistent launch walks the sections by these)
     const uint32_t lane = threadIdx.x & 63u;
     const bool live = t < L.tileStart[L.n];
     uint32_t sec = 0;
@@ -199,8 +200,7 @@ constexpr int WIN = 32; // largest LDS texel window edge
 template <bool FP32, bool SLICED, int TILE, class MD>
 __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(ClassifyParams P, ItemArrays A, const uint32_t* __restrict__ itemIds,
                                                         uint32_t numItems, uint32_t levelArg, uint64_t numTiles,
-                                                        const uint4* __restrict__ tileQueue, const uint32_t* __restrict__ queueCount, uint32_t* __restrict__ queueHead,
-                                                        uint32_t sectionBase)
+                                                        const uint4* __restrict__ tileQueue, uint32_t* __restrict__ queueCtl, uint32_t numSections)
 {
     __shared__ uint8_t  s_state[TILE];
     __shared__ uint16_t s_queue[TILE];
@@ -212,6 +212,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     __shared__ uint32_t s_mask, s_known;
     __shared__ uint32_t s_pending, s_fine;       // single-texel pass: micro-triangles left for the generic pass / level-line statistic
     __shared__ uint32_t s_next;                  // sliced: next tile-queue position of this (persistent) workgroup
+    __shared__ uint32_t s_sec, s_nsec, s_retired; // sliced: section of the current tile / of the next one, tiles of the current section this workgroup has finished
     __shared__ uint32_t s_gdec[SLICED ? TILE / GROUP : 1];   // sliced: bird-curve decode of each 64-group of the tile (classify_device.h: BirdGroup)
     __shared__ uint8_t  s_btab[SLICED ? 256 : 1];            // ... and the 4 x 64 table of the low decode bits, filled once per workgroup
     __shared__ float    s_wtex[SLICED ? WIN * WIN : 1];
@@ -220,13 +221,22 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     const uint32_t tid = threadIdx.x;
     // SLICED: persistent workgroups drain the queue of open tiles that triage_tiles filled (all levels >= log4 TILE in one launch);
     // the position of the NEXT tile is fetched while the current one is being classified.
-    // One launch drains ONE section of the queue (TileSections): records [sectionBase, sectionBase + *queueCount).  A streamed bake (ommCpuBake) has a
-    // section per range of work items, so that the finished blocks of one range travel to the host while the next range is classified.
-    uint32_t qpos = 0, qtotal = 0, qfirst = 0;
+    // The queue is cut into sections (TileSections; queueCtl: SectionCtl words per section), drained one after the other by the SAME launch.  A streamed
+    // bake (ommCpuBake) has a section per range of work items: a workgroup that leaves a section adds the tiles it finished there to the section's `done`
+    // count behind a device-scope release, and `done == tail` tells the placement stream (tail_kernels.hip: stream_wait_section) that every block of
+    // that range is in memory -- the finished blocks of one range travel to the host while the same launch classifies the next ranges.
+    uint32_t qpos = 0;
+    // next record of this workgroup (tid 0): the head of the first section that still has one
+    auto next_record = [&](uint32_t& sec) -> uint32_t {
+        for (; sec < numSections; ++sec) {
+            const uint32_t p = atomicAdd(queueCtl + kSecHeads + sec, 1u);
+            if (p < queueCtl[kSecTails + sec]) return queueCtl[kSecBases + sec] + p;
+        }
+        return 0xFFFFFFFFu;
+    };
     if (SLICED) {
-        qfirst = sectionBase; qtotal = sectionBase + *queueCount;
         s_btab[tid] = (uint8_t)bird_table_entry(tid >> 6, tid & 63u);   // (BLOCK == 256 entries)
-        if (tid == 0) s_next = qfirst + atomicAdd(queueHead, 1u);
+        if (tid == 0) { uint32_t sec = 0; s_next = next_record(sec); s_sec = sec; s_nsec = sec; s_retired = 0; }
         __syncthreads();
         qpos = uniform_u32(s_next);
     }
@@ -235,11 +245,11 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     uint4 rec = make_uint4(0u, 0u, 0u, 0u), rec1 = rec, rec2 = rec;
     uint32_t nextPos = 0;
     if (SLICED) {
-        if (qpos >= qtotal) return;
+        if (qpos == 0xFFFFFFFFu) return;
         const uint4* rp = tileQueue + (size_t)kTileRecordWords * qpos;
         rec = rp[0]; rec1 = rp[1]; rec2 = rp[2];   // three independent loads: one round trip for item, rectangle, UVs and output address
         rec.x = uniform_u32(rec.x); rec.y = uniform_u32(rec.y); rec.z = uniform_u32(rec.z); rec.w = uniform_u32(rec.w);
-        if (tid == 0) nextPos = qfirst + atomicAdd(queueHead, 1u);   // consumed at the end of this tile
+        if (tid == 0) { uint32_t sec = s_nsec; nextPos = next_record(sec); s_nsec = sec; }   // consumed at the end of this tile
         level = rec.y >> 24;
         // a sliced tile implies 4^level >= TILE; without the hint clang hoists micro_triangle()'s level-0 branch (three loop-invariant
         // vertices) out of the phase-1/2 loops and keeps them in VGPRs for the whole kernel
@@ -486,6 +496,14 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         if (tid == 0) {
             atomicOr(&A.stateMask[uItem], s_mask);
             if (P.wantKnownCount) atomicAdd(&A.knownCount[uItem], s_known);
+            // leaving the section (its queue ran dry while this tile was classified): every store of this workgroup's tiles is ordered before the
+            // count -- the barrier above collected the other waves' stores, the device-scope release makes them visible to the other XCDs
+            const uint32_t sec = s_sec, retired = s_retired + 1u;
+            if (s_nsec != sec) {
+                __threadfence();
+                __hip_atomic_fetch_add(queueCtl + kSecDone + sec, retired, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                s_sec = s_nsec; s_retired = 0;
+            } else s_retired = retired;
         }
         // Every LDS array of this tile was last read before that barrier, so the next tile starts right here: no further synchronisation.
         qpos = uniform_u32(s_next);
@@ -545,8 +563,8 @@ template <bool FP32, class MD>
 static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, const uint32_t* activeIds, const uint32_t first[kNumLevels],
                                const uint32_t count[kNumLevels], uint4* queue, uint32_t* queueCtl, uint32_t numCUs, const ClassifyChunks& chunks, hipStream_t stream)
 {
-    // queueCtl: [0] tail and [1] head of the 1024-tile queue, then per section of the 4096-tile queue its tail [2 + k] and its head [2 + kMaxClassifyChunks + k]
-    uint32_t* tail1024 = queueCtl; uint32_t* head1024 = queueCtl + 1; uint32_t* secTails = queueCtl + 2; uint32_t* secHeads = queueCtl + 2 + kMaxClassifyChunks;
+    // queueCtl: the 4096-tile queue's section words (kSecTails / kSecHeads / kSecBases / kSecDone), then the same four words of the 1024-tile queue (one section)
+    uint32_t* ctl1024 = queueCtl + kCtl1024;
     struct Cls { TileLevels L; uint64_t total; } cls[2];
     for (int c = 0; c < 2; ++c) {   // 0: 4096-tiles (levels 6..12, highest first), 1: 1024-tiles (level 5)
         TileLevels& L = cls[c].L; memset(&L, 0, sizeof L);
@@ -585,9 +603,11 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
     TileSections one; memset(&one, 0, sizeof one); one.n = 1;
     // ---- sliced items, step 1: tile triage of both tile sizes (settled tiles are final after it, open ones are queued) ----
     if (cls[0].total)
-        hipLaunchKernelGGL((triage_tiles<4096>), dim3((uint32_t)((cls[0].total + 255u) / 256u)), dim3(256), 0, stream, P, A, activeIds, cls[0].L, queue, secTails, S, chunks.early);
+        hipLaunchKernelGGL((triage_tiles<4096>), dim3((uint32_t)((cls[0].total + 255u) / 256u)), dim3(256), 0, stream, P, A, activeIds, cls[0].L, queue, queueCtl + kSecTails, S, chunks.early,
+                           queueCtl + kSecBases);
     if (cls[1].total)
-        hipLaunchKernelGGL((triage_tiles<1024>), dim3((uint32_t)((cls[1].total + 255u) / 256u)), dim3(256), 0, stream, P, A, activeIds, cls[1].L, q1024, tail1024, one, (const uint8_t*)nullptr);
+        hipLaunchKernelGGL((triage_tiles<1024>), dim3((uint32_t)((cls[1].total + 255u) / 256u)), dim3(256), 0, stream, P, A, activeIds, cls[1].L, q1024, ctl1024 + kSecTails, one, (const uint8_t*)nullptr,
+                           ctl1024 + kSecBases);
     // ---- small items: one launch per level ----
     for (uint32_t level = 0; level < 5u; ++level) {
         if (!count[level]) continue;
@@ -595,24 +615,21 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
         const uint64_t tiles = ((uint64_t)count[level] * M + 1023u) / 1024u;
         const uint32_t gx = tiles < (1u << 20) ? (uint32_t)tiles : (1u << 20), gy = (uint32_t)((tiles + gx - 1) / gx);
         hipLaunchKernelGGL((classify_tiles<FP32, false, 1024, MD>), dim3(gx, gy), dim3(BLOCK), 0, stream, P, A, activeIds + first[level], count[level], level, tiles,
-                           (const uint4*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
+                           (const uint4*)nullptr, (uint32_t*)nullptr, 0u);
     }
-    // ---- sliced items, step 2: persistent launches drain the queues; every CU holds OMMX_CLASSIFY_WAVES workgroups of 4 waves (one per SIMD) ----
-    // (streamed bakes leave one workgroup slot per CU to the placement kernels that run next to the persistent launches)
+    // ---- sliced items, step 2: one persistent launch per queue; every CU holds OMMX_CLASSIFY_WAVES workgroups of 4 waves (one per SIMD) ----
+    // (streamed bakes leave one workgroup slot per CU to the placement kernels that run next to the persistent launch)
     const uint64_t want = (uint64_t)numCUs * (chunks.after ? OMMX_CLASSIFY_WAVES - 1 : OMMX_CLASSIFY_WAVES);
     if (cls[1].total) {
         const dim3 cg((uint32_t)(cls[1].total < want ? cls[1].total : want)), cb(BLOCK);
-        hipLaunchKernelGGL((classify_tiles<FP32, true, 1024, MD>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)q1024,
-                           (const uint32_t*)tail1024, head1024, 0u);
+        hipLaunchKernelGGL((classify_tiles<FP32, true, 1024, MD>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)q1024, ctl1024, 1u);
     }
-    if (chunks.mark) chunks.mark(chunks.user);   // (everything but the persistent launches of the levels >= 6 is enqueued)
+    if (chunks.mark) chunks.mark(chunks.user);   // (everything but the persistent launch of the levels >= 6 is enqueued)
+    if (cls[0].total) {
+        const dim3 cg((uint32_t)(cls[0].total < want ? cls[0].total : want)), cb(BLOCK);
+        hipLaunchKernelGGL((classify_tiles<FP32, true, 4096, MD>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)queue, queueCtl, K);
+    }
     for (uint32_t k = 0; k < K; ++k) {
-        const uint64_t tiles = k == 0 && K > 1 ? cls[0].total : (uint64_t)(S.cut[k + 1] - S.cut[k]);   // (upper bound of the section's open tiles)
-        if (tiles) {
-            const dim3 cg((uint32_t)(tiles < want ? tiles : want)), cb(BLOCK);
-            hipLaunchKernelGGL((classify_tiles<FP32, true, 4096, MD>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)queue,
-                               (const uint32_t*)(secTails + k), secHeads + k, S.base[k]);
-        }
         if (k == 0 && chunks.afterEarly && chunks.early) {   // every level >= 6 as one segment: the hook looks at the early items in it
             ClassifySegment segs[kNumLevels]; uint32_t ns = 0;
             for (uint32_t g = 0; g < cls[0].L.n; ++g) { segs[ns].level = cls[0].L.level[g]; segs[ns].first = cls[0].L.first[g]; segs[ns].count = count[cls[0].L.level[g]]; ns++; }
@@ -671,7 +688,7 @@ hipError_t launch_classify_items(const ClassifyParams& P, const ItemArrays& A, c
     const uint64_t tiles = ((uint64_t)count * M + 1023u) / 1024u;
     const uint32_t gx = tiles < (1u << 20) ? (uint32_t)tiles : (1u << 20), gy = (uint32_t)((tiles + gx - 1) / gx);
 #define OMMX_ITEMS(FP, MD) hipLaunchKernelGGL((classify_tiles<FP, false, 1024, MD>), dim3(gx, gy), dim3(BLOCK), 0, stream, P, A, ids, count, level, tiles, \
-                                              (const uint4*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u)
+                                              (const uint4*)nullptr, (uint32_t*)nullptr, 0u)
     const bool wrapP2 = P.addrMode == 0 && P.pow2Dispatch, clampP2 = P.addrMode == 2 && P.pow2Dispatch;
     typedef ModeStatic<0, 1> WrapP2; typedef ModeStatic<2, 1> ClampP2;
     if (P.texIsFp32) { if (wrapP2) OMMX_ITEMS(true, WrapP2); else if (clampP2) OMMX_ITEMS(true, ClampP2); else OMMX_ITEMS(true, ModeDynamic); }
@@ -721,10 +738,11 @@ __device__ __forceinline__ uint32_t state_at(const uint8_t* p, uint32_t u, uint3
 
 __global__ __launch_bounds__(256) void digest_items(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs,
                                                     const uint32_t* __restrict__ itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
-                                                    uint64_t* __restrict__ digests, const uint8_t* __restrict__ only, int want)
+                                                    uint64_t* __restrict__ digests, const uint8_t* __restrict__ only, int want, const uint32_t* __restrict__ liveCount)
 {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t it = gid >> 2, acc = gid & 3u;
+    if (liveCount && *liveCount < numItems) numItems = *liveCount;   // (the list's fill count lives on the device)
     bool live = it < numItems;
     const uint32_t item = live ? itemIds[it] : 0u;
     if (live && only && (only[item] != 0) != (want != 0)) live = false;   // (streamed bakes: the items of one class only)
@@ -783,12 +801,14 @@ constexpr int DG_ITEMS = 64;
 template <int DG_CHUNK>
 __global__ __launch_bounds__(256) void digest_items_lds(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs,
                                                         const uint32_t* __restrict__ itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
-                                                        uint64_t* __restrict__ digests, const uint8_t* __restrict__ only, int want)
+                                                        uint64_t* __restrict__ digests, const uint8_t* __restrict__ only, int want, const uint32_t* __restrict__ liveCount)
 {
     constexpr int DG_STRIDE = DG_CHUNK / 4 + 1;
     __shared__ uint32_t s_buf[DG_ITEMS * DG_STRIDE];
     __shared__ const uint8_t* s_ptr[DG_ITEMS];
     const uint32_t tid = threadIdx.x, first = blockIdx.x * DG_ITEMS;
+    if (liveCount && *liveCount < numItems) numItems = *liveCount;   // (the list's fill count lives on the device: the grid covers its capacity)
+    if (first >= numItems) return;
     const uint32_t il = tid >> 2, acc = tid & 3u, it = first + il;
     bool live = it < numItems;
     if (live && only && (only[itemIds[it]] != 0) != (want != 0)) live = false;   // (streamed bakes: the items of one class only)
@@ -835,22 +855,18 @@ __global__ __launch_bounds__(256) void digest_items_lds(const uint8_t* __restric
 }
 
 void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
-                   uint64_t* digests, hipStream_t stream, const uint8_t* only, int want)
+                   uint64_t* digests, hipStream_t stream, const uint8_t* only, int want, const uint32_t* liveCount)
 {
     if (numItems == 0) return;
     const uint32_t bytesPerItem = ((1u << (2 * level)) * bits) >> 3;
-    // (measured: a full-size launch is faster with the small chunks -- 0.77 vs 1.12 ms for 127 k items, more workgroups per CU hide the latency --, a
-    //  range of a streamed bake, a few thousand items, with the large ones)
-    if (bytesPerItem >= 1024u && numItems <= 32768u) { // (powers of two: a multiple of the chunk size)
-        hipLaunchKernelGGL(digest_items_lds<1024>, dim3((numItems + DG_ITEMS - 1) / DG_ITEMS), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests, only, want);
-        return;
-    }
-    if (bytesPerItem >= 256u) {
-        hipLaunchKernelGGL(digest_items_lds<256>, dim3((numItems + DG_ITEMS - 1) / DG_ITEMS), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests, only, want);
+    // (256-byte chunks = 17 KB of LDS: a full-size launch is faster with them than with 1 KB chunks -- 0.77 vs 1.12 ms for 127 k items, more workgroups
+    //  per CU hide the latency --, and the digests of a streamed bake's ranges run in the 29 KB that the persistent classification launch leaves free on a CU)
+    if (bytesPerItem >= 256u) { // (powers of two: a multiple of the chunk size)
+        hipLaunchKernelGGL(digest_items_lds<256>, dim3((numItems + DG_ITEMS - 1) / DG_ITEMS), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests, only, want, liveCount);
         return;
     }
     const uint32_t threads = numItems * 4u;
-    hipLaunchKernelGGL(digest_items, dim3((threads + 255u) / 256u), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests, only, want);
+    hipLaunchKernelGGL(digest_items, dim3((threads + 255u) / 256u), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests, only, want, liveCount);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -582,14 +582,23 @@ struct StreamOut {
 struct StreamCtx {   // what the hook behind a classification launch needs
     hipStream_t stream, place; hipEvent_t* fences; const uint32_t* activeIds; uint32_t numActive; StreamSegment proto; void* scratch; size_t scratchBytes;
     uint64_t* digests; unsigned long long* cursor; uint8_t* stage; uint64_t* placed; uint32_t* ctl; unsigned long long* hostCursor; hipEvent_t* events; uint32_t numEvents, recorded; bool ok;
+    const uint32_t* queueCtl; const uint32_t* earlyList;   // (indexed like activeIds: the early items of a level start where the level starts)
 };
-void stream_hook(void* user, uint32_t chunk, const ClassifySegment* segs, uint32_t numSegs, bool /*last*/)
+// in front of the persistent launch: the placement stream starts behind the tile triage (the section tails are final from here on)
+void stream_mark_hook(void* user)
 {
-    // The placement runs on a second, high-priority stream behind a fence on the classification launch: the next classification launch starts at
-    // once, and the digest kernel of a range (a latency-bound ~1 ms for a few thousand items) hides behind it instead of standing between two launches.
+    StreamCtx& c = *(StreamCtx*)user;
+    c.ok = c.ok && hipEventRecord(c.fences[0], c.stream) == hipSuccess && hipStreamWaitEvent(c.place, c.fences[0], 0) == hipSuccess;
+}
+void stream_hook(void* user, uint32_t chunk, const ClassifySegment* segs, uint32_t numSegs, bool last)
+{
+    // The placement runs on a second, high-priority stream next to the ONE persistent classification launch: a one-lane kernel holds that stream until
+    // the range's section of the tile queue is complete (device-side count, no launch boundary, no host round trip), then the digest / placement kernels
+    // of the range run in the workgroup slot the classification leaves free on every CU.
     StreamCtx& c = *(StreamCtx*)user;
     if (chunk >= c.numEvents) { c.ok = false; return; }
-    c.ok = c.ok && hipEventRecord(c.fences[chunk], c.stream) == hipSuccess && hipStreamWaitEvent(c.place, c.fences[chunk], 0) == hipSuccess;
+    if (last) c.ok = c.ok && hipEventRecord(c.fences[1], c.stream) == hipSuccess && hipStreamWaitEvent(c.place, c.fences[1], 0) == hipSuccess;   // (the lower levels: behind everything)
+    else launch_stream_wait_section(c.queueCtl, chunk, c.ctl, c.place);
     for (uint32_t k = 0; k < numSegs && c.ok; ++k) {
         StreamSegment g = c.proto; g.ids = c.activeIds + segs[k].first; g.count = segs[k].count; g.level = segs[k].level; g.range = chunk;
         if (!g.disableDedup) launch_digest(g.states, g.stateOfs, g.ids, g.count, g.level, (uint32_t)g.bits, c.digests, c.place, g.early, 0);   // CalcDigest (bake_cpu_impl.cpp:1038-1040); early items have theirs
@@ -603,11 +612,12 @@ void stream_hook(void* user, uint32_t chunk, const ClassifySegment* segs, uint32
 void stream_early_hook(void* user, const ClassifySegment* segs, uint32_t numSegs)
 {
     StreamCtx& c = *(StreamCtx*)user;
-    c.ok = c.ok && hipEventRecord(c.fences[c.numEvents], c.stream) == hipSuccess && hipStreamWaitEvent(c.place, c.fences[c.numEvents], 0) == hipSuccess;   // (the extra fence of the early launch)
+    launch_stream_wait_section(c.queueCtl, 0u, c.ctl, c.place);   // (the early items live in section 0)
     for (uint32_t k = 0; k < numSegs && c.ok; ++k) {
-        StreamSegment g = c.proto; g.ids = c.activeIds + segs[k].first; g.count = segs[k].count; g.level = segs[k].level; g.range = 0;
+        StreamSegment g = c.proto; g.ids = c.earlyList + segs[k].first; g.count = segs[k].count; g.level = segs[k].level; g.range = 0;
+        g.liveCount = c.ctl + kStreamCtlEarly + segs[k].level;
         if (g.disableDedup || !g.early) continue;
-        launch_digest(g.states, g.stateOfs, g.ids, g.count, g.level, (uint32_t)g.bits, c.digests, c.place, g.early, 1);
+        launch_digest(g.states, g.stateOfs, g.ids, g.count, g.level, (uint32_t)g.bits, c.digests, c.place, nullptr, 0, g.liveCount);
         launch_stream_insert_early(g, c.numActive, c.scratch, c.scratchBytes, c.place);
     }
 }
@@ -718,7 +728,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     const size_t i32 = pad256((size_t)maxItems * 4), i64 = pad256((size_t)maxItems * 8);
     const size_t shardBytes = sh ? pad256((size_t)maxItems * 16) + pad256(maxItems) + i64 + pad256(sizeof(uint64_t) * kMaxRanks) : 0;
     // streamed result: placed offset per item, cursor + control words; preview: collapsed UVs, 16-byte state slots, offsets, masks, early flags
-    const size_t streamBytes = so ? i64 + 512 + pad256((size_t)maxItems * 24) + pad256((size_t)maxItems * kPreviewSlotBytes) + i64 + i32 + pad256(maxItems) + pad256(sizeof(unsigned long long) * kFineSlots * kFineStride) : 0;
+    const size_t streamBytes = so ? i64 + 512 + pad256((size_t)maxItems * 24) + pad256((size_t)maxItems * kPreviewSlotBytes) + i64 + i32 * 2 + pad256(maxItems) + pad256(sizeof(unsigned long long) * kFineSlots * kFineStride) : 0;
     const size_t need = pad256((size_t)maxItems * 24) + 3 * pad256(maxItems) + i64 * 2 + i32 * 13 + pad256(sizeof(SetupCounters)) + 4096 + pad256(sizeof(unsigned long long) * kFineSlots * kFineStride) + pad256(scratchBytes) + shardBytes + streamBytes;
     if (!arena->reserve(need)) return L.failure("[Failure] - out of device memory for the bake working set");
     float* dUv = arena->take<float>((size_t)maxItems * 6);
@@ -738,12 +748,13 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     uint8_t* dScratch = arena->take<uint8_t>(scratchBytes);
     if (sh) { sh->dMeta = arena->take<uint32_t>((size_t)maxItems * 4); sh->dOwner = arena->take<uint8_t>(maxItems); sh->dCofs = arena->take<uint64_t>(maxItems); sh->dTotals = arena->take<uint64_t>(kMaxRanks); }
     uint64_t* dPlaced = nullptr; unsigned long long* dCursor = nullptr; uint32_t* dStreamCtl = nullptr;
-    float* dUv2 = nullptr; uint8_t *dStates2 = nullptr, *dEarly = nullptr; uint64_t* dOfs2 = nullptr; uint32_t* dMask2 = nullptr; unsigned long long* dFine2 = nullptr;
+    float* dUv2 = nullptr; uint8_t *dStates2 = nullptr, *dEarly = nullptr; uint32_t* dEarlyList = nullptr; uint64_t* dOfs2 = nullptr; uint32_t* dMask2 = nullptr; unsigned long long* dFine2 = nullptr;
     if (so) {
-        dPlaced = arena->take<uint64_t>(maxItems); dCursor = arena->take<unsigned long long>(1); dStreamCtl = arena->take<uint32_t>(4);
+        dPlaced = arena->take<uint64_t>(maxItems); dCursor = arena->take<unsigned long long>(1); dStreamCtl = arena->take<uint32_t>(kStreamCtlWords);
         dUv2 = arena->take<float>((size_t)maxItems * 6); dStates2 = arena->take<uint8_t>((size_t)maxItems * kPreviewSlotBytes); dOfs2 = arena->take<uint64_t>(maxItems);
-        dMask2 = arena->take<uint32_t>(maxItems); dEarly = arena->take<uint8_t>(maxItems); dFine2 = arena->take<unsigned long long>(kFineSlots * kFineStride);
+        dMask2 = arena->take<uint32_t>(maxItems); dEarly = arena->take<uint8_t>(maxItems); dEarlyList = arena->take<uint32_t>(maxItems); dFine2 = arena->take<unsigned long long>(kFineSlots * kFineStride);
     }
+    if (arena->used > arena->cap) return L.failure("[Failure] - internal error: the working-set layout exceeds its reservation");
 
     // ---- SetupWorkItems (bake_cpu_impl.cpp:589-660) on the device ----
     const int e0 = et.mark();
@@ -922,7 +933,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     MarkCtx mk; mk.et = &et; mk.mark = -1;
     const bool noDedup = (flags & (1u << 3)) != 0;
     if (streamChunks) {
-        bool oks = HIP_OK(hipMemsetAsync(dPlaced, 0xFF, (size_t)maxItems * 8, stream)) && HIP_OK(hipMemsetAsync(dCursor, 0, 8, stream)) && HIP_OK(hipMemsetAsync(dStreamCtl, 0, 16, stream));
+        bool oks = HIP_OK(hipMemsetAsync(dPlaced, 0xFF, (size_t)maxItems * 8, stream)) && HIP_OK(hipMemsetAsync(dCursor, 0, 8, stream)) && HIP_OK(hipMemsetAsync(dStreamCtl, 0, sizeof(uint32_t) * kStreamCtlWords, stream));
         oks = oks && HIP_OK(run_stream_begin(dActiveIds, numActiveAll, dUv, dLevel, dScratch, scratchBytes, stream));
         for (uint32_t k = 0; oks && k < 2u * streamChunks + 3u; ++k) { oks = HIP_OK(hipEventCreateWithFlags(&chunkEvents.ev[k], hipEventDisableTiming)); chunkEvents.n += oks ? 1u : 0u; }
         if (!oks) return L.failure("[Failure] - could not set up the streamed result");
@@ -931,7 +942,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         memset(&sc.proto, 0, sizeof sc.proto);
         sc.proto.stateMask = dMask; sc.proto.knownCount = dKnown; sc.proto.digests = dDigests; sc.proto.states = dStates; sc.proto.stateOfs = dStateOfs;
         sc.proto.rejectionThreshold = d.rejectionThreshold; sc.proto.bits = bits; sc.proto.disableDedup = noDedup ? 1 : 0;
-        cc.count = streamChunks; cc.after = stream_hook; cc.user = &sc; cc.early = nullptr;
+        cc.count = streamChunks; cc.after = stream_hook; cc.mark = stream_mark_hook; cc.user = &sc; cc.early = nullptr; sc.queueCtl = dQueueCtl;
         // preview (tail_kernels.hip): level-5 classification of the items of level >= 6 into buffers of its own; items that share their preview are classified early
         const uint32_t first6 = hc.activeStart[6], count6 = numActiveAll - hc.activeStart[6];
         if (count6 && streamChunks > 1) {
@@ -940,9 +951,9 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             bool okp = HIP_OK(hipMemsetAsync(dEarly, 0, maxItems, stream)) && HIP_OK(hipMemsetAsync(dMask2, 0, (size_t)maxItems * 4, stream));
             launch_stream_preview_prepare(dActiveIds + first6, count6, dUv, P.mips[0].fw, P.mips[0].fh, dUv2, dOfs2, dEarly, stream);
             okp = okp && HIP_OK(launch_classify_items(P2, A2, dActiveIds + first6, count6, kPreviewLevel, stream));
-            okp = okp && HIP_OK(run_stream_preview_flags(dActiveIds + first6, count6, numActiveAll, dStates2, dLevel, dEarly, dStreamCtl, dScratch, scratchBytes, stream));
+            okp = okp && HIP_OK(run_stream_preview_flags(dActiveIds + first6, count6, numActiveAll, dStates2, dLevel, dEarly, dStreamCtl, dScratch, scratchBytes, dEarlyList, hc.activeStart, stream));
             if (!okp) return L.failure("[Failure] - could not set up the streamed result");
-            cc.early = dEarly; cc.afterEarly = stream_early_hook; sc.proto.early = dEarly;
+            cc.early = dEarly; cc.afterEarly = stream_early_hook; sc.proto.early = dEarly; sc.earlyList = dEarlyList;
         }
     } else { cc.mark = mark_hook; cc.user = &mk; cc.early = nullptr; }   // (HIP event in front of the persistent launch of the levels >= 6)
     if (!HIP_OK(launch_classify(P, A, dActiveIds, lvlFirst, lvlCount, dTileQueue, dQueueCtl, device_cu_count(), stream, &cc))) return L.failure("[Failure] - kernel launch failed");
@@ -1062,7 +1073,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     tm.uploadMs = 0.f; tm.hostSetupMs = 0.f; tm.setupMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.digestMs = et.ms(e2, e3);
     tm.tailMs = et.ms(e3, e4); tm.gatherMs = et.ms(e4, e5); tm.persistentMs = mk.mark >= 0 ? et.ms(mk.mark, e2) : 0.f;
     for (int k = 0; k < kFineSlots; ++k) fineCount += fineSlots[(size_t)k * kFineStride];
-    queueTails[1] = hostCtl[0]; for (uint32_t k = 0; k < kMaxClassifyChunks; ++k) queueTails[0] += hostCtl[2 + k];   // (1024-tile queue; sections of the 4096-tile queue)
+    queueTails[1] = hostCtl[kCtl1024 + kSecTails]; for (uint32_t k = 0; k < kMaxClassifyChunks; ++k) queueTails[0] += hostCtl[kSecTails + k];   // (1024-tile queue; sections of the 4096-tile queue)
     tm.openTiles = queueTails[0] + queueTails[1]; tm.openTileMicroTriangles = (uint64_t)queueTails[0] * 4096u + (uint64_t)queueTails[1] * 1024u;
     tm.fineMicroTriangles = fineCount; tm.uniqueItems = U; tm.activeItems = hc.activeStart[kNumLevels]; tm.stateBytes = hc.stateBytes; tm.microTriangles = 0;
     for (int l = 0; l < kNumLevels; ++l) tm.microTriangles += (uint64_t)hc.levelCount[l] << (2 * l);

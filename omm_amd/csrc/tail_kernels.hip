@@ -574,18 +574,38 @@ __global__ __launch_bounds__(256) void stream_preview_followers(const uint32_t* 
     const uint32_t item = ids[p], slot = hash_find_slot(table, sig[p]);
     if (slot != 0xFFFFFFFFu && table.vals[slot] != item) { early[item] = 1; followed[slot] = 1; }
 }
+struct LevelStarts { uint32_t at[kNumLevels]; };
+// ... and the early class as lists, one per level (list[start of the level + k], k < ctl[kStreamCtlEarly + level]): its digests are computed from these,
+// next to the running classification, where a pass over every item with a filter would take as long as the whole digest
 __global__ __launch_bounds__(256) void stream_preview_leaders(const uint32_t* __restrict__ ids, uint32_t n, const uint64_t* __restrict__ sig, HashTable table,
-                                                              const uint8_t* __restrict__ followed, uint8_t* __restrict__ early, uint32_t* __restrict__ ctl)
+                                                              const uint8_t* __restrict__ followed, uint8_t* __restrict__ early, uint32_t* __restrict__ ctl,
+                                                              const uint8_t* __restrict__ level, uint32_t* __restrict__ earlyList, LevelStarts starts)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    bool e = false;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    bool e = false; uint32_t item = 0, l = 0, at = 0;
     if (p < n && sig[p] != kEmptyKey) {
-        const uint32_t item = ids[p], slot = hash_find_slot(table, sig[p]);
+        item = ids[p];
+        const uint32_t slot = hash_find_slot(table, sig[p]);
         if (slot != 0xFFFFFFFFu && table.vals[slot] == item && followed[slot]) early[item] = 1;
         e = early[item] != 0;
+        l = level[item] < (uint32_t)kNumLevels ? level[item] : 0u;
+        #pragma unroll
+        for (int q = 0; q < kNumLevels; ++q) at = l == (uint32_t)q ? starts.at[q] : at;   // (select chain: the by-value array stays in scalar registers)
     }
     const unsigned long long b = __ballot(e);
-    if ((threadIdx.x & 63u) == 0 && b) atomicAdd(ctl + 3, (uint32_t)__popcll(b));   // statistics: size of the early class
+    // wave-aggregated append (the list is sorted by level, so a wave sees one level, two at a boundary)
+    unsigned long long todo = b;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t l0 = (uint32_t)__shfl((int)l, leader);
+        const unsigned long long same = __ballot(e && l == l0) & todo;
+        todo &= ~same;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(ctl + kStreamCtlEarly + l0, (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (e && l == l0) earlyList[at + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = item;
+    }
+    if (lane == 0 && b) atomicAdd(ctl + 3, (uint32_t)__popcll(b));   // statistics: size of the early class
 }
 void launch_stream_preview_prepare(const uint32_t* ids, uint32_t n, const float* uv, float texW, float texH, float* uv2, uint64_t* ofs2, uint8_t* early, hipStream_t stream)
 {
@@ -593,8 +613,9 @@ void launch_stream_preview_prepare(const uint32_t* ids, uint32_t n, const float*
 }
 // after the preview classification.  Uses the (still empty) digest table of the streamed placement for the signatures and clears it again.
 hipError_t run_stream_preview_flags(const uint32_t* ids, uint32_t n, uint32_t numActive, const uint8_t* states2, const uint8_t* level, uint8_t* early, uint32_t* ctl,
-                                    void* scratch, size_t scratchBytes, hipStream_t stream)
+                                    void* scratch, size_t scratchBytes, uint32_t* earlyList, const uint32_t levelStart[kNumLevels], hipStream_t stream)
 {
+    LevelStarts starts; for (int l = 0; l < kNumLevels; ++l) starts.at[l] = levelStart[l];
     if (n == 0) return hipSuccess;
     if (scratchBytes < stream_scratch_bytes(numActive)) return hipErrorInvalidValue;
     StreamScratch s = stream_carve(scratch, numActive);
@@ -602,7 +623,7 @@ hipError_t run_stream_preview_flags(const uint32_t* ids, uint32_t n, uint32_t nu
     const uint32_t slots = s.table.mask + 1u;
     hipLaunchKernelGGL(stream_preview_signature, grid, block, 0, stream, ids, n, states2, level, early, s.sizes64, s.table);   // (sizes64: free until the first segment)
     hipLaunchKernelGGL(stream_preview_followers, grid, block, 0, stream, ids, n, (const uint64_t*)s.sizes64, s.table, s.claimed, early);
-    hipLaunchKernelGGL(stream_preview_leaders, grid, block, 0, stream, ids, n, (const uint64_t*)s.sizes64, s.table, (const uint8_t*)s.claimed, early, ctl);
+    hipLaunchKernelGGL(stream_preview_leaders, grid, block, 0, stream, ids, n, (const uint64_t*)s.sizes64, s.table, (const uint8_t*)s.claimed, early, ctl, level, earlyList, starts);
     TAIL_CHECK(hipMemsetAsync(s.table.keys, 0xFF, hash_table_bytes(slots), stream));
     TAIL_CHECK(hipMemsetAsync(s.claimed, 0, (size_t)slots + 1, stream));
     return hipGetLastError();
@@ -622,7 +643,7 @@ __device__ __forceinline__ bool stream_candidate(const StreamSegment& g, uint32_
 __global__ __launch_bounds__(256) void stream_insert(StreamSegment g, HashTable table, int earlyOnly)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= g.count) return;
+    if (p >= g.count || (g.liveCount && p >= *g.liveCount)) return;
     const uint32_t item = g.ids[p];
     if (earlyOnly && !(g.early && g.early[item])) return;
     if (stream_candidate(g, item)) hash_put_min(table, g.digests[item], item);
@@ -697,6 +718,22 @@ hipError_t run_stream_segment(const StreamSegment& g, uint32_t numActive, void* 
                        (const unsigned long long*)cursor, stage, placed);
     hipLaunchKernelGGL(stream_advance, dim3(1), dim3(1), 0, stream, cursor, (const uint64_t*)s.sizes64, (const uint64_t*)s.ofs64, g.count);
     return hipGetLastError();
+}
+// Holds the placement stream until section `sec` of the tile queue is complete: done == tail (bake_kernels.hip: classify_tiles).  One lane, asleep
+// between two looks.  The tail is final (the stream was fenced behind the tile triage); a count that never arrives -- it cannot, short of a fault in
+// the classification launch -- ends the wait after ~4 s of the 100 MHz wall clock with the violation word set, which discards the streamed result.
+__global__ void stream_wait_section(const uint32_t* __restrict__ queueCtl, uint32_t sec, uint32_t* __restrict__ ctl)
+{
+    const uint32_t want = __hip_atomic_load(queueCtl + kSecTails + sec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t t0 = wall_clock64();
+    while (__hip_atomic_load(queueCtl + kSecDone + sec, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want) {
+        __builtin_amdgcn_s_sleep(64);
+        if (wall_clock64() - t0 > 400000000ull) { atomicOr(ctl + 1, 1u); break; }
+    }
+}
+void launch_stream_wait_section(const uint32_t* queueCtl, uint32_t section, uint32_t* ctl, hipStream_t stream)
+{
+    hipLaunchKernelGGL(stream_wait_section, dim3(1), dim3(1), 0, stream, queueCtl, section, ctl);
 }
 void launch_stream_publish(const unsigned long long* cursor, unsigned long long* hostSlot, hipStream_t stream)
 {
