@@ -29,15 +29,16 @@ typedef struct ommxBakeTimings {
     uint64_t fineMicroTriangles; /* micro-triangles that needed the level-line (fine) pass */
     float    setupMs;          /* device work-item setup: UV fetch, level selection, first-occurrence dedup, level grouping */
     /* ommCpuBake only: the finished OMM blocks are copied to their final place in the host array WHILE the classification runs (ommxBakerKnob_StreamChunks) */
-    uint32_t streamChunks;     /* classification launches whose blocks were streamed (0 = the result was copied after the bake) */
+    uint32_t streamChunks;     /* ranges of the classification whose blocks were streamed (0 = the result was copied after the bake) */
     uint64_t streamedBytes;    /* bytes that crossed PCIe that way */
     float    streamTailMs;     /* wall clock from the end of the classification to the last streamed byte on the host (the exposed part of the copy) */
     uint32_t openTiles;        /* tiles (4096 micro-triangles; 1024 for level-5 items) that the tile triage left open, i.e. the units the persistent
                                   classify_tiles launches really process */
     uint64_t openTileMicroTriangles; /* micro-triangles in those tiles */
-    uint32_t streamEarlyItems; /* streamed bakes: work items classified before the first range because another item shares their level-5 preview */
-    float    persistentMs;     /* HIP events around the persistent classify_tiles launch of the levels >= 6 alone (classifyMs also holds the tile triage and the
-                                  launches of the lower levels); 0 for streamed bakes, whose classification is several launches */
+    uint32_t streamEarlyItems; /* streamed bakes: work items classified with an EARLIER range than their own because another item shares their level-5
+                                  preview (possible duplicates: the first member of such a family pulls the others into its range) */
+    float    persistentMs;     /* HIP events around the persistent classify_tiles launch of the levels >= 6 alone (classifyMs also holds the tile triage, the
+                                  launches of the lower levels and, for streamed bakes, the preview); 0 for streamed bakes */
 } ommxBakeTimings;
 
 OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings* out);
@@ -49,10 +50,10 @@ typedef enum ommxBakerKnob {
     ommxBakerKnob_SetupKeyBits     = 0, /* TEST ONLY: work-item dedup keys are cut to this many bits (1..62), which forces 64-bit key collisions and with
                                            them the exact host form of SetupWorkItems; 0 = full 64-bit keys */
     ommxBakerKnob_ShardChunkBytes  = 1, /* sharded bake: bytes per rank and chunk of the block all-gather (>= 256; default 64 MiB, at most 8 chunks) */
-    ommxBakerKnob_StreamChunks     = 2, /* ommCpuBake: number of classification launches (ranges of work items in the order of the result) whose finished
-                                           OMM blocks are copied to their place in the host array while the next range is being classified; a value forces
-                                           streaming whatever the size of the bake (1 = classify everything, then one copy).  Default: bakes with >= 64 MiB
-                                           of packed states stream, one range per 32 MiB, at most 16 */
+    ommxBakerKnob_StreamChunks     = 2, /* ommCpuBake: number of ranges (of work items, in the order of the result) whose finished OMM blocks are copied to
+                                           their place in the host array while the following ranges are being classified; a value (1..32) forces streaming
+                                           whatever the size of the bake (1 = classify everything, then one copy).  Default: bakes with >= 64 MiB of packed
+                                           states stream, one range per 32 MiB, at most 24 */
     ommxBakerKnob_MAX_NUM          = 3
 } ommxBakerKnob;
 OMM_MI355X_API ommResult ommxSetBakerKnob(ommBaker baker, ommxBakerKnob knob, uint64_t value);

@@ -16,21 +16,47 @@ uint64_t classify_queue_records(const uint32_t count[kNumLevels], bool sections 
 // [kSecBases + k] first record, [kSecDone + k] records whose tiles are finished AND visible device-wide (== tail: the section is complete); the same four
 // words of the 1024-tile queue (one section) follow at kCtl1024.
 // `chunks` (optional, streamed bakes): the work items of the levels >= 6 are cut into `count` ranges of about equal tile counts -- in the order of the final
-// result: highest level first, then the position in that level's active list -- and every range gets a section of the queue; ONE persistent launch drains the
-// sections in order.  after(user, k, segments, n, false) is called once per range (after that launch is enqueued) with the range as segments of the active
-// lists: its work must wait for section k (launch_stream_wait_section).  after(user, count, ..., true) follows with the lower levels (which come last in the
+// result: highest level first, then the position in that level's active list -- and every range gets a PAIR of queue sections: 2k for its own items, 2k + 1 for
+// the early items of later ranges whose family starts in it; ONE persistent launch drains the sections in order.  after(user, k, segments, n, false) is called
+// once per range (after that launch is enqueued) with the range as segments of the active lists: its work must wait for sections 2k and 2k + 1
+// (launch_stream_wait_sections).  after(user, count, ..., true) follows with the lower levels (which come last in the
 // result).  mark(user) is called right before the persistent launch of the levels >= 6.
-constexpr uint32_t kMaxClassifyChunks = 64;
+constexpr uint32_t kMaxClassifyChunks = 64;   // sections of the 4096-tile queue; a streamed bake uses two per range (kMaxStreamRanges ranges at most)
+constexpr uint32_t kMaxStreamRanges = kMaxClassifyChunks / 2;
 constexpr uint32_t kSecTails = 0, kSecHeads = kMaxClassifyChunks, kSecBases = 2 * kMaxClassifyChunks, kSecDone = 3 * kMaxClassifyChunks, kCtl1024 = 4 * kMaxClassifyChunks;
+// (free words of the 1024-tile block: records in the staging list of the early items' tiles, per-range fill counts of their scatter)
+constexpr uint32_t kCtlEarlyStaged = kCtl1024 + 1, kCtlEarlyFill = kCtl1024 + 2;
 constexpr uint32_t kClassifyCtlWords = 8 * kMaxClassifyChunks;
 struct ClassifySegment { uint32_t level, first, count; };   // activeIds[first .. first + count), all of one level
+// the sliced levels of one tile size, highest level first: items activeIds[first[k] ..), tiles [tileStart[k], tileStart[k + 1]) of the tile enumeration
+struct TileLevels { uint32_t n; uint32_t level[kNumLevels], first[kNumLevels], tileStart[kNumLevels + 1]; };
+// ranges of the 4096-tile enumeration (= of the final order of the result), cut at work-item boundaries: range k = tiles [cut[k], cut[k + 1])
+struct TileSections { uint32_t n; uint32_t cut[kMaxClassifyChunks + 1]; };
+struct ClassifyPlan { TileLevels big, small; uint64_t totalBig, totalSmall; TileSections ranges; };
+// range of the work item at position `pos` of the active list
+__device__ __forceinline__ uint32_t section_of_position(uint32_t pos, const TileLevels& L, const TileSections& S)
+{
+    uint32_t t = 0;
+    for (uint32_t g = 0; g < L.n; ++g) {
+        const uint32_t shift = 2u * (L.level[g] - 6u), cnt = (L.tileStart[g + 1] - L.tileStart[g]) >> shift;
+        if (pos >= L.first[g] && pos - L.first[g] < cnt) t = L.tileStart[g] + ((pos - L.first[g]) << shift);
+    }
+    uint32_t sec = 0;
+    while (sec + 1u < S.n && t >= S.cut[sec + 1u]) ++sec;
+    return sec;
+}
+
+// the plan launch_classify follows for these lists (pure host arithmetic; a streamed bake needs the ranges before the launch: section_of_position)
+void classify_plan(const uint32_t first[kNumLevels], const uint32_t count[kNumLevels], uint32_t ranges, ClassifyPlan* plan);
 struct ClassifyChunks {
     uint32_t count;
     void (*after)(void* user, uint32_t chunk, const ClassifySegment* segs, uint32_t numSegs, bool last);
     void (*mark)(void* user);
     void* user;
-    const uint8_t* early;   // or null.  Per item: 1 = classify it in a launch of its own class BEFORE the first range (streamed bakes: possible duplicates)
-    void (*afterEarly)(void* user, const ClassifySegment* segs, uint32_t numSegs);   // behind that launch: one segment per level >= 6 (all its items)
+    // Streamed bakes, or null: early[item] == 1 marks a possible duplicate (tail_kernels.hip "preview"); it is classified in the range of the FIRST member of
+    // its family, earlyLead[item] = that member's position in activeIds -- so a range's section pair holds everything the placement of the range depends on.
+    const uint8_t* early; const uint32_t* earlyLead;
+    void* earlyStage;       // >= kTileRecordBytes x (open tiles of early items) bytes of scratch, free until the persistent launch starts
 };
 // the whole-item kernel at `level` over a plain item list (used for the level-2 preview of a streamed bake)
 hipError_t launch_classify_items(const ClassifyParams& P, const ItemArrays& A, const uint32_t* ids, uint32_t count, uint32_t level, hipStream_t stream);
@@ -39,9 +65,17 @@ hipError_t launch_classify(const ClassifyParams& P, const ItemArrays& A, const u
 // level-0 hierarchical query per work item: uniform items get stateMask = 1 << state and active = 0
 void launch_triage(const ClassifyParams& P, const float* uv, const SetupCounters* counters, uint32_t maxItems, uint32_t* stateMask, uint8_t* active, hipStream_t stream);
 // XXH64(seed 42) of the 3-state byte stream of each listed item -> digests[item]
-// (only != null: the listed items with (only[item] != 0) == (want != 0); liveCount != null: a device word with the number of listed items, <= numItems)
+// (only != null: the listed items with (only[item] != 0) == (want != 0))
 void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
-                   uint64_t* digests, hipStream_t stream, const uint8_t* only = nullptr, int want = 0, const uint32_t* liveCount = nullptr);
+                   uint64_t* digests, hipStream_t stream, const uint8_t* only = nullptr, int want = 0);
+// streamed bakes, levels >= 6: two lists in one launch of small workgroups (runs next to the persistent classification launch)
+struct DigestLists {
+    // list A: ids[0 .. count) of ONE level, optionally only the items with (only[item] != 0) == (want != 0)
+    const uint32_t* ids; uint32_t count, level; const uint8_t* only; int want;
+    // list B: listB[*liveStart .. + *liveCount) (device words), at most capacityB entries, every item with its own level itemLevel[item] >= 6
+    const uint32_t* listB; uint32_t capacityB; const uint32_t* liveStart; const uint32_t* liveCount; const uint8_t* itemLevel;
+};
+void launch_digest_lists(const uint8_t* states, const uint64_t* stateOfs, const DigestLists& lists, uint32_t bits, uint64_t* digests, hipStream_t stream);
 // summed-area table of (alpha > cutoff)
 // (scratch: sat_scratch_bytes(w, h) bytes of device memory, free again once the stream has passed the build)
 size_t sat_scratch_bytes(int w, int h);
@@ -100,27 +134,29 @@ struct StreamSegment {
     const uint32_t* stateMask; const uint32_t* knownCount; const uint64_t* digests; const uint8_t* states; const uint64_t* stateOfs;
     float rejectionThreshold; int bits, disableDedup;
     const uint8_t* early;   // or null: per item, 1 = classified (and its digest entered into the table) before the first range
-    const uint32_t* liveCount;   // or null: device word with the number of ids in use (<= count; the early lists are filled on the device)
+    const uint32_t* liveCount; const uint32_t* liveStart;   // or null: the ids in use are the device-side slice ids[*liveStart .. + *liveCount) (count = capacity)
+    const uint8_t* itemLevel;    // or null: per-item level (a slice of the early list mixes levels; `level` is ignored then)
 };
-// the early items of a segment: their digests enter the table before anything is placed (run after their classification + launch_digest(.., early, 1))
-void launch_stream_insert_early(const StreamSegment& g, uint32_t numActive, void* scratch, size_t scratchBytes, hipStream_t stream);
+// a slice of the early list (g.liveStart / g.liveCount / g.itemLevel): digests into the table (run after launch_digest_list on the same slice)
+void launch_stream_insert_list(const StreamSegment& g, uint32_t numActive, void* scratch, size_t scratchBytes, hipStream_t stream);
 size_t stream_scratch_bytes(uint32_t numActive);
 hipError_t run_stream_begin(uint32_t* activeIds, uint32_t numActive, const float* uv, const uint8_t* level, void* scratch, size_t scratchBytes, hipStream_t stream);
 // placed[item] <- final arrayData offset of the item's block (~0: no block); *cursor advances by the bytes placed; ctl: 3 words {blocks placed, violation, mismatch}
 hipError_t run_stream_segment(const StreamSegment& g, uint32_t numActive, void* scratch, size_t scratchBytes, unsigned long long* cursor, uint8_t* stage,
                               uint64_t* placed, uint32_t* ctl, hipStream_t stream);
 void launch_stream_publish(const unsigned long long* cursor, unsigned long long* hostSlot, hipStream_t stream);
-// `stream` does not pass until section `section` of the 4096-tile queue is complete (every block of that range classified and visible); the stream must
-// already be ordered behind the tile triage.  ctl: the streamed result's control words (a wait that gives up sets the violation word)
-void launch_stream_wait_section(const uint32_t* queueCtl, uint32_t section, uint32_t* ctl, hipStream_t stream);
+// `stream` does not pass until sections [first, first + n) of the 4096-tile queue are complete (every block in them classified and visible); the stream
+// must already be ordered behind the tile triage.  ctl: the streamed result's control words (a wait that gives up sets the violation word)
+void launch_stream_wait_sections(const uint32_t* queueCtl, uint32_t first, uint32_t n, uint32_t* ctl, hipStream_t stream);
 // preview of the items of level >= 6 (tail_kernels.hip "preview"): prepare -> launch_classify_items(kPreviewLevel, preview buffers) -> flags
 constexpr uint32_t kPreviewLevel = 5, kPreviewSlotBytes = 256;   // 1024 micro-triangles x 2 bits
 void launch_stream_preview_prepare(const uint32_t* ids, uint32_t n, const float* uv, float texW, float texH, float* uv2, uint64_t* ofs2, uint8_t* early, hipStream_t stream);
-// ctl: kStreamCtlWords words {blocks placed, violation, mismatch, early items, early items per level [kStreamCtlEarly + level]}
-constexpr uint32_t kStreamCtlEarly = 4, kStreamCtlWords = 4 + 16;
-// early[item] <- 1 for the early class; the class also as per-level lists earlyList[levelStart[level] + k], k < ctl[kStreamCtlEarly + level]
-hipError_t run_stream_preview_flags(const uint32_t* ids, uint32_t n, uint32_t numActive, const uint8_t* states2, const uint8_t* level, uint8_t* early, uint32_t* ctl,
-                                    void* scratch, size_t scratchBytes, uint32_t* earlyList, const uint32_t levelStart[kNumLevels], hipStream_t stream);
+// ctl: kStreamCtlWords words {blocks placed, violation, mismatch, early items; per range: early items classified with it, start of their slice of the early list, fill}
+constexpr uint32_t kStreamCtlEarlyCount = 4, kStreamCtlEarlyStart = 4 + kMaxStreamRanges, kStreamCtlEarlyFill = 4 + 2 * kMaxStreamRanges, kStreamCtlWords = 4 + 3 * kMaxStreamRanges;
+// ids = activeIds + listOffset (the levels >= 6).  early[item] <- 1 for the early class, earlyLead[item] <- position (in activeIds) of the first member of its
+// family; the class also as a list ordered by the range of that member: earlyList[ctl[kStreamCtlEarlyStart + k] .. + ctl[kStreamCtlEarlyCount + k])
+hipError_t run_stream_preview_flags(const uint32_t* ids, uint32_t n, uint32_t listOffset, uint32_t numActive, const uint8_t* states2, const uint8_t* level, uint8_t* early,
+                                    uint32_t* ctl, void* scratch, size_t scratchBytes, uint32_t* earlyLead, uint32_t* earlyList, const ClassifyPlan& plan, hipStream_t stream);
 void launch_stream_verify(const uint32_t* order, const uint32_t* dstOfs, uint32_t numOmms, const uint64_t* placed, uint32_t* ctl, hipStream_t stream);
 
 // ---- device tail (tail_kernels.hip) ----

@@ -103,33 +103,27 @@ void launch_narrow_indices(const int32_t* in, uint32_t n, int bytesPerIndex, voi
 //               persistent classify_tiles launch drains (all levels of one tile size share one queue: no per-level launches)
 // At the bench configuration 59 % of the 2.04 M tiles are settled here.
 // ------------------------------------------------------------------------------------------------
-struct TileLevels {                 // the sliced levels of one tile size, highest level first
-    uint32_t n;
-    uint32_t level[kNumLevels], first[kNumLevels], tileStart[kNumLevels + 1]; // items activeIds[first .. ), tiles [tileStart[k], tileStart[k+1])
-};
-// The queue of one tile size is cut into sections, each drained by a persistent launch of its own.  Ordinary bakes: one section.  Streamed bakes
-// (ommCpuBake): section 0 = the items classified early (all ranges) + range 0, section k = range k; a section's records start at base[k], its fill
-// count is queueCtl word tails[k]; capacity = every tile that can land there.
-struct TileSections {
-    uint32_t n;                                   // sections in use
-    uint32_t cut[kMaxClassifyChunks + 1];         // range k = tiles [cut[k], cut[k + 1]) of the tile enumeration (section k; range 0 -> section 0)
-    uint32_t base[kMaxClassifyChunks];            // first record of section k
-};
+// The 4096-tile queue is cut into sections that ONE persistent launch drains in order (TileLevels / TileSections / ClassifyPlan: bake_kernels.h).  Ordinary
+// bakes: one section.  Streamed bakes (ommCpuBake) with K ranges: section 2k = the tiles of range k's own items, at records [cut[k], ..) of the queue's
+// first copy; section 2k + 1 = the tiles of EARLY items of later ranges whose family starts in range k, in the queue's second copy ([total, 2 total)),
+// ordered by range with a staging pass (early_tiles_*).
 // record = 3 x uint4 (everything a tile's workgroup needs, in ONE memory round trip):
 //   [0] x = item | degenerate << 30 | rectOk << 31, y = tile in item | level << 24, z = sx | sy << 16, w = ex | ey << 16 (addressed texel rectangle)
 //   [1] the item's uv[0..3]      [2] uv[4], uv[5], address of the tile's packed states (lo, hi)
 constexpr uint32_t kTileRecordWords = 3;   // uint4 per record (bake_kernels.h: kTileRecordBytes)
 template <int TILE>
 __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays A, const uint32_t* __restrict__ activeIds, TileLevels L,
-                                                    uint4* __restrict__ queue, uint32_t* __restrict__ sectionTails, TileSections S,
-                                                    const uint8_t* __restrict__ early, uint32_t* __restrict__ sectionBases)
+                                                    uint4* __restrict__ queue, uint32_t* __restrict__ queueCtl, TileSections S,
+                                                    const uint8_t* __restrict__ early, const uint32_t* __restrict__ earlyLead, uint4* __restrict__ earlyStage)
 {
     constexpr uint32_t TILE_LOG4 = TILE == 4096 ? 6u : 5u;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < S.n) sectionBases[t] = S.base[t];   // (the persistent launch walks the sections by these)
+    uint32_t* sectionTails = queueCtl + kSecTails;
+    const uint32_t stride = S.n > 1u ? 2u : 1u;   // (streamed: the ranges' own sections are the even ones)
+    if (t < S.n) queueCtl[kSecBases + stride * t] = S.cut[t];   // (the persistent launch walks the sections by these; the odd ones: early_tiles_bases)
     const uint32_t lane = threadIdx.x & 63u;
     const bool live = t < L.tileStart[L.n];
-    uint32_t sec = 0;
+    uint32_t sec = 0; bool isEarly = false;
     int st = -1; uint32_t item = 0, tileInItem = 0, level = TILE_LOG4; TexRect r; r.sx = r.sy = r.ex = r.ey = 0; r.ok = false;
     float uvv[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
     const uint32_t bits = (uint32_t)P.format, tileBytes = (uint32_t)TILE * bits / 8u;
@@ -139,7 +133,11 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
         level = L.level[k];
         const uint32_t shift = 2u * (level - TILE_LOG4), rel = t - L.tileStart[k];   // tiles per item = 4^(level - log4 TILE)
         item = activeIds[L.first[k] + (rel >> shift)]; tileInItem = rel & ((1u << shift) - 1u);
-        if (S.n > 1u && !(early && early[item])) while (sec + 1u < S.n && t >= S.cut[sec + 1u]) ++sec;   // (early items: section 0, whatever their range)
+        if (S.n > 1u) {
+            isEarly = TILE == 4096 && early && early[item] == 1;
+            if (isEarly) sec = section_of_position(earlyLead[item], L, S);   // the range of the family's first member (<= the item's own range)
+            else while (sec + 1u < S.n && t >= S.cut[sec + 1u]) ++sec;
+        }
         const float* uv = A.uv + 6ull * item;
         #pragma unroll
         for (int q = 0; q < 6; ++q) uvv[q] = uv[q];
@@ -149,20 +147,26 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
         if (P.useCoarse) st = region_state<ModeDynamic>(P, sub, maxAbs, no_window());
     }
     // ---- open tiles: wave-compacted append, section by section (a wave sees one section, two at a range boundary, early items apart) ----
+    // (the tiles of early items go to the staging list with their range in bits 16..21 of word 1; early_tiles_scatter orders them by range)
     const bool open = live && st < 0;
+    const uint32_t key = sec * 2u + (isEarly ? 1u : 0u);
     unsigned long long todo = __ballot(open);
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t s0 = (uint32_t)__shfl((int)sec, leader);
-        const unsigned long long ob = __ballot(open && sec == s0) & todo;
+        const uint32_t k0 = (uint32_t)__shfl((int)key, leader);
+        const unsigned long long ob = __ballot(open && key == k0) & todo;
         todo &= ~ob;
         uint32_t wbase = 0;
-        if ((int)lane == leader) wbase = S.base[s0] + atomicAdd(sectionTails + s0, (uint32_t)__popcll(ob));
+        if ((int)lane == leader) {
+            const uint32_t n = (uint32_t)__popcll(ob), s0 = k0 >> 1;
+            if (k0 & 1u) { wbase = atomicAdd(queueCtl + kCtlEarlyStaged, n); atomicAdd(sectionTails + 2u * s0 + 1u, n); }
+            else wbase = S.cut[s0] + atomicAdd(sectionTails + stride * s0, n);
+        }
         wbase = __shfl(wbase, leader);
-        if (open && sec == s0) {
-            uint4* rec = queue + (size_t)kTileRecordWords * (wbase + __popcll(ob & ((1ull << lane) - 1ull)));
+        if (open && key == k0) {
+            uint4* rec = ((k0 & 1u) ? earlyStage : queue) + (size_t)kTileRecordWords * (wbase + __popcll(ob & ((1ull << lane) - 1ull)));
             const unsigned long long dst = (unsigned long long)(A.states + A.stateOfs[item] + (size_t)tileInItem * tileBytes);
-            rec[0] = make_uint4(item | (A.degenerate[item] ? 0x40000000u : 0u) | (r.ok ? 0x80000000u : 0u), tileInItem | (level << 24),
+            rec[0] = make_uint4(item | (A.degenerate[item] ? 0x40000000u : 0u) | (r.ok ? 0x80000000u : 0u), tileInItem | (level << 24) | ((k0 & 1u) ? (k0 >> 1) << 16 : 0u),
                                 (uint32_t)r.sx | ((uint32_t)r.sy << 16), (uint32_t)r.ex | ((uint32_t)r.ey << 16));
             rec[1] = make_uint4(__float_as_uint(uvv[0]), __float_as_uint(uvv[1]), __float_as_uint(uvv[2]), __float_as_uint(uvv[3]));
             rec[2] = make_uint4(__float_as_uint(uvv[4]), __float_as_uint(uvv[5]), (uint32_t)dst, (uint32_t)(dst >> 32));
@@ -559,15 +563,11 @@ uint64_t classify_queue_records(const uint32_t count[kNumLevels], bool sections)
     return n;
 }
 
-template <bool FP32, class MD>
-static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, const uint32_t* activeIds, const uint32_t first[kNumLevels],
-                               const uint32_t count[kNumLevels], uint4* queue, uint32_t* queueCtl, uint32_t numCUs, const ClassifyChunks& chunks, hipStream_t stream)
+void classify_plan(const uint32_t first[kNumLevels], const uint32_t count[kNumLevels], uint32_t ranges, ClassifyPlan* plan)
 {
-    // queueCtl: the 4096-tile queue's section words (kSecTails / kSecHeads / kSecBases / kSecDone), then the same four words of the 1024-tile queue (one section)
-    uint32_t* ctl1024 = queueCtl + kCtl1024;
-    struct Cls { TileLevels L; uint64_t total; } cls[2];
+    memset(plan, 0, sizeof *plan);
     for (int c = 0; c < 2; ++c) {   // 0: 4096-tiles (levels 6..12, highest first), 1: 1024-tiles (level 5)
-        TileLevels& L = cls[c].L; memset(&L, 0, sizeof L);
+        TileLevels& L = c == 0 ? plan->big : plan->small;
         uint64_t total = 0;
         for (int level = c == 0 ? kMaxLevel : 5; level >= (c == 0 ? 6 : 5); --level) {
             if (!count[level]) continue;
@@ -577,37 +577,82 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
         }
         if (total > 0x7FFFFFFFull) total = 0;   // (that many tiles cannot happen: their packed states would not fit in HBM)
         L.tileStart[L.n] = (uint32_t)total;
-        cls[c].total = total;
+        (c == 0 ? plan->totalBig : plan->totalSmall) = total;
     }
-    // sections of the 4096-tile queue (TileSections): K ranges of (about) equal tile counts, cut at work-item boundaries, in the order of the tile
-    // enumeration = the order of the final result (highest level first, then the position in that level's active list)
-    const uint32_t K = cls[0].total ? (chunks.count ? chunks.count : 1u) : 0u;
-    TileSections S; memset(&S, 0, sizeof S); S.n = K;
+    // ranges of the 4096-tile enumeration: K pieces of (about) equal tile counts, cut at work-item boundaries, in the order of the tile enumeration = the order
+    // of the final result (highest level first, then the position in that level's active list)
     // (equal ranges: measured against growing and bell-shaped splits, which leave the copy engine idle early or a large last range exposed -- the PCIe copy
-    //  is the slower pipe from the first range on, so it wants a steady supply of small pieces; a launch boundary costs ~0.25 ms of drain and refill)
+    //  is the slower pipe from the first range on, so it wants a steady supply of small pieces)
+    if (ranges > kMaxStreamRanges) ranges = kMaxStreamRanges;
+    const uint32_t K = plan->totalBig ? (ranges ? ranges : 1u) : 0u;
+    TileSections& S = plan->ranges; S.n = K;
     for (uint32_t k = 1; k <= K; ++k) {
-        uint64_t t = cls[0].total * k / K;
+        uint64_t t = plan->totalBig * k / K;
         if (k < K) {
-            const TileLevels& L = cls[0].L; uint32_t g = 0;
+            const TileLevels& L = plan->big; uint32_t g = 0;
             while (g + 1 < L.n && t >= L.tileStart[g + 1]) ++g;
             const uint32_t per = tiles_per_item(L.level[g], 6u);
             t = L.tileStart[g] + (t - L.tileStart[g]) / per * per;
         }
         S.cut[k] = (uint32_t)t;
     }
-    // section 0 can receive every tile (the early items of all ranges); section k >= 1 the tiles of its range
-    uint64_t recOfs = K > 1 ? cls[0].total : 0;
-    for (uint32_t k = 1; k < K; ++k) { S.base[k] = (uint32_t)(recOfs + S.cut[k]); }
-    recOfs += cls[0].total;
-    uint4* q1024 = queue + recOfs * kTileRecordWords;
+}
+
+// the staged tiles of the early items, ordered by range into the queue's second copy: bases of the odd sections (their tails were counted by triage_tiles) ...
+__global__ void early_tiles_bases(uint32_t* __restrict__ queueCtl, uint32_t ranges, uint32_t secondCopy)
+{
+    uint32_t run = secondCopy;
+    for (uint32_t k = 0; k < ranges; ++k) { queueCtl[kSecBases + 2u * k + 1u] = run; run += queueCtl[kSecTails + 2u * k + 1u]; }
+}
+// ... and the records (bits 16..21 of word 1 = range, removed here)
+__global__ __launch_bounds__(256) void early_tiles_scatter(const uint4* __restrict__ staged, uint4* __restrict__ queue, uint32_t* __restrict__ queueCtl)
+{
+    __shared__ uint32_t s_cnt[kMaxStreamRanges], s_base[kMaxStreamRanges];   // (one global atomic per range and 256 records, not per record)
+    const uint32_t n = queueCtl[kCtlEarlyStaged];
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + threadIdx.x;
+        if (threadIdx.x < kMaxStreamRanges) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = r0, r2 = r0; uint32_t k = 0, local = 0;
+        if (i < n) {
+            r0 = staged[(size_t)kTileRecordWords * i]; r1 = staged[(size_t)kTileRecordWords * i + 1]; r2 = staged[(size_t)kTileRecordWords * i + 2];
+            k = (r0.y >> 16) & (kMaxStreamRanges - 1u);
+            local = atomicAdd(&s_cnt[k], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < kMaxStreamRanges && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(queueCtl + kCtlEarlyFill + threadIdx.x, s_cnt[threadIdx.x]);
+        __syncthreads();
+        if (i < n) {
+            uint4* dst = queue + (size_t)kTileRecordWords * (queueCtl[kSecBases + 2u * k + 1u] + s_base[k] + local);
+            dst[0] = make_uint4(r0.x, r0.y & 0xFF00FFFFu, r0.z, r0.w); dst[1] = r1; dst[2] = r2;
+        }
+        __syncthreads();
+    }
+}
+
+template <bool FP32, class MD>
+static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, const uint32_t* activeIds, const uint32_t first[kNumLevels],
+                               const uint32_t count[kNumLevels], uint4* queue, uint32_t* queueCtl, uint32_t numCUs, const ClassifyChunks& chunks, hipStream_t stream)
+{
+    // queueCtl: the 4096-tile queue's section words (kSecTails / kSecHeads / kSecBases / kSecDone), then the same four words of the 1024-tile queue (one section)
+    uint32_t* ctl1024 = queueCtl + kCtl1024;
+    ClassifyPlan plan; classify_plan(first, count, chunks.count, &plan);
+    const TileSections& S = plan.ranges; const uint32_t K = S.n;
+    const bool paired = K > 1u;   // (two sections per range; the queue holds a second copy of the levels >= 6 for the odd ones: classify_queue_records)
+    uint4* q1024 = queue + (plan.totalBig * (paired ? 2u : 1u)) * kTileRecordWords;
     TileSections one; memset(&one, 0, sizeof one); one.n = 1;
     // ---- sliced items, step 1: tile triage of both tile sizes (settled tiles are final after it, open ones are queued) ----
-    if (cls[0].total)
-        hipLaunchKernelGGL((triage_tiles<4096>), dim3((uint32_t)((cls[0].total + 255u) / 256u)), dim3(256), 0, stream, P, A, activeIds, cls[0].L, queue, queueCtl + kSecTails, S, chunks.early,
-                           queueCtl + kSecBases);
-    if (cls[1].total)
-        hipLaunchKernelGGL((triage_tiles<1024>), dim3((uint32_t)((cls[1].total + 255u) / 256u)), dim3(256), 0, stream, P, A, activeIds, cls[1].L, q1024, ctl1024 + kSecTails, one, (const uint8_t*)nullptr,
-                           ctl1024 + kSecBases);
+    if (plan.totalBig) {
+        hipLaunchKernelGGL((triage_tiles<4096>), dim3((uint32_t)((plan.totalBig + 255u) / 256u)), dim3(256), 0, stream, P, A, activeIds, plan.big, queue, queueCtl, S,
+                           paired ? chunks.early : (const uint8_t*)nullptr, chunks.earlyLead, (uint4*)chunks.earlyStage);
+        if (paired && chunks.early) {
+            hipLaunchKernelGGL(early_tiles_bases, dim3(1), dim3(1), 0, stream, queueCtl, K, (uint32_t)plan.totalBig);
+            hipLaunchKernelGGL(early_tiles_scatter, dim3(1024), dim3(256), 0, stream, (const uint4*)chunks.earlyStage, queue, queueCtl);
+        }
+    }
+    if (plan.totalSmall)
+        hipLaunchKernelGGL((triage_tiles<1024>), dim3((uint32_t)((plan.totalSmall + 255u) / 256u)), dim3(256), 0, stream, P, A, activeIds, plan.small, q1024, ctl1024, one,
+                           (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint4*)nullptr);
     // ---- small items: one launch per level ----
     for (uint32_t level = 0; level < 5u; ++level) {
         if (!count[level]) continue;
@@ -620,24 +665,20 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
     // ---- sliced items, step 2: one persistent launch per queue; every CU holds OMMX_CLASSIFY_WAVES workgroups of 4 waves (one per SIMD) ----
     // (streamed bakes leave one workgroup slot per CU to the placement kernels that run next to the persistent launch)
     const uint64_t want = (uint64_t)numCUs * (chunks.after ? OMMX_CLASSIFY_WAVES - 1 : OMMX_CLASSIFY_WAVES);
-    if (cls[1].total) {
-        const dim3 cg((uint32_t)(cls[1].total < want ? cls[1].total : want)), cb(BLOCK);
+    if (plan.totalSmall) {
+        const dim3 cg((uint32_t)(plan.totalSmall < want ? plan.totalSmall : want)), cb(BLOCK);
         hipLaunchKernelGGL((classify_tiles<FP32, true, 1024, MD>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)q1024, ctl1024, 1u);
     }
     if (chunks.mark) chunks.mark(chunks.user);   // (everything but the persistent launch of the levels >= 6 is enqueued)
-    if (cls[0].total) {
-        const dim3 cg((uint32_t)(cls[0].total < want ? cls[0].total : want)), cb(BLOCK);
-        hipLaunchKernelGGL((classify_tiles<FP32, true, 4096, MD>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)queue, queueCtl, K);
+    if (plan.totalBig) {
+        const dim3 cg((uint32_t)(plan.totalBig < want ? plan.totalBig : want)), cb(BLOCK);
+        hipLaunchKernelGGL((classify_tiles<FP32, true, 4096, MD>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)queue, queueCtl,
+                           paired ? 2u * K : K);
     }
     for (uint32_t k = 0; k < K; ++k) {
-        if (k == 0 && chunks.afterEarly && chunks.early) {   // every level >= 6 as one segment: the hook looks at the early items in it
-            ClassifySegment segs[kNumLevels]; uint32_t ns = 0;
-            for (uint32_t g = 0; g < cls[0].L.n; ++g) { segs[ns].level = cls[0].L.level[g]; segs[ns].first = cls[0].L.first[g]; segs[ns].count = count[cls[0].L.level[g]]; ns++; }
-            chunks.afterEarly(chunks.user, segs, ns);
-        }
         if (chunks.after) {   // the work items of this range, as segments of the per-level active lists, in the order of the final result
             ClassifySegment segs[kNumLevels]; uint32_t ns = 0;
-            const TileLevels& L = cls[0].L;
+            const TileLevels& L = plan.big;
             for (uint32_t g = 0; g < L.n; ++g) {
                 const uint32_t lo = S.cut[k] > L.tileStart[g] ? S.cut[k] : L.tileStart[g], hi = S.cut[k + 1] < L.tileStart[g + 1] ? S.cut[k + 1] : L.tileStart[g + 1];
                 if (lo >= hi) continue;
@@ -657,9 +698,9 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
 hipError_t launch_classify(const ClassifyParams& P, const ItemArrays& A, const uint32_t* activeIds, const uint32_t first[kNumLevels], const uint32_t count[kNumLevels],
                            void* queue, uint32_t* queueCtl, uint32_t numCUs, hipStream_t stream, const ClassifyChunks* chunksIn)
 {
-    ClassifyChunks chunks; chunks.count = 1; chunks.after = nullptr; chunks.mark = nullptr; chunks.user = nullptr; chunks.early = nullptr; chunks.afterEarly = nullptr;
+    ClassifyChunks chunks; memset(&chunks, 0, sizeof chunks); chunks.count = 1;
     if (chunksIn) chunks = *chunksIn;
-    if (chunks.count > kMaxClassifyChunks - 1) chunks.count = kMaxClassifyChunks - 1;
+    if (chunks.count > kMaxStreamRanges) chunks.count = kMaxStreamRanges;
     uint64_t any = 0; for (int l = 0; l < kNumLevels; ++l) any += count[l];
     if (!any) return hipSuccess;
     hipError_t e = hipMemsetAsync(queueCtl, 0, kClassifyCtlWords * sizeof(uint32_t), stream);
@@ -738,11 +779,10 @@ __device__ __forceinline__ uint32_t state_at(const uint8_t* p, uint32_t u, uint3
 
 __global__ __launch_bounds__(256) void digest_items(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs,
                                                     const uint32_t* __restrict__ itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
-                                                    uint64_t* __restrict__ digests, const uint8_t* __restrict__ only, int want, const uint32_t* __restrict__ liveCount)
+                                                    uint64_t* __restrict__ digests, const uint8_t* __restrict__ only, int want)
 {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t it = gid >> 2, acc = gid & 3u;
-    if (liveCount && *liveCount < numItems) numItems = *liveCount;   // (the list's fill count lives on the device)
     bool live = it < numItems;
     const uint32_t item = live ? itemIds[it] : 0u;
     if (live && only && (only[item] != 0) != (want != 0)) live = false;   // (streamed bakes: the items of one class only)
@@ -797,44 +837,59 @@ __global__ __launch_bounds__(256) void digest_items(const uint8_t* __restrict__ 
 // The walk over an item is sequential (XXH64's accumulators are chains), so a workgroup's run time is (bytes per item / chunk) round trips to HBM,
 // however few items a launch has: with 256-byte chunks a 16 KiB item took 64 round trips (0.7 ms even for a handful of items, and the streamed bake
 // digests range by range); items of >= 1 KiB are staged in 1 KiB chunks (65.8 KB of LDS per workgroup), 16 round trips.
-constexpr int DG_ITEMS = 64;
-template <int DG_CHUNK>
-__global__ __launch_bounds__(256) void digest_items_lds(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs,
-                                                        const uint32_t* __restrict__ itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
-                                                        uint64_t* __restrict__ digests, const uint8_t* __restrict__ only, int want, const uint32_t* __restrict__ liveCount)
+// A streamed bake digests range by range, next to the persistent classification launch (29 KB of LDS and one wave slot per SIMD are free on a CU): a
+// few thousand items per launch, so the launch takes as long as ONE workgroup -- 16 items x 1 KiB chunks (16 round trips for a 16 KiB item instead of
+// 64, at raised wave priority) serve those; the hash lanes are the first 4 x ITEMS threads, all 256 load.
+template <int DG_CHUNK, int DG_ITEMS, bool MIXED>
+__global__ __launch_bounds__(256) void digest_items_lds(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs, DigestLists D, uint32_t blocksA, uint32_t bits,
+                                                        uint64_t* __restrict__ digests)
 {
     constexpr int DG_STRIDE = DG_CHUNK / 4 + 1;
     __shared__ uint32_t s_buf[DG_ITEMS * DG_STRIDE];
     __shared__ const uint8_t* s_ptr[DG_ITEMS];
-    const uint32_t tid = threadIdx.x, first = blockIdx.x * DG_ITEMS;
-    if (liveCount && *liveCount < numItems) numItems = *liveCount;   // (the list's fill count lives on the device: the grid covers its capacity)
-    if (first >= numItems) return;
-    const uint32_t il = tid >> 2, acc = tid & 3u, it = first + il;
-    bool live = it < numItems;
-    if (live && only && (only[itemIds[it]] != 0) != (want != 0)) live = false;   // (streamed bakes: the items of one class only)
-    if (tid < DG_ITEMS) {
-        const uint32_t j = first + tid;
-        const bool take = j < numItems && !(only && (only[itemIds[j]] != 0) != (want != 0));
-        s_ptr[tid] = take ? states + stateOfs[itemIds[j]] : nullptr;
+    __shared__ uint32_t s_bytes[MIXED ? DG_ITEMS : 1], s_maxBytes;
+    const uint32_t tid = threadIdx.x;
+    const bool listB = MIXED && blockIdx.x >= blocksA;
+    const uint32_t* itemIds = D.ids; uint32_t numItems = D.count, first = blockIdx.x * DG_ITEMS;
+    const uint8_t* only = D.only;
+    if (listB) {
+        numItems = *D.liveCount < D.capacityB ? *D.liveCount : D.capacityB; itemIds = D.listB + *D.liveStart; first = (blockIdx.x - blocksA) * DG_ITEMS; only = nullptr;
     }
+    if (first >= numItems) return;
+    if (DG_ITEMS < 64) __builtin_amdgcn_s_setprio(3);   // (a latency-bound guest next to the classification: its few instructions should not queue behind 6 waves per SIMD)
+    const uint32_t il = tid >> 2, acc = tid & 3u, it = first + il;
+    const bool hasher = il < (uint32_t)DG_ITEMS;
+    bool live = hasher && it < numItems;
+    if (live && only && (only[itemIds[it]] != 0) != (D.want != 0)) live = false;   // (streamed bakes: the items of one class only)
+    if (MIXED) { if (tid == 0) s_maxBytes = 0; __syncthreads(); }
+    uint32_t level = D.level;
+    if (tid < (uint32_t)DG_ITEMS) {
+        const uint32_t j = first + tid;
+        const bool take = j < numItems && !(only && (only[itemIds[j]] != 0) != (D.want != 0));
+        s_ptr[tid] = take ? states + stateOfs[itemIds[j]] : nullptr;
+        if (MIXED) { const uint32_t l = listB ? (uint32_t)D.itemLevel[itemIds[j < numItems ? j : first]] : level; const uint32_t b = take ? ((1u << (2u * l)) * bits) >> 3 : 0u; s_bytes[tid] = b; atomicMax(&s_maxBytes, b); }
+    }
+    if (listB && live) level = D.itemLevel[itemIds[it]];
     const uint32_t M = 1u << (2 * level);
-    const uint32_t bytesPerItem = (M * bits) >> 3;            // multiple of DG_CHUNK (launch_digest)
+    const uint32_t myBytes = (M * bits) >> 3;                 // multiple of DG_CHUNK (the launchers check)
     const uint32_t stripesPerChunk = DG_CHUNK / (4u * bits);  // a 32-byte stripe of the byte stream = 4*bits packed bytes
     const uint64_t seed = 42;
     uint64_t v = acc == 0 ? seed + XP1 + XP2 : (acc == 1 ? seed + XP2 : (acc == 2 ? seed : seed - XP1));
     __syncthreads();
+    const uint32_t bytesPerItem = MIXED ? s_maxBytes : myBytes;
     for (uint32_t chunk = 0; chunk < bytesPerItem; chunk += DG_CHUNK) {
         #pragma unroll 4
         for (uint32_t k = tid; k < DG_ITEMS * (DG_CHUNK / 16); k += 256) {
             const uint32_t row = k / (DG_CHUNK / 16), part = k % (DG_CHUNK / 16);
             const uint8_t* src = s_ptr[row];
             uint4 w = make_uint4(0u, 0u, 0u, 0u);
-            if (src) w = *(const uint4*)(src + chunk + part * 16u);
+            if (src && (!MIXED || chunk < s_bytes[row])) w = *(const uint4*)(src + chunk + part * 16u);
             uint32_t* dst = s_buf + row * DG_STRIDE + part * 4u;
             dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
         }
         __syncthreads();
-        if (bits == 2) {
+        if (!hasher || (MIXED && chunk >= myBytes)) { /* a load-only thread, or this item's stream has ended */ }
+        else if (bits == 2) {
             const uint16_t* q = (const uint16_t*)(s_buf + il * DG_STRIDE) + acc;
             #pragma unroll 4
             for (uint32_t st = 0; st < stripesPerChunk; ++st) v = xxh_round(v, expand8((uint32_t)q[4 * st], 2));
@@ -855,18 +910,32 @@ __global__ __launch_bounds__(256) void digest_items_lds(const uint8_t* __restric
 }
 
 void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
-                   uint64_t* digests, hipStream_t stream, const uint8_t* only, int want, const uint32_t* liveCount)
+                   uint64_t* digests, hipStream_t stream, const uint8_t* only, int want)
 {
     if (numItems == 0) return;
     const uint32_t bytesPerItem = ((1u << (2 * level)) * bits) >> 3;
-    // (256-byte chunks = 17 KB of LDS: a full-size launch is faster with them than with 1 KB chunks -- 0.77 vs 1.12 ms for 127 k items, more workgroups
-    //  per CU hide the latency --, and the digests of a streamed bake's ranges run in the 29 KB that the persistent classification launch leaves free on a CU)
+    DigestLists D; memset(&D, 0, sizeof D); D.ids = itemIds; D.count = numItems; D.level = level; D.only = only; D.want = want;
+    // (256-byte chunks x 64 items: a full-size launch is faster with them than with 1 KB chunks -- 0.77 vs 1.12 ms for 127 k items, more workgroups per CU
+    //  hide the latency)
     if (bytesPerItem >= 256u) { // (powers of two: a multiple of the chunk size)
-        hipLaunchKernelGGL(digest_items_lds<256>, dim3((numItems + DG_ITEMS - 1) / DG_ITEMS), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests, only, want, liveCount);
+        hipLaunchKernelGGL((digest_items_lds<256, 64, false>), dim3((numItems + 63u) / 64u), dim3(256), 0, stream, states, stateOfs, D, 0u, bits, digests);
         return;
     }
     const uint32_t threads = numItems * 4u;
-    hipLaunchKernelGGL(digest_items, dim3((threads + 255u) / 256u), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests, only, want, liveCount);
+    hipLaunchKernelGGL(digest_items, dim3((threads + 255u) / 256u), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests, only, want);
+}
+
+// streamed bakes: list A (a range's own items of one level >= 6, filtered) and list B (a device-side slice of the early list) in ONE small-workgroup launch
+void launch_digest_lists(const uint8_t* states, const uint64_t* stateOfs, const DigestLists& D, uint32_t bits, uint64_t* digests, hipStream_t stream)
+{
+    if (D.count == 0 && D.capacityB == 0) return;
+    if (bits == 2) {   // every item has >= 1 KiB of packed states
+        const uint32_t a = (D.count + 15u) / 16u, b = (D.capacityB + 15u) / 16u;
+        hipLaunchKernelGGL((digest_items_lds<1024, 16, true>), dim3(a + b), dim3(256), 0, stream, states, stateOfs, D, a, bits, digests);
+    } else {           // >= 512 bytes
+        const uint32_t a = (D.count + 31u) / 32u, b = (D.capacityB + 31u) / 32u;
+        hipLaunchKernelGGL((digest_items_lds<512, 32, true>), dim3(a + b), dim3(256), 0, stream, states, stateOfs, D, a, bits, digests);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -582,7 +582,8 @@ struct StreamOut {
 struct StreamCtx {   // what the hook behind a classification launch needs
     hipStream_t stream, place; hipEvent_t* fences; const uint32_t* activeIds; uint32_t numActive; StreamSegment proto; void* scratch; size_t scratchBytes;
     uint64_t* digests; unsigned long long* cursor; uint8_t* stage; uint64_t* placed; uint32_t* ctl; unsigned long long* hostCursor; hipEvent_t* events; uint32_t numEvents, recorded; bool ok;
-    const uint32_t* queueCtl; const uint32_t* earlyList;   // (indexed like activeIds: the early items of a level start where the level starts)
+    const uint32_t* queueCtl; bool paired;                 // paired: two queue sections per range (bake_kernels.h: ClassifyChunks)
+    const uint32_t* earlyList; uint32_t earlyCapacity; const uint8_t* itemLevel;   // the early class ordered by the range it is classified with (ctl: start / count per range)
 };
 // in front of the persistent launch: the placement stream starts behind the tile triage (the section tails are final from here on)
 void stream_mark_hook(void* user)
@@ -598,28 +599,28 @@ void stream_hook(void* user, uint32_t chunk, const ClassifySegment* segs, uint32
     StreamCtx& c = *(StreamCtx*)user;
     if (chunk >= c.numEvents) { c.ok = false; return; }
     if (last) c.ok = c.ok && hipEventRecord(c.fences[1], c.stream) == hipSuccess && hipStreamWaitEvent(c.place, c.fences[1], 0) == hipSuccess;   // (the lower levels: behind everything)
-    else launch_stream_wait_section(c.queueCtl, chunk, c.ctl, c.place);
+    else launch_stream_wait_sections(c.queueCtl, c.paired ? 2u * chunk : chunk, c.paired ? 2u : 1u, c.ctl, c.place);
+    // CalcDigest (bake_cpu_impl.cpp:1038-1040).  A range of the levels >= 6: its own items (the early ones among them have their digest from this range
+    // or an earlier one) and, in the same launch, the early items classified WITH this range -- the families that start in it, wherever their members lie --,
+    // which then enter the table ahead of the range's placement
+    const bool lists = !last && !c.proto.disableDedup;
+    StreamSegment e = c.proto; e.ids = c.earlyList; e.count = c.earlyList ? c.earlyCapacity : 0u; e.level = 6; e.range = chunk;
+    e.liveStart = c.ctl + kStreamCtlEarlyStart + chunk; e.liveCount = c.ctl + kStreamCtlEarlyCount + chunk; e.itemLevel = c.itemLevel;
+    for (uint32_t k = 0; lists && k < (numSegs ? numSegs : 1u); ++k) {
+        DigestLists D; memset(&D, 0, sizeof D);
+        if (k < numSegs) { D.ids = c.activeIds + segs[k].first; D.count = segs[k].count; D.level = segs[k].level; D.only = c.proto.early; D.want = 0; }
+        if (k == 0) { D.listB = e.ids; D.capacityB = e.count; D.liveStart = e.liveStart; D.liveCount = e.liveCount; D.itemLevel = e.itemLevel; }
+        launch_digest_lists(c.proto.states, c.proto.stateOfs, D, (uint32_t)c.proto.bits, c.digests, c.place);
+    }
+    if (lists && e.count) launch_stream_insert_list(e, c.numActive, c.scratch, c.scratchBytes, c.place);
     for (uint32_t k = 0; k < numSegs && c.ok; ++k) {
         StreamSegment g = c.proto; g.ids = c.activeIds + segs[k].first; g.count = segs[k].count; g.level = segs[k].level; g.range = chunk;
-        if (!g.disableDedup) launch_digest(g.states, g.stateOfs, g.ids, g.count, g.level, (uint32_t)g.bits, c.digests, c.place, g.early, 0);   // CalcDigest (bake_cpu_impl.cpp:1038-1040); early items have theirs
+        if (last && !g.disableDedup) launch_digest(g.states, g.stateOfs, g.ids, g.count, g.level, (uint32_t)g.bits, c.digests, c.place);   // (the levels below 6)
         c.ok = run_stream_segment(g, c.numActive, c.scratch, c.scratchBytes, c.cursor, c.stage, c.placed, c.ctl, c.place) == hipSuccess;
     }
     launch_stream_publish(c.cursor, c.hostCursor + chunk, c.place);
     c.ok = c.ok && hipEventRecord(c.events[chunk], c.place) == hipSuccess;
     if (c.ok) c.recorded = chunk + 1u;
-}
-// behind the launch of the early class: digests of the early items, entered into the table before the first range is placed
-void stream_early_hook(void* user, const ClassifySegment* segs, uint32_t numSegs)
-{
-    StreamCtx& c = *(StreamCtx*)user;
-    launch_stream_wait_section(c.queueCtl, 0u, c.ctl, c.place);   // (the early items live in section 0)
-    for (uint32_t k = 0; k < numSegs && c.ok; ++k) {
-        StreamSegment g = c.proto; g.ids = c.earlyList + segs[k].first; g.count = segs[k].count; g.level = segs[k].level; g.range = 0;
-        g.liveCount = c.ctl + kStreamCtlEarly + segs[k].level;
-        if (g.disableDedup || !g.early) continue;
-        launch_digest(g.states, g.stateOfs, g.ids, g.count, g.level, (uint32_t)g.bits, c.digests, c.place, nullptr, 0, g.liveCount);
-        launch_stream_insert_early(g, c.numActive, c.scratch, c.scratchBytes, c.place);
-    }
 }
 struct MarkCtx { EventTimer* et; int mark; };
 void mark_hook(void* user) { MarkCtx& c = *(MarkCtx*)user; c.mark = c.et->mark(); }
@@ -728,7 +729,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     const size_t i32 = pad256((size_t)maxItems * 4), i64 = pad256((size_t)maxItems * 8);
     const size_t shardBytes = sh ? pad256((size_t)maxItems * 16) + pad256(maxItems) + i64 + pad256(sizeof(uint64_t) * kMaxRanks) : 0;
     // streamed result: placed offset per item, cursor + control words; preview: collapsed UVs, 16-byte state slots, offsets, masks, early flags
-    const size_t streamBytes = so ? i64 + 512 + pad256((size_t)maxItems * 24) + pad256((size_t)maxItems * kPreviewSlotBytes) + i64 + i32 * 2 + pad256(maxItems) + pad256(sizeof(unsigned long long) * kFineSlots * kFineStride) : 0;
+    const size_t streamBytes = so ? i64 + 512 + pad256((size_t)maxItems * 24) + pad256((size_t)maxItems * kPreviewSlotBytes) + i64 + i32 * 3 + pad256(maxItems) + pad256(sizeof(unsigned long long) * kFineSlots * kFineStride) : 0;
     const size_t need = pad256((size_t)maxItems * 24) + 3 * pad256(maxItems) + i64 * 2 + i32 * 13 + pad256(sizeof(SetupCounters)) + 4096 + pad256(sizeof(unsigned long long) * kFineSlots * kFineStride) + pad256(scratchBytes) + shardBytes + streamBytes;
     if (!arena->reserve(need)) return L.failure("[Failure] - out of device memory for the bake working set");
     float* dUv = arena->take<float>((size_t)maxItems * 6);
@@ -748,11 +749,11 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     uint8_t* dScratch = arena->take<uint8_t>(scratchBytes);
     if (sh) { sh->dMeta = arena->take<uint32_t>((size_t)maxItems * 4); sh->dOwner = arena->take<uint8_t>(maxItems); sh->dCofs = arena->take<uint64_t>(maxItems); sh->dTotals = arena->take<uint64_t>(kMaxRanks); }
     uint64_t* dPlaced = nullptr; unsigned long long* dCursor = nullptr; uint32_t* dStreamCtl = nullptr;
-    float* dUv2 = nullptr; uint8_t *dStates2 = nullptr, *dEarly = nullptr; uint32_t* dEarlyList = nullptr; uint64_t* dOfs2 = nullptr; uint32_t* dMask2 = nullptr; unsigned long long* dFine2 = nullptr;
+    float* dUv2 = nullptr; uint8_t *dStates2 = nullptr, *dEarly = nullptr; uint32_t *dEarlyList = nullptr, *dEarlyLead = nullptr; uint64_t* dOfs2 = nullptr; uint32_t* dMask2 = nullptr; unsigned long long* dFine2 = nullptr;
     if (so) {
         dPlaced = arena->take<uint64_t>(maxItems); dCursor = arena->take<unsigned long long>(1); dStreamCtl = arena->take<uint32_t>(kStreamCtlWords);
         dUv2 = arena->take<float>((size_t)maxItems * 6); dStates2 = arena->take<uint8_t>((size_t)maxItems * kPreviewSlotBytes); dOfs2 = arena->take<uint64_t>(maxItems);
-        dMask2 = arena->take<uint32_t>(maxItems); dEarly = arena->take<uint8_t>(maxItems); dEarlyList = arena->take<uint32_t>(maxItems); dFine2 = arena->take<unsigned long long>(kFineSlots * kFineStride);
+        dMask2 = arena->take<uint32_t>(maxItems); dEarly = arena->take<uint8_t>(maxItems); dEarlyList = arena->take<uint32_t>(maxItems); dEarlyLead = arena->take<uint32_t>(maxItems); dFine2 = arena->take<unsigned long long>(kFineSlots * kFineStride);
     }
     if (arena->used > arena->cap) return L.failure("[Failure] - internal error: the working-set layout exceeds its reservation");
 
@@ -897,8 +898,8 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     uint8_t* hostArray = nullptr; unsigned long long* hCursor = nullptr; bool hostPinned = false;
     if (so && numActiveAll && !(flags & (1u << 1)) && !hc.collision) {   // (with special indices disabled every uniform item is a block too: the plain path handles that)
         uint32_t k = so->chunksWanted;
-        if (!so->forced) { k = hc.stateBytes >= (64ull << 20) ? (uint32_t)(hc.stateBytes >> 25) : 0u; if (k > 16u) k = 16u; }   // >= 64 MiB of packed states: one range per 32 MiB, at most 16
-        if (k > kMaxClassifyChunks) k = kMaxClassifyChunks;
+        if (!so->forced) { k = hc.stateBytes >= (64ull << 20) ? (uint32_t)(hc.stateBytes >> 25) : 0u; if (k > 24u) k = 24u; }   // >= 64 MiB of packed states: one range per 32 MiB, at most 24 (measured at 1.27 GB: 8 / 16 / 24 / 32 ranges = 38.4 / 36.7 / 36.2 / 36.2 ms)
+        if (k > kMaxStreamRanges) k = kMaxStreamRanges;
         if (k && so->set->pinned.reserve(4096) && (hostArray = so->alloc(so->allocUser, hc.stateBytes, &hostPinned)) != nullptr) { streamChunks = k; hCursor = (unsigned long long*)so->set->pinned.base; }
     }
     const size_t queueBytes = pad256((size_t)classify_queue_records(lvlCount, streamChunks > 1) * kTileRecordBytes + 16);
@@ -929,7 +930,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     }
     // streamed: the active lists in the order of the final result, events behind the classification launches, the cursor published to a pinned word after each
     struct EventList { hipEvent_t ev[2 * kMaxClassifyChunks + 3]; uint32_t n = 0; ~EventList() { for (uint32_t k = 0; k < n; ++k) (void)hipEventDestroy(ev[k]); } } chunkEvents;   // placement done [K + 1] | fences [K + 2]
-    StreamCtx sc; ClassifyChunks cc; cc.count = 1; cc.after = nullptr; cc.mark = nullptr; cc.user = nullptr; cc.early = nullptr; cc.afterEarly = nullptr;
+    StreamCtx sc; ClassifyChunks cc; memset(&cc, 0, sizeof cc); cc.count = 1;
     MarkCtx mk; mk.et = &et; mk.mark = -1;
     const bool noDedup = (flags & (1u << 3)) != 0;
     if (streamChunks) {
@@ -943,6 +944,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         sc.proto.stateMask = dMask; sc.proto.knownCount = dKnown; sc.proto.digests = dDigests; sc.proto.states = dStates; sc.proto.stateOfs = dStateOfs;
         sc.proto.rejectionThreshold = d.rejectionThreshold; sc.proto.bits = bits; sc.proto.disableDedup = noDedup ? 1 : 0;
         cc.count = streamChunks; cc.after = stream_hook; cc.mark = stream_mark_hook; cc.user = &sc; cc.early = nullptr; sc.queueCtl = dQueueCtl;
+        sc.paired = streamChunks > 1; sc.earlyList = nullptr; sc.earlyCapacity = 0; sc.itemLevel = dLevel;
         // preview (tail_kernels.hip): level-5 classification of the items of level >= 6 into buffers of its own; items that share their preview are classified early
         const uint32_t first6 = hc.activeStart[6], count6 = numActiveAll - hc.activeStart[6];
         if (count6 && streamChunks > 1) {
@@ -951,9 +953,10 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             bool okp = HIP_OK(hipMemsetAsync(dEarly, 0, maxItems, stream)) && HIP_OK(hipMemsetAsync(dMask2, 0, (size_t)maxItems * 4, stream));
             launch_stream_preview_prepare(dActiveIds + first6, count6, dUv, P.mips[0].fw, P.mips[0].fh, dUv2, dOfs2, dEarly, stream);
             okp = okp && HIP_OK(launch_classify_items(P2, A2, dActiveIds + first6, count6, kPreviewLevel, stream));
-            okp = okp && HIP_OK(run_stream_preview_flags(dActiveIds + first6, count6, numActiveAll, dStates2, dLevel, dEarly, dStreamCtl, dScratch, scratchBytes, dEarlyList, hc.activeStart, stream));
+            ClassifyPlan plan; classify_plan(lvlFirst, lvlCount, streamChunks, &plan);   // (the ranges launch_classify will cut)
+            okp = okp && HIP_OK(run_stream_preview_flags(dActiveIds + first6, count6, first6, numActiveAll, dStates2, dLevel, dEarly, dStreamCtl, dScratch, scratchBytes, dEarlyLead, dEarlyList, plan, stream));
             if (!okp) return L.failure("[Failure] - could not set up the streamed result");
-            cc.early = dEarly; cc.afterEarly = stream_early_hook; sc.proto.early = dEarly; sc.earlyList = dEarlyList;
+            cc.early = dEarly; cc.earlyLead = dEarlyLead; cc.earlyStage = dStage; sc.proto.early = dEarly; sc.earlyList = dEarlyList; sc.earlyCapacity = count6;
         }
     } else { cc.mark = mark_hook; cc.user = &mk; cc.early = nullptr; }   // (HIP event in front of the persistent launch of the levels >= 6)
     if (!HIP_OK(launch_classify(P, A, dActiveIds, lvlFirst, lvlCount, dTileQueue, dQueueCtl, device_cu_count(), stream, &cc))) return L.failure("[Failure] - kernel launch failed");
@@ -2076,7 +2079,7 @@ OMM_MI355X_API ommResult ommxSetBakerKnob(ommBaker baker, ommxBakerKnob knob, ui
     if (baker == 0 || tag_of(baker) != kCpuBaker || (unsigned)knob >= (unsigned)ommxBakerKnob_MAX_NUM) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_SetupKeyBits && value > 62) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_ShardChunkBytes && value != 0 && value < 256) return ommResult_INVALID_ARGUMENT;
-    if (knob == ommxBakerKnob_StreamChunks && value > 64) return ommResult_INVALID_ARGUMENT;
+    if (knob == ommxBakerKnob_StreamChunks && value > kMaxStreamRanges) return ommResult_INVALID_ARGUMENT;
     untag<Baker>(baker)->knobs[knob].store(value);
     return ommResult_SUCCESS;
 }

@@ -544,7 +544,8 @@ __global__ __launch_bounds__(256) void stream_preview_prepare(const uint32_t* __
     ofs2[item] = (uint64_t)item * kPreviewSlotBytes;
     early[item] = large ? 2 : 0;                                              // 2 = not previewed
 }
-// signature of the preview: 64-bit hash of its 256 bytes (and the level); previews of one single state and items that were not previewed get none
+// signature of the preview: 64-bit hash of its 256 bytes (and the level); previews of one single state and items that were not previewed get none.
+// The table keeps, per signature, the FIRST position (in the order of the final result) that carries it: the family's first member.
 __global__ __launch_bounds__(256) void stream_preview_signature(const uint32_t* __restrict__ ids, uint32_t n, const uint8_t* __restrict__ states2, const uint8_t* __restrict__ level,
                                                                 uint8_t* __restrict__ early, uint64_t* __restrict__ sig, HashTable table)
 {
@@ -563,59 +564,76 @@ __global__ __launch_bounds__(256) void stream_preview_signature(const uint32_t* 
     uniform = uniform && (w0 == 0u || w0 == 0x55555555u || w0 == 0xAAAAAAAAu || w0 == 0xFFFFFFFFu);
     if (h == kEmptyKey) h = 0;
     sig[p] = uniform ? kEmptyKey : h;
-    if (!uniform) hash_put_min(table, h, item);
+    if (!uniform) hash_put_min(table, h, p);
 }
-// every member of a family of >= 2 items is early: the later members see another first occurrence, and tell it
+// every member of a family of >= 2 items is early: the later members see another first position, and tell it
 __global__ __launch_bounds__(256) void stream_preview_followers(const uint32_t* __restrict__ ids, uint32_t n, const uint64_t* __restrict__ sig, HashTable table,
                                                                 uint8_t* __restrict__ followed, uint8_t* __restrict__ early)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n || sig[p] == kEmptyKey) return;
-    const uint32_t item = ids[p], slot = hash_find_slot(table, sig[p]);
-    if (slot != 0xFFFFFFFFu && table.vals[slot] != item) { early[item] = 1; followed[slot] = 1; }
+    const uint32_t slot = hash_find_slot(table, sig[p]);
+    if (slot != 0xFFFFFFFFu && table.vals[slot] != p) { early[ids[p]] = 1; followed[slot] = 1; }
 }
-struct LevelStarts { uint32_t at[kNumLevels]; };
-// ... and the early class as lists, one per level (list[start of the level + k], k < ctl[kStreamCtlEarly + level]): its digests are computed from these,
-// next to the running classification, where a pass over every item with a filter would take as long as the whole digest
-__global__ __launch_bounds__(256) void stream_preview_leaders(const uint32_t* __restrict__ ids, uint32_t n, const uint64_t* __restrict__ sig, HashTable table,
-                                                              const uint8_t* __restrict__ followed, uint8_t* __restrict__ early, uint32_t* __restrict__ ctl,
-                                                              const uint8_t* __restrict__ level, uint32_t* __restrict__ earlyList, LevelStarts starts)
+// ... the first members join, every early item learns the position of its family's first member (lead[item], a position of the whole active list) and
+// is counted for that member's range: ctl[kStreamCtlEarlyCount + range]
+__global__ __launch_bounds__(256) void stream_preview_leaders(const uint32_t* __restrict__ ids, uint32_t n, uint32_t listOffset, const uint64_t* __restrict__ sig, HashTable table,
+                                                              const uint8_t* __restrict__ followed, uint8_t* __restrict__ early, uint32_t* __restrict__ lead,
+                                                              uint32_t* __restrict__ ctl, TileLevels L, TileSections S)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
-    bool e = false; uint32_t item = 0, l = 0, at = 0;
+    bool e = false; uint32_t range = 0;
     if (p < n && sig[p] != kEmptyKey) {
-        item = ids[p];
-        const uint32_t slot = hash_find_slot(table, sig[p]);
-        if (slot != 0xFFFFFFFFu && table.vals[slot] == item && followed[slot]) early[item] = 1;
-        e = early[item] != 0;
-        l = level[item] < (uint32_t)kNumLevels ? level[item] : 0u;
-        #pragma unroll
-        for (int q = 0; q < kNumLevels; ++q) at = l == (uint32_t)q ? starts.at[q] : at;   // (select chain: the by-value array stays in scalar registers)
+        const uint32_t item = ids[p], slot = hash_find_slot(table, sig[p]);
+        if (slot != 0xFFFFFFFFu) {
+            const uint32_t first = table.vals[slot];
+            if (first == p && followed[slot]) early[item] = 1;
+            e = early[item] == 1;
+            if (e) { lead[item] = listOffset + first; range = section_of_position(listOffset + first, L, S); }
+        }
     }
     const unsigned long long b = __ballot(e);
-    // wave-aggregated append (the list is sorted by level, so a wave sees one level, two at a boundary)
     unsigned long long todo = b;
-    while (todo) {
+    while (todo) {   // (wave-aggregated: neighbours in the final order mostly share their range)
         const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t l0 = (uint32_t)__shfl((int)l, leader);
-        const unsigned long long same = __ballot(e && l == l0) & todo;
+        const uint32_t r0 = (uint32_t)__shfl((int)range, leader);
+        const unsigned long long same = __ballot(e && range == r0) & todo;
         todo &= ~same;
-        uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(ctl + kStreamCtlEarly + l0, (uint32_t)__popcll(same));
-        base = (uint32_t)__shfl((int)base, leader);
-        if (e && l == l0) earlyList[at + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = item;
+        if ((int)lane == leader) atomicAdd(ctl + kStreamCtlEarlyCount + r0, (uint32_t)__popcll(same));
     }
     if (lane == 0 && b) atomicAdd(ctl + 3, (uint32_t)__popcll(b));   // statistics: size of the early class
+}
+// the early class as one list ordered by the range its items are classified in: starts ...
+__global__ void stream_early_starts(uint32_t* __restrict__ ctl, uint32_t ranges)
+{
+    uint32_t run = 0;
+    for (uint32_t k = 0; k < ranges; ++k) { ctl[kStreamCtlEarlyStart + k] = run; run += ctl[kStreamCtlEarlyCount + k]; }
+}
+// ... and entries
+__global__ __launch_bounds__(256) void stream_early_scatter(const uint32_t* __restrict__ ids, uint32_t n, const uint8_t* __restrict__ early, const uint32_t* __restrict__ lead,
+                                                            uint32_t* __restrict__ ctl, uint32_t* __restrict__ earlyList, TileLevels L, TileSections S)
+{
+    __shared__ uint32_t s_cnt[kMaxStreamRanges], s_base[kMaxStreamRanges];   // (one global atomic per range and workgroup)
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x < kMaxStreamRanges) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t item = p < n ? ids[p] : 0u;
+    const bool e = p < n && early[item] == 1;
+    uint32_t range = 0, local = 0;
+    if (e) { range = section_of_position(lead[item], L, S); local = atomicAdd(&s_cnt[range], 1u); }
+    __syncthreads();
+    if (threadIdx.x < kMaxStreamRanges && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(ctl + kStreamCtlEarlyFill + threadIdx.x, s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (e) earlyList[ctl[kStreamCtlEarlyStart + range] + s_base[range] + local] = item;
 }
 void launch_stream_preview_prepare(const uint32_t* ids, uint32_t n, const float* uv, float texW, float texH, float* uv2, uint64_t* ofs2, uint8_t* early, hipStream_t stream)
 {
     if (n) hipLaunchKernelGGL(stream_preview_prepare, dim3((n + 255u) / 256u), dim3(256), 0, stream, ids, n, uv, texW, texH, uv2, ofs2, early);
 }
 // after the preview classification.  Uses the (still empty) digest table of the streamed placement for the signatures and clears it again.
-hipError_t run_stream_preview_flags(const uint32_t* ids, uint32_t n, uint32_t numActive, const uint8_t* states2, const uint8_t* level, uint8_t* early, uint32_t* ctl,
-                                    void* scratch, size_t scratchBytes, uint32_t* earlyList, const uint32_t levelStart[kNumLevels], hipStream_t stream)
+hipError_t run_stream_preview_flags(const uint32_t* ids, uint32_t n, uint32_t listOffset, uint32_t numActive, const uint8_t* states2, const uint8_t* level, uint8_t* early,
+                                    uint32_t* ctl, void* scratch, size_t scratchBytes, uint32_t* earlyLead, uint32_t* earlyList, const ClassifyPlan& plan, hipStream_t stream)
 {
-    LevelStarts starts; for (int l = 0; l < kNumLevels; ++l) starts.at[l] = levelStart[l];
     if (n == 0) return hipSuccess;
     if (scratchBytes < stream_scratch_bytes(numActive)) return hipErrorInvalidValue;
     StreamScratch s = stream_carve(scratch, numActive);
@@ -623,7 +641,10 @@ hipError_t run_stream_preview_flags(const uint32_t* ids, uint32_t n, uint32_t nu
     const uint32_t slots = s.table.mask + 1u;
     hipLaunchKernelGGL(stream_preview_signature, grid, block, 0, stream, ids, n, states2, level, early, s.sizes64, s.table);   // (sizes64: free until the first segment)
     hipLaunchKernelGGL(stream_preview_followers, grid, block, 0, stream, ids, n, (const uint64_t*)s.sizes64, s.table, s.claimed, early);
-    hipLaunchKernelGGL(stream_preview_leaders, grid, block, 0, stream, ids, n, (const uint64_t*)s.sizes64, s.table, (const uint8_t*)s.claimed, early, ctl, level, earlyList, starts);
+    hipLaunchKernelGGL(stream_preview_leaders, grid, block, 0, stream, ids, n, listOffset, (const uint64_t*)s.sizes64, s.table, (const uint8_t*)s.claimed, early, earlyLead, ctl,
+                       plan.big, plan.ranges);
+    hipLaunchKernelGGL(stream_early_starts, dim3(1), dim3(1), 0, stream, ctl, plan.ranges.n);
+    hipLaunchKernelGGL(stream_early_scatter, grid, block, 0, stream, ids, n, (const uint8_t*)early, (const uint32_t*)earlyLead, ctl, earlyList, plan.big, plan.ranges);
     TAIL_CHECK(hipMemsetAsync(s.table.keys, 0xFF, hash_table_bytes(slots), stream));
     TAIL_CHECK(hipMemsetAsync(s.claimed, 0, (size_t)slots + 1, stream));
     return hipGetLastError();
@@ -635,24 +656,27 @@ __device__ __forceinline__ bool stream_candidate(const StreamSegment& g, uint32_
     const uint32_t mask = g.stateMask[item];
     if ((mask & (mask - 1u)) == 0u) return false;
     if (g.rejectionThreshold > 0.f) {
-        const float frac = (float)g.knownCount[item] / (float)(1u << (2u * g.level));
+        const uint32_t lvl = g.itemLevel ? (uint32_t)g.itemLevel[item] : g.level;
+        const float frac = (float)g.knownCount[item] / (float)(1u << (2u * lvl));
         if (frac < g.rejectionThreshold) return false;
     }
     return true;
 }
-__global__ __launch_bounds__(256) void stream_insert(StreamSegment g, HashTable table, int earlyOnly)
+// (g.liveCount: the ids are a device-side slice, g.ids[*g.liveStart .. + *g.liveCount), of a list of capacity g.count)
+__global__ __launch_bounds__(256) void stream_insert(StreamSegment g, HashTable table)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= g.count || (g.liveCount && p >= *g.liveCount)) return;
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.count) return;
+    if (g.liveCount) { if (p >= *g.liveCount) return; p += *g.liveStart; }
     const uint32_t item = g.ids[p];
-    if (earlyOnly && !(g.early && g.early[item])) return;
     if (stream_candidate(g, item)) hash_put_min(table, g.digests[item], item);
 }
-void launch_stream_insert_early(const StreamSegment& g, uint32_t numActive, void* scratch, size_t scratchBytes, hipStream_t stream)
+// the early items that were classified with a range (a slice of the early list, mixed levels): their digests enter the table with the range's own
+void launch_stream_insert_list(const StreamSegment& g, uint32_t numActive, void* scratch, size_t scratchBytes, hipStream_t stream)
 {
     if (g.count == 0 || g.disableDedup || scratchBytes < stream_scratch_bytes(numActive)) return;
     StreamScratch s = stream_carve(scratch, numActive);
-    hipLaunchKernelGGL(stream_insert, dim3((g.count + 255u) / 256u), dim3(256), 0, stream, g, s.table, 1);
+    hipLaunchKernelGGL(stream_insert, dim3((g.count + 255u) / 256u), dim3(256), 0, stream, g, s.table);
 }
 __global__ __launch_bounds__(256) void stream_flags(StreamSegment g, HashTable table, uint8_t* __restrict__ claimed, uint64_t* __restrict__ sizes64, uint32_t* __restrict__ ctl)
 {
@@ -709,7 +733,7 @@ hipError_t run_stream_segment(const StreamSegment& g, uint32_t numActive, void* 
     if (scratchBytes < stream_scratch_bytes(numActive)) return hipErrorInvalidValue;
     StreamScratch s = stream_carve(scratch, numActive);
     const dim3 grid((g.count + 255u) / 256u), block(256);
-    if (!g.disableDedup) hipLaunchKernelGGL(stream_insert, grid, block, 0, stream, g, s.table, 0);
+    if (!g.disableDedup) hipLaunchKernelGGL(stream_insert, grid, block, 0, stream, g, s.table);
     hipLaunchKernelGGL(stream_flags, grid, block, 0, stream, g, s.table, s.claimed, s.sizes64, ctl);
     size_t tb = s.tmpBytes;
     TAIL_CHECK(rocprim::exclusive_scan(s.tmp, tb, s.sizes64, s.ofs64, (uint64_t)0, (size_t)g.count, rocprim::plus<uint64_t>(), stream));
@@ -719,21 +743,23 @@ hipError_t run_stream_segment(const StreamSegment& g, uint32_t numActive, void* 
     hipLaunchKernelGGL(stream_advance, dim3(1), dim3(1), 0, stream, cursor, (const uint64_t*)s.sizes64, (const uint64_t*)s.ofs64, g.count);
     return hipGetLastError();
 }
-// Holds the placement stream until section `sec` of the tile queue is complete: done == tail (bake_kernels.hip: classify_tiles).  One lane, asleep
+// Holds the placement stream until sections [first, first + n) of the tile queue are complete: done == tail (bake_kernels.hip: classify_tiles).  One lane, asleep
 // between two looks.  The tail is final (the stream was fenced behind the tile triage); a count that never arrives -- it cannot, short of a fault in
 // the classification launch -- ends the wait after ~4 s of the 100 MHz wall clock with the violation word set, which discards the streamed result.
-__global__ void stream_wait_section(const uint32_t* __restrict__ queueCtl, uint32_t sec, uint32_t* __restrict__ ctl)
+__global__ void stream_wait_sections(const uint32_t* __restrict__ queueCtl, uint32_t first, uint32_t n, uint32_t* __restrict__ ctl)
 {
-    const uint32_t want = __hip_atomic_load(queueCtl + kSecTails + sec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint64_t t0 = wall_clock64();
-    while (__hip_atomic_load(queueCtl + kSecDone + sec, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want) {
-        __builtin_amdgcn_s_sleep(64);
-        if (wall_clock64() - t0 > 400000000ull) { atomicOr(ctl + 1, 1u); break; }
+    for (uint32_t sec = first; sec < first + n; ++sec) {
+        const uint32_t want = __hip_atomic_load(queueCtl + kSecTails + sec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(queueCtl + kSecDone + sec, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want) {
+            __builtin_amdgcn_s_sleep(64);
+            if (wall_clock64() - t0 > 400000000ull) { atomicOr(ctl + 1, 1u); return; }
+        }
     }
 }
-void launch_stream_wait_section(const uint32_t* queueCtl, uint32_t section, uint32_t* ctl, hipStream_t stream)
+void launch_stream_wait_sections(const uint32_t* queueCtl, uint32_t first, uint32_t n, uint32_t* ctl, hipStream_t stream)
 {
-    hipLaunchKernelGGL(stream_wait_section, dim3(1), dim3(1), 0, stream, queueCtl, section, ctl);
+    hipLaunchKernelGGL(stream_wait_sections, dim3(1), dim3(1), 0, stream, queueCtl, first, n, ctl);
 }
 void launch_stream_publish(const unsigned long long* cursor, unsigned long long* hostSlot, hipStream_t stream)
 {
