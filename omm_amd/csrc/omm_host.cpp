@@ -1703,7 +1703,7 @@ struct ShardedBake {
 // process already holds an RCCL (e.g. torch's) its SONAME librccl.so.1 resolves to that instance.
 typedef void* rcclComm_t;
 struct RcclUniqueId { char internal[128]; };                       // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
-enum { kRcclSum = 0, kRcclUint8 = 1, kRcclUint32 = 3 };            // ncclRedOp_t / ncclDataType_t values of rccl.h
+enum { kRcclSum = 0, kRcclMin = 3, kRcclUint8 = 1, kRcclUint32 = 3 };   // ncclRedOp_t (sum, min) / ncclDataType_t (uint8, uint32) values of rccl.h
 struct RcclApi {
     void* dso = nullptr; std::string error;
     int (*getUniqueId)(RcclUniqueId*) = nullptr;
@@ -1735,7 +1735,26 @@ const RcclApi& rccl()
     }();
     return api;
 }
-struct RcclComm { rcclComm_t comm = nullptr; bool owned = false; int rank = 0, world = 1; };
+struct RcclComm {
+    rcclComm_t comm = nullptr; bool owned = false; int rank = 0, world = 1;
+    uint32_t* dStatus = nullptr; hipStream_t statusStream = nullptr;   // status agreement (rccl_agree): two device words and a stream for ranks that have no bake stream
+};
+// A rank-local failure (out of memory, mostly) must not leave the other ranks waiting in the next collective: before every data collective each rank
+// contributes its status to a one-element MIN all-reduce and all of them go on, or none.  `stream`: the bake's stream (idle ranks: the communicator's own).
+bool rccl_agree(RcclComm* rc, hipStream_t stream, bool mineOk, const Logger& L, const char* stage)
+{
+    bool ok = true;
+    if (!rc->dStatus) ok = HIP_OK(hipMalloc((void**)&rc->dStatus, 2 * sizeof(uint32_t)));
+    if (ok && !stream) { if (!rc->statusStream) ok = HIP_OK(hipStreamCreateWithFlags(&rc->statusStream, hipStreamNonBlocking)); stream = rc->statusStream; }
+    if (!ok) { (void)hipGetLastError(); L.failure("[Failure] - sharded bake: no device memory for the status word (the other ranks may be waiting in a collective)"); return false; }
+    const uint32_t mine = mineOk ? 1u : 0u; uint32_t all = 0;
+    ok = HIP_OK(hipMemcpyAsync(rc->dStatus, &mine, sizeof mine, hipMemcpyHostToDevice, stream)) && HIP_OK(hipStreamSynchronize(stream));
+    ok = ok && rccl().allReduce(rc->dStatus, rc->dStatus + 1, 1, kRcclUint32, kRcclMin, rc->comm, stream) == 0;
+    ok = ok && HIP_OK(hipMemcpyAsync(&all, rc->dStatus + 1, sizeof all, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipStreamSynchronize(stream));
+    if (!ok) { L.failure("[Failure] - sharded bake: the status all-reduce failed"); return false; }
+    if (mineOk && all == 0u) { char buf[200]; snprintf(buf, sizeof buf, "[Failure] - sharded bake: another rank failed (%s); this rank stops with it", stage); L.failure(buf); }
+    return mineOk && all != 0u;
+}
 
 // The all-gather of the block contributions moves in chunks of <= 64 MiB per rank (at most 8 chunks, multiples of 256 bytes), so that the
 // scatter of one chunk overlaps the transfer of the next.  ommxBakerKnob_ShardChunkBytes overrides the chunk size (tests use tiny chunks to
@@ -1824,10 +1843,8 @@ ommResult sharded_finish(ShardedBake* sb, ScatterFn&& scatter, ommxDeviceBakeRes
     if (E) {
         R.arrayData = (uint8_t*)R.dev_alloc((size_t)c.counts.arrayDataSize); R.descs = (ommCpuOpacityMicromapDesc*)R.dev_alloc(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E);
         ok = R.arrayData != nullptr && R.descs != nullptr;
-        if (ok) {
-            ok = scatter(R.arrayData);
-            launch_write_descs(c.to.order, c.to.dstOfs, c.dLevel, c.bits, E, R.descs, stream);
-        }
+        ok = scatter(ok ? R.arrayData : nullptr) && ok;   // (called either way: the RCCL form agrees on the allocation across ranks before its all-gathers)
+        if (ok) launch_write_descs(c.to.order, c.to.dstOfs, c.dLevel, c.bits, E, R.descs, stream);
     }
     const bool allow8 = (c.flags & (1u << 6)) != 0, force32 = (c.flags & (1u << 2)) != 0;
     int idxBytes = 4; R.indexFormat = ommIndexFormat_UINT_32;
@@ -1909,6 +1926,7 @@ OMM_MI355X_API ommResult ommxShardedFinish(ommxShardedBake h, const void* gather
         const DeviceScope onBakersDevice(sb->baker->bind_device());
         const double t1 = now_ms();
         const ommResult r = sharded_finish(sb, [&](uint8_t* arrayData) {
+            if (!arrayData) return false;   // (the result could not be allocated)
             // same chunk walk as the RCCL path (there each chunk arrives separately): a block that straddles a chunk boundary is placed in pieces
             const uint64_t chunkBytes = shard_chunk_bytes(*sb->baker, c.strideBytes);
             for (uint64_t lo = 0; lo < c.strideBytes; lo += chunkBytes) {
@@ -1969,6 +1987,8 @@ OMM_MI355X_API ommResult ommxRcclCommDestroy(ommxRcclComm comm)
 {
     if (comm == 0) return ommResult_INVALID_ARGUMENT;
     RcclComm* c = (RcclComm*)comm;
+    if (c->statusStream) { (void)hipStreamSynchronize(c->statusStream); (void)hipStreamDestroy(c->statusStream); }
+    if (c->dStatus) (void)hipFree(c->dStatus);
     if (c->owned && c->comm) (void)rccl().commDestroy(c->comm);
     delete c;
     return ommResult_SUCCESS;
@@ -1992,8 +2012,9 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
         const bool hostTail = wants_host_tail(*desc);
         ShardedBake* sb = nullptr;
         ommResult r = sharded_begin(b, desc, (uint32_t)rc->rank, (uint32_t)rc->world, true, &sb, hostTail);
-        if (r != ommResult_SUCCESS) return r;
-        struct Owner { Baker* b; ShardedBake* sb; ~Owner() { b->mem.destroy(sb); } } owner{ b, sb };
+        if (r != ommResult_SUCCESS) sb = nullptr;
+        struct Owner { Baker* b; ShardedBake* sb; ~Owner() { if (sb) b->mem.destroy(sb); } } owner{ b, sb };
+        if (!rccl_agree(rc, sb ? sb->ses.stream : nullptr, r == ommResult_SUCCESS, L, "classification of its share")) return r != ommResult_SUCCESS ? r : ommResult_FAILURE;
         ShardCtx& c = sb->ctx; hipStream_t stream = sb->ses.stream;
         const double t1 = now_ms();
         if (hostTail) {
@@ -2015,6 +2036,10 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
             res->mem = b->mem; memset(&res->desc, 0, sizeof res->desc);
             r = upload_host_tail(*b, hres, ifmt, c.T, c.bits, stream, res);
             if (r != ommResult_SUCCESS) { b->mem.destroy(res); return r; }
+            const int* ev = c.ev;
+            sb->tm.setupMs = sb->et->ms(ev[0], ev[1]); sb->tm.triageMs = sb->et->ms(ev[1], ev[2]); sb->tm.classifyMs = sb->et->ms(ev[2], ev[3]);
+            sb->tm.tailMs = (float)(now_ms() - t1); sb->tm.totalMs = (float)(now_ms() - sb->t0);
+            { std::lock_guard<std::mutex> g(b->timingsMu); b->timings = sb->tm; b->haveTimings = true; }
             *outResult = (ommxDeviceBakeResult)res;
             return ommResult_SUCCESS;
         }
@@ -2022,7 +2047,7 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
         const size_t words = 4ull * c.hc.activeStart[kNumLevels];
         if (words) { const int e = rccl().allReduce(c.dMeta, c.dMeta, words, kRcclUint32, kRcclSum, rc->comm, stream); if (e != 0) return nccl_fail(e, "ncclAllReduce of the work-item metadata"); }
         r = sharded_tail(sb);
-        if (r != ommResult_SUCCESS) return r;
+        if (!rccl_agree(rc, stream, r == ommResult_SUCCESS, L, "tail of the bake")) return r != ommResult_SUCCESS ? r : ommResult_FAILURE;
         sb->tm.tailMs = (float)(now_ms() - t1);
         const double t2 = now_ms();
         // exchange 2: the padded contributions, all-gathered in chunks on a second stream; every chunk is scattered to its final arrayData
@@ -2030,12 +2055,15 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
         const uint32_t E = c.counts.numOmms;
         r = sharded_finish(sb, [&](uint8_t* arrayData) -> bool {
             // (a one-rank communicator takes the same route: the collectives degenerate to copies, the plumbing is the same)
-            if (!sb->ses.open_comm()) return false;
+            // (arrayData is null when this rank could not allocate the result: it still takes part in the agreement, so that nobody waits for it)
+            hipEvent_t ready = nullptr, done[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+            bool ok = arrayData != nullptr && sb->ses.open_comm() && HIP_OK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+            ok = rccl_agree(rc, stream, ok, L, "allocation of the result") && ok;
+            if (!ok) { if (ready) (void)hipEventDestroy(ready); return false; }
             hipStream_t cs = sb->ses.commStream;
             const uint64_t chunkBytes = shard_chunk_bytes(*sb->baker, c.strideBytes);              // per rank and chunk; at most 8 chunks
             uint64_t chunks = (c.strideBytes + chunkBytes - 1) / chunkBytes;
-            hipEvent_t ready = nullptr, done[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-            bool ok = HIP_OK(hipEventCreateWithFlags(&ready, hipEventDisableTiming)) && HIP_OK(hipEventRecord(ready, stream)) && HIP_OK(hipStreamWaitEvent(cs, ready, 0));
+            ok = HIP_OK(hipEventRecord(ready, stream)) && HIP_OK(hipStreamWaitEvent(cs, ready, 0));
             int ncclErr = 0;
             for (uint64_t k = 0; ok && k < chunks; ++k) {
                 const uint64_t lo = k * chunkBytes, hi = lo + chunkBytes < c.strideBytes ? lo + chunkBytes : c.strideBytes;
