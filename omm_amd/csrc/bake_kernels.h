@@ -48,6 +48,14 @@ __device__ __forceinline__ uint32_t section_of_position(uint32_t pos, const Tile
 
 // the plan launch_classify follows for these lists (pure host arithmetic; a streamed bake needs the ranges before the launch: section_of_position)
 void classify_plan(const uint32_t first[kNumLevels], const uint32_t count[kNumLevels], uint32_t ranges, ClassifyPlan* plan);
+// The range an early item is classified with: that of the first member of its family -- but never later than its own.  (The first member of a real family
+// comes first by construction; the clamp makes "every block of a range is complete when the range's sections are" hold whatever the preview's
+// signatures did -- a hash collision then costs a fallback through the duplicate check, never an unfinished block.)
+__device__ __forceinline__ uint32_t early_range(uint32_t leadPos, uint32_t ownPos, const TileLevels& L, const TileSections& S)
+{
+    const uint32_t a = section_of_position(leadPos, L, S), b = section_of_position(ownPos, L, S);
+    return a < b ? a : b;
+}
 struct ClassifyChunks {
     uint32_t count;
     void (*after)(void* user, uint32_t chunk, const ClassifySegment* segs, uint32_t numSegs, bool last);

@@ -765,7 +765,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     S.uvFormat = d.texCoordFormat; S.indexFormat = d.indexFormat; S.numTris = T;
     S.globalLevel = d.maxSubdivisionLevel; S.dynScale = d.dynamicSubdivisionScale; S.edgeHeuristic = (flags & (1u << 11)) != 0;   // (EnableEdgeHeuristic, bake_cpu_impl.cpp:48,547)
     S.texW = tex.mips[0].w; S.texH = tex.mips[0].h; S.disableDedup = (flags & (1u << 3)) != 0;
-    S.wantWorkload = ((flags & (1u << 5)) != 0) || d.maxWorkloadSize != 0xFFFFFFFFFFFFFFFFull;
+    S.wantWorkload = ((flags & (1u << 5)) != 0) || d.maxWorkloadSize != 0xFFFFFFFFFFFFFFFFull || so != nullptr;   // (ommCpuBake: input of the streaming decision below)
     S.keyMask = ~0ull;
     if (const uint64_t kb = baker.knob(ommxBakerKnob_SetupKeyBits)) S.keyMask = (1ull << kb) - 1ull;   // (tests: forced key collisions)
     bool ok = HIP_OK(hipMemcpyAsync(dUniformDigest, uniform_digests().v, sizeof(uint64_t) * kNumLevels * 4, hipMemcpyHostToDevice, stream));
@@ -898,7 +898,18 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     uint8_t* hostArray = nullptr; unsigned long long* hCursor = nullptr; bool hostPinned = false;
     if (so && numActiveAll && !(flags & (1u << 1)) && !hc.collision) {   // (with special indices disabled every uniform item is a block too: the plain path handles that)
         uint32_t k = so->chunksWanted;
-        if (!so->forced) { k = hc.stateBytes >= (64ull << 20) ? (uint32_t)(hc.stateBytes >> 25) : 0u; if (k > 24u) k = 24u; }   // >= 64 MiB of packed states: one range per 32 MiB, at most 24 (measured at 1.27 GB: 8 / 16 / 24 / 32 ranges = 38.4 / 36.7 / 36.2 / 36.2 ms)
+        if (!so->forced) {
+            // >= 64 MiB of packed states: one range per 32 MiB, at most 24 (measured at 1.27 GB: 8 / 16 / 24 / 32 ranges = 38.4 / 36.7 / 36.2 / 36.2 ms)
+            k = hc.stateBytes >= (64ull << 20) ? (uint32_t)(hc.stateBytes >> 25) : 0u; if (k > 24u) k = 24u;
+            // ... and only when the copy is worth hiding.  Streaming costs the classification about a quarter of its time (6 instead of 7 workgroups per CU,
+            // the placement kernels next to it) and saves at most the copy (~57 GB/s over PCIe).  The classification time is estimated from the two
+            // quantities that drive it: micro-triangles (sub-texel ones, mostly culled: 2.5e-10 ms each -- 27 ms for 6.5e10, 128 ms for 6.0e11 measured) and
+            // texels under the triangles' boxes (micro-triangles of several texels walk them: 4e-9 ms each -- 55 ms for 1.4e10 measured on asset-sized
+            // cards, where streaming the 0.28 GB result made the bake 10 ms SLOWER).
+            double micro = 0; for (int l = 0; l < kNumLevels; ++l) micro += (double)hc.levelCount[l] * (double)(1ull << (2 * l));
+            const double classifyMs = 2.5e-10 * micro + 4e-9 * (double)hc.workload, copyMs = (double)hc.stateBytes / 57e6;
+            if (copyMs <= 0.25 * classifyMs) k = 0;
+        }
         if (k > kMaxStreamRanges) k = kMaxStreamRanges;
         if (k && so->set->pinned.reserve(4096) && (hostArray = so->alloc(so->allocUser, hc.stateBytes, &hostPinned)) != nullptr) { streamChunks = k; hCursor = (unsigned long long*)so->set->pinned.base; }
     }

@@ -554,7 +554,10 @@ __global__ __launch_bounds__(256) void stream_preview_signature(const uint32_t* 
     const uint32_t item = ids[p];
     if (early[item] == 2) { early[item] = 0; sig[p] = kEmptyKey; return; }
     const uint4* w = (const uint4*)(states2 + (size_t)item * kPreviewSlotBytes);
-    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)level[item]; bool uniform = true; const uint32_t w0 = w[0].x;
+    // (the level goes through a mixing round of its own: XORed straight into the seed it cancels against the first data word -- level 10 / first byte 03 and
+    //  level 6 / first byte 0f gave one signature, a family across levels)
+    uint64_t h = (0x9E3779B97F4A7C15ull ^ (uint64_t)level[item]) * 0xff51afd7ed558ccdull; h ^= h >> 32;
+    bool uniform = true; const uint32_t w0 = w[0].x;
     for (uint32_t k = 0; k < kPreviewSlotBytes / 16u; ++k) {
         const uint4 v = w[k];
         uniform = uniform && v.x == w0 && v.y == w0 && v.z == w0 && v.w == w0;
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(256) void stream_preview_leaders(const uint32_t* __
             const uint32_t first = table.vals[slot];
             if (first == p && followed[slot]) early[item] = 1;
             e = early[item] == 1;
-            if (e) { lead[item] = listOffset + first; range = section_of_position(listOffset + first, L, S); }
+            if (e) { lead[item] = listOffset + first; range = early_range(listOffset + first, listOffset + p, L, S); }
         }
     }
     const unsigned long long b = __ballot(e);
@@ -610,7 +613,7 @@ __global__ void stream_early_starts(uint32_t* __restrict__ ctl, uint32_t ranges)
     for (uint32_t k = 0; k < ranges; ++k) { ctl[kStreamCtlEarlyStart + k] = run; run += ctl[kStreamCtlEarlyCount + k]; }
 }
 // ... and entries
-__global__ __launch_bounds__(256) void stream_early_scatter(const uint32_t* __restrict__ ids, uint32_t n, const uint8_t* __restrict__ early, const uint32_t* __restrict__ lead,
+__global__ __launch_bounds__(256) void stream_early_scatter(const uint32_t* __restrict__ ids, uint32_t n, uint32_t listOffset, const uint8_t* __restrict__ early, const uint32_t* __restrict__ lead,
                                                             uint32_t* __restrict__ ctl, uint32_t* __restrict__ earlyList, TileLevels L, TileSections S)
 {
     __shared__ uint32_t s_cnt[kMaxStreamRanges], s_base[kMaxStreamRanges];   // (one global atomic per range and workgroup)
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(256) void stream_early_scatter(const uint32_t* __re
     const uint32_t item = p < n ? ids[p] : 0u;
     const bool e = p < n && early[item] == 1;
     uint32_t range = 0, local = 0;
-    if (e) { range = section_of_position(lead[item], L, S); local = atomicAdd(&s_cnt[range], 1u); }
+    if (e) { range = early_range(lead[item], listOffset + p, L, S); local = atomicAdd(&s_cnt[range], 1u); }
     __syncthreads();
     if (threadIdx.x < kMaxStreamRanges && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(ctl + kStreamCtlEarlyFill + threadIdx.x, s_cnt[threadIdx.x]);
     __syncthreads();
@@ -644,7 +647,7 @@ hipError_t run_stream_preview_flags(const uint32_t* ids, uint32_t n, uint32_t li
     hipLaunchKernelGGL(stream_preview_leaders, grid, block, 0, stream, ids, n, listOffset, (const uint64_t*)s.sizes64, s.table, (const uint8_t*)s.claimed, early, earlyLead, ctl,
                        plan.big, plan.ranges);
     hipLaunchKernelGGL(stream_early_starts, dim3(1), dim3(1), 0, stream, ctl, plan.ranges.n);
-    hipLaunchKernelGGL(stream_early_scatter, grid, block, 0, stream, ids, n, (const uint8_t*)early, (const uint32_t*)earlyLead, ctl, earlyList, plan.big, plan.ranges);
+    hipLaunchKernelGGL(stream_early_scatter, grid, block, 0, stream, ids, n, listOffset, (const uint8_t*)early, (const uint32_t*)earlyLead, ctl, earlyList, plan.big, plan.ranges);
     TAIL_CHECK(hipMemsetAsync(s.table.keys, 0xFF, hash_table_bytes(slots), stream));
     TAIL_CHECK(hipMemsetAsync(s.claimed, 0, (size_t)slots + 1, stream));
     return hipGetLastError();
