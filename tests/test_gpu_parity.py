@@ -381,7 +381,19 @@ def test_full_size_mixed_levels_config4(product, oracle):
     b = product.create_baker()
     t = product.create_texture(b, [tex], alpha_cutoff=0.5)
     kw = dict(addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, dyn_scale=2.0)
-    full = product.bake(b, ot.make_desc(t, uv, ix, 10, levels=lv, **kw), want_stats=False)
+    d = ot.make_desc(t, uv, ix, 10, levels=lv, **kw)
+    full = product.bake(b, d, want_stats=False)
+    # ommCpuBake streams this result while it classifies (tail_kernels.hip "Streamed result"): it must not have fallen back -- at this size a family of
+    # possible duplicates once spanned two levels and pulled level-10 items behind their own placement -- and the bytes must be those of the
+    # device-resident entry, which assembles the result after the classification
+    import bench, ctypes
+    tm = bench.BakeTimings()
+    product.dll.ommxGetLastBakeTimings.argtypes = [ctypes.c_void_p, ctypes.POINTER(bench.BakeTimings)]
+    product.dll.ommxGetLastBakeTimings(b, ctypes.byref(tm))
+    assert tm.streamChunks > 1 and tm.streamedBytes == full.array_data.size, (tm.streamChunks, tm.streamedBytes)
+    dev = ot.bake_device(product, ot.Hip(), b, d, uv, ix, levels=lv)
+    assert dev.same_as(full), dev.diff(full)
+    del dev
     product.destroy_texture(b, t)
     product.destroy_baker(b)
     assert full.index.size == n and len(full.descs) > 30000 and full.array_data.size > (2 << 30)
