@@ -306,10 +306,12 @@ def main():
             havg = lambda f: avg(f, host_tms)
             line["host_api"] = {"entry": "ommCpuBake (host arrays in/out, PCIe inclusive)", "ms_per_bake": host_ms, "bakes": host_steps, "first_call_ms": host_first_ms,
                                 "micro_triangles_per_s": micro_tris / (host_ms * 1e-3),
-                                "stream": {"chunks": int(host_tms[-1].streamChunks), "streamed_bytes": int(host_tms[-1].streamedBytes), "exposed_copy_ms": havg("streamTailMs"),
+                                "stream": {"ranges": int(host_tms[-1].streamChunks), "streamed_bytes": int(host_tms[-1].streamedBytes), "exposed_copy_ms": havg("streamTailMs"),
                                            "early_items": int(host_tms[-1].streamEarlyItems),
-                                           "note": "finished OMM blocks cross PCIe, straight to their final arrayData offsets, while the classification runs (one copy per classification "
-                                                   "launch); exposed = from the end of the classification to the last byte on the host"},
+                                           "note": "ranges > 0: finished OMM blocks cross PCIe (SDMA) straight to their final arrayData offsets while the ONE persistent classification "
+                                                   "launch is still running, one copy per range of work items; exposed = from the end of the classification to the last byte on the "
+                                                   "host; early_items = possible duplicates, classified with an earlier range than their own; ranges == 0: one copy after the bake "
+                                                   "(small results, or a classification so long that the copy is not worth a quarter of its speed)"},
                                 "phases_ms": {k: havg(k) for k in ("uploadMs", "setupMs", "triageMs", "classifyMs", "digestMs", "tailMs", "gatherMs", "downloadMs", "totalMs")}}
 
         # ---- roofline of the dominant kernel, classify_tiles (the persistent launch of the levels >= 6) ----

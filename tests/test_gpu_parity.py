@@ -866,7 +866,7 @@ def test_bench_contract_small():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["bake_wall_time_entry"].startswith("ommCpuBake") and d["bake_wall_time_ms"] > 0 and d["host_api"]["stream"]["chunks"] == 3 and d["value_entry"] == "ommxBakeDevice"
+    assert d["bake_wall_time_entry"].startswith("ommCpuBake") and d["bake_wall_time_ms"] > 0 and d["host_api"]["stream"]["ranges"] == 3 and d["value_entry"] == "ommxBakeDevice"
     assert d["cpu_baseline"]["fine_pass_only"] > 0 and d["roofline"]["bound"] == "hbm"      # (the issue-slot roofline needs the PMC summary of the full-size workload)
     for cfgname in ("c1", "c4", "cards"):
         o2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", cfgname, "--tris", "1500", "--steps", "1", "--warmup", "1", "--cpu-sample", "200",
