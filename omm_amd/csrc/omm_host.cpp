@@ -563,11 +563,11 @@ struct HostTailRequest { std::vector<HostItem> items; };
 
 // ommCpuBake: the result has to end up in host memory, and the 1.3 GB of arrayData of the metric configuration need 23 ms of PCIe time -- nearly
 // as long as the classification itself.  The final ORDER of the blocks is known up front (descending level / spatial key / item index over the items
-// that are emitted), so the classification of the levels >= 6 runs as `chunks` launches over consecutive ranges of that order; behind each launch the
-// blocks of its range are packed behind those of the earlier ranges -- a contiguous piece of the final arrayData -- and ONE asynchronous copy on a second
-// stream moves that piece to its final place in the caller's array while the next launch classifies (tail_kernels.hip: "Streamed result").  The
-// placement is verified against the ordinary tail at the end; on a mismatch (a duplicate block whose first occurrence was classified later) the bake
-// falls back to the ordinary gather + copy.
+// that are emitted), so the tile queue of the levels >= 6 is cut into `chunks` consecutive ranges of that order, which one persistent launch drains in
+// turn; when a range is complete (device-side count), its blocks are packed behind those of the earlier ranges -- a contiguous piece of the final
+// arrayData -- on a second stream, and ONE SDMA copy moves that piece to its final place in the caller's array while the launch classifies the
+// following ranges (tail_kernels.hip: "Streamed result").  The placement is verified against the ordinary tail at the end; on a mismatch (a duplicate
+// block whose first occurrence was classified later) the bake falls back to the ordinary gather + copy.
 struct StreamOut {
     // in
     uint32_t chunksWanted = 0;        // 0 = decide from the size of the bake

@@ -447,17 +447,21 @@ void launch_shard_scatter(const uint8_t* gathered, uint64_t rankPitch, uint64_t 
 //
 // The final order of the blocks is known before anything is classified: descending (level, Morton key of the centroid, item index)
 // over the items that end up EMITTED (bake_cpu_impl.cpp:1707-1754).  So the per-level lists of active items are sorted into that order
-// first (run_stream_sort), the classification of the levels >= 6 proceeds range by range in it (launch_classify: chunks), and behind every
-// range run_stream_segment() decides which of its items are emitted -- non-uniform, not rejected, first occurrence of their digest --,
-// scans their sizes and packs their blocks behind the blocks of the earlier ranges: a contiguous piece of the final arrayData, which one
-// device-to-host copy on a second stream moves while the next range is classified.
+// first (run_stream_begin), the tile queue of the levels >= 6 is cut into ranges of it (classify_plan; ONE persistent launch drains them in
+// order and counts each range's finished tiles: bake_kernels.hip), and on a second, high-priority stream, behind a one-lane kernel that waits
+// for the range's count (stream_wait_sections), run_stream_segment() decides which of the range's items are emitted -- non-uniform, not
+// rejected, first occurrence of their digest --, scans their sizes and packs their blocks behind the blocks of the earlier ranges: a
+// contiguous piece of the final arrayData, which one SDMA copy moves to the host while the launch classifies the following ranges.
 //
-// "First occurrence of the digest" (DeduplicateExact, bake_cpu_impl.cpp:1031-1066: the LOWEST work-item index keeps the block) is only known
-// for the ranges classified so far, so the placement is speculative in exactly one respect: if a later range brings a LOWER index for a
-// digest that an earlier range has already emitted, the earlier block should not have been there.  That event is detected (claimed[] below)
-// and, belt and braces, the complete result layout of the ordinary tail is compared with the streamed one at the end (stream_verify); on any
-// difference the bake falls back to the ordinary gather + copy.  Identical non-uniform blocks of DIFFERENT UV triangles at levels >= 6 are
-// rare (>= 4096 states each), and a bake full of them has a small arrayData anyway.
+// "First occurrence of the digest" (DeduplicateExact, bake_cpu_impl.cpp:1031-1066: the LOWEST work-item index keeps the block) needs the
+// digests of every item that could carry the same block.  The preview below finds those families before the classification; the members of a
+// family are classified with the range of its FIRST member (never later than their own: early_range), so when a range is placed every digest
+// that can decide about its blocks is in the table.  What the preview cannot see (items it does not cover, a family it split) makes the
+// placement speculative in exactly one respect: a later range may bring a LOWER index for a digest that an earlier range has already
+// emitted.  That event is detected (claimed[] below) and, belt and braces, the complete result layout of the ordinary tail is compared with
+// the streamed one at the end (stream_verify); on any difference the bake falls back to the ordinary gather + copy.  The DATA of a placed
+// block is complete by construction: all tiles of an item lie in sections of its own range or an earlier one, and a range is placed only
+// when both of its sections have reported every tile (device-scope release / acquire on the section's count).
 // ------------------------------------------------------------------------------------------------------------------------------
 struct StreamScratch {
     HashTable table; uint8_t* claimed;        // digest -> lowest emitted-candidate index; claimed[slot] = 1 + range that emitted a block for it
@@ -527,10 +531,13 @@ hipError_t run_stream_begin(uint32_t* activeIds, uint32_t numActive, const float
 // Two items with the same block have the same block at every coarser level too (a coarse micro-triangle is T / O exactly when all of its
 // descendants are), so the preview classifies every active item of level >= 6 at level 5 (1024 micro-triangles, the whole-item kernel with
 // 4-state / ForceOpaque parameters, buffers of its own: < 2 % of the work of the bake), hashes the 256 bytes, and marks as `early` every item
-// whose preview (a) is not one single state -- those become special indices, not blocks -- and (b) is shared with another item.  The early
-// items are classified, digested and entered into the digest table before the first range is placed, so every first-occurrence relation that
-// can exist is exact when the placement starts.  Items whose preview micro-triangles would be large (> 256 texels each: asset-sized triangles)
-// are not previewed (a collapsed triangle stands in for them) and never early.  A wrong guess costs speed only: the placement is verified.
+// whose preview (a) is not one single state -- those become special indices, not blocks -- and (b) is shared with another item: a family.
+// On the bench workload 41 425 of the 79 869 items with a mixed preview are early (8 392 families: the digital lines a 32 x 32 lattice can tell
+// apart are few).  Classifying them all before the first range held the first copy back by 10 ms (their tiles are a third of the open tiles), so
+// a family is classified with the range of its first member instead (stream_preview_leaders: lead[], early_range; the tile triage routes its
+// tiles into that range's second queue section) and is digested and entered into the table with that range.  Items whose preview micro-triangles
+// would be large (> 256 texels each: asset-sized triangles) are not previewed (a collapsed triangle stands in for them) and never early.  A wrong
+// guess costs speed only: the placement is verified.
 __global__ __launch_bounds__(256) void stream_preview_prepare(const uint32_t* __restrict__ ids, uint32_t n, const float* __restrict__ uv, float texW, float texH,
                                                               float* __restrict__ uv2, uint64_t* __restrict__ ofs2, uint8_t* __restrict__ early)
 {
