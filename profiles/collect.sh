@@ -24,3 +24,5 @@ cd $R
 python profiles/summarize_rocprof.py $(find $O/trace -name "*.db" | head -1) > $O/kernel_stats.md 2> $O/kernel_stats.err
 python profiles/summarize_pmc.py $tag $O "python bench.py --config $cfg $PM" > $O/pmc_summary.json 2> $O/pmc_summary.err
 tail -c 900 $O/bench.json; echo; cat $O/pmc_summary.json; head -14 $O/kernel_stats.md
+# only the summaries travel back (gpurun merges at most 64 MiB; the raw trace database and counter CSVs of one configuration are larger than that)
+[ -z "$OMMX_KEEP_RAW" ] && rm -rf $O/trace $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_C1 $O/pmc_C2 $O/pmc_C3 $O/pmc_C4
