@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="triangles baked by the CPU baseline (-1 = the configuration's default, 0 = skip)")
     ap.add_argument("--create-texture", type=int, default=1, help="time ommCpuCreateTexture at 4K and 8K (0 = skip)")
     ap.add_argument("--sat-off-sample", type=int, default=50000, help="c2 only: triangles of the SAT-off (no coarse pass) GPU measurement; CPU uses 1/20 of it (0 = skip)")
+    ap.add_argument("--generic-pass", type=int, default=0, help="ommxBakerKnob_GenericPass (0 = library default, 1 = inside the persistent launch, 2 = deferred pass)")
     ap.add_argument("--stream-chunks", type=int, default=0, help="ommxBakerKnob_StreamChunks for the ommCpuBake measurement (0 = library default)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -179,6 +180,8 @@ def main():
     baker = prod.create_baker()
     if args.stream_chunks:
         prod.set_knob(baker, ot.KNOB_STREAM_CHUNKS, args.stream_chunks)
+    if args.generic_pass:
+        prod.set_knob(baker, ot.KNOB_GENERIC_PASS, args.generic_pass)
     th = prod.create_texture(baker, [tex], alpha_cutoff=0.5)
     host_desc = desc_for(th, uv, ix, lv, kw)
     # inputs resident in HBM before the timed region: torch owns the device buffers, the library gets raw pointers

@@ -56,6 +56,11 @@ __device__ __forceinline__ uint32_t early_range(uint32_t leadPos, uint32_t ownPo
     const uint32_t a = section_of_position(leadPos, L, S), b = section_of_position(ownPos, L, S);
     return a < b ? a : b;
 }
+// Deferred generic pass (asset-sized triangles: micro-triangles of several texels).  The persistent launch queues the micro-triangles that need the
+// generic texel loops instead of walking them itself -- entry = {item | degenerate << 30, level << 24 | micro-triangle index}, their packed state left 0 --
+// and classify_generic() classifies them afterwards, eight lanes per micro-triangle, and ORs the states in.  *count may exceed capacity: a tile that did not
+// fit walked its micro-triangles itself and took its reservation back.
+struct GenericQueue { uint2* entries; uint32_t* count; uint32_t capacity; };
 struct ClassifyChunks {
     uint32_t count;
     void (*after)(void* user, uint32_t chunk, const ClassifySegment* segs, uint32_t numSegs, bool last);
@@ -65,6 +70,7 @@ struct ClassifyChunks {
     // its family, earlyLead[item] = that member's position in activeIds -- so a range's section pair holds everything the placement of the range depends on.
     const uint8_t* early; const uint32_t* earlyLead;
     void* earlyStage;       // >= kTileRecordBytes x (open tiles of early items) bytes of scratch, free until the persistent launch starts
+    GenericQueue generic;   // entries != null: deferred generic pass (not together with `after`: a streamed range must be complete when its sections are)
 };
 // the whole-item kernel at `level` over a plain item list (used for the level-2 preview of a streamed bake)
 hipError_t launch_classify_items(const ClassifyParams& P, const ItemArrays& A, const uint32_t* ids, uint32_t count, uint32_t level, hipStream_t stream);

@@ -201,11 +201,13 @@ constexpr int WIN = 32; // largest LDS texel window edge
 #define OMMX_CLASSIFY_WAVES 7
 #endif
 // TILE micro-triangles per workgroup: 4096 for levels >= 6, 1024 below (a level-5 item is exactly one 1024-tile)
-template <bool FP32, bool SLICED, int TILE, class MD>
+constexpr uint32_t kDeferredState = 0xFEu;   // s_state code of a micro-triangle that classify_generic() will classify
+template <bool FP32, bool SLICED, int TILE, class MD, bool DEFER = false>
 __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(ClassifyParams P, ItemArrays A, const uint32_t* __restrict__ itemIds,
                                                         uint32_t numItems, uint32_t levelArg, uint64_t numTiles,
-                                                        const uint4* __restrict__ tileQueue, uint32_t* __restrict__ queueCtl, uint32_t numSections)
+                                                        const uint4* __restrict__ tileQueue, uint32_t* __restrict__ queueCtl, uint32_t numSections, GenericQueue G)
 {
+    __shared__ uint32_t s_gbase;                 // DEFER: first entry of this tile's reservation in the generic queue (0xFFFFFFFF: none, walk inline)
     __shared__ uint8_t  s_state[TILE];
     __shared__ uint16_t s_queue[TILE];
     __shared__ int      s_group[TILE / GROUP];
@@ -216,6 +218,23 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     __shared__ uint32_t s_mask, s_known;
     __shared__ uint32_t s_pending, s_fine;       // single-texel pass: micro-triangles left for the generic pass / level-line statistic
     __shared__ uint32_t s_next;                  // sliced: next tile-queue position of this (persistent) workgroup
+    // DEFER: hand `n` queued micro-triangles (s_queue[0 .. n)) to the generic queue; false = no room, the caller walks them itself.  Block-uniform.
+    auto defer_generic = [&](uint32_t n, uint32_t itemWord, uint32_t level, uint32_t base) -> bool {
+        if (!DEFER || !SLICED || n == 0u) return false;
+        if (threadIdx.x == 0) {
+            const uint32_t b = atomicAdd(G.count, n);
+            if ((uint64_t)b + n <= (uint64_t)G.capacity) s_gbase = b; else { s_gbase = 0xFFFFFFFFu; atomicSub(G.count, n); }
+        }
+        __syncthreads();
+        const uint32_t gb = s_gbase;
+        if (gb == 0xFFFFFFFFu) return false;
+        for (uint32_t q = threadIdx.x; q < n; q += BLOCK) {
+            const uint32_t i = s_queue[q];
+            G.entries[gb + q] = make_uint2(itemWord & 0x7FFFFFFFu, (level << 24) | (base + i));
+            s_state[i] = (uint8_t)kDeferredState;
+        }
+        return true;
+    };
     __shared__ uint32_t s_sec, s_nsec, s_retired; // sliced: section of the current tile / of the next one, tiles of the current section this workgroup has finished
     __shared__ uint32_t s_gdec[SLICED ? TILE / GROUP : 1];   // sliced: bird-curve decode of each 64-group of the tile (classify_device.h: BirdGroup)
     __shared__ uint8_t  s_btab[SLICED ? 256 : 1];            // ... and the 4 x 64 table of the low decode bits, filled once per workgroup
@@ -446,6 +465,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
             }
             // ---- phase 2c: the generic pass for whatever did not fit the single-texel pattern ----
             if (tid == 0 && s_fine) atomicAdd(A.fineCount + (size_t)((blockIdx.x + 7u * blockIdx.y) & (kFineSlots - 1)) * kFineStride, (unsigned long long)s_fine);
+            if (!defer_generic(qn2, rec.x, level, base))
             for (uint32_t q0 = 0; q0 < qn2; q0 += BLOCK) {
                 const uint32_t q = q0 + tid;
                 if (q < qn2) {
@@ -453,7 +473,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                     s_state[i] = (uint8_t)fine_state<FP32, MD>(P, tile_micro_triangle(i), uDegenerate, W);
                 }
             }
-        } else
+        } else if (!defer_generic(qn, rec.x, level, base))
         for (uint32_t q0 = 0; q0 < qn; q0 += BLOCK) { // q0 is block-uniform (scalar loop counter): one VGPR less across the level-line pass
             const uint32_t q = q0 + tid;
             if (q < qn) {
@@ -485,7 +505,8 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 localKnown += gs < 2 ? perWord : 0u;
             } else {
                 for (uint32_t k = 0; k < perWord; ++k) {
-                    const uint32_t st = s_state[w * perWord + k];
+                    uint32_t st = s_state[w * perWord + k];
+                    if (DEFER && st == kDeferredState) continue;   // (its bits stay 0 for classify_generic's atomicOr; mask and known count come from there too)
                     v |= st << (k * bits);
                     localMask |= 1u << st;
                     localKnown += st < 2u;
@@ -552,6 +573,156 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     }
     return;   // (!SLICED: one tile per workgroup)
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Deferred generic pass.  Micro-triangles that span several texels (asset-sized triangles) walk the texels of their raster box (conservative
+// raster + level-line kernel / nearest vote per texel: fine_state).  Inside classify_tiles one lane walks one box: neighbouring boxes differ in
+// size by orders of magnitude, two thirds of the walks end at their first mixed texel after a handful of visits and the rest visit every texel
+// under the triangle, so a fifth of the lanes does useful work (profiles/r03_v3_cards_pmc.md).  Here the walk has two phases per wave of 64
+// queued micro-triangles:
+//   A  one lane per micro-triangle, at most OMMX_GENERIC_SOLO visits of texels under the triangle: settles the short walks at full width;
+//   B  the unfinished walks, eight at a time, EIGHT lanes each: texel k of the box goes to lane k mod 8 from where phase A stopped, the counters
+//      are combined with two wave ballots after every round, and a sub-group stops as soon as both are non-zero (when the promotion does not
+//      look at the counts) -- the early exit of the serial walk at a granularity of eight texels.
+// (Eight lanes per walk from the start -- the first form -- took as long as the serial walk: it pays 8 x for every short walk what it gains on
+// the long ones.)  The result depends on the two counters only through (above != 0, below != 0) or, for the Nearest promotion, their totals
+// (state_from_coverage), and every texel of the box is visited at most once: same state as the serial walk.  Mip chains and degenerate items
+// take the serial fine_state().  The state is ORed into the packed word the persistent launch left 0; item mask / known count are folded per wave.
+// ------------------------------------------------------------------------------------------------
+#ifndef OMMX_GENERIC_SOLO
+#define OMMX_GENERIC_SOLO 4
+#endif
+struct RasterBox { EdgeEq e0, e1, e2; int minx, miny; uint32_t w, cnt; };
+__device__ __forceinline__ RasterBox raster_box(const DevMip& m, const MicroTri& t, float off)
+{
+    // same set-up as raster_micro_triangle (classify_device.h): winding, raster-space vertices, box
+    const double ax = (double)(t.p2.x - t.p0.x), ay = (double)(t.p2.y - t.p0.y);
+    const double bx = (double)(t.p1.x - t.p0.x), by = (double)(t.p1.y - t.p0.y);
+    const bool ccw = (ax * by - bx * ay) < 0;
+    V2 a = mk2(t.p0.x * m.fw + off, t.p0.y * m.fh + off);
+    const V2 b = mk2(t.p1.x * m.fw + off, t.p1.y * m.fh + off);
+    V2 c = mk2(t.p2.x * m.fw + off, t.p2.y * m.fh + off);
+    if (!ccw) { V2 s = a; a = c; c = s; }
+    const float lox = std_min(std_min(a.x, b.x), c.x), loy = std_min(std_min(a.y, b.y), c.y);
+    const float hix = std_max(std_max(a.x, b.x), c.x), hiy = std_max(std_max(a.y, b.y), c.y);
+    const int minx = cvt_trunc_x86(__builtin_floorf(lox)), miny = cvt_trunc_x86(__builtin_floorf(loy));
+    const int maxx = cvt_trunc_x86(__builtin_ceilf(hix)), maxy = cvt_trunc_x86(__builtin_ceilf(hiy));
+    RasterBox B; B.e0 = edge_eq(a, b); B.e1 = edge_eq(b, c); B.e2 = edge_eq(c, a); B.minx = minx; B.miny = miny;
+    const long long w = (long long)maxx - (long long)minx, h = (long long)maxy - (long long)miny;
+    const unsigned long long cnt64 = (w > 0 && h > 0) ? (unsigned long long)w * (unsigned long long)h : 0ull;
+    B.w = w > 0 ? (uint32_t)w : 1u; B.cnt = cnt64 > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)cnt64;
+    return B;
+}
+// texel k of the box (row-major); returns whether it lies under the (conservative) triangle, and votes if so
+template <bool FP32, int KIND, class MD>
+__device__ __forceinline__ bool visit_texel(const ClassifyParams& P, const DevMip& m, const MicroTri& t, const RasterBox& B, uint32_t k, uint32_t& above, uint32_t& below)
+{
+    const int x = B.minx + (int)(k % B.w), y = B.miny + (int)(k / B.w);
+    const float sx = (float)x, sy = (float)y;
+    if (!(eval_cons(B.e0, sx, sy) < 0.f && eval_cons(B.e1, sx, sy) < 0.f && eval_cons(B.e2, sx, sy) < 0.f)) return false;
+    if (KIND == 0) level_line_texel<FP32, false, MD>(P, m, t, x, y, above, below, no_window());
+    else nearest_texel<FP32, MD>(P, m, x, y, above, below, no_window());
+    return true;
+}
+// sum of a counter over the 8 lanes of a sub-group
+__device__ __forceinline__ uint32_t sum8(uint32_t v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
+
+template <bool FP32, int KIND, class MD>
+__device__ __forceinline__ int generic_two_phase(const ClassifyParams& P, const float* __restrict__ uvAll, uint32_t item, uint32_t levelWord, bool live)
+{
+    const DevMip& m = P.mips[0];
+    const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, sg = lane >> 3;
+    const bool countsMatter = P.promotion == 0;
+    const float off = KIND == 0 ? -0.5f : 0.f;
+    uint32_t above = 0, below = 0, k = 0;
+    bool finished = !live;
+    {   // ---- phase A: one lane per micro-triangle ----
+        const MicroTri t = micro_triangle(uvAll + 6ull * item, levelWord & 0xFFFFFFu, levelWord >> 24);
+        if (KIND == 0 && live) vote(P.cutoff < bilinear<FP32, MD>(P, m, t.p0, no_window()), above, below);
+        const RasterBox B = raster_box(m, t, off);
+        uint32_t visits = 0;
+        while (!finished) {
+            if (k >= B.cnt) { finished = true; break; }
+            const bool under = visit_texel<FP32, KIND, MD>(P, m, t, B, k, above, below);
+            ++k;
+            if (!countsMatter && above != 0 && below != 0) { finished = true; break; }
+            if (under && ++visits >= (uint32_t)OMMX_GENERIC_SOLO) break;
+        }
+        if (!finished && k >= B.cnt) finished = true;
+    }
+    // ---- phase B: the unfinished walks, eight at a time, eight lanes each ----
+    unsigned long long pending = __ballot(!finished);
+    while (pending) {
+        unsigned long long mine = pending;
+        for (uint32_t q = 0; q < sg; ++q) mine &= mine - 1ull;               // drop the sg lowest set bits: this sub-group takes the next one
+        const int src = mine ? __ffsll((long long)mine) - 1 : -1;
+        const bool work = src >= 0;
+        const int from = work ? src : (int)lane;
+        const uint32_t it2 = (uint32_t)__shfl((int)item, from), lw2 = (uint32_t)__shfl((int)levelWord, from), k0 = (uint32_t)__shfl((int)k, from);
+        const uint32_t a0 = (uint32_t)__shfl((int)above, from), b0 = (uint32_t)__shfl((int)below, from);
+        const MicroTri t = micro_triangle(uvAll + 6ull * it2, lw2 & 0xFFFFFFu, lw2 >> 24);
+        const RasterBox B = raster_box(m, t, off);
+        uint32_t la = sub == 0u ? a0 : 0u, lb = sub == 0u ? b0 : 0u;          // (lane 0 of the sub-group carries the walk's counters so far)
+        const uint32_t shift = lane & 56u;
+        bool done = !work;
+        for (uint32_t kk = k0 + sub; ; kk += 8u) {
+            const bool go = !done && kk < B.cnt;
+            if (__ballot(go) == 0ull) break;
+            if (go) (void)visit_texel<FP32, KIND, MD>(P, m, t, B, kk, la, lb);
+            if (!countsMatter) {   // the sub-group has seen both sides: the state is final
+                const unsigned long long ba = __ballot(la != 0), bb = __ballot(lb != 0);
+                if (((ba >> shift) & 0xFFull) != 0ull && ((bb >> shift) & 0xFFull) != 0ull) done = true;
+            }
+        }
+        const uint32_t ta = sum8(la), tb = sum8(lb);
+        // hand the totals back to the lanes that own the walks: owner of the r-th set bit <- sub-group r
+        const uint32_t rank = (uint32_t)__popcll(pending & ((1ull << lane) - 1ull));
+        const bool owner = ((pending >> lane) & 1ull) != 0ull && rank < 8u;
+        const uint32_t ra = (uint32_t)__shfl((int)ta, (int)((owner ? rank : 0u) * 8u)), rb = (uint32_t)__shfl((int)tb, (int)((owner ? rank : 0u) * 8u));
+        if (owner) { above = ra; below = rb; finished = true; }
+        for (int q = 0; q < 8 && pending; ++q) pending &= pending - 1ull;
+    }
+    return state_from_coverage(P, above, below);
+}
+
+template <bool FP32, class MD>
+__global__ __launch_bounds__(256) void classify_generic(ClassifyParams P, ItemArrays A, GenericQueue G)
+{
+    const uint32_t n = *G.count < G.capacity ? *G.count : G.capacity;
+    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * 256u + threadIdx.x) >> 6, waves = (gridDim.x * 256u) >> 6;
+    const uint32_t bits = (uint32_t)P.format;
+    for (uint32_t e0 = wave * 64u; e0 < n; e0 += waves * 64u) {   // (wave-uniform)
+        const uint32_t e = e0 + lane;
+        const bool live = e < n;
+        const uint2 ent = live ? G.entries[e] : make_uint2(0u, 0u);
+        const uint32_t item = ent.x & 0x3FFFFFFFu;
+        const bool degenerate = ((ent.x >> 30) & 1u) != 0u;
+        int state = 0;
+        const bool serial = P.mipCount != 1 || degenerate;      // (wave-uniform in practice: mip chains are a bake property, degenerate items are rare)
+        if (__ballot(live && serial) != 0ull) {
+            if (live) state = fine_state<FP32, MD>(P, micro_triangle(A.uv + 6ull * item, ent.y & 0xFFFFFFu, ent.y >> 24), degenerate, no_window());
+        } else if (P.filterLinear) state = generic_two_phase<FP32, 0, MD>(P, A.uv, item, ent.y, live);
+        else state = generic_two_phase<FP32, 1, MD>(P, A.uv, item, ent.y, live);
+        if (live) {
+            const uint64_t bit = (uint64_t)(ent.y & 0xFFFFFFu) * bits;
+            atomicOr((uint32_t*)(A.states + A.stateOfs[item]) + (bit >> 5), (uint32_t)state << (uint32_t)(bit & 31u));
+        }
+        // item mask / known count: one atomic per item and wave (the entries of a wave mostly share their item)
+        unsigned long long todo = __ballot(live);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t it0 = (uint32_t)__shfl((int)item, leader);
+            const unsigned long long same = __ballot(live && item == it0) & todo;
+            todo &= ~same;
+            uint32_t mask = 0;
+            #pragma unroll
+            for (int s = 0; s < 4; ++s) if (__ballot(live && item == it0 && state == s) & same) mask |= 1u << s;
+            const uint32_t known = (uint32_t)__popcll(__ballot(live && item == it0 && state < 2) & same);
+            if ((int)lane == leader) { atomicOr(&A.stateMask[it0], mask); if (P.wantKnownCount && known) atomicAdd(&A.knownCount[it0], known); }
+        }
+    }
 }
 
 // ---- launches ----
@@ -643,6 +814,8 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
     ClassifyPlan plan; classify_plan(first, count, chunks.count, &plan);
     const TileSections& S = plan.ranges; const uint32_t K = S.n;
     const bool paired = K > 1u;   // (two sections per range; the queue holds a second copy of the levels >= 6 for the odd ones: classify_queue_records)
+    const bool deferred = chunks.generic.entries != nullptr && chunks.after == nullptr;
+    GenericQueue noGeneric; noGeneric.entries = nullptr; noGeneric.count = nullptr; noGeneric.capacity = 0;
     uint4* q1024 = queue + (plan.totalBig * (paired ? 2u : 1u)) * kTileRecordWords;
     TileSections one; memset(&one, 0, sizeof one); one.n = 1;
     // ---- sliced items, step 1: tile triage of both tile sizes (settled tiles are final after it, open ones are queued) ----
@@ -664,21 +837,26 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
         const uint64_t tiles = ((uint64_t)count[level] * M + 1023u) / 1024u;
         const uint32_t gx = tiles < (1u << 20) ? (uint32_t)tiles : (1u << 20), gy = (uint32_t)((tiles + gx - 1) / gx);
         hipLaunchKernelGGL((classify_tiles<FP32, false, 1024, MD>), dim3(gx, gy), dim3(BLOCK), 0, stream, P, A, activeIds + first[level], count[level], level, tiles,
-                           (const uint4*)nullptr, (uint32_t*)nullptr, 0u);
+                           (const uint4*)nullptr, (uint32_t*)nullptr, 0u, noGeneric);
     }
     // ---- sliced items, step 2: one persistent launch per queue; every CU holds OMMX_CLASSIFY_WAVES workgroups of 4 waves (one per SIMD) ----
     // (streamed bakes leave one workgroup slot per CU to the placement kernels that run next to the persistent launch)
     const uint64_t want = (uint64_t)numCUs * (chunks.after ? OMMX_CLASSIFY_WAVES - 1 : OMMX_CLASSIFY_WAVES);
     if (plan.totalSmall) {
         const dim3 cg((uint32_t)(plan.totalSmall < want ? plan.totalSmall : want)), cb(BLOCK);
-        hipLaunchKernelGGL((classify_tiles<FP32, true, 1024, MD>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)q1024, ctl1024, 1u);
+        if (deferred) hipLaunchKernelGGL((classify_tiles<FP32, true, 1024, MD, true>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)q1024, ctl1024, 1u, chunks.generic);
+        else hipLaunchKernelGGL((classify_tiles<FP32, true, 1024, MD>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)q1024, ctl1024, 1u, noGeneric);
     }
     if (chunks.mark) chunks.mark(chunks.user);   // (everything but the persistent launch of the levels >= 6 is enqueued)
     if (plan.totalBig) {
         const dim3 cg((uint32_t)(plan.totalBig < want ? plan.totalBig : want)), cb(BLOCK);
-        hipLaunchKernelGGL((classify_tiles<FP32, true, 4096, MD>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)queue, queueCtl,
-                           paired ? 2u * K : K);
+        if (deferred) hipLaunchKernelGGL((classify_tiles<FP32, true, 4096, MD, true>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)queue, queueCtl,
+                                         paired ? 2u * K : K, chunks.generic);
+        else hipLaunchKernelGGL((classify_tiles<FP32, true, 4096, MD>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)queue, queueCtl,
+                                paired ? 2u * K : K, noGeneric);
     }
+    // ---- deferred generic pass: the micro-triangles of several texels that the persistent launches queued instead of walking ----
+    if (deferred) hipLaunchKernelGGL((classify_generic<FP32, MD>), dim3(numCUs * 8u), dim3(256), 0, stream, P, A, chunks.generic);
     for (uint32_t k = 0; k < K; ++k) {
         if (chunks.after) {   // the work items of this range, as segments of the per-level active lists, in the order of the final result
             ClassifySegment segs[kNumLevels]; uint32_t ns = 0;
@@ -732,8 +910,9 @@ hipError_t launch_classify_items(const ClassifyParams& P, const ItemArrays& A, c
     const uint64_t M = 1ull << (2 * level);
     const uint64_t tiles = ((uint64_t)count * M + 1023u) / 1024u;
     const uint32_t gx = tiles < (1u << 20) ? (uint32_t)tiles : (1u << 20), gy = (uint32_t)((tiles + gx - 1) / gx);
+    GenericQueue noGeneric; noGeneric.entries = nullptr; noGeneric.count = nullptr; noGeneric.capacity = 0;
 #define OMMX_ITEMS(FP, MD) hipLaunchKernelGGL((classify_tiles<FP, false, 1024, MD>), dim3(gx, gy), dim3(BLOCK), 0, stream, P, A, ids, count, level, tiles, \
-                                              (const uint4*)nullptr, (uint32_t*)nullptr, 0u)
+                                              (const uint4*)nullptr, (uint32_t*)nullptr, 0u, noGeneric)
     const bool wrapP2 = P.addrMode == 0 && P.pow2Dispatch, clampP2 = P.addrMode == 2 && P.pow2Dispatch;
     typedef ModeStatic<0, 1> WrapP2; typedef ModeStatic<2, 1> ClampP2;
     if (P.texIsFp32) { if (wrapP2) OMMX_ITEMS(true, WrapP2); else if (clampP2) OMMX_ITEMS(true, ClampP2); else OMMX_ITEMS(true, ModeDynamic); }

@@ -765,7 +765,8 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     S.uvFormat = d.texCoordFormat; S.indexFormat = d.indexFormat; S.numTris = T;
     S.globalLevel = d.maxSubdivisionLevel; S.dynScale = d.dynamicSubdivisionScale; S.edgeHeuristic = (flags & (1u << 11)) != 0;   // (EnableEdgeHeuristic, bake_cpu_impl.cpp:48,547)
     S.texW = tex.mips[0].w; S.texH = tex.mips[0].h; S.disableDedup = (flags & (1u << 3)) != 0;
-    S.wantWorkload = ((flags & (1u << 5)) != 0) || d.maxWorkloadSize != 0xFFFFFFFFFFFFFFFFull || so != nullptr;   // (ommCpuBake: input of the streaming decision below)
+    S.wantWorkload = 1;   // (also the input of the two shape decisions below: streamed result, deferred generic pass)
+    const bool checkWorkload = ((flags & (1u << 5)) != 0) || d.maxWorkloadSize != 0xFFFFFFFFFFFFFFFFull;
     S.keyMask = ~0ull;
     if (const uint64_t kb = baker.knob(ommxBakerKnob_SetupKeyBits)) S.keyMask = (1ull << kb) - 1ull;   // (tests: forced key collisions)
     bool ok = HIP_OK(hipMemcpyAsync(dUniformDigest, uniform_digests().v, sizeof(uint64_t) * kNumLevels * 4, hipMemcpyHostToDevice, stream));
@@ -873,7 +874,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         L.msg(ommMessageSeverity_Info, buf);
     }
     // ---- ValidateWorkloadSize (bake_cpu_impl.cpp:662-713) ----
-    if (S.wantWorkload) {
+    if (checkWorkload) {
         if (d.maxWorkloadSize != 0xFFFFFFFFFFFFFFFFull && hc.workload > d.maxWorkloadSize) return ommResult_WORKLOAD_TOO_BIG;
         if ((flags & (1u << 5)) && hc.workload > (1ull << 27)) {
             char buf[256];
@@ -893,6 +894,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     }
     // packed states of the active items + the queue of open tiles (48-byte records, bake_kernels.hip) + its 4 control words
     const size_t stateBytes = pad256(hc.stateBytes ? (size_t)hc.stateBytes : 256), ctlBytes = pad256(sizeof(uint32_t) * kClassifyCtlWords);
+    double microAll = 0; for (int l = 0; l < kNumLevels; ++l) microAll += (double)hc.levelCount[l] * (double)(1ull << (2 * l));
     // ---- streamed result (ommCpuBake)?  Worth it when the packed states are large enough for the copy to matter ----
     uint32_t streamChunks = 0; const uint32_t numActiveAll = hc.activeStart[kNumLevels];
     uint8_t* hostArray = nullptr; unsigned long long* hCursor = nullptr; bool hostPinned = false;
@@ -906,18 +908,30 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             // quantities that drive it: micro-triangles (sub-texel ones, mostly culled: 2.5e-10 ms each -- 27 ms for 6.5e10, 128 ms for 6.0e11 measured) and
             // texels under the triangles' boxes (micro-triangles of several texels walk them: 4e-9 ms each -- 55 ms for 1.4e10 measured on asset-sized
             // cards, where streaming the 0.28 GB result made the bake 10 ms SLOWER).
-            double micro = 0; for (int l = 0; l < kNumLevels; ++l) micro += (double)hc.levelCount[l] * (double)(1ull << (2 * l));
-            const double classifyMs = 2.5e-10 * micro + 4e-9 * (double)hc.workload, copyMs = (double)hc.stateBytes / 57e6;
+            const double classifyMs = 2.5e-10 * microAll + 4e-9 * (double)hc.workload, copyMs = (double)hc.stateBytes / 57e6;
             if (copyMs <= 0.25 * classifyMs) k = 0;
         }
         if (k > kMaxStreamRanges) k = kMaxStreamRanges;
         if (k && so->set->pinned.reserve(4096) && (hostArray = so->alloc(so->allocUser, hc.stateBytes, &hostPinned)) != nullptr) { streamChunks = k; hCursor = (unsigned long long*)so->set->pinned.base; }
     }
     const size_t queueBytes = pad256((size_t)classify_queue_records(lvlCount, streamChunks > 1) * kTileRecordBytes + 16);
-    if (!statesArena->reserve(stateBytes + queueBytes + ctlBytes + (streamChunks ? stateBytes : 0))) return L.failure("[Failure] - out of device memory for the packed micro-triangle states");
+    // ---- deferred generic pass?  (bake_kernels.hip: classify_generic)  For bakes whose cost is in the texels under their micro-triangles, not in their number:
+    // the same two terms as above.  Not for streamed bakes (a range must be complete when its queue sections are) and not for sharded ones.
+    uint64_t genericCapacity = 0;
+    {
+        const uint64_t mode = baker.knob(ommxBakerKnob_GenericPass);
+        const bool wanted = mode == 2 || (mode == 0 && 4e-9 * (double)hc.workload > 2.5e-10 * microAll);
+        if (wanted && !streamChunks && !sh && !ht && numActiveAll) {
+            genericCapacity = hc.stateBytes * 8ull / (uint64_t)bits;            // every micro-triangle of every active item ...
+            if (genericCapacity > (256ull << 20)) genericCapacity = 256ull << 20;   // ... at most 2 GB of entries (a tile that finds no room walks its micro-triangles itself)
+        }
+    }
+    const size_t genericBytes = genericCapacity ? pad256((size_t)genericCapacity * 8) + 256 : 0;
+    if (!statesArena->reserve(stateBytes + queueBytes + ctlBytes + (streamChunks ? stateBytes : 0) + genericBytes)) return L.failure("[Failure] - out of device memory for the packed micro-triangle states");
     uint8_t* dStates = statesArena->base;
     void* dTileQueue = statesArena->base + stateBytes; uint32_t* dQueueCtl = (uint32_t*)(statesArena->base + stateBytes + queueBytes);
     uint8_t* dStage = streamChunks ? statesArena->base + stateBytes + queueBytes + ctlBytes : nullptr;
+    uint8_t* dGeneric = genericCapacity ? statesArena->base + stateBytes + queueBytes + ctlBytes + (streamChunks ? stateBytes : 0) : nullptr;   // count word (256 B), then the entries
     const int e1b = et.mark();
 
     // ---- ResampleCoarse + ResampleFine (bake_cpu_impl.cpp:715-1029) on the active items ----
@@ -970,6 +984,10 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             cc.early = dEarly; cc.earlyLead = dEarlyLead; cc.earlyStage = dStage; sc.proto.early = dEarly; sc.earlyList = dEarlyList; sc.earlyCapacity = count6;
         }
     } else { cc.mark = mark_hook; cc.user = &mk; cc.early = nullptr; }   // (HIP event in front of the persistent launch of the levels >= 6)
+    if (dGeneric) {
+        if (!HIP_OK(hipMemsetAsync(dGeneric, 0, 256, stream))) return L.failure("[Failure] - device memset failed");
+        cc.generic.count = (uint32_t*)dGeneric; cc.generic.entries = (uint2*)(dGeneric + 256); cc.generic.capacity = (uint32_t)genericCapacity;
+    }
     if (!HIP_OK(launch_classify(P, A, dActiveIds, lvlFirst, lvlCount, dTileQueue, dQueueCtl, device_cu_count(), stream, &cc))) return L.failure("[Failure] - kernel launch failed");
     if (streamChunks && !sc.ok) return L.failure("[Failure] - kernel launch failed");
     const int e2 = et.mark();
@@ -2119,6 +2137,7 @@ OMM_MI355X_API ommResult ommxSetBakerKnob(ommBaker baker, ommxBakerKnob knob, ui
     if (knob == ommxBakerKnob_SetupKeyBits && value > 62) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_ShardChunkBytes && value != 0 && value < 256) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_StreamChunks && value > kMaxStreamRanges) return ommResult_INVALID_ARGUMENT;
+    if (knob == ommxBakerKnob_GenericPass && value > 2) return ommResult_INVALID_ARGUMENT;
     untag<Baker>(baker)->knobs[knob].store(value);
     return ommResult_SUCCESS;
 }

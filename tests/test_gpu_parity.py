@@ -1290,24 +1290,27 @@ def test_streamed_result_falls_back_when_a_later_range_owns_the_block(product, o
     assert fell_back == [False, True], fell_back      # previewed copies stream; the asset-sized ones stream, notice, and take the ordinary path
 
 
-def test_micro_triangles_of_several_texels(product, oracle):
+@pytest.mark.parametrize("generic_pass", [1, 2])
+def test_micro_triangles_of_several_texels(product, oracle, generic_pass):
     """Micro-triangles that span several texels (asset-sized triangles: the shape of the reference's Leaflet KATs at production size): the generic
     texel-loop path (conservative raster + level-line kernel per texel) with every promotion.  Quads of 40 .. 700 texels at levels 6 .. 9,
-    Clamp / Wrap / Mirror / Border, UNORM8 and FP32, SAT on and off, 2-state."""
+    Clamp / Wrap / Mirror / Border, UNORM8 and FP32, SAT on and off, 2-state.  Both homes of that path (ommxBakerKnob_GenericPass): inside the
+    persistent classification launch, one lane per micro-triangle, and the deferred pass (bake_kernels.hip: classify_generic), eight lanes each."""
     import workloads as wl
+    knobs = [(ot.KNOB_GENERIC_PASS, generic_pass)]
     tex8 = ot.foliage_texture(77, 1024, 1024, feature=48)
     texf = ot.value_noise(13, 700, 500, octaves=4, base_cell=40).astype(np.float32)
     uv, ix, lv = wl.card_quads(3, 40, 1024, lo_texels=40.0, hi_texels=700.0)
     lv9 = lv.copy(); lv9[::5] = 9
     for promo in (ot.PROMO_FORCE_OPAQUE, ot.PROMO_FORCE_TRANSPARENT, ot.PROMO_NEAREST):
-        both(product, oracle, [tex8], uv, ix, 8, addr=ot.CLAMP, promo=promo, levels=lv)
-    both(product, oracle, [tex8], uv, ix, 9, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv9)
-    both(product, oracle, [tex8], uv, ix, 8, sat=False, addr=ot.MIRROR, promo=ot.PROMO_FORCE_OPAQUE, levels=lv)
-    both(product, oracle, [texf], uv, ix, 7, addr=ot.CLAMP, promo=ot.PROMO_FORCE_TRANSPARENT, fmt=ot.FMT_2STATE)
-    both(product, oracle, [texf], uv * np.float32(1.7) - np.float32(0.3), ix, 6, addr=ot.BORDER, promo=ot.PROMO_FORCE_OPAQUE, border_alpha=0.7)
+        both(product, oracle, [tex8], uv, ix, 8, addr=ot.CLAMP, promo=promo, levels=lv, knobs=knobs)
+    both(product, oracle, [tex8], uv, ix, 9, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv9, knobs=knobs)
+    both(product, oracle, [tex8], uv, ix, 8, sat=False, addr=ot.MIRROR, promo=ot.PROMO_FORCE_OPAQUE, levels=lv, knobs=knobs)
+    both(product, oracle, [texf], uv, ix, 7, addr=ot.CLAMP, promo=ot.PROMO_FORCE_TRANSPARENT, fmt=ot.FMT_2STATE, knobs=knobs)
+    both(product, oracle, [texf], uv * np.float32(1.7) - np.float32(0.3), ix, 6, addr=ot.BORDER, promo=ot.PROMO_FORCE_OPAQUE, border_alpha=0.7, knobs=knobs)
     # random triangles of 20 .. 60 texels (no axis-aligned edges), level 6
     uv2, ix2 = ot.random_triangles(61, 300, 0.05)
-    both(product, oracle, [tex8], uv2, ix2, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+    both(product, oracle, [tex8], uv2, ix2, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, knobs=knobs)
 
 
 def test_near_duplicate_merge_and_budget_at_scale(product, oracle):
