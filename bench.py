@@ -49,7 +49,8 @@ class BakeTimings(C.Structure):
                 ("microTriangles", C.c_uint64), ("uniqueItems", C.c_uint32), ("classifyLaunches", C.c_uint32),
                 ("stateBytes", C.c_uint64), ("triageMs", C.c_float), ("activeItems", C.c_uint32), ("fineMicroTriangles", C.c_uint64), ("setupMs", C.c_float),
                 ("streamChunks", C.c_uint32), ("streamedBytes", C.c_uint64), ("streamTailMs", C.c_float),
-                ("openTiles", C.c_uint32), ("openTileMicroTriangles", C.c_uint64), ("streamEarlyItems", C.c_uint32), ("persistentMs", C.c_float)]
+                ("openTiles", C.c_uint32), ("openTileMicroTriangles", C.c_uint64), ("streamEarlyItems", C.c_uint32), ("persistentMs", C.c_float),
+                ("genericMs", C.c_float), ("genericMicroTriangles", C.c_uint64)]
 
 
 def source_hash():
@@ -285,6 +286,12 @@ def main():
         avg = lambda f, ts=tms: float(np.mean([getattr(t, f) for t in ts]))
         classify_ms = avg("classifyMs")
         persistent_ms = avg("persistentMs") or classify_ms
+        generic_ms = avg("genericMs")
+        # the dominant kernel: the persistent classify_tiles launch, or -- bakes of asset-sized triangles -- the deferred generic pass behind it
+        dom_kernel = "classify_generic" if generic_ms > persistent_ms else "classify_tiles"
+        tiles_ms = persistent_ms
+        if dom_kernel == "classify_generic":
+            persistent_ms = generic_ms   # (every roofline figure below is about the dominant kernel)
         t_last = tms[-1]
         bits = 2
         line = {
@@ -295,18 +302,19 @@ def main():
                        "entry": (("ommxShardedBakeRccl (collectives issued by the library)" if native else "ommxSharded* + torch.distributed") if world > 1 else "ommxBakeDevice") + " (ommCpuBake contract, UV/index inputs and result arrays resident in HBM)",
                        "sharding": "active work items partitioned over ranks; RCCL all-reduce of item metadata + chunked all-gather of OMM blocks" if world > 1 else "none",
                        "result": result_info, "unique_items": int(t_last.uniqueItems), "active_items": int(t_last.activeItems),
-                       "open_tiles": int(t_last.openTiles), "fine_micro_triangles": int(t_last.fineMicroTriangles)},
+                       "open_tiles": int(t_last.openTiles), "fine_micro_triangles": int(t_last.fineMicroTriangles),
+                       "generic_pass_micro_triangles": int(t_last.genericMicroTriangles)},
             # `value` / `ms_per_step`: device-resident entry (the bench contract: inputs resident in HBM when the clock starts).
             # `bake_wall_time_ms`: the SDK call a drop-in user makes, ommCpuBake, host arrays in and out, PCIe inclusive -- same steps, same warm-up.
             "value_entry": "ommxBakeDevice" if world == 1 else ("ommxShardedBakeRccl" if native else "ommxSharded* + torch.distributed"),
             "bake_wall_time_ms": host_ms if host_ms is not None else ms_per_step,
             "bake_wall_time_entry": "ommCpuBake (host arrays in/out, PCIe inclusive)" if host_ms is not None else "ommxBakeDevice (ommCpuBake was not timed in this run)",
             "rates": {"all_work_items": micro_tris / (elapsed / args.steps),
-                      "open_tiles_only": float(t_last.openTileMicroTriangles) / (persistent_ms * 1e-3) if persistent_ms > 0 else None,
+                      "open_tiles_only": float(t_last.openTileMicroTriangles) / ((tiles_ms + generic_ms) * 1e-3) if tiles_ms + generic_ms > 0 else None,
                       "fine_pass_only": float(t_last.fineMicroTriangles) / (classify_ms * 1e-3) if classify_ms > 0 else None,
                       "note": "`value` counts 4^level micro-triangles for every unique work item like the reference's loop does; most items are settled by one summed-area-table "
                               "query (hierarchical culling), so the rate over the micro-triangles of the tiles that reach classify_tiles and over those that reach the level-line pass are given too"},
-            "phases_ms": {k: avg(k) for k in ("uploadMs", "setupMs", "triageMs", "classifyMs", "persistentMs", "digestMs", "tailMs", "gatherMs", "downloadMs", "totalMs")},
+            "phases_ms": {k: avg(k) for k in ("uploadMs", "setupMs", "triageMs", "classifyMs", "persistentMs", "genericMs", "digestMs", "tailMs", "gatherMs", "downloadMs", "totalMs")},
         }
         if host_ms is not None:
             havg = lambda f: avg(f, host_tms)
@@ -329,10 +337,14 @@ def main():
         # one pass over the texture and its summed-area table (5 B per texel)
         tw, thh = tex.shape[1], tex.shape[0]
         alg_bytes = bits / 8.0 * float(t_last.openTileMicroTriangles) + 48.0 * t_last.openTiles + tw * thh * 5.0
+        formula = "(0.25 B x micro-triangles of the open tiles + 48 B x open tiles + 5 B x texels) / HIP-event duration of the launch"
+        if dom_kernel == "classify_generic":   # queue entry read (8 B) + state ORed in (4 B word) per queued micro-triangle, one pass over the texture
+            alg_bytes = 12.0 * float(t_last.genericMicroTriangles) + tw * thh * (4.0 if tex.dtype == np.float32 else 1.0)
+            formula = "(12 B x queued micro-triangles + one pass over the texels) / HIP-event duration of the launch"
         hbm_achieved = alg_bytes / (persistent_ms * 1e-3) / 1e9 if persistent_ms > 0 else 0.0
-        roof_hbm = {"bound": "hbm", "kernel": "classify_tiles", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS, "traffic": None,
+        roof_hbm = {"bound": "hbm", "kernel": dom_kernel, "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS, "traffic": None,
                     "avg_launch_ms": persistent_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                    "formula": "(0.25 B x micro-triangles of the open tiles + 48 B x open tiles + 5 B x texels) / HIP-event duration of the launch",
+                    "formula": formula,
                     "all_work_items_view": {"note": "SURVEY.md section 8d per-unit figure (0.25 B per micro-triangle of EVERY unique work item + 24 B per item + 5 B per texel) over the same duration; "
                                                     "95 % of those micro-triangles are settled by hierarchical SAT queries and never reach this launch",
                                             "achieved": (bits / 8.0 * micro_tris + 24.0 * t_last.uniqueItems + tw * thh * 5.0) / (persistent_ms * 1e-3) / 1e9 if persistent_ms > 0 else None}}
@@ -342,14 +354,14 @@ def main():
         default_workload = tris == cfg["tris"]
         if world == 1 and default_workload and os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("source_sha256_16") == source_hash():
+            if tj.get("source_sha256_16") == source_hash() and tj.get("kernel", "classify_tiles") == dom_kernel:
                 src = "profiles/%s_pmc.md (separate rocprofv3 --pmc passes of `%s`; %s; sources %s)" % (tj.get("tag"), tj.get("command"), tj.get("corrections"), tj.get("source_sha256_16"))
                 roof_hbm["traffic"] = tj.get("traffic_bytes_per_launch")
                 roof_hbm["traffic_source"] = src
                 valu = tj.get("valu_wave_instructions_per_launch"); hz = tj.get("shader_clock_hz")
                 if valu and hz and persistent_ms > 0:
                     ipc = valu / (persistent_ms * 1e-3 * hz * NUM_SIMDS)
-                    line["roofline"] = {"bound": "valu_issue", "kernel": "classify_tiles", "achieved": ipc, "peak": VALU_ISSUE_PEAK, "unit": "VALU wave-instructions / cycle / SIMD",
+                    line["roofline"] = {"bound": "valu_issue", "kernel": dom_kernel, "achieved": ipc, "peak": VALU_ISSUE_PEAK, "unit": "VALU wave-instructions / cycle / SIMD",
                                         "frac": ipc / VALU_ISSUE_PEAK, "traffic": tj.get("traffic_bytes_per_launch"), "avg_launch_ms": persistent_ms,
                                         "formula": "SQ_INSTS_VALU per launch (%.4g, PMC pass) / (HIP-event duration of the launch x %.4g Hz shader clock (GRBM_GUI_ACTIVE / 8 / duration of the counter pass) x 1024 SIMDs) / 0.5" % (valu, hz),
                                         "calibrated_issue_utilisation": tj.get("valu_issue_utilisation"), "scalar_issue_utilisation": tj.get("scalar_issue_utilisation"),

@@ -39,6 +39,9 @@ typedef struct ommxBakeTimings {
                                   preview (possible duplicates: the first member of such a family pulls the others into its range) */
     float    persistentMs;     /* HIP events around the persistent classify_tiles launch of the levels >= 6 alone (classifyMs also holds the tile triage, the
                                   launches of the lower levels and, for streamed bakes, the preview); 0 for streamed bakes */
+    float    genericMs;        /* HIP events around the deferred generic pass (classify_generic: micro-triangles of several texels, ommxBakerKnob_GenericPass); 0 when
+                                  that work ran inside the persistent launch */
+    uint64_t genericMicroTriangles; /* micro-triangles that pass classified */
 } ommxBakeTimings;
 
 OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings* out);

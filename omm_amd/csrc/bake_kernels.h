@@ -65,6 +65,7 @@ struct ClassifyChunks {
     uint32_t count;
     void (*after)(void* user, uint32_t chunk, const ClassifySegment* segs, uint32_t numSegs, bool last);
     void (*mark)(void* user);
+    void (*markGeneric)(void* user);   // or null: called right before the deferred generic pass is enqueued
     void* user;
     // Streamed bakes, or null: early[item] == 1 marks a possible duplicate (tail_kernels.hip "preview"); it is classified in the range of the FIRST member of
     // its family, earlyLead[item] = that member's position in activeIds -- so a range's section pair holds everything the placement of the range depends on.

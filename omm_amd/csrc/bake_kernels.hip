@@ -615,16 +615,22 @@ __device__ __forceinline__ RasterBox raster_box(const DevMip& m, const MicroTri&
     B.w = w > 0 ? (uint32_t)w : 1u; B.cnt = cnt64 > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)cnt64;
     return B;
 }
-// texel k of the box (row-major); returns whether it lies under the (conservative) triangle, and votes if so
+// does texel k of the box (row-major) lie under the (conservative) triangle?  (the cheap half of a visit: a lane skips to its next covered texel in a loop
+// of these, so that the expensive half below runs with every lane that still has one -- half the texels of a box are not under its triangle)
+__device__ __forceinline__ bool texel_under(const RasterBox& B, uint32_t k)
+{
+    const float sx = (float)(B.minx + (int)(k % B.w)), sy = (float)(B.miny + (int)(k / B.w));
+    return eval_cons(B.e0, sx, sy) < 0.f && eval_cons(B.e1, sx, sy) < 0.f && eval_cons(B.e2, sx, sy) < 0.f;
+}
+// the vote of a covered texel: level-line kernel (linear filter) or nearest sample.  (Splitting the level-line kernel once more -- cell fetch and corner
+// votes first, the three edge tests for the lanes that need them in a second round -- was measured and is slower, 51.8 vs 38.9 ms on the cards
+// workload: in a smooth alpha texture nearly every covered texel needs its edge tests, so the second round gathers nothing and the cell is fetched twice.)
 template <bool FP32, int KIND, class MD>
-__device__ __forceinline__ bool visit_texel(const ClassifyParams& P, const DevMip& m, const MicroTri& t, const RasterBox& B, uint32_t k, uint32_t& above, uint32_t& below)
+__device__ __forceinline__ void texel_vote(const ClassifyParams& P, const DevMip& m, const MicroTri& t, const RasterBox& B, uint32_t k, uint32_t& above, uint32_t& below)
 {
     const int x = B.minx + (int)(k % B.w), y = B.miny + (int)(k / B.w);
-    const float sx = (float)x, sy = (float)y;
-    if (!(eval_cons(B.e0, sx, sy) < 0.f && eval_cons(B.e1, sx, sy) < 0.f && eval_cons(B.e2, sx, sy) < 0.f)) return false;
     if (KIND == 0) level_line_texel<FP32, false, MD>(P, m, t, x, y, above, below, no_window());
     else nearest_texel<FP32, MD>(P, m, x, y, above, below, no_window());
-    return true;
 }
 // sum of a counter over the 8 lanes of a sub-group
 __device__ __forceinline__ uint32_t sum8(uint32_t v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
@@ -642,15 +648,14 @@ __device__ __forceinline__ int generic_two_phase(const ClassifyParams& P, const 
         const MicroTri t = micro_triangle(uvAll + 6ull * item, levelWord & 0xFFFFFFu, levelWord >> 24);
         if (KIND == 0 && live) vote(P.cutoff < bilinear<FP32, MD>(P, m, t.p0, no_window()), above, below);
         const RasterBox B = raster_box(m, t, off);
-        uint32_t visits = 0;
-        while (!finished) {
+        for (uint32_t visits = 0; !finished && visits < (uint32_t)OMMX_GENERIC_SOLO; ++visits) {
+            while (k < B.cnt && !texel_under(B, k)) ++k;
             if (k >= B.cnt) { finished = true; break; }
-            const bool under = visit_texel<FP32, KIND, MD>(P, m, t, B, k, above, below);
+            texel_vote<FP32, KIND, MD>(P, m, t, B, k, above, below);
             ++k;
-            if (!countsMatter && above != 0 && below != 0) { finished = true; break; }
-            if (under && ++visits >= (uint32_t)OMMX_GENERIC_SOLO) break;
+            if (!countsMatter && above != 0 && below != 0) finished = true;
         }
-        if (!finished && k >= B.cnt) finished = true;
+        if (!finished) { while (k < B.cnt && !texel_under(B, k)) ++k; if (k >= B.cnt) finished = true; }
     }
     // ---- phase B: the unfinished walks, eight at a time, eight lanes each ----
     unsigned long long pending = __ballot(!finished);
@@ -667,10 +672,11 @@ __device__ __forceinline__ int generic_two_phase(const ClassifyParams& P, const 
         uint32_t la = sub == 0u ? a0 : 0u, lb = sub == 0u ? b0 : 0u;          // (lane 0 of the sub-group carries the walk's counters so far)
         const uint32_t shift = lane & 56u;
         bool done = !work;
-        for (uint32_t kk = k0 + sub; ; kk += 8u) {
+        for (uint32_t kk = k0 + sub; ; ) {
+            while (!done && kk < B.cnt && !texel_under(B, kk)) kk += 8u;
             const bool go = !done && kk < B.cnt;
             if (__ballot(go) == 0ull) break;
-            if (go) (void)visit_texel<FP32, KIND, MD>(P, m, t, B, kk, la, lb);
+            if (go) { texel_vote<FP32, KIND, MD>(P, m, t, B, kk, la, lb); kk += 8u; }
             if (!countsMatter) {   // the sub-group has seen both sides: the state is final
                 const unsigned long long ba = __ballot(la != 0), bb = __ballot(lb != 0);
                 if (((ba >> shift) & 0xFFull) != 0ull && ((bb >> shift) & 0xFFull) != 0ull) done = true;
@@ -856,7 +862,10 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
                                 paired ? 2u * K : K, noGeneric);
     }
     // ---- deferred generic pass: the micro-triangles of several texels that the persistent launches queued instead of walking ----
-    if (deferred) hipLaunchKernelGGL((classify_generic<FP32, MD>), dim3(numCUs * 8u), dim3(256), 0, stream, P, A, chunks.generic);
+    if (deferred) {
+        if (chunks.markGeneric) chunks.markGeneric(chunks.user);
+        hipLaunchKernelGGL((classify_generic<FP32, MD>), dim3(numCUs * 8u), dim3(256), 0, stream, P, A, chunks.generic);
+    }
     for (uint32_t k = 0; k < K; ++k) {
         if (chunks.after) {   // the work items of this range, as segments of the per-level active lists, in the order of the final result
             ClassifySegment segs[kNumLevels]; uint32_t ns = 0;

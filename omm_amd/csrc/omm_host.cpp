@@ -622,8 +622,9 @@ void stream_hook(void* user, uint32_t chunk, const ClassifySegment* segs, uint32
     c.ok = c.ok && hipEventRecord(c.events[chunk], c.place) == hipSuccess;
     if (c.ok) c.recorded = chunk + 1u;
 }
-struct MarkCtx { EventTimer* et; int mark; };
+struct MarkCtx { EventTimer* et; int mark, markGeneric; };
 void mark_hook(void* user) { MarkCtx& c = *(MarkCtx*)user; c.mark = c.et->mark(); }
+void mark_generic_hook(void* user) { MarkCtx& c = *(MarkCtx*)user; c.markGeneric = c.et->mark(); }
 
 // host form of SetupWorkItems, used when the device setup reports a hash collision (never observed; 2^-64 class event)
 void setup_on_host(const ommCpuBakeInputDesc& d, uint32_t flags, const Texture& tex, std::vector<HostTri>& itemUv, std::vector<uint8_t>& itemLevel,
@@ -956,7 +957,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     // streamed: the active lists in the order of the final result, events behind the classification launches, the cursor published to a pinned word after each
     struct EventList { hipEvent_t ev[2 * kMaxClassifyChunks + 3]; uint32_t n = 0; ~EventList() { for (uint32_t k = 0; k < n; ++k) (void)hipEventDestroy(ev[k]); } } chunkEvents;   // placement done [K + 1] | fences [K + 2]
     StreamCtx sc; ClassifyChunks cc; memset(&cc, 0, sizeof cc); cc.count = 1;
-    MarkCtx mk; mk.et = &et; mk.mark = -1;
+    MarkCtx mk; mk.et = &et; mk.mark = -1; mk.markGeneric = -1;
     const bool noDedup = (flags & (1u << 3)) != 0;
     if (streamChunks) {
         bool oks = HIP_OK(hipMemsetAsync(dPlaced, 0xFF, (size_t)maxItems * 8, stream)) && HIP_OK(hipMemsetAsync(dCursor, 0, 8, stream)) && HIP_OK(hipMemsetAsync(dStreamCtl, 0, sizeof(uint32_t) * kStreamCtlWords, stream));
@@ -987,6 +988,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     if (dGeneric) {
         if (!HIP_OK(hipMemsetAsync(dGeneric, 0, 256, stream))) return L.failure("[Failure] - device memset failed");
         cc.generic.count = (uint32_t*)dGeneric; cc.generic.entries = (uint2*)(dGeneric + 256); cc.generic.capacity = (uint32_t)genericCapacity;
+        cc.markGeneric = mark_generic_hook;   // (cc.user is the MarkCtx: a deferred pass and a streamed result exclude each other)
     }
     if (!HIP_OK(launch_classify(P, A, dActiveIds, lvlFirst, lvlCount, dTileQueue, dQueueCtl, device_cu_count(), stream, &cc))) return L.failure("[Failure] - kernel launch failed");
     if (streamChunks && !sc.ok) return L.failure("[Failure] - kernel launch failed");
@@ -1094,6 +1096,8 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     uint32_t queueTails[2] = { 0u, 0u };   // open tiles of the two tile sizes (statistics)
     uint32_t hostCtl[kClassifyCtlWords]; memset(hostCtl, 0, sizeof hostCtl);
     if (hc.activeStart[kNumLevels]) ok = ok && HIP_OK(hipMemcpyAsync(hostCtl, dQueueCtl, sizeof hostCtl, hipMemcpyDeviceToHost, stream));
+    uint32_t genericCount = 0;
+    if (dGeneric) ok = ok && HIP_OK(hipMemcpyAsync(&genericCount, dGeneric, sizeof genericCount, hipMemcpyDeviceToHost, stream));
     const int e5 = et.mark();
     ok = ok && HIP_OK(hipStreamSynchronize(stream));
     if (streamChunks) { ok = HIP_OK(hipStreamSynchronize(so->copyStream)) && ok; ok = sdma.wait() && ok; so->lastByteMs = now_ms(); }
@@ -1103,7 +1107,8 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     memcpy(fineSlots.data(), span.data() + ((const uint8_t*)dFine - (const uint8_t*)dArrayHist), sizeof(unsigned long long) * fineSlots.size());
 
     tm.uploadMs = 0.f; tm.hostSetupMs = 0.f; tm.setupMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.digestMs = et.ms(e2, e3);
-    tm.tailMs = et.ms(e3, e4); tm.gatherMs = et.ms(e4, e5); tm.persistentMs = mk.mark >= 0 ? et.ms(mk.mark, e2) : 0.f;
+    tm.tailMs = et.ms(e3, e4); tm.gatherMs = et.ms(e4, e5); tm.persistentMs = mk.mark >= 0 ? et.ms(mk.mark, mk.markGeneric >= 0 ? mk.markGeneric : e2) : 0.f;
+    tm.genericMs = mk.markGeneric >= 0 ? et.ms(mk.markGeneric, e2) : 0.f; tm.genericMicroTriangles = genericCount < genericCapacity ? genericCount : genericCapacity;
     for (int k = 0; k < kFineSlots; ++k) fineCount += fineSlots[(size_t)k * kFineStride];
     queueTails[1] = hostCtl[kCtl1024 + kSecTails]; for (uint32_t k = 0; k < kMaxClassifyChunks; ++k) queueTails[0] += hostCtl[kSecTails + k];   // (1024-tile queue; sections of the 4096-tile queue)
     tm.openTiles = queueTails[0] + queueTails[1]; tm.openTileMicroTriangles = (uint64_t)queueTails[0] * 4096u + (uint64_t)queueTails[1] * 1024u;

@@ -101,13 +101,22 @@ def main():
     for k, n, rd, wr in rows[:24]:
         out.append("| `%s` | %d | %.2f | %.2f |" % (k, n, rd / 1e6, wr / 1e6))
 
-    # ---- instruction classes and issue cycles of the classification kernel ----
+    # ---- instruction classes and issue cycles of the dominant classification kernel: the persistent classify_tiles launch, or the deferred generic
+    #      pass (classify_generic) when a bake of asset-sized triangles spends longer there ----
+    KERNEL = "ommx::classify_tiles"
+    for p in ("C1", "C4"):
+        _, dur = load(os.path.join(root, "pmc_" + p, "pmc_counter_collection.csv"))
+        dt, dg = dur.get("ommx::classify_tiles"), dur.get("ommx::classify_generic")
+        if dt and dg and dg[0] and dt[0] and dg[1] / dg[0] > dt[1] / dt[0]:
+            KERNEL = "ommx::classify_generic"
+        if dt or dg: break
+    KSHORT = KERNEL.split("::")[1]
     c, dur_ms = {}, None
     for p in ("C1", "C2", "C3", "C4", "SQ"):
         agg, dur = load(os.path.join(root, "pmc_" + p, "pmc_counter_collection.csv"))
-        for n, v in agg.get("ommx::classify_tiles", {}).items():
+        for n, v in agg.get(KERNEL, {}).items():
             c[n] = v[1] / max(1, v[0])
-        d = dur.get("ommx::classify_tiles")
+        d = dur.get(KERNEL)
         if d and d[0] and dur_ms is None:
             dur_ms = d[1] / d[0]
     summary = {}
@@ -115,7 +124,7 @@ def main():
         R = rates()
         cyc = (c["GRBM_GUI_ACTIVE"] / 8.0) if "GRBM_GUI_ACTIVE" in c else (dur_ms or 0) * 1e-3 * CLOCK_HZ   # shader cycles of one launch (GRBM sums the 8 XCDs)
         simd_cycles, cu_cycles = cyc * NUM_CU * SIMD_PER_CU, cyc * NUM_CU
-        out += ["", "## `classify_tiles`: instructions per launch by class (SQ_INSTS_*, wave-instructions) and the SIMD cycles they occupy", "",
+        out += ["", "## `%s`: instructions per launch by class (SQ_INSTS_*, wave-instructions) and the SIMD cycles they occupy" % KSHORT, "",
                 "kernel duration in the counter passes: %s ms; shader cycles per launch %.4g (GRBM_GUI_ACTIVE / 8 XCDs)" % ("%.2f" % dur_ms if dur_ms else "?", cyc), "",
                 "| class | counter | wave-instructions | cycles each (profiles/valu_rates_mi355x.json) | share of the VALU pipe (1024 SIMDs x cycles) |", "|---|---|---|---|---|"]
         valu = c.get("SQ_INSTS_VALU", 0.0)
@@ -156,8 +165,8 @@ def main():
             out += ["", "SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.2f" % (c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"])]
         out += ["", "raw counters: " + ", ".join("%s=%.4g" % kv for kv in sorted(c.items()))]
     open(os.path.join(root, tag + "_pmc.md"), "w").write("\n".join(out) + "\n")
-    ck = [r for r in rows if r[0] == "ommx::classify_tiles"]
-    js = {"tag": tag, "command": cmd, "kernel": "classify_tiles", "source_sha256_16": lib_stamp(),
+    ck = [r for r in rows if r[0] == KERNEL]
+    js = {"tag": tag, "command": cmd, "kernel": KSHORT, "source_sha256_16": lib_stamp(),
           "read_bytes_per_launch": ck[0][2] if ck else None, "written_bytes_per_launch": ck[0][3] if ck else None,
           "traffic_bytes_per_launch": (ck[0][2] + ck[0][3]) if ck else None, "corrections": "FETCH_SIZE KiB x2 (gfx950), WRITE_SIZE KiB x1", **summary}
     json.dump(js, open(os.path.join(root, tag + "_hbm_traffic.json"), "w"), indent=1)
