@@ -1311,6 +1311,18 @@ def test_micro_triangles_of_several_texels(product, oracle, generic_pass):
     # random triangles of 20 .. 60 texels (no axis-aligned edges), level 6
     uv2, ix2 = ot.random_triangles(61, 300, 0.05)
     both(product, oracle, [tex8], uv2, ix2, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, knobs=knobs)
+    # Nearest filter (every covered texel votes with its sample; the counts decide under the Nearest promotion), a mip chain (the walk of a micro-triangle
+    # ends at the first mip that leaves it unknown), degenerate triangles among the cards (line walks)
+    both(product, oracle, [tex8], uv, ix, 7, filt=ot.NEAREST, addr=ot.WRAP, promo=ot.PROMO_NEAREST, levels=lv, knobs=knobs)
+    both(product, oracle, [tex8], uv, ix, 7, sat=False, filt=ot.NEAREST, addr=ot.CLAMP, promo=ot.PROMO_FORCE_TRANSPARENT, knobs=knobs)
+    mips = [texf]
+    while min(mips[-1].shape) > 40:
+        t = mips[-1][:mips[-1].shape[0] // 2 * 2, :mips[-1].shape[1] // 2 * 2]
+        mips.append(((t[0::2, 0::2] + t[1::2, 0::2]) + t[0::2, 1::2] + t[1::2, 1::2]) * np.float32(0.25))
+    both(product, oracle, mips[:3], uv, ix, 6, sat=False, addr=ot.WRAP, promo=ot.PROMO_NEAREST, knobs=knobs)
+    both(product, oracle, mips[:3], uv, ix, 7, sat=False, addr=ot.CLAMP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv, knobs=knobs)
+    uvd = uv.copy().reshape(-1, 2); uvd[ix[3::18]] = uvd[ix[4::18]]          # every sixth triangle collapses onto an edge
+    both(product, oracle, [tex8], uvd, ix, 7, addr=ot.CLAMP, promo=ot.PROMO_FORCE_OPAQUE, knobs=knobs)
 
 
 def test_near_duplicate_merge_and_budget_at_scale(product, oracle):
