@@ -594,7 +594,13 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
 #ifndef OMMX_GENERIC_SOLO
 #define OMMX_GENERIC_SOLO 4
 #endif
-struct RasterBox { EdgeEq e0, e1, e2; int minx, miny; uint32_t w, cnt; };
+struct RasterBox { EdgeEq e0, e1, e2; int minx, miny, xend, yend; uint32_t w, cnt; };   // texels [minx, xend) x [miny, yend), row-major index k < cnt
+struct TexelCursor { int x, y; };
+__device__ __forceinline__ TexelCursor cursor_at(const RasterBox& B, uint32_t k) { TexelCursor c; c.x = B.minx + (int)(k % B.w); c.y = B.miny + (int)(k / B.w); return c; }
+__device__ __forceinline__ bool cursor_live(const RasterBox& B, const TexelCursor& c) { return c.y < B.yend; }
+__device__ __forceinline__ void cursor_step(const RasterBox& B, TexelCursor& c) { if (++c.x == B.xend) { c.x = B.minx; ++c.y; } }
+__device__ __forceinline__ void cursor_step8(const RasterBox& B, TexelCursor& c) { c.x += 8; while (c.x >= B.xend && c.y < B.yend) { c.x -= (int)B.w; ++c.y; } }
+__device__ __forceinline__ uint32_t cursor_index(const RasterBox& B, const TexelCursor& c) { return c.y >= B.yend ? B.cnt : (uint32_t)(c.y - B.miny) * B.w + (uint32_t)(c.x - B.minx); }
 __device__ __forceinline__ RasterBox raster_box(const DevMip& m, const MicroTri& t, float off)
 {
     // same set-up as raster_micro_triangle (classify_device.h): winding, raster-space vertices, box
@@ -612,25 +618,26 @@ __device__ __forceinline__ RasterBox raster_box(const DevMip& m, const MicroTri&
     RasterBox B; B.e0 = edge_eq(a, b); B.e1 = edge_eq(b, c); B.e2 = edge_eq(c, a); B.minx = minx; B.miny = miny;
     const long long w = (long long)maxx - (long long)minx, h = (long long)maxy - (long long)miny;
     const unsigned long long cnt64 = (w > 0 && h > 0) ? (unsigned long long)w * (unsigned long long)h : 0ull;
-    B.w = w > 0 ? (uint32_t)w : 1u; B.cnt = cnt64 > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)cnt64;
+    // (boxes beyond 2^32 texels cannot be walked in any case -- the serial loop would not end either --: they count as empty)
+    const bool ok = cnt64 != 0ull && cnt64 <= 0xFFFFFFF0ull;
+    B.w = ok ? (uint32_t)w : 1u; B.cnt = ok ? (uint32_t)cnt64 : 0u; B.xend = ok ? maxx : minx + 1; B.yend = ok ? maxy : miny;
     return B;
 }
 // does texel k of the box (row-major) lie under the (conservative) triangle?  (the cheap half of a visit: a lane skips to its next covered texel in a loop
 // of these, so that the expensive half below runs with every lane that still has one -- half the texels of a box are not under its triangle)
-__device__ __forceinline__ bool texel_under(const RasterBox& B, uint32_t k)
+__device__ __forceinline__ bool texel_under(const RasterBox& B, const TexelCursor& c)
 {
-    const float sx = (float)(B.minx + (int)(k % B.w)), sy = (float)(B.miny + (int)(k / B.w));
+    const float sx = (float)c.x, sy = (float)c.y;
     return eval_cons(B.e0, sx, sy) < 0.f && eval_cons(B.e1, sx, sy) < 0.f && eval_cons(B.e2, sx, sy) < 0.f;
 }
 // the vote of a covered texel: level-line kernel (linear filter) or nearest sample.  (Splitting the level-line kernel once more -- cell fetch and corner
 // votes first, the three edge tests for the lanes that need them in a second round -- was measured and is slower, 51.8 vs 38.9 ms on the cards
 // workload: in a smooth alpha texture nearly every covered texel needs its edge tests, so the second round gathers nothing and the cell is fetched twice.)
 template <bool FP32, int KIND, class MD>
-__device__ __forceinline__ void texel_vote(const ClassifyParams& P, const DevMip& m, const MicroTri& t, const RasterBox& B, uint32_t k, uint32_t& above, uint32_t& below)
+__device__ __forceinline__ void texel_vote(const ClassifyParams& P, const DevMip& m, const MicroTri& t, const TexelCursor& c, uint32_t& above, uint32_t& below)
 {
-    const int x = B.minx + (int)(k % B.w), y = B.miny + (int)(k / B.w);
-    if (KIND == 0) level_line_texel<FP32, false, MD>(P, m, t, x, y, above, below, no_window());
-    else nearest_texel<FP32, MD>(P, m, x, y, above, below, no_window());
+    if (KIND == 0) level_line_texel<FP32, false, MD>(P, m, t, c.x, c.y, above, below, no_window());
+    else nearest_texel<FP32, MD>(P, m, c.x, c.y, above, below, no_window());
 }
 // sum of a counter over the 8 lanes of a sub-group
 __device__ __forceinline__ uint32_t sum8(uint32_t v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
@@ -648,14 +655,16 @@ __device__ __forceinline__ int generic_two_phase(const ClassifyParams& P, const 
         const MicroTri t = micro_triangle(uvAll + 6ull * item, levelWord & 0xFFFFFFu, levelWord >> 24);
         if (KIND == 0 && live) vote(P.cutoff < bilinear<FP32, MD>(P, m, t.p0, no_window()), above, below);
         const RasterBox B = raster_box(m, t, off);
+        TexelCursor c = cursor_at(B, 0u);   // (no integer division per texel: the cursor steps)
         for (uint32_t visits = 0; !finished && visits < (uint32_t)OMMX_GENERIC_SOLO; ++visits) {
-            while (k < B.cnt && !texel_under(B, k)) ++k;
-            if (k >= B.cnt) { finished = true; break; }
-            texel_vote<FP32, KIND, MD>(P, m, t, B, k, above, below);
-            ++k;
+            while (cursor_live(B, c) && !texel_under(B, c)) cursor_step(B, c);
+            if (!cursor_live(B, c)) { finished = true; break; }
+            texel_vote<FP32, KIND, MD>(P, m, t, c, above, below);
+            cursor_step(B, c);
             if (!countsMatter && above != 0 && below != 0) finished = true;
         }
-        if (!finished) { while (k < B.cnt && !texel_under(B, k)) ++k; if (k >= B.cnt) finished = true; }
+        if (!finished) { while (cursor_live(B, c) && !texel_under(B, c)) cursor_step(B, c); if (!cursor_live(B, c)) finished = true; }
+        k = cursor_index(B, c);
     }
     // ---- phase B: the unfinished walks, eight at a time, eight lanes each ----
     unsigned long long pending = __ballot(!finished);
@@ -672,11 +681,12 @@ __device__ __forceinline__ int generic_two_phase(const ClassifyParams& P, const 
         uint32_t la = sub == 0u ? a0 : 0u, lb = sub == 0u ? b0 : 0u;          // (lane 0 of the sub-group carries the walk's counters so far)
         const uint32_t shift = lane & 56u;
         bool done = !work;
-        for (uint32_t kk = k0 + sub; ; ) {
-            while (!done && kk < B.cnt && !texel_under(B, kk)) kk += 8u;
-            const bool go = !done && kk < B.cnt;
+        TexelCursor c = cursor_at(B, k0 + sub < B.cnt ? k0 + sub : 0u); if (k0 + sub >= B.cnt) c.y = B.yend;
+        for (;;) {
+            while (!done && cursor_live(B, c) && !texel_under(B, c)) cursor_step8(B, c);
+            const bool go = !done && cursor_live(B, c);
             if (__ballot(go) == 0ull) break;
-            if (go) { texel_vote<FP32, KIND, MD>(P, m, t, B, kk, la, lb); kk += 8u; }
+            if (go) { texel_vote<FP32, KIND, MD>(P, m, t, c, la, lb); cursor_step8(B, c); }
             if (!countsMatter) {   // the sub-group has seen both sides: the state is final
                 const unsigned long long ba = __ballot(la != 0), bb = __ballot(lb != 0);
                 if (((ba >> shift) & 0xFFull) != 0ull && ((bb >> shift) & 0xFFull) != 0ull) done = true;
