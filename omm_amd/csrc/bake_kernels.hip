@@ -582,7 +582,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
 // size by orders of magnitude, two thirds of the walks end at their first mixed texel after a handful of visits and the rest visit every texel
 // under the triangle, so a fifth of the lanes does useful work (profiles/r03_v3_cards_pmc.md).  Here the walk has two phases per wave of 64
 // queued micro-triangles:
-//   A  one lane per micro-triangle, at most OMMX_GENERIC_SOLO visits of texels under the triangle: settles the short walks at full width;
+//   A  one lane per micro-triangle, at most OMMX_GENERIC_SOLO (12) visits of texels under the triangle: settles the short walks at full width;
 //   B  the unfinished walks, eight at a time, EIGHT lanes each: texel k of the box goes to lane k mod 8 from where phase A stopped, the counters
 //      are combined with two wave ballots after every round, and a sub-group stops as soon as both are non-zero (when the promotion does not
 //      look at the counts) -- the early exit of the serial walk at a granularity of eight texels.
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
 // take the serial fine_state().  The state is ORed into the packed word the persistent launch left 0; item mask / known count are folded per wave.
 // ------------------------------------------------------------------------------------------------
 #ifndef OMMX_GENERIC_SOLO
-#define OMMX_GENERIC_SOLO 4
+#define OMMX_GENERIC_SOLO 12   // measured on the cards workload (generic pass alone): 2 / 4 / 8 / 12 / 24 / 64 / unbounded = 43.4 / 39.4 / 37.6 / 37.1 / 38.3 / 41.3 / 46.6 ms
 #endif
 struct RasterBox { EdgeEq e0, e1, e2; int minx, miny, xend, yend; uint32_t w, cnt; };   // texels [minx, xend) x [miny, yend), row-major index k < cnt
 struct TexelCursor { int x, y; };
