@@ -844,6 +844,17 @@ def test_user_allocator_is_honoured_and_balanced(product):
     assert r1.array_data.size > (8 << 20) and stats["biggest"] >= r1.array_data.size     # the big block came through the callbacks
     r2 = product.bake(b, desc)
     assert r1.same_as(r2)
+    # a streamed result with the user's (pageable) memory: the array is requested up front with the upper bound of the result -- the packed states of
+    # every non-uniform item -- and the blocks arrive through hipMemcpyAsync instead of the SDMA path of the pinned default block
+    import bench
+    product.set_knob(b, ot.KNOB_STREAM_CHUNKS, 3)
+    before = stats["biggest"]
+    r3 = product.bake(b, desc)
+    tm = bench.BakeTimings()
+    product.dll.ommxGetLastBakeTimings.argtypes = [C.c_void_p, C.POINTER(bench.BakeTimings)]
+    product.dll.ommxGetLastBakeTimings(b, C.byref(tm))
+    assert r3.same_as(r1) and tm.streamChunks == 3 and tm.streamedBytes == r1.array_data.size
+    assert stats["biggest"] >= before and stats["biggest"] >= tm.stateBytes >= r1.array_data.size
     product.destroy_texture(b, t)
     assert product.destroy_baker(b) == ot.SUCCESS
     assert not live and stats["allocs"] == stats["frees"] and stats["allocs"] >= 6, stats
