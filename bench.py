@@ -50,7 +50,7 @@ class BakeTimings(C.Structure):
                 ("stateBytes", C.c_uint64), ("triageMs", C.c_float), ("activeItems", C.c_uint32), ("fineMicroTriangles", C.c_uint64), ("setupMs", C.c_float),
                 ("streamChunks", C.c_uint32), ("streamedBytes", C.c_uint64), ("streamTailMs", C.c_float),
                 ("openTiles", C.c_uint32), ("openTileMicroTriangles", C.c_uint64), ("streamEarlyItems", C.c_uint32), ("persistentMs", C.c_float),
-                ("genericMs", C.c_float), ("genericMicroTriangles", C.c_uint64)]
+                ("genericMs", C.c_float), ("genericMicroTriangles", C.c_uint64), ("exchangeBytes", C.c_uint64), ("contributionBytes", C.c_uint64)]
 
 
 def source_hash():

@@ -42,6 +42,9 @@ typedef struct ommxBakeTimings {
     float    genericMs;        /* HIP events around the deferred generic pass (classify_generic: micro-triangles of several texels, ommxBakerKnob_GenericPass); 0 when
                                   that work ran inside the persistent launch */
     uint64_t genericMicroTriangles; /* micro-triangles that pass classified */
+    uint64_t exchangeBytes;    /* ommxShardedBakeRccl: bytes every rank put on the wire in the block all-gather (the contributions travel as unit codes + raw
+                                  units; a contribution that does not shrink below half its size travels as it is) */
+    uint64_t contributionBytes; /* ... and the size of a rank's (padded) contribution before that */
 } ommxBakeTimings;
 
 OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings* out);
@@ -104,9 +107,11 @@ OMM_MI355X_API ommResult ommxShardedDestroy(ommxShardedBake bake);
 
 /* ---- the same sharded bake as ONE call, collectives included (RCCL over xGMI, issued by the library from C++) ----
  * Every rank calls ommxShardedBakeRccl with the SAME desc; the library runs Begin, the SUM all-reduce of the metadata words
- * (ncclAllReduce, in place, on the bake's own stream), Tail, the all-gather of the padded contributions (ncclAllGather in chunks of
- * <= 64 MiB per rank on a second stream, each chunk scattered to its final arrayData offsets while the next one is on the wire) and
- * Finish.  Every rank returns the same merged ommxDeviceBakeResult, bit-identical to a single-GPU ommxBakeDevice of the desc.
+ * (ncclAllReduce, in place, on the bake's own stream), Tail, the all-gather of the contributions and Finish.  The contributions cross the links
+ * as codec streams -- one nibble per 16-byte unit (which of the four states it repeats, or "raw") plus the raw units: a few per cent of the bytes
+ * for ordinary bakes -- and are expanded and scattered to their final arrayData offsets on arrival; if a rank's contribution does not shrink
+ * below half its size, all ranks send the padded contributions themselves (ncclAllGather in chunks of <= 64 MiB per rank on a second stream,
+ * each chunk scattered while the next one is on the wire).  A rank-local failure stops all ranks (status agreement before each exchange).  Every rank returns the same merged ommxDeviceBakeResult, bit-identical to a single-GPU ommxBakeDevice of the desc.
  * librccl.so.1 is bound with dlopen at the first call: callers that never shard need no RCCL.
  *
  * Communicator: either wrap an ncclComm_t the application already owns (ommxRcclCommWrap; not destroyed by the library), or let the

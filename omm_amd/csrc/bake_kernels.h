@@ -139,6 +139,11 @@ hipError_t run_shard_layout(const uint32_t* order, const uint32_t* sizes, const 
 void launch_shard_gather(const uint8_t* states, const uint64_t* stateOfs, const uint8_t* active, const uint8_t* owner, uint32_t rank, const uint32_t* order,
                          const uint64_t* cofs, const uint32_t* sizes, uint32_t numOmms, uint8_t* contrib, hipStream_t stream);
 // gathered = bytes [lo, hi) of every rank's contribution, rank r at gathered + r * rankPitch (one call per all-gather chunk)
+// block exchange codec (tail_kernels.hip): a rank's contribution (a multiple of 256 bytes) as a stream of unit codes + raw units
+constexpr uint32_t kCodecIncompressible = 0xFFFFFFFEu;
+size_t shard_codec_scratch_bytes(uint64_t contributionBytes);
+hipError_t run_shard_compress(const uint8_t* contrib, uint64_t contributionBytes, uint8_t* comp, uint64_t capBytes, uint32_t* sizeWord, void* scratch, size_t scratchBytes, hipStream_t stream);
+void launch_shard_expand(const uint8_t* comp, uint64_t contributionBytes, uint8_t* out, hipStream_t stream);
 void launch_shard_scatter(const uint8_t* gathered, uint64_t rankPitch, uint64_t lo, uint64_t hi, const uint8_t* active, const uint8_t* owner, const uint32_t* stateMask,
                           const uint8_t* level, int bits, const uint32_t* order, const uint64_t* cofs, const uint32_t* dstOfs, const uint32_t* sizes,
                           uint32_t numOmms, uint8_t* arrayData, hipStream_t stream);

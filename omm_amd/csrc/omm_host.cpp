@@ -555,6 +555,7 @@ struct ShardCtx {
     int ev[5] = { -1, -1, -1, -1, -1 };   // HIP event marks of Begin: setup | triage | classify | digest
     // exchange buffers: carved from the session's arenas (tables: dMeta .. dTotals; xchg: contribution + gather staging), nothing to free
     uint32_t* dMeta = nullptr; uint8_t* dOwner = nullptr; uint64_t *dCofs = nullptr, *dTotals = nullptr; uint8_t *dContrib = nullptr, *dGathered = nullptr;
+    uint8_t *dComp = nullptr, *dGatherComp = nullptr; uint32_t* dCompSize = nullptr; uint64_t compCap = 0;   // block exchange codec (RCCL path): own stream, all ranks' streams, own size word
     uint64_t totals[kMaxRanks]; uint64_t strideBytes = 0;
 };
 
@@ -1737,7 +1738,7 @@ struct ShardedBake {
 // process already holds an RCCL (e.g. torch's) its SONAME librccl.so.1 resolves to that instance.
 typedef void* rcclComm_t;
 struct RcclUniqueId { char internal[128]; };                       // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
-enum { kRcclSum = 0, kRcclMin = 3, kRcclUint8 = 1, kRcclUint32 = 3 };   // ncclRedOp_t (sum, min) / ncclDataType_t (uint8, uint32) values of rccl.h
+enum { kRcclSum = 0, kRcclMax = 2, kRcclMin = 3, kRcclUint8 = 1, kRcclUint32 = 3 };   // ncclRedOp_t (sum, max, min) / ncclDataType_t (uint8, uint32) values of rccl.h
 struct RcclApi {
     void* dso = nullptr; std::string error;
     int (*getUniqueId)(RcclUniqueId*) = nullptr;
@@ -1788,6 +1789,22 @@ bool rccl_agree(RcclComm* rc, hipStream_t stream, bool mineOk, const Logger& L, 
     if (!ok) { L.failure("[Failure] - sharded bake: the status all-reduce failed"); return false; }
     if (mineOk && all == 0u) { char buf[200]; snprintf(buf, sizeof buf, "[Failure] - sharded bake: another rank failed (%s); this rank stops with it", stage); L.failure(buf); }
     return mineOk && all != 0u;
+}
+// The same agreement carrying a number: every rank contributes the device word *dWord (0xFFFFFFFF if it failed) to a MAX all-reduce; *outMax = the
+// largest one.  false = a rank failed (this one or another).
+bool rccl_agree_max(RcclComm* rc, hipStream_t stream, bool mineOk, uint32_t* dWord, uint32_t* outMax, const Logger& L, const char* stage)
+{
+    bool ok = true;
+    if (!rc->dStatus) ok = HIP_OK(hipMalloc((void**)&rc->dStatus, 2 * sizeof(uint32_t)));
+    if (!ok) { (void)hipGetLastError(); L.failure("[Failure] - sharded bake: no device memory for the status word (the other ranks may be waiting in a collective)"); return false; }
+    const uint32_t failed = 0xFFFFFFFFu; uint32_t all = failed;
+    if (!mineOk) ok = HIP_OK(hipMemcpyAsync(dWord, &failed, sizeof failed, hipMemcpyHostToDevice, stream)) && HIP_OK(hipStreamSynchronize(stream));
+    ok = ok && rccl().allReduce(dWord, rc->dStatus + 1, 1, kRcclUint32, kRcclMax, rc->comm, stream) == 0;
+    ok = ok && HIP_OK(hipMemcpyAsync(&all, rc->dStatus + 1, sizeof all, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipStreamSynchronize(stream));
+    if (!ok) { L.failure("[Failure] - sharded bake: the status all-reduce failed"); return false; }
+    if (mineOk && all == failed) { char buf[200]; snprintf(buf, sizeof buf, "[Failure] - sharded bake: another rank failed (%s); this rank stops with it", stage); L.failure(buf); }
+    *outMax = all;
+    return mineOk && all != failed;
 }
 
 // The all-gather of the block contributions moves in chunks of <= 64 MiB per rank (at most 8 chunks, multiples of 256 bytes), so that the
@@ -1854,9 +1871,15 @@ ommResult sharded_tail(ShardedBake* sb)
     c.strideBytes = (mx + 255) & ~255ull; if (c.strideBytes == 0) c.strideBytes = 256;
     // contribution + (for the RCCL path) the gather staging of all ranks: one grow-only block of the session's working set
     const size_t gatherBytes = c.asyncBegin ? (size_t)c.strideBytes * c.world + 4096 : 0;
-    if (!sb->ses.set->xchg.reserve((size_t)c.strideBytes + 256 + gatherBytes)) return L.failure("[Failure] - out of device memory for the shard contribution");
+    // (RCCL path) the contributions cross the links as codec streams of at most half their size: this rank's and the gathered ones
+    c.compCap = c.asyncBegin ? pad256((size_t)(c.strideBytes / 2) + 4096) : 0;
+    const size_t codecBytes = c.asyncBegin ? (size_t)c.compCap * (c.world + 1) + 256 : 0;
+    if (!sb->ses.set->xchg.reserve((size_t)c.strideBytes + 256 + gatherBytes + codecBytes)) return L.failure("[Failure] - out of device memory for the shard contribution");
     c.dContrib = sb->ses.set->xchg.take<uint8_t>((size_t)c.strideBytes);
     c.dGathered = gatherBytes ? sb->ses.set->xchg.take<uint8_t>(gatherBytes) : nullptr;
+    if (codecBytes) { c.dComp = sb->ses.set->xchg.take<uint8_t>((size_t)c.compCap); c.dGatherComp = sb->ses.set->xchg.take<uint8_t>((size_t)c.compCap * c.world); c.dCompSize = sb->ses.set->xchg.take<uint32_t>(1); }
+    // (the padding behind this rank's blocks travels too: zeros, which the codec folds away)
+    if (c.strideBytes > c.totals[c.rank] && !HIP_OK(hipMemsetAsync(c.dContrib + c.totals[c.rank], 0, (size_t)(c.strideBytes - c.totals[c.rank]), stream))) return L.failure("[Failure] - device memset failed");
     launch_shard_gather(c.dStates, c.dStateOfs, c.dActive, c.dOwner, c.rank, c.to.order, c.dCofs, c.to.sizes, c.counts.numOmms, c.dContrib, stream);
     return HIP_OK(hipGetLastError()) ? ommResult_SUCCESS : L.failure("[Failure] - shard gather failed");
 }
@@ -2092,8 +2115,25 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
             // (arrayData is null when this rank could not allocate the result: it still takes part in the agreement, so that nobody waits for it)
             hipEvent_t ready = nullptr, done[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
             bool ok = arrayData != nullptr && sb->ses.open_comm() && HIP_OK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-            ok = rccl_agree(rc, stream, ok, L, "allocation of the result") && ok;
+            // the contribution as a codec stream (tail_kernels.hip "block exchange codec"); the agreement on the ranks' status carries the stream sizes:
+            // MAX over the ranks = what every rank sends (the all-gather needs equal counts), or "one of them does not shrink" = everybody sends raw
+            ok = ok && HIP_OK(run_shard_compress(c.dContrib, c.strideBytes, c.dComp, c.compCap, c.dCompSize, c.dScratch, c.scratchBytes, stream));
+            uint32_t maxUnits = 0;
+            ok = rccl_agree_max(rc, stream, ok, c.dCompSize, &maxUnits, L, "allocation of the result") && ok;
             if (!ok) { if (ready) (void)hipEventDestroy(ready); return false; }
+            sb->tm.contributionBytes = c.strideBytes;
+            if (maxUnits != kCodecIncompressible) {
+                const size_t sendBytes = (size_t)maxUnits * 16u;   // (<= compCap by construction)
+                sb->tm.exchangeBytes = sendBytes;
+                const int e = rccl().allGather(c.dComp, c.dGatherComp, sendBytes, kRcclUint8, rc->comm, stream);
+                if (e != 0) { (void)nccl_fail(e, "ncclAllGather of the OMM blocks"); (void)hipEventDestroy(ready); return false; }
+                for (int r2 = 0; r2 < rc->world; ++r2) launch_shard_expand(c.dGatherComp + (size_t)r2 * sendBytes, c.strideBytes, c.dGathered + (size_t)r2 * c.strideBytes, stream);
+                launch_shard_scatter(c.dGathered, c.strideBytes, 0, c.strideBytes, c.dActive, c.dOwner, c.dMask, c.dLevel, c.bits, c.to.order, c.dCofs, c.to.dstOfs, c.to.sizes, E, arrayData, stream);
+                ok = HIP_OK(hipGetLastError()) && HIP_OK(hipStreamSynchronize(stream));
+                (void)hipEventDestroy(ready);
+                return ok;
+            }
+            sb->tm.exchangeBytes = c.strideBytes;
             hipStream_t cs = sb->ses.commStream;
             const uint64_t chunkBytes = shard_chunk_bytes(*sb->baker, c.strideBytes);              // per rank and chunk; at most 8 chunks
             uint64_t chunks = (c.strideBytes + chunkBytes - 1) / chunkBytes;
@@ -2115,7 +2155,7 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
             return ok;
         }, outResult);
         sb->tm.gatherMs = (float)(now_ms() - t2);
-        if (r == ommResult_SUCCESS) { std::lock_guard<std::mutex> g(b->timingsMu); b->timings.tailMs = sb->tm.tailMs; b->timings.gatherMs = sb->tm.gatherMs; }
+        if (r == ommResult_SUCCESS) { std::lock_guard<std::mutex> g(b->timingsMu); b->timings.tailMs = sb->tm.tailMs; b->timings.gatherMs = sb->tm.gatherMs; b->timings.exchangeBytes = sb->tm.exchangeBytes; b->timings.contributionBytes = sb->tm.contributionBytes; }
         return r;
     });
 }

@@ -425,6 +425,110 @@ __global__ __launch_bounds__(256) void shard_scatter_contributions(const uint8_t
     }
 }
 
+// ---- block exchange codec (multi-GPU: what crosses xGMI) ----
+// The blocks of a bake are long runs of one state with a thin band of mixed micro-triangles along the alpha edge: of the 16-byte units of the metric
+// workload's arrayData (64 micro-triangles in 4-state) 96.7 % hold one repeated state (configs[4]: 98.8 %, asset-sized cards: 58.6 %;
+// profiles/scripts/r03_block_compressibility.py).  A rank's contribution therefore travels as
+//     [0] bytes of the stream, [8] units | offsets: first raw unit of every 256-unit block (uint32, blocks + 1) | codes: one nibble per unit, 0..3 = the
+//     unit is 16 bytes of 0x00 / 0x55 / 0xAA / 0xFF, 4 = raw | the raw units, 16 bytes each
+// -- 6.4 % of the bytes at the metric configuration -- and is expanded again on arrival.  Lossless for any data; a contribution that does not shrink
+// below half its size is sent as it is (size word = kCodecIncompressible).
+constexpr uint32_t kCodecBlock = 256;
+struct CodecLayout { uint64_t units, blocks, offOfs, offCodes, offRaw; };
+__host__ __device__ inline CodecLayout codec_layout(uint64_t contributionBytes)
+{
+    CodecLayout c; c.units = contributionBytes / 16u; c.blocks = (c.units + kCodecBlock - 1u) / kCodecBlock; c.offOfs = 16u;
+    c.offCodes = (c.offOfs + 4u * (c.blocks + 1u) + 15u) & ~15ull; c.offRaw = (c.offCodes + (c.units + 1u) / 2u + 15u) & ~15ull;
+    return c;
+}
+__device__ __forceinline__ uint32_t codec_code(const uint4& v)
+{
+    const bool same = v.x == v.y && v.x == v.z && v.x == v.w;
+    return !same ? 4u : (v.x == 0u ? 0u : (v.x == 0x55555555u ? 1u : (v.x == 0xAAAAAAAAu ? 2u : (v.x == 0xFFFFFFFFu ? 3u : 4u))));
+}
+// raw units in front of this thread inside its 256-unit block, and the block's total (all threads call; s: 4 words of LDS)
+__device__ __forceinline__ uint32_t codec_rank(bool raw, uint32_t* s, uint32_t& total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long v = __ballot(raw);
+    if (lane == 0) s[wave] = (uint32_t)__popcll(v);
+    __syncthreads();
+    uint32_t before = 0; total = 0;
+    for (uint32_t w = 0; w < 4u; ++w) { before += w < wave ? s[w] : 0u; total += s[w]; }
+    return before + (uint32_t)__popcll(v & ((1ull << lane) - 1ull));
+}
+__global__ __launch_bounds__(256) void shard_codec_count(const uint4* __restrict__ contrib, CodecLayout c, uint32_t* __restrict__ counts)
+{
+    __shared__ uint32_t s[4];
+    const uint64_t u = (uint64_t)blockIdx.x * kCodecBlock + threadIdx.x;
+    uint32_t total;
+    (void)codec_rank(u < c.units && codec_code(contrib[u]) == 4u, s, total);
+    if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void shard_codec_write(const uint4* __restrict__ contrib, CodecLayout c, uint8_t* __restrict__ comp, uint64_t capBytes)
+{
+    __shared__ uint32_t s[4];
+    const uint32_t* ofs = (const uint32_t*)(comp + c.offOfs);
+    if (c.offRaw + 16ull * ofs[c.blocks] > capBytes) return;   // does not shrink enough: nothing is written (shard_codec_finish says so)
+    const uint64_t u = (uint64_t)blockIdx.x * kCodecBlock + threadIdx.x;
+    const bool live = u < c.units;
+    const uint4 v = live ? contrib[u] : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t code = live ? codec_code(v) : 0u;
+    uint32_t total;
+    const uint32_t rank = codec_rank(live && code == 4u, s, total);
+    const uint32_t other = (uint32_t)__shfl_xor((int)code, 1);
+    if (live && (threadIdx.x & 1u) == 0u) comp[c.offCodes + u / 2u] = (uint8_t)(code | (other << 4));   // (units is even: contributions are multiples of 256 bytes)
+    if (live && code == 4u) ((uint4*)(comp + c.offRaw))[ofs[blockIdx.x] + rank] = v;
+}
+__global__ void shard_codec_finish(CodecLayout c, uint8_t* __restrict__ comp, uint64_t capBytes, uint32_t* __restrict__ sizeWord)
+{
+    const uint64_t bytes = c.offRaw + 16ull * ((const uint32_t*)(comp + c.offOfs))[c.blocks];
+    ((uint64_t*)comp)[0] = bytes; ((uint64_t*)comp)[1] = c.units;
+    *sizeWord = bytes <= capBytes ? (uint32_t)(bytes / 16u) : kCodecIncompressible;
+}
+__global__ __launch_bounds__(256) void shard_codec_expand(const uint8_t* __restrict__ comp, CodecLayout c, uint4* __restrict__ out)
+{
+    __shared__ uint32_t s[4];
+    const uint64_t u = (uint64_t)blockIdx.x * kCodecBlock + threadIdx.x;
+    const bool live = u < c.units;
+    const uint32_t code = live ? (comp[c.offCodes + u / 2u] >> ((u & 1u) * 4u)) & 15u : 0u;
+    uint32_t total;
+    const uint32_t rank = codec_rank(live && code == 4u, s, total);
+    if (!live) return;
+    uint4 v;
+    if (code == 4u) v = ((const uint4*)(comp + c.offRaw))[((const uint32_t*)(comp + c.offOfs))[blockIdx.x] + rank];
+    else { const uint32_t p = code == 0u ? 0u : (code == 1u ? 0x55555555u : (code == 2u ? 0xAAAAAAAAu : 0xFFFFFFFFu)); v = make_uint4(p, p, p, p); }
+    out[u] = v;
+}
+size_t shard_codec_scratch_bytes(uint64_t contributionBytes)
+{
+    const CodecLayout c = codec_layout(contributionBytes);
+    size_t tb = 0;
+    (void)rocprim::exclusive_scan(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)0, (size_t)(c.blocks + 1), rocprim::plus<uint32_t>());
+    return ((size_t)(c.blocks + 1) * 4 + 255) / 256 * 256 + tb + 256;
+}
+// contribution (a multiple of 256 bytes) -> comp (capacity capBytes); *sizeWord <- length of the stream in 16-byte units, or kCodecIncompressible
+hipError_t run_shard_compress(const uint8_t* contrib, uint64_t contributionBytes, uint8_t* comp, uint64_t capBytes, uint32_t* sizeWord, void* scratch, size_t scratchBytes, hipStream_t stream)
+{
+    const CodecLayout c = codec_layout(contributionBytes);
+    if (scratchBytes < shard_codec_scratch_bytes(contributionBytes) || capBytes < c.offRaw + 16u || c.blocks >= 0x7FFFFFFFull) return hipErrorInvalidValue;
+    uint32_t* counts = (uint32_t*)scratch;
+    void* tmp = (uint8_t*)scratch + ((size_t)(c.blocks + 1) * 4 + 255) / 256 * 256;
+    size_t tb = scratchBytes - ((size_t)(c.blocks + 1) * 4 + 255) / 256 * 256;
+    TAIL_CHECK(hipMemsetAsync(counts + c.blocks, 0, 4, stream));
+    hipLaunchKernelGGL(shard_codec_count, dim3((uint32_t)c.blocks), dim3(256), 0, stream, (const uint4*)contrib, c, counts);
+    TAIL_CHECK(rocprim::exclusive_scan(tmp, tb, counts, (uint32_t*)(comp + c.offOfs), (uint32_t)0, (size_t)(c.blocks + 1), rocprim::plus<uint32_t>(), stream));
+    hipLaunchKernelGGL(shard_codec_write, dim3((uint32_t)c.blocks), dim3(256), 0, stream, (const uint4*)contrib, c, comp, capBytes);
+    hipLaunchKernelGGL(shard_codec_finish, dim3(1), dim3(1), 0, stream, c, comp, capBytes, sizeWord);
+    return hipGetLastError();
+}
+// comp (a stream of run_shard_compress for a contribution of contributionBytes) -> out
+void launch_shard_expand(const uint8_t* comp, uint64_t contributionBytes, uint8_t* out, hipStream_t stream)
+{
+    const CodecLayout c = codec_layout(contributionBytes);
+    if (c.blocks) hipLaunchKernelGGL(shard_codec_expand, dim3((uint32_t)c.blocks), dim3(256), 0, stream, comp, c, (uint4*)out);
+}
+
 void launch_shard_gather(const uint8_t* states, const uint64_t* stateOfs, const uint8_t* active, const uint8_t* owner, uint32_t rank, const uint32_t* order,
                          const uint64_t* cofs, const uint32_t* sizes, uint32_t numOmms, uint8_t* contrib, hipStream_t stream)
 {

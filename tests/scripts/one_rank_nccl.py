@@ -33,6 +33,39 @@ dd3 = ot.BakeInputDesc.from_buffer_copy(dd); dd3.maxArrayDataSize = 300000
 out3 = sh.sharded_bake_rccl(prod.dll, b, C.byref(dd3), comm)
 res3 = ot.device_result_to_host(prod, ot.Hip(), out3)
 assert res3.same_as(ref3) and res3.array_data.size <= 300000 < ref.array_data.size, (res3.diff(ref3), res3.array_data.size, ref.array_data.size)
+# the block exchange codec (tail_kernels.hip): the contributions cross the links as unit codes + raw units.  A level-8 bake of the metric workload's kind
+# shrinks to a few per cent and must arrive bit for bit; blocks of noise do not shrink below half and travel as they are
+import bench
+def timings():
+    tm = bench.BakeTimings()
+    prod.dll.ommxGetLastBakeTimings.argtypes = [C.c_void_p, C.POINTER(bench.BakeTimings)]
+    prod.dll.ommxGetLastBakeTimings(b, C.byref(tm))
+    return tm
+res2b = ot.device_result_to_host(prod, ot.Hip(), sh.sharded_bake_rccl(prod.dll, b, C.byref(dd), comm))
+tm2 = timings()
+assert res2b.same_as(ref)
+assert 0 < tm2.exchangeBytes < tm2.contributionBytes // 2, (tm2.exchangeBytes, tm2.contributionBytes)
+uv8, ix8 = ot.random_triangles(811, 30000, 8.0 / 1024)
+d8 = ot.make_desc(t, uv8, ix8, 8, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+ref8 = prod.bake(b, d8, want_stats=False)
+duv8 = torch.from_numpy(uv8).cuda(); dix8 = torch.from_numpy(ix8.astype(np.int32)).cuda()
+dd8 = ot.BakeInputDesc.from_buffer_copy(d8); dd8.texCoords, dd8.indexBuffer = duv8.data_ptr(), dix8.data_ptr()
+res8 = ot.device_result_to_host(prod, ot.Hip(), sh.sharded_bake_rccl(prod.dll, b, C.byref(dd8), comm))
+tm8 = timings()
+assert res8.same_as(ref8), res8.diff(ref8)
+assert ref8.array_data.size > (20 << 20) and tm8.exchangeBytes * 8 < tm8.contributionBytes, (ref8.array_data.size, tm8.exchangeBytes, tm8.contributionBytes)
+noise = (np.random.RandomState(5).rand(512, 512) * 255).astype(np.uint8)
+tn = prod.create_texture(b, [noise], alpha_cutoff=0.5)
+uvn, ixn = ot.random_triangles(812, 400, 0.3)
+dn = ot.make_desc(tn, uvn, ixn, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+refn = prod.bake(b, dn, want_stats=False)
+duvn = torch.from_numpy(uvn).cuda(); dixn = torch.from_numpy(ixn.astype(np.int32)).cuda()
+ddn = ot.BakeInputDesc.from_buffer_copy(dn); ddn.texCoords, ddn.indexBuffer = duvn.data_ptr(), dixn.data_ptr()
+resn = ot.device_result_to_host(prod, ot.Hip(), sh.sharded_bake_rccl(prod.dll, b, C.byref(ddn), comm))
+tmn = timings()
+assert resn.same_as(refn), resn.diff(refn)
+assert tmn.exchangeBytes == tmn.contributionBytes > 0, (tmn.exchangeBytes, tmn.contributionBytes)      # (sent raw: the chunked all-gather of round 2)
+print("codec: %d -> %d bytes (foliage, level 8), %d -> %d (noise)" % (tm8.contributionBytes, tm8.exchangeBytes, tmn.contributionBytes, tmn.exchangeBytes))
 prod.dll.ommxRcclCommDestroy(comm)
 print("one-rank nccl plumbing ok", len(res.descs))
 dist.destroy_process_group()

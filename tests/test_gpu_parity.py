@@ -553,7 +553,7 @@ def test_cpp_user_of_the_rccl_entry_point(tmp_path):
     assert r.returncode == 0 and "sharded == single-GPU" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
-def test_torch_distributed_plumbing_one_rank():
+def test_torch_distributed_plumbing_one_rank_nccl():
     """omm_amd/sharded.py over a real (1-rank) RCCL process group: raw-pointer tensor views, all_reduce, all_gather_into_tensor, and a
     sharded bake compared with ommCpuBake (the multi-rank exchange itself is covered by test_sharded_bake_equals_single_gpu and the gloo test)."""
     import os, subprocess, sys
