@@ -300,7 +300,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["what"] % tris, "name": args.config,
                        "entry": (("ommxShardedBakeRccl (collectives issued by the library)" if native else "ommxSharded* + torch.distributed") if world > 1 else "ommxBakeDevice") + " (ommCpuBake contract, UV/index inputs and result arrays resident in HBM)",
-                       "sharding": "active work items partitioned over ranks; RCCL all-reduce of item metadata + chunked all-gather of OMM blocks" if world > 1 else "none",
+                       "sharding": ("active work items partitioned over ranks; RCCL all-reduce of item metadata + all-gather of the OMM blocks as codec streams "
+                                    "(%d of %d contribution bytes per rank on the wire)" % (int(tms[-1].exchangeBytes), int(tms[-1].contributionBytes))) if world > 1 else "none",
                        "result": result_info, "unique_items": int(t_last.uniqueItems), "active_items": int(t_last.activeItems),
                        "open_tiles": int(t_last.openTiles), "fine_micro_triangles": int(t_last.fineMicroTriangles),
                        "generic_pass_micro_triangles": int(t_last.genericMicroTriangles)},
