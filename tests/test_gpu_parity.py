@@ -1301,6 +1301,39 @@ def test_streamed_result_falls_back_when_a_later_range_owns_the_block(product, o
     assert fell_back == [False, True], fell_back      # previewed copies stream; the asset-sized ones stream, notice, and take the ordinary path
 
 
+def test_both_formats_and_both_generic_passes_at_scale(product):
+    """Size-independent cross checks of this round's machinery at sizes the oracle cannot follow: (a) a 2-state bake large enough to stream its result on its
+    own (512-byte digest chunks, one-bit blocks) equals the device-resident bake, which assembles its result after the classification; (b) the asset-shaped
+    workload gives the same bytes with the generic texel-loop path inside the persistent kernel and as the deferred pass."""
+    import workloads as wl, bench, ctypes
+    hip = ot.Hip()
+    # (a)
+    tex, uv, ix, lv, kw = wl.workload("c2", 200000, fmt=ot.FMT_2STATE)
+    kw = dict(kw, fmt=ot.FMT_2STATE); lvl = kw.pop("level")
+    b = product.create_baker(); t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+    d = ot.make_desc(t, uv, ix, lvl, **kw)
+    host = product.bake(b, d, want_stats=False)
+    tm = bench.BakeTimings()
+    product.dll.ommxGetLastBakeTimings.argtypes = [ctypes.c_void_p, ctypes.POINTER(bench.BakeTimings)]
+    product.dll.ommxGetLastBakeTimings(b, ctypes.byref(tm))
+    assert tm.streamChunks > 1 and tm.streamedBytes == host.array_data.size > (64 << 20), (tm.streamChunks, tm.streamedBytes, host.array_data.size)
+    dev = ot.bake_device(product, hip, b, d, uv, ix)
+    assert dev.same_as(host), dev.diff(host)
+    product.destroy_texture(b, t); product.destroy_baker(b)
+    # (b)
+    tex, uv, ix, lv, kw = wl.workload("cards", 8000)
+    kw = dict(kw); lvl = kw.pop("level")
+    results = []
+    for mode in (1, 2):
+        b = product.create_baker(); product.set_knob(b, ot.KNOB_GENERIC_PASS, mode)
+        t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+        results.append(ot.bake_device(product, hip, b, ot.make_desc(t, uv, ix, lvl, levels=lv, **kw), uv, ix, levels=lv))
+        product.dll.ommxGetLastBakeTimings(b, ctypes.byref(tm))
+        assert (tm.genericMicroTriangles > 1000000) == (mode == 2), (mode, tm.genericMicroTriangles)
+        product.destroy_texture(b, t); product.destroy_baker(b)
+    assert results[0].same_as(results[1]), results[0].diff(results[1])
+
+
 @pytest.mark.parametrize("generic_pass", [1, 2])
 def test_micro_triangles_of_several_texels(product, oracle, generic_pass):
     """Micro-triangles that span several texels (asset-sized triangles: the shape of the reference's Leaflet KATs at production size): the generic
