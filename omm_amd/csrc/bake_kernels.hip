@@ -48,7 +48,7 @@ __device__ __forceinline__ float item_max_abs(const float* __restrict__ uv)
 }
 
 // Block-uniform values that arrive through vector loads / LDS (the tile record, the item's UVs) are moved to scalar registers: the
-// classification loops are VGPR-bound (72 VGPRs = 7 waves per SIMD), and a uniform value parked in a VGPR costs 64 lanes of it.
+// classification loops are VGPR-bound (80 VGPRs = 6 waves per SIMD), and a uniform value parked in a VGPR costs 64 lanes of it.
 __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ float uniform_f32(float v) { return __uint_as_float(uniform_u32(__float_as_uint(v))); }
 
@@ -194,11 +194,12 @@ constexpr int WIN = 32; // largest LDS texel window edge
 
 // SLICED: 4^level >= TILE, the tile is a slice of ONE work item (block-uniform item data, LDS texel/SAT window).
 // !SLICED: the tile holds TILE / 4^level whole items.
-// 7 waves/SIMD = 72 VGPRs (and 7 x 21.5 KB of LDS per CU).  The level-line body needs one register more, so the sliced
-// instantiations spill ONE dword per unresolved micro-triangle (its queue entry, dead across the pass): 52.3 -> 50.0 ms against
-// the spill-free 6-wave build, and the extra HBM writes stay below the kernel's algorithmic bytes (profiles/).
+// Waves per SIMD of the persistent launch, measured again every time the kernel's instruction mix moved: round 1 asked for 7 (72 VGPRs, one spilled dword:
+// 52.3 -> 50.0 ms against 6), round 2 kept 7 (36.8 / 33.1 / 40.9 ms at 6 / 7 / 8); since curve_excluded() took the edge tests out of 88 % of the
+// micro-triangles 6 waves (80 VGPRs, 25 instead of 34 spilled, 2.8 instead of 7.1 GB of HBM traffic per launch) win: 26.4 / 24.5 / 25.1 / 29.9 ms at
+// 5 / 6 / 7 / 8 on the metric configuration, 131.0 / 122.5 / 127.2 ms on configs[4].
 #ifndef OMMX_CLASSIFY_WAVES
-#define OMMX_CLASSIFY_WAVES 7
+#define OMMX_CLASSIFY_WAVES 6
 #endif
 // TILE micro-triangles per workgroup: 4096 for levels >= 6, 1024 below (a level-5 item is exactly one 1024-tile)
 constexpr uint32_t kDeferredState = 0xFEu;   // s_state code of a micro-triangle that classify_generic() will classify
@@ -857,7 +858,10 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
     }
     // ---- sliced items, step 2: one persistent launch per queue; every CU holds OMMX_CLASSIFY_WAVES workgroups of 4 waves (one per SIMD) ----
     // (streamed bakes leave one workgroup slot per CU to the placement kernels that run next to the persistent launch)
-    const uint64_t want = (uint64_t)numCUs * (chunks.after ? OMMX_CLASSIFY_WAVES - 1 : OMMX_CLASSIFY_WAVES);
+    #ifndef OMMX_STREAM_WAVES
+#define OMMX_STREAM_WAVES (OMMX_CLASSIFY_WAVES - 1)
+#endif
+    const uint64_t want = (uint64_t)numCUs * (chunks.after ? OMMX_STREAM_WAVES : OMMX_CLASSIFY_WAVES);
     if (plan.totalSmall) {
         const dim3 cg((uint32_t)(plan.totalSmall < want ? plan.totalSmall : want)), cb(BLOCK);
         if (deferred) hipLaunchKernelGGL((classify_tiles<FP32, true, 1024, MD, true>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)q1024, ctl1024, 1u, chunks.generic);
@@ -1042,9 +1046,26 @@ __global__ __launch_bounds__(256) void digest_items(const uint8_t* __restrict__ 
 // A streamed bake digests range by range, next to the persistent classification launch (29 KB of LDS and one wave slot per SIMD are free on a CU): a
 // few thousand items per launch, so the launch takes as long as ONE workgroup -- 16 items x 1 KiB chunks (16 round trips for a 16 KiB item instead of
 // 64, at raised wave priority) serve those; the hash lanes are the first 4 x ITEMS threads, all 256 load.
+// (the small-workgroup forms run NEXT TO the persistent classification launch of a streamed bake -- OMMX_STREAM_WAVES workgroups of <= 80 VGPRs per CU --:
+//  like every kernel of the placement stream they stay small, 25 VGPRs with rolled loops)
+template <int DG_CHUNK, int DG_ITEMS, bool MIXED>
+__device__ __forceinline__ void digest_items_lds_body(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs, const DigestLists& D, uint32_t blocksA, uint32_t bits,
+                                                      uint64_t* __restrict__ digests);
 template <int DG_CHUNK, int DG_ITEMS, bool MIXED>
 __global__ __launch_bounds__(256) void digest_items_lds(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs, DigestLists D, uint32_t blocksA, uint32_t bits,
                                                         uint64_t* __restrict__ digests)
+{
+    digest_items_lds_body<DG_CHUNK, DG_ITEMS, MIXED>(states, stateOfs, D, blocksA, bits, digests);
+}
+template <int DG_CHUNK, int DG_ITEMS, bool MIXED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void digest_items_lds_guest(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs, DigestLists D,
+                                                                                                   uint32_t blocksA, uint32_t bits, uint64_t* __restrict__ digests)
+{
+    digest_items_lds_body<DG_CHUNK, DG_ITEMS, MIXED>(states, stateOfs, D, blocksA, bits, digests);
+}
+template <int DG_CHUNK, int DG_ITEMS, bool MIXED>
+__device__ __forceinline__ void digest_items_lds_body(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs, const DigestLists& D, uint32_t blocksA, uint32_t bits,
+                                                      uint64_t* __restrict__ digests)
 {
     constexpr int DG_STRIDE = DG_CHUNK / 4 + 1;
     __shared__ uint32_t s_buf[DG_ITEMS * DG_STRIDE];
@@ -1080,7 +1101,7 @@ __global__ __launch_bounds__(256) void digest_items_lds(const uint8_t* __restric
     __syncthreads();
     const uint32_t bytesPerItem = MIXED ? s_maxBytes : myBytes;
     for (uint32_t chunk = 0; chunk < bytesPerItem; chunk += DG_CHUNK) {
-        #pragma unroll 4
+        #pragma unroll DG_ITEMS < 64 ? 1 : 4   // (the guest forms keep their register count down: see digest_items_lds_guest)
         for (uint32_t k = tid; k < DG_ITEMS * (DG_CHUNK / 16); k += 256) {
             const uint32_t row = k / (DG_CHUNK / 16), part = k % (DG_CHUNK / 16);
             const uint8_t* src = s_ptr[row];
@@ -1093,11 +1114,11 @@ __global__ __launch_bounds__(256) void digest_items_lds(const uint8_t* __restric
         if (!hasher || (MIXED && chunk >= myBytes)) { /* a load-only thread, or this item's stream has ended */ }
         else if (bits == 2) {
             const uint16_t* q = (const uint16_t*)(s_buf + il * DG_STRIDE) + acc;
-            #pragma unroll 4
+            #pragma unroll DG_ITEMS < 64 ? 2 : 4
             for (uint32_t st = 0; st < stripesPerChunk; ++st) v = xxh_round(v, expand8((uint32_t)q[4 * st], 2));
         } else {
             const uint8_t* q = (const uint8_t*)(s_buf + il * DG_STRIDE) + acc;
-            #pragma unroll 4
+            #pragma unroll DG_ITEMS < 64 ? 2 : 4
             for (uint32_t st = 0; st < stripesPerChunk; ++st) v = xxh_round(v, expand8((uint32_t)q[4 * st], 1));
         }
         __syncthreads();
@@ -1133,10 +1154,10 @@ void launch_digest_lists(const uint8_t* states, const uint64_t* stateOfs, const 
     if (D.count == 0 && D.capacityB == 0) return;
     if (bits == 2) {   // every item has >= 1 KiB of packed states
         const uint32_t a = (D.count + 15u) / 16u, b = (D.capacityB + 15u) / 16u;
-        hipLaunchKernelGGL((digest_items_lds<1024, 16, true>), dim3(a + b), dim3(256), 0, stream, states, stateOfs, D, a, bits, digests);
+        hipLaunchKernelGGL((digest_items_lds_guest<1024, 16, true>), dim3(a + b), dim3(256), 0, stream, states, stateOfs, D, a, bits, digests);
     } else {           // >= 512 bytes
         const uint32_t a = (D.count + 31u) / 32u, b = (D.capacityB + 31u) / 32u;
-        hipLaunchKernelGGL((digest_items_lds<512, 32, true>), dim3(a + b), dim3(256), 0, stream, states, stateOfs, D, a, bits, digests);
+        hipLaunchKernelGGL((digest_items_lds_guest<512, 32, true>), dim3(a + b), dim3(256), 0, stream, states, stateOfs, D, a, bits, digests);
     }
 }
 

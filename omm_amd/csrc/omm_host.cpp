@@ -905,7 +905,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         if (!so->forced) {
             // >= 64 MiB of packed states: one range per 32 MiB, at most 24 (measured at 1.27 GB: 8 / 16 / 24 / 32 ranges = 38.4 / 36.7 / 36.2 / 36.2 ms)
             k = hc.stateBytes >= (64ull << 20) ? (uint32_t)(hc.stateBytes >> 25) : 0u; if (k > 24u) k = 24u;
-            // ... and only when the copy is worth hiding.  Streaming costs the classification about a quarter of its time (6 instead of 7 workgroups per CU,
+            // ... and only when the copy is worth hiding.  Streaming costs the classification about a quarter of its time (5 instead of 6 workgroups per CU,
             // the placement kernels next to it) and saves at most the copy (~57 GB/s over PCIe).  The classification time is estimated from the two
             // quantities that drive it: micro-triangles (sub-texel ones, mostly culled: 2.5e-10 ms each -- 27 ms for 6.5e10, 128 ms for 6.0e11 measured) and
             // texels under the triangles' boxes (micro-triangles of several texels walk them: 4e-9 ms each -- 55 ms for 1.4e10 measured on asset-sized

@@ -814,6 +814,27 @@ __global__ __launch_bounds__(256) void stream_flags(StreamSegment g, HashTable t
     const unsigned long long b = __ballot(emit);
     if ((threadIdx.x & 63u) == 0 && b) atomicAdd(ctl, (uint32_t)__popcll(b));   // number of blocks placed so far
 }
+// exclusive scan of up to a few ten thousand sizes by one workgroup (wave scans + a carried total)
+__global__ __launch_bounds__(256) void stream_scan_small(const uint64_t* __restrict__ sizes, uint64_t* __restrict__ ofs, uint32_t n)
+{
+    __shared__ uint64_t s_wave[4];
+    uint64_t carry = 0;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t i0 = 0; i0 < n; i0 += 256u) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint64_t v = i < n ? sizes[i] : 0ull;
+        uint64_t x = v;
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint64_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+        if (lane == 63u) s_wave[wave] = x;
+        __syncthreads();
+        uint64_t before = 0, total = 0;
+        for (uint32_t w = 0; w < 4u; ++w) { before += w < wave ? s_wave[w] : 0ull; total += s_wave[w]; }
+        if (i < n) ofs[i] = carry + before + x - v;
+        carry += total;
+        __syncthreads();
+    }
+}
 // one wave per item: the block goes behind everything placed so far
 __global__ __launch_bounds__(256) void stream_copy(StreamSegment g, const uint64_t* __restrict__ sizes64, const uint64_t* __restrict__ ofs64,
                                                    const unsigned long long* __restrict__ cursor, uint8_t* __restrict__ stage, uint64_t* __restrict__ placed)
@@ -849,8 +870,13 @@ hipError_t run_stream_segment(const StreamSegment& g, uint32_t numActive, void* 
     const dim3 grid((g.count + 255u) / 256u), block(256);
     if (!g.disableDedup) hipLaunchKernelGGL(stream_insert, grid, block, 0, stream, g, s.table);
     hipLaunchKernelGGL(stream_flags, grid, block, 0, stream, g, s.table, s.claimed, s.sizes64, ctl);
-    size_t tb = s.tmpBytes;
-    TAIL_CHECK(rocprim::exclusive_scan(s.tmp, tb, s.sizes64, s.ofs64, (uint64_t)0, (size_t)g.count, rocprim::plus<uint64_t>(), stream));
+    // (a range has a few thousand items: one small workgroup scans them -- 16 VGPRs, so that it runs next to the persistent classification launch like the
+    //  rest of the placement; the lower levels, behind that launch and possibly millions of items, keep rocPRIM)
+    if (g.count <= 65536u) hipLaunchKernelGGL(stream_scan_small, dim3(1), dim3(256), 0, stream, (const uint64_t*)s.sizes64, s.ofs64, g.count);
+    else {
+        size_t tb = s.tmpBytes;
+        TAIL_CHECK(rocprim::exclusive_scan(s.tmp, tb, s.sizes64, s.ofs64, (uint64_t)0, (size_t)g.count, rocprim::plus<uint64_t>(), stream));
+    }
     const uint32_t blocks = (g.count + 3u) / 4u;
     hipLaunchKernelGGL(stream_copy, dim3(blocks < 8192u ? blocks : 8192u), dim3(256), 0, stream, g, (const uint64_t*)s.sizes64, (const uint64_t*)s.ofs64,
                        (const unsigned long long*)cursor, stage, placed);
