@@ -857,11 +857,12 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
                            (const uint4*)nullptr, (uint32_t*)nullptr, 0u, noGeneric);
     }
     // ---- sliced items, step 2: one persistent launch per queue; every CU holds OMMX_CLASSIFY_WAVES workgroups of 4 waves (one per SIMD) ----
-    // (streamed bakes leave one workgroup slot per CU to the placement kernels that run next to the persistent launch)
-    #ifndef OMMX_STREAM_WAVES
-#define OMMX_STREAM_WAVES (OMMX_CLASSIFY_WAVES - 1)
-#endif
-    const uint64_t want = (uint64_t)numCUs * (chunks.after ? OMMX_STREAM_WAVES : OMMX_CLASSIFY_WAVES);
+    // A streamed bake runs its placement kernels NEXT TO the persistent launch.  They are small (<= 25 VGPRs, <= 17 KB of LDS: they fit beside six of these
+    // workgroups on a CU), but the grid must stay below what the chip can hold: with every slot requested (or 16 fewer) the dispatcher keeps workgroups of
+    // this launch pending and lets nothing else in -- measured with device time stamps: the one-lane wait kernel of the first range then starts 24 ms late,
+    // when the first of these workgroups exits.  Half a workgroup per CU less than full is the measured optimum (metric configuration, ms per ommCpuBake, by
+    // workgroups held back: 0 / 16: 52.7, 64: 34.6 .. 37.7 (unstable), 96: 34.9, 128: 34.8, 192: 35.4, 256: 35.4; configs[4]: 64: 145, 128: 148, 256: 155).
+    const uint64_t want = (uint64_t)numCUs * OMMX_CLASSIFY_WAVES - (chunks.after ? numCUs / 2u : 0u);
     if (plan.totalSmall) {
         const dim3 cg((uint32_t)(plan.totalSmall < want ? plan.totalSmall : want)), cb(BLOCK);
         if (deferred) hipLaunchKernelGGL((classify_tiles<FP32, true, 1024, MD, true>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)q1024, ctl1024, 1u, chunks.generic);
@@ -1046,7 +1047,7 @@ __global__ __launch_bounds__(256) void digest_items(const uint8_t* __restrict__ 
 // A streamed bake digests range by range, next to the persistent classification launch (29 KB of LDS and one wave slot per SIMD are free on a CU): a
 // few thousand items per launch, so the launch takes as long as ONE workgroup -- 16 items x 1 KiB chunks (16 round trips for a 16 KiB item instead of
 // 64, at raised wave priority) serve those; the hash lanes are the first 4 x ITEMS threads, all 256 load.
-// (the small-workgroup forms run NEXT TO the persistent classification launch of a streamed bake -- OMMX_STREAM_WAVES workgroups of <= 80 VGPRs per CU --:
+// (the small-workgroup forms run NEXT TO the persistent classification launch of a streamed bake -- up to six workgroups of <= 80 VGPRs per CU --:
 //  like every kernel of the placement stream they stay small, 25 VGPRs with rolled loops)
 template <int DG_CHUNK, int DG_ITEMS, bool MIXED>
 __device__ __forceinline__ void digest_items_lds_body(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs, const DigestLists& D, uint32_t blocksA, uint32_t bits,
