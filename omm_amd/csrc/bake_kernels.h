@@ -73,8 +73,6 @@ struct ClassifyChunks {
     void* earlyStage;       // >= kTileRecordBytes x (open tiles of early items) bytes of scratch, free until the persistent launch starts
     GenericQueue generic;   // entries != null: deferred generic pass (not together with `after`: a streamed range must be complete when its sections are)
 };
-// the whole-item kernel at `level` over a plain item list (used for the level-2 preview of a streamed bake)
-hipError_t launch_classify_items(const ClassifyParams& P, const ItemArrays& A, const uint32_t* ids, uint32_t count, uint32_t level, hipStream_t stream);
 hipError_t launch_classify(const ClassifyParams& P, const ItemArrays& A, const uint32_t* activeIds, const uint32_t first[kNumLevels], const uint32_t count[kNumLevels],
                            void* queue, uint32_t* queueCtl, uint32_t numCUs, hipStream_t stream, const ClassifyChunks* chunks = nullptr);
 // level-0 hierarchical query per work item: uniform items get stateMask = 1 << state and active = 0
@@ -168,7 +166,7 @@ void launch_stream_publish(const unsigned long long* cursor, unsigned long long*
 // `stream` does not pass until sections [first, first + n) of the 4096-tile queue are complete (every block in them classified and visible); the stream
 // must already be ordered behind the tile triage.  ctl: the streamed result's control words (a wait that gives up sets the violation word)
 void launch_stream_wait_sections(const uint32_t* queueCtl, uint32_t first, uint32_t n, uint32_t* ctl, hipStream_t stream);
-// preview of the items of level >= 6 (tail_kernels.hip "preview"): prepare -> launch_classify_items(kPreviewLevel, preview buffers) -> flags
+// preview of the items of level >= 6 (tail_kernels.hip "preview"): prepare -> launch_classify() of the items as ONE level-5 class into the preview buffers -> flags
 constexpr uint32_t kPreviewLevel = 5, kPreviewSlotBytes = 256;   // 1024 micro-triangles x 2 bits
 void launch_stream_preview_prepare(const uint32_t* ids, uint32_t n, const float* uv, float texW, float texH, float* uv2, uint64_t* ofs2, uint8_t* early, hipStream_t stream);
 // ctl: kStreamCtlWords words {blocks placed, violation, mismatch, early items; per range: early items classified with it, start of their slice of the early list, fill}

@@ -926,25 +926,6 @@ hipError_t launch_classify(const ClassifyParams& P, const ItemArrays& A, const u
     return hipGetLastError();
 }
 
-// Plain grid launch of the whole-item kernel at an arbitrary level (streamed bakes: a level-2 preview of every active item, 16 micro-triangles =
-// its sixteenths, written to preview buffers of their own).
-hipError_t launch_classify_items(const ClassifyParams& P, const ItemArrays& A, const uint32_t* ids, uint32_t count, uint32_t level, hipStream_t stream)
-{
-    if (!count) return hipSuccess;
-    const uint64_t M = 1ull << (2 * level);
-    const uint64_t tiles = ((uint64_t)count * M + 1023u) / 1024u;
-    const uint32_t gx = tiles < (1u << 20) ? (uint32_t)tiles : (1u << 20), gy = (uint32_t)((tiles + gx - 1) / gx);
-    GenericQueue noGeneric; noGeneric.entries = nullptr; noGeneric.count = nullptr; noGeneric.capacity = 0;
-#define OMMX_ITEMS(FP, MD) hipLaunchKernelGGL((classify_tiles<FP, false, 1024, MD>), dim3(gx, gy), dim3(BLOCK), 0, stream, P, A, ids, count, level, tiles, \
-                                              (const uint4*)nullptr, (uint32_t*)nullptr, 0u, noGeneric)
-    const bool wrapP2 = P.addrMode == 0 && P.pow2Dispatch, clampP2 = P.addrMode == 2 && P.pow2Dispatch;
-    typedef ModeStatic<0, 1> WrapP2; typedef ModeStatic<2, 1> ClampP2;
-    if (P.texIsFp32) { if (wrapP2) OMMX_ITEMS(true, WrapP2); else if (clampP2) OMMX_ITEMS(true, ClampP2); else OMMX_ITEMS(true, ModeDynamic); }
-    else             { if (wrapP2) OMMX_ITEMS(false, WrapP2); else if (clampP2) OMMX_ITEMS(false, ClampP2); else OMMX_ITEMS(false, ModeDynamic); }
-#undef OMMX_ITEMS
-    return hipGetLastError();
-}
-
 // ------------------------------------------------------------------------------------------------
 // XXH64 (seed 42) over the item's 3-state byte stream: one byte per micro-triangle, UT folded into
 // UO (bake_cpu_impl.cpp:374-377,1038-1040).  The bytes are never materialised: each lane expands

@@ -979,7 +979,14 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             ItemArrays A2 = A; A2.uv = dUv2; A2.stateOfs = dOfs2; A2.states = dStates2; A2.stateMask = dMask2; A2.fineCount = dFine2;   // (its level-line statistic goes nowhere)
             bool okp = HIP_OK(hipMemsetAsync(dEarly, 0, maxItems, stream)) && HIP_OK(hipMemsetAsync(dMask2, 0, (size_t)maxItems * 4, stream));
             launch_stream_preview_prepare(dActiveIds + first6, count6, dUv, P.mips[0].fw, P.mips[0].fh, dUv2, dOfs2, dEarly, stream);
-            okp = okp && HIP_OK(launch_classify_items(P2, A2, dActiveIds + first6, count6, kPreviewLevel, stream));
+            {   // the preview items as ONE level-5 class of the ordinary classification: a 1024-tile each, tile triage (most previews are settled by one SAT
+                // query), LDS window and the single-texel pass for the rest -- through the bake's own tile queue, which is free until the real launch
+                static_assert(kPreviewLevel == 5, "the preview is the 1024-tile class");
+                uint32_t first2[kNumLevels], count2[kNumLevels];
+                for (int l = 0; l < kNumLevels; ++l) { first2[l] = 0; count2[l] = 0; }
+                first2[kPreviewLevel] = first6; count2[kPreviewLevel] = count6;
+                okp = okp && HIP_OK(launch_classify(P2, A2, dActiveIds, first2, count2, dTileQueue, dQueueCtl, device_cu_count(), stream, nullptr));
+            }
             ClassifyPlan plan; classify_plan(lvlFirst, lvlCount, streamChunks, &plan);   // (the ranges launch_classify will cut)
             okp = okp && HIP_OK(run_stream_preview_flags(dActiveIds + first6, count6, first6, numActiveAll, dStates2, dLevel, dEarly, dStreamCtl, dScratch, scratchBytes, dEarlyLead, dEarlyList, plan, stream));
             if (!okp) return L.failure("[Failure] - could not set up the streamed result");

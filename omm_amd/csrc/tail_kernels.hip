@@ -633,8 +633,8 @@ hipError_t run_stream_begin(uint32_t* activeIds, uint32_t numActive, const float
 // families -- a corner or edge point that is just touched (a handful of unknown micro-triangles, one state everywhere else), k complete rows of
 // micro-triangles parallel to an edge, ... -- measured on the bench workload: 959 of 77 627 blocks are shared by 2 .. 4 triangles.
 // Two items with the same block have the same block at every coarser level too (a coarse micro-triangle is T / O exactly when all of its
-// descendants are), so the preview classifies every active item of level >= 6 at level 5 (1024 micro-triangles, the whole-item kernel with
-// 4-state / ForceOpaque parameters, buffers of its own: < 2 % of the work of the bake), hashes the 256 bytes, and marks as `early` every item
+// descendants are), so the preview classifies every active item of level >= 6 at level 5 (1024 micro-triangles: one 1024-tile each through the ordinary
+// tile triage + persistent launch, with 4-state / ForceOpaque parameters and buffers of its own: < 2 % of the work of the bake), hashes the 256 bytes, and marks as `early` every item
 // whose preview (a) is not one single state -- those become special indices, not blocks -- and (b) is shared with another item: a family.
 // On the bench workload 41 425 of the 79 869 items with a mixed preview are early (8 392 families: the digital lines a 32 x 32 lattice can tell
 // apart are few).  Classifying them all before the first range held the first copy back by 10 ms (their tiles are a third of the open tiles), so
