@@ -195,20 +195,28 @@ def main():
 
     import omm_amd.sharded as shard
 
-    # N > 1: the library's one-call sharded bake, RCCL collectives issued from C++ (ommxShardedBakeRccl); OMM_BENCH_COLLECTIVES=torch keeps
-    # the caller-driven path (collectives through torch.distributed) for the gloo self-tests
-    native = world > 1 and os.environ.get("OMM_BENCH_COLLECTIVES", "native") == "native" and os.environ.get("OMM_BENCH_BACKEND", "nccl") == "nccl"
+    # N > 1: the library's one-call sharded bake (ommxShardedBakeRccl).  Its collectives are RCCL calls issued from C++; where the library cannot
+    # have an RCCL communicator of its own (it could not be created, or the gloo self-test: two ranks on one GPU) the SAME call runs over the
+    # process group's collectives (ommxCommFromCollectives).  OMM_BENCH_COLLECTIVES=torch keeps the caller-driven four-call path for the self-tests
+    one_call = world > 1 and os.environ.get("OMM_BENCH_COLLECTIVES", "native") == "native"
+    native = one_call and os.environ.get("OMM_BENCH_BACKEND", "nccl") == "nccl"
     comm = None
+    borrowed = None
     if native:
         try:
             comm = shard.rccl_comm(prod.dll, torch, dist, rank, world)   # raises on every rank or on none
         except RuntimeError as e:
             if rank == 0:
-                print("bench: native RCCL communicator unavailable (%s): collectives through torch.distributed instead" % e, file=sys.stderr)
+                print("bench: native RCCL communicator unavailable (%s): the same call over torch.distributed's collectives instead" % e, file=sys.stderr)
             native = False
+    if one_call and not native:
+        borrowed = shard.CollectivesComm(prod.dll, torch, dist, rank, world)
+        comm = borrowed.handle
+    entry_n = ("ommxShardedBakeRccl (collectives issued by the library)" if native else
+               ("ommxShardedBakeRccl over the process group's collectives (ommxCommFromCollectives)" if one_call else "ommxSharded* + torch.distributed"))
 
     def step():
-        if native:
+        if one_call:
             return shard.sharded_bake_rccl(prod.dll, baker, C.byref(desc), comm)
         if world > 1:
             return shard.sharded_bake(prod.dll, baker, C.byref(desc), rank, world, torch, dist)
@@ -299,7 +307,7 @@ def main():
             "unit": "micro-triangles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["what"] % tris, "name": args.config,
-                       "entry": (("ommxShardedBakeRccl (collectives issued by the library)" if native else "ommxSharded* + torch.distributed") if world > 1 else "ommxBakeDevice") + " (ommCpuBake contract, UV/index inputs and result arrays resident in HBM)",
+                       "entry": (entry_n if world > 1 else "ommxBakeDevice") + " (ommCpuBake contract, UV/index inputs and result arrays resident in HBM)",
                        "sharding": ("active work items partitioned over ranks; RCCL all-reduce of item metadata + all-gather of the OMM blocks as codec streams "
                                     "(%d of %d contribution bytes per rank on the wire)" % (int(tms[-1].exchangeBytes), int(tms[-1].contributionBytes))) if world > 1 else "none",
                        "result": result_info, "unique_items": int(t_last.uniqueItems), "active_items": int(t_last.activeItems),
@@ -307,7 +315,7 @@ def main():
                        "generic_pass_micro_triangles": int(t_last.genericMicroTriangles)},
             # `value` / `ms_per_step`: device-resident entry (the bench contract: inputs resident in HBM when the clock starts).
             # `bake_wall_time_ms`: the SDK call a drop-in user makes, ommCpuBake, host arrays in and out, PCIe inclusive -- same steps, same warm-up.
-            "value_entry": "ommxBakeDevice" if world == 1 else ("ommxShardedBakeRccl" if native else "ommxSharded* + torch.distributed"),
+            "value_entry": "ommxBakeDevice" if world == 1 else ("ommxShardedBakeRccl" if one_call else "ommxSharded* + torch.distributed"),
             "bake_wall_time_ms": host_ms if host_ms is not None else ms_per_step,
             "bake_wall_time_entry": "ommCpuBake (host arrays in/out, PCIe inclusive)" if host_ms is not None else "ommxBakeDevice (ommCpuBake was not timed in this run)",
             "rates": {"all_work_items": micro_tris / (elapsed / args.steps),
@@ -421,7 +429,9 @@ def main():
         dist.barrier()   # rank 0 has done more (host-API bakes, the JSON line): all ranks tear their communicators down together
     prod.destroy_texture(baker, th)
     prod.destroy_baker(baker)
-    if comm is not None:
+    if borrowed is not None:
+        borrowed.destroy()
+    elif comm is not None:
         prod.dll.ommxRcclCommDestroy(comm)
     if world > 1:
         dist.destroy_process_group()

@@ -125,4 +125,20 @@ OMM_MI355X_API ommResult ommxRcclCommWrap(void* ncclComm, ommxRcclComm* outComm)
 OMM_MI355X_API ommResult ommxRcclCommDestroy(ommxRcclComm comm);
 OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInputDesc* deviceDesc, ommxRcclComm comm, ommxDeviceBakeResult* outResult);
 
+/* ---- the one-call sharded bake over a transport of the caller (MPI with device pointers, torch.distributed, a test harness) ----
+ * ommxCommFromCollectives makes a communicator whose two collectives are the caller's functions instead of RCCL's; ommxShardedBakeRccl takes it like
+ * any other and runs the identical sequence (status agreement, metadata all-reduce, codec streams or raw chunks, expansion, scatter).  Both functions
+ * work on DEVICE pointers and are collective: every rank calls them in the same order with the same counts.  They are stream-ordered like their RCCL
+ * counterparts: `send` is complete once the work queued on `hipStream` so far has run, and work queued on `hipStream` after the call must see `recv`
+ * (a blocking implementation synchronises the stream, exchanges, and returns).  `send` may equal `recv` in allReduceU32.  Return 0 for success.
+ * The structure is copied; `user` must stay valid until ommxRcclCommDestroy. */
+typedef enum ommxReduceOp { ommxReduceOp_Sum = 0, ommxReduceOp_Max = 1, ommxReduceOp_Min = 2 } ommxReduceOp;
+typedef struct ommxCollectives
+{
+    int (*allReduceU32)(void* user, const void* send, void* recv, size_t count, ommxReduceOp op, void* hipStream);       /* `count` uint32 elements */
+    int (*allGatherBytes)(void* user, const void* send, void* recv, size_t bytesPerRank, void* hipStream);               /* recv[rank r] = recv + r * bytesPerRank */
+    void* user;
+} ommxCollectives;
+OMM_MI355X_API ommResult ommxCommFromCollectives(const ommxCollectives* collectives, uint32_t rank, uint32_t worldSize, ommxRcclComm* outComm);
+
 #endif

@@ -1780,6 +1780,19 @@ const RcclApi& rccl()
 struct RcclComm {
     rcclComm_t comm = nullptr; bool owned = false; int rank = 0, world = 1;
     uint32_t* dStatus = nullptr; hipStream_t statusStream = nullptr;   // status agreement (rccl_agree): two device words and a stream for ranks that have no bake stream
+    bool custom = false; ommxCollectives user{};                       // ommxCommFromCollectives: the caller's transport instead of RCCL
+    // the two collectives of the sharded bake (uint32 all-reduce, byte all-gather), stream-ordered; 0 = success
+    int all_reduce(const void* send, void* recv, size_t count, int rcclOp, hipStream_t stream) const
+    {
+        if (!custom) return rccl().allReduce(send, recv, count, kRcclUint32, rcclOp, comm, stream);
+        return user.allReduceU32(user.user, send, recv, count, rcclOp == kRcclSum ? ommxReduceOp_Sum : (rcclOp == kRcclMax ? ommxReduceOp_Max : ommxReduceOp_Min), (void*)stream);
+    }
+    int all_gather(const void* send, void* recv, size_t bytesPerRank, hipStream_t stream) const
+    {
+        if (!custom) return rccl().allGather(send, recv, bytesPerRank, kRcclUint8, comm, stream);
+        return user.allGatherBytes(user.user, send, recv, bytesPerRank, (void*)stream);
+    }
+    const char* error_string(int code) const { return custom ? "the caller's collective reported a failure" : (rccl().getErrorString ? rccl().getErrorString(code) : "RCCL error"); }
 };
 // A rank-local failure (out of memory, mostly) must not leave the other ranks waiting in the next collective: before every data collective each rank
 // contributes its status to a one-element MIN all-reduce and all of them go on, or none.  `stream`: the bake's stream (idle ranks: the communicator's own).
@@ -1791,7 +1804,7 @@ bool rccl_agree(RcclComm* rc, hipStream_t stream, bool mineOk, const Logger& L, 
     if (!ok) { (void)hipGetLastError(); L.failure("[Failure] - sharded bake: no device memory for the status word (the other ranks may be waiting in a collective)"); return false; }
     const uint32_t mine = mineOk ? 1u : 0u; uint32_t all = 0;
     ok = HIP_OK(hipMemcpyAsync(rc->dStatus, &mine, sizeof mine, hipMemcpyHostToDevice, stream)) && HIP_OK(hipStreamSynchronize(stream));
-    ok = ok && rccl().allReduce(rc->dStatus, rc->dStatus + 1, 1, kRcclUint32, kRcclMin, rc->comm, stream) == 0;
+    ok = ok && rc->all_reduce(rc->dStatus, rc->dStatus + 1, 1, kRcclMin, stream) == 0;
     ok = ok && HIP_OK(hipMemcpyAsync(&all, rc->dStatus + 1, sizeof all, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipStreamSynchronize(stream));
     if (!ok) { L.failure("[Failure] - sharded bake: the status all-reduce failed"); return false; }
     if (mineOk && all == 0u) { char buf[200]; snprintf(buf, sizeof buf, "[Failure] - sharded bake: another rank failed (%s); this rank stops with it", stage); L.failure(buf); }
@@ -1806,7 +1819,7 @@ bool rccl_agree_max(RcclComm* rc, hipStream_t stream, bool mineOk, uint32_t* dWo
     if (!ok) { (void)hipGetLastError(); L.failure("[Failure] - sharded bake: no device memory for the status word (the other ranks may be waiting in a collective)"); return false; }
     const uint32_t failed = 0xFFFFFFFFu; uint32_t all = failed;
     if (!mineOk) ok = HIP_OK(hipMemcpyAsync(dWord, &failed, sizeof failed, hipMemcpyHostToDevice, stream)) && HIP_OK(hipStreamSynchronize(stream));
-    ok = ok && rccl().allReduce(dWord, rc->dStatus + 1, 1, kRcclUint32, kRcclMax, rc->comm, stream) == 0;
+    ok = ok && rc->all_reduce(dWord, rc->dStatus + 1, 1, kRcclMax, stream) == 0;
     ok = ok && HIP_OK(hipMemcpyAsync(&all, rc->dStatus + 1, sizeof all, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipStreamSynchronize(stream));
     if (!ok) { L.failure("[Failure] - sharded bake: the status all-reduce failed"); return false; }
     if (mineOk && all == failed) { char buf[200]; snprintf(buf, sizeof buf, "[Failure] - sharded bake: another rank failed (%s); this rank stops with it", stage); L.failure(buf); }
@@ -2047,6 +2060,17 @@ OMM_MI355X_API ommResult ommxRcclCommWrap(void* ncclComm, ommxRcclComm* outComm)
     return ommResult_SUCCESS;
 }
 
+OMM_MI355X_API ommResult ommxCommFromCollectives(const ommxCollectives* collectives, uint32_t rank, uint32_t worldSize, ommxRcclComm* outComm)
+{
+    if (collectives == nullptr || collectives->allReduceU32 == nullptr || collectives->allGatherBytes == nullptr || outComm == nullptr ||
+        worldSize == 0 || worldSize > (uint32_t)kMaxRanks || rank >= worldSize) return ommResult_INVALID_ARGUMENT;
+    RcclComm* c = new (std::nothrow) RcclComm();
+    if (!c) return ommResult_FAILURE;
+    c->custom = true; c->user = *collectives; c->rank = (int)rank; c->world = (int)worldSize;
+    *outComm = (ommxRcclComm)c;
+    return ommResult_SUCCESS;
+}
+
 OMM_MI355X_API ommResult ommxRcclCommDestroy(ommxRcclComm comm)
 {
     if (comm == 0) return ommResult_INVALID_ARGUMENT;
@@ -2065,12 +2089,12 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
     const ommResult r0 = sharded_checks(baker, desc, &b, true);
     if (r0 != ommResult_SUCCESS) return r0;
     const Logger& L = b->log;
-    if (!rccl().ok()) return L.failure(("[Failure] - RCCL is not available: " + rccl().error).c_str());
     RcclComm* rc = (RcclComm*)comm;
+    if (!rc->custom && !rccl().ok()) return L.failure(("[Failure] - RCCL is not available: " + rccl().error).c_str());
     return guarded(&L, [&]() -> ommResult {
         const DeviceScope onBakersDevice(b->bind_device());   // (the communicator must have been created on this device)
         auto nccl_fail = [&](int code, const char* what) {
-            char buf[256]; snprintf(buf, sizeof buf, "[Failure] - %s: %s", what, rccl().getErrorString ? rccl().getErrorString(code) : "RCCL error");
+            char buf[256]; snprintf(buf, sizeof buf, "[Failure] - %s: %s", what, rc->error_string(code));
             return L.failure(buf);
         };
         const bool hostTail = wants_host_tail(*desc);
@@ -2086,8 +2110,8 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
             // Every rank classified its share into a zeroed buffer, so SUM all-reduces of the metadata words and of the packed states merge
             // them; each rank then runs the identical serial tail on the host and uploads the (identical) result.
             const size_t words = 4ull * c.hc.activeStart[kNumLevels], stateWords = (size_t)(c.hc.stateBytes / 4);
-            int e = words ? rccl().allReduce(c.dMeta, c.dMeta, words, kRcclUint32, kRcclSum, rc->comm, stream) : 0;
-            if (e == 0 && stateWords) e = rccl().allReduce(c.dStates, c.dStates, stateWords, kRcclUint32, kRcclSum, rc->comm, stream);
+            int e = words ? rc->all_reduce(c.dMeta, c.dMeta, words, kRcclSum, stream) : 0;
+            if (e == 0 && stateWords) e = rc->all_reduce(c.dStates, c.dStates, stateWords, kRcclSum, stream);
             if (e != 0) return nccl_fail(e, "ncclAllReduce of the micro-triangle states");
             launch_shard_unpack_meta(c.bounds, c.dActiveIds, c.hc.activeStart[kNumLevels], c.dMeta, c.dMask, (uint32_t*)c.ti.knownCount, c.ti.digests, c.dOwner, stream);
             std::vector<HostItem> items;
@@ -2109,7 +2133,7 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
         }
         // exchange 1: per-item metadata, SUM all-reduce in place, on the bake's own stream right behind the digests
         const size_t words = 4ull * c.hc.activeStart[kNumLevels];
-        if (words) { const int e = rccl().allReduce(c.dMeta, c.dMeta, words, kRcclUint32, kRcclSum, rc->comm, stream); if (e != 0) return nccl_fail(e, "ncclAllReduce of the work-item metadata"); }
+        if (words) { const int e = rc->all_reduce(c.dMeta, c.dMeta, words, kRcclSum, stream); if (e != 0) return nccl_fail(e, "ncclAllReduce of the work-item metadata"); }
         r = sharded_tail(sb);
         if (!rccl_agree(rc, stream, r == ommResult_SUCCESS, L, "tail of the bake")) return r != ommResult_SUCCESS ? r : ommResult_FAILURE;
         sb->tm.tailMs = (float)(now_ms() - t1);
@@ -2132,7 +2156,7 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
             if (maxUnits != kCodecIncompressible) {
                 const size_t sendBytes = (size_t)maxUnits * 16u;   // (<= compCap by construction)
                 sb->tm.exchangeBytes = sendBytes;
-                const int e = rccl().allGather(c.dComp, c.dGatherComp, sendBytes, kRcclUint8, rc->comm, stream);
+                const int e = rc->all_gather(c.dComp, c.dGatherComp, sendBytes, stream);
                 if (e != 0) { (void)nccl_fail(e, "ncclAllGather of the OMM blocks"); (void)hipEventDestroy(ready); return false; }
                 for (int r2 = 0; r2 < rc->world; ++r2) launch_shard_expand(c.dGatherComp + (size_t)r2 * sendBytes, c.strideBytes, c.dGathered + (size_t)r2 * c.strideBytes, stream);
                 launch_shard_scatter(c.dGathered, c.strideBytes, 0, c.strideBytes, c.dActive, c.dOwner, c.dMask, c.dLevel, c.bits, c.to.order, c.dCofs, c.to.dstOfs, c.to.sizes, E, arrayData, stream);
@@ -2150,7 +2174,7 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
                 const uint64_t lo = k * chunkBytes, hi = lo + chunkBytes < c.strideBytes ? lo + chunkBytes : c.strideBytes;
                 if (lo >= hi) { chunks = k; break; }
                 uint8_t* stage = c.dGathered + lo * (uint64_t)rc->world;               // chunk k of all ranks: world x (hi - lo) bytes
-                ncclErr = rccl().allGather(c.dContrib + lo, stage, (size_t)(hi - lo), kRcclUint8, rc->comm, cs);
+                ncclErr = rc->all_gather(c.dContrib + lo, stage, (size_t)(hi - lo), cs);
                 ok = ncclErr == 0 && HIP_OK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming)) && HIP_OK(hipEventRecord(done[k], cs)) && HIP_OK(hipStreamWaitEvent(stream, done[k], 0));
                 if (ok) launch_shard_scatter(stage, hi - lo, lo, hi, c.dActive, c.dOwner, c.dMask, c.dLevel, c.bits, c.to.order, c.dCofs, c.to.dstOfs, c.to.sizes, E, arrayData, stream);
             }

@@ -3,6 +3,8 @@
   * native path (what bench.py --gpus N runs): ommxShardedBakeRccl -- the library itself issues the two RCCL collectives from C++ on its own
     streams.  This module only helps with the communicator bootstrap: rank 0 asks the library for an RCCL unique id, the 128 bytes travel
     through torch.distributed, every rank joins with ommxRcclCommInitRank (rccl_comm()).
+  * the same one call over another transport: CollectivesComm -- the library runs the identical sequence and calls back into
+    torch.distributed (any backend) for its all-reduce and all-gather (ommxCommFromCollectives).
   * caller-driven path (tests, transports other than RCCL): the four ommxSharded* phases with the two exchanges done here through
     torch.distributed ("gloo" in the CPU tests):
 
@@ -81,6 +83,86 @@ def rccl_comm(dll, torch, dist, rank, world):
             dll.ommxRcclCommDestroy(comm)
         raise RuntimeError("ommxRcclCommInitRank failed (this rank: %d)" % r)
     return comm
+
+
+class CollectivesComm:
+    """Communicator for ommxShardedBakeRccl whose two collectives run through torch.distributed on ANY initialised backend
+    (ommxCommFromCollectives): the library hands device pointers and its stream to the callbacks below.  Blocking implementation: the
+    library's stream is synchronised before the exchange and torch's after it.  `.handle` goes where an ommxRcclComm goes; destroy()
+    when done (the object keeps the ctypes callbacks alive)."""
+
+    def __init__(self, dll, torch, dist, rank, world):
+        ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+        ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+        class Collectives(C.Structure):
+            _fields_ = [("allReduceU32", ALLREDUCE), ("allGatherBytes", ALLGATHER), ("user", C.c_void_p)]
+
+        def wait_for(stream):
+            if stream:
+                torch.cuda.ExternalStream(int(stream)).synchronize()
+            else:
+                torch.cuda.synchronize()
+
+        def all_reduce(_user, send, recv, count, op, stream):
+            try:
+                if count == 0:
+                    return 0
+                wait_for(stream)
+                src = device_tensor(torch, send, count, torch.int32)
+                dst = src if recv == send else device_tensor(torch, recv, count, torch.int32)
+                if op == 0:   # SUM: the int32 view wraps exactly like uint32
+                    t = src if recv == send else src.clone()
+                    if world > 1:
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                    if recv != send:
+                        dst.copy_(t)
+                else:         # MAX / MIN compare as UNSIGNED words: through int64
+                    t = src.to(torch.int64) & 0xFFFFFFFF
+                    if world > 1:
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.MIN)
+                    dst.copy_(torch.where(t >= 2 ** 31, t - 2 ** 32, t).to(torch.int32))
+                torch.cuda.current_stream().synchronize()
+                return 0
+            except Exception:   # (an exception must not unwind through the C frames)
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def all_gather(_user, send, recv, nbytes, stream):
+            try:
+                if nbytes == 0:
+                    return 0
+                wait_for(stream)
+                src = device_tensor(torch, send, nbytes, torch.uint8)
+                out = device_tensor(torch, recv, nbytes * world, torch.uint8)
+                if world == 1:
+                    out.copy_(src)
+                elif dist.get_backend() == "gloo":
+                    dist.all_gather(list(out.view(world, -1).unbind(0)), src)
+                else:
+                    dist.all_gather_into_tensor(out, src)
+                torch.cuda.current_stream().synchronize()
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._callbacks = (ALLREDUCE(all_reduce), ALLGATHER(all_gather))
+        self._table = Collectives(self._callbacks[0], self._callbacks[1], None)
+        self._dll = dll
+        dll.ommxCommFromCollectives.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        dll.ommxRcclCommDestroy.argtypes = [C.c_void_p]
+        self.handle = C.c_void_p()
+        r = dll.ommxCommFromCollectives(C.byref(self._table), rank, world, C.byref(self.handle))
+        if r != 0:
+            raise RuntimeError("ommxCommFromCollectives failed: %d" % r)
+
+    def destroy(self):
+        if self.handle:
+            self._dll.ommxRcclCommDestroy(self.handle)
+            self.handle = C.c_void_p()
 
 
 def sharded_bake_rccl(dll, baker, desc_ptr, comm):

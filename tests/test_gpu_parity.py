@@ -553,6 +553,18 @@ def test_cpp_user_of_the_rccl_entry_point(tmp_path):
     assert r.returncode == 0 and "sharded == single-GPU" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_call_sharded_bake_over_caller_collectives(world):
+    """ommxShardedBakeRccl at world_size > 1: real processes sharing GPU 0, the library's own sequence (status agreement, metadata merge, codec
+    streams at rank offsets / raw chunks, expansion, scatter, host-tail route, idle ranks) over ommxCommFromCollectives + gloo -- everything
+    but the two RCCL calls themselves, which one GPU cannot run with two ranks."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "scripts", "ranks_one_call_gloo_gpu.py"), str(world)], cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+    assert r.returncode == 0 and "one-call sharded bake over caller collectives ok" in r.stdout, r.stdout[-4000:]
+
+
 def test_torch_distributed_plumbing_one_rank_nccl():
     """omm_amd/sharded.py over a real (1-rank) RCCL process group: raw-pointer tensor views, all_reduce, all_gather_into_tensor, and a
     sharded bake compared with ommCpuBake (the multi-rank exchange itself is covered by test_sharded_bake_equals_single_gpu and the gloo test)."""
@@ -1139,12 +1151,14 @@ def test_two_process_sharded_bake_on_one_gpu():
     assert out.returncode == 0 and "two-process sharded bake ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
 
 
-def test_bench_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("collectives", ["native", "torch"])
+def test_bench_two_ranks_on_one_gpu(collectives):
     """bench.py's N > 1 path end to end (launch through torch.distributed.run, barrier + max-over-ranks timing, one JSON line from rank 0),
-    with both ranks on GPU 0 over gloo (self-test hooks of bench.py)"""
+    with both ranks on GPU 0 over gloo (self-test hooks of bench.py): the one-call entry ommxShardedBakeRccl over the process group's
+    collectives, and the caller-driven four-call path"""
     import json, subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, OMM_BENCH_ONE_GPU="1", OMM_BENCH_BACKEND="gloo")
+    env = dict(os.environ, OMM_BENCH_ONE_GPU="1", OMM_BENCH_BACKEND="gloo", OMM_BENCH_COLLECTIVES=collectives)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--tris", "20000"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
@@ -1153,6 +1167,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["sharding"] != "none"
+    assert d["value_entry"] == ("ommxShardedBakeRccl" if collectives == "native" else "ommxSharded* + torch.distributed")
     assert "cpu_baseline" not in d          # rank 0 at N = 1 only
 
 
