@@ -890,7 +890,8 @@ def test_bench_contract_small():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["bake_wall_time_entry"].startswith("ommCpuBake") and d["bake_wall_time_ms"] > 0 and d["host_api"]["stream"]["ranges"] == 3 and d["value_entry"] == "ommxBakeDevice"
-    assert d["cpu_baseline"]["fine_pass_only"] > 0 and d["roofline"]["bound"] == "hbm"      # (the issue-slot roofline needs the PMC summary of the full-size workload)
+    fpo = d["cpu_baseline"]["fine_pass_only"]       # (None when the pair of CPU timings differs by less than its noise)
+    assert (fpo is None or fpo > 0) and d["roofline"]["bound"] == "hbm"      # (the issue-slot roofline needs the PMC summary of the full-size workload)
     for cfgname in ("c1", "c4", "cards"):
         o2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", cfgname, "--tris", "1500", "--steps", "1", "--warmup", "1", "--cpu-sample", "200",
                              "--host-api-steps", "1"], capture_output=True, text=True, timeout=600)
