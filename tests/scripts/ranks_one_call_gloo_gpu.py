@@ -2,7 +2,9 @@
 collectives (ommxCommFromCollectives; backend gloo: RCCL refuses two ranks on one GPU).  Everything the library does between its collectives
 at world_size > 1 -- status agreement, metadata merge, codec streams at their rank offsets, expansion, scatter, the raw chunked exchange,
 the host-tail route, ranks without a share -- runs exactly as under RCCL; only the two transport calls differ.
-usage: python tests/scripts/ranks_one_call_gloo_gpu.py [world] [full]     (full: the metric workload at its full size only -- 1 M triangles, 1.27 GB of blocks)"""
+usage: python tests/scripts/ranks_one_call_gloo_gpu.py [world] [full]     (full: the metric workload at its full size only -- 1 M triangles, 1.27 GB of blocks)
+       python tests/scripts/ranks_one_call_gloo_gpu.py world fuzz LO HI  (the randomized cases LO..HI-1 of test_gpu_parity._fuzz_case -- formats, filters, address modes, mip chains,
+                                                                          per-triangle levels, flags -- sharded, against the single-GPU ommCpuBake of the same library)"""
 import os, sys, ctypes as C, socket
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -48,6 +50,28 @@ def worker(rank, world, port, outdir, full):
         prod.destroy_texture(b, t)
         return ok
 
+    if isinstance(full, tuple):
+        import test_gpu_parity as T
+        bad = 0
+        for seed in range(full[0], full[1]):
+            mips, uv, ix, level, cutoff, sat, kw = T._fuzz_case(seed)
+            t = prod.create_texture(b, mips, alpha_cutoff=cutoff if sat else -1.0)
+            d = ot.make_desc(t, uv, ix, level, alpha_cutoff=cutoff, **kw)
+            ref = prod.bake(b, d, want_stats=False)
+            keep = [torch.from_numpy(uv).cuda(), torch.from_numpy(ix.astype(np.int32)).cuda()]
+            dd = ot.BakeInputDesc.from_buffer_copy(d); dd.texCoords, dd.indexBuffer = keep[0].data_ptr(), keep[1].data_ptr()
+            if kw.get("levels") is not None:
+                keep.append(torch.from_numpy(kw["levels"]).cuda()); dd.subdivisionLevels = keep[2].data_ptr()
+            prod.set_knob(b, ot.KNOB_SHARD_CHUNK_BYTES, (0, 256, 4096)[seed % 3])
+            res = ot.device_result_to_host(prod, hip, sh.sharded_bake_rccl(prod.dll, b, C.byref(dd), comm.handle))
+            if not res.same_as(ref):
+                bad += 1
+                print("MISMATCH rank", rank, "seed", seed, res.diff(ref)[:300], flush=True)
+            prod.destroy_texture(b, t)
+        open(os.path.join(outdir, "rank%d" % rank), "w").write("%d\nseeds %d..%d: %d mismatches" % (bad == 0, full[0], full[1], bad))
+        comm.destroy()
+        dist.barrier(); dist.destroy_process_group()
+        return
     if full:
         texf = ot.foliage_texture(1234, 4096, 4096, feature=64)
         uvf, ixf = ot.random_triangles(1235, 1000000, 8.0 / 4096)
@@ -82,7 +106,8 @@ if __name__ == "__main__":
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     with tempfile.TemporaryDirectory() as td:
-        mp.spawn(worker, args=(world, port, td, len(sys.argv) > 2 and sys.argv[2] == "full"), nprocs=world, join=True)
+        mode = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 and sys.argv[2] == "fuzz" else (len(sys.argv) > 2 and sys.argv[2] == "full")
+        mp.spawn(worker, args=(world, port, td, mode), nprocs=world, join=True)
         res = [open(os.path.join(td, "rank%d" % r)).read().split("\n") for r in range(world)]
     for r in res:
         print(r)
