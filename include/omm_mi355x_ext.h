@@ -109,7 +109,7 @@ OMM_MI355X_API ommResult ommxShardedDestroy(ommxShardedBake bake);
  * Every rank calls ommxShardedBakeRccl with the SAME desc; the library runs Begin, the SUM all-reduce of the metadata words
  * (ncclAllReduce, in place, on the bake's own stream), Tail, the all-gather of the contributions and Finish.  The contributions cross the links
  * as codec streams -- one nibble per 16-byte unit (which of the four states it repeats, or "raw") plus the raw units: a few per cent of the bytes
- * for ordinary bakes -- and are expanded and scattered to their final arrayData offsets on arrival; if a rank's contribution does not shrink
+ * for ordinary bakes -- and are decoded straight to their final arrayData offsets on arrival; if a rank's contribution does not shrink
  * below half its size, all ranks send the padded contributions themselves (ncclAllGather in chunks of <= 64 MiB per rank on a second stream,
  * each chunk scattered while the next one is on the wire).  A rank-local failure stops all ranks (status agreement before each exchange).  Every rank returns the same merged ommxDeviceBakeResult, bit-identical to a single-GPU ommxBakeDevice of the desc.
  * librccl.so.1 is bound with dlopen at the first call: callers that never shard need no RCCL.
@@ -127,7 +127,7 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
 
 /* ---- the one-call sharded bake over a transport of the caller (MPI with device pointers, torch.distributed, a test harness) ----
  * ommxCommFromCollectives makes a communicator whose two collectives are the caller's functions instead of RCCL's; ommxShardedBakeRccl takes it like
- * any other and runs the identical sequence (status agreement, metadata all-reduce, codec streams or raw chunks, expansion, scatter).  Both functions
+ * any other and runs the identical sequence (status agreement, metadata all-reduce, codec streams or raw chunks, scatter).  Both functions
  * work on DEVICE pointers and are collective: every rank calls them in the same order with the same counts.  They are stream-ordered like their RCCL
  * counterparts: `send` is complete once the work queued on `hipStream` so far has run, and work queued on `hipStream` after the call must see `recv`
  * (a blocking implementation synchronises the stream, exchanges, and returns).  `send` may equal `recv` in allReduceU32.  Return 0 for success.

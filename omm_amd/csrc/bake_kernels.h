@@ -141,7 +141,9 @@ void launch_shard_gather(const uint8_t* states, const uint64_t* stateOfs, const 
 constexpr uint32_t kCodecIncompressible = 0xFFFFFFFEu;
 size_t shard_codec_scratch_bytes(uint64_t contributionBytes);
 hipError_t run_shard_compress(const uint8_t* contrib, uint64_t contributionBytes, uint8_t* comp, uint64_t capBytes, uint32_t* sizeWord, void* scratch, size_t scratchBytes, hipStream_t stream);
-void launch_shard_expand(const uint8_t* comp, uint64_t contributionBytes, uint8_t* out, hipStream_t stream);
+void launch_shard_scatter_streams(const uint8_t* streams, uint64_t streamPitch, uint64_t contributionBytes, const uint8_t* active, const uint8_t* owner,
+                                  const uint32_t* stateMask, const uint8_t* level, int bits, const uint32_t* order, const uint64_t* cofs, const uint32_t* dstOfs,
+                                  const uint32_t* sizes, uint32_t numOmms, uint8_t* arrayData, hipStream_t stream);
 void launch_shard_scatter(const uint8_t* gathered, uint64_t rankPitch, uint64_t lo, uint64_t hi, const uint8_t* active, const uint8_t* owner, const uint32_t* stateMask,
                           const uint8_t* level, int bits, const uint32_t* order, const uint64_t* cofs, const uint32_t* dstOfs, const uint32_t* sizes,
                           uint32_t numOmms, uint8_t* arrayData, hipStream_t stream);

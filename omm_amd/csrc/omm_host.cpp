@@ -2158,8 +2158,8 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
                 sb->tm.exchangeBytes = sendBytes;
                 const int e = rc->all_gather(c.dComp, c.dGatherComp, sendBytes, stream);
                 if (e != 0) { (void)nccl_fail(e, "ncclAllGather of the OMM blocks"); (void)hipEventDestroy(ready); return false; }
-                for (int r2 = 0; r2 < rc->world; ++r2) launch_shard_expand(c.dGatherComp + (size_t)r2 * sendBytes, c.strideBytes, c.dGathered + (size_t)r2 * c.strideBytes, stream);
-                launch_shard_scatter(c.dGathered, c.strideBytes, 0, c.strideBytes, c.dActive, c.dOwner, c.dMask, c.dLevel, c.bits, c.to.order, c.dCofs, c.to.dstOfs, c.to.sizes, E, arrayData, stream);
+                // every block straight from its owner's stream to its final offset (no expanded copy of the contributions)
+                launch_shard_scatter_streams(c.dGatherComp, sendBytes, c.strideBytes, c.dActive, c.dOwner, c.dMask, c.dLevel, c.bits, c.to.order, c.dCofs, c.to.dstOfs, c.to.sizes, E, arrayData, stream);
                 ok = HIP_OK(hipGetLastError()) && HIP_OK(hipStreamSynchronize(stream));
                 (void)hipEventDestroy(ready);
                 return ok;

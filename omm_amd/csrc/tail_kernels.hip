@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void shard_scatter_contributions(const uint8_t
 // profiles/scripts/r03_block_compressibility.py).  A rank's contribution therefore travels as
 //     [0] bytes of the stream, [8] units | offsets: first raw unit of every 256-unit block (uint32, blocks + 1) | codes: one nibble per unit, 0..3 = the
 //     unit is 16 bytes of 0x00 / 0x55 / 0xAA / 0xFF, 4 = raw | the raw units, 16 bytes each
-// -- 6.4 % of the bytes at the metric configuration -- and is expanded again on arrival.  Lossless for any data; a contribution that does not shrink
+// -- 6.4 % of the bytes at the metric configuration -- and is decoded on arrival, straight into the result (shard_scatter_streams).  Lossless for any data; a contribution that does not shrink
 // below half its size is sent as it is (size word = kCodecIncompressible).
 constexpr uint32_t kCodecBlock = 256;
 struct CodecLayout { uint64_t units, blocks, offOfs, offCodes, offRaw; };
@@ -486,19 +486,69 @@ __global__ void shard_codec_finish(CodecLayout c, uint8_t* __restrict__ comp, ui
     ((uint64_t*)comp)[0] = bytes; ((uint64_t*)comp)[1] = c.units;
     *sizeWord = bytes <= capBytes ? (uint32_t)(bytes / 16u) : kCodecIncompressible;
 }
-__global__ __launch_bounds__(256) void shard_codec_expand(const uint8_t* __restrict__ comp, CodecLayout c, uint4* __restrict__ out)
+// After the all-gather of the codec streams: every block goes from its owner's stream STRAIGHT to its final arrayData offset -- no expanded copy of the
+// contributions in between (expansion + scatter moved 3 x the result through HBM; this writes it once).  One workgroup per OMM block, like
+// shard_scatter_contributions; it walks the 256-unit codec blocks its bytes [cofs, cofs + size) overlap, thread t decoding unit t of each (the rank
+// of a raw unit inside its codec block comes from the same ballots as in the expansion), and writes the part of the unit that belongs to the block:
+// whole aligned units as one 16-byte store, the ragged ends of small or unaligned blocks byte by byte.  `streams` holds rank r's stream at
+// streams + r * streamPitch; every stream describes a contribution of the same (padded) size, hence one layout `c`.
+__global__ __launch_bounds__(256) void shard_scatter_streams(const uint8_t* __restrict__ streams, uint64_t streamPitch, CodecLayout c,
+                                                             const uint8_t* __restrict__ active, const uint8_t* __restrict__ owner,
+                                                             const uint32_t* __restrict__ stateMask, const uint8_t* __restrict__ level, int bits,
+                                                             const uint32_t* __restrict__ order, const uint64_t* __restrict__ cofs,
+                                                             const uint32_t* __restrict__ dstOfs, const uint32_t* __restrict__ sizes, uint32_t numOmms,
+                                                             uint8_t* __restrict__ arrayData)
 {
     __shared__ uint32_t s[4];
-    const uint64_t u = (uint64_t)blockIdx.x * kCodecBlock + threadIdx.x;
-    const bool live = u < c.units;
-    const uint32_t code = live ? (comp[c.offCodes + u / 2u] >> ((u & 1u) * 4u)) & 15u : 0u;
-    uint32_t total;
-    const uint32_t rank = codec_rank(live && code == 4u, s, total);
-    if (!live) return;
-    uint4 v;
-    if (code == 4u) v = ((const uint4*)(comp + c.offRaw))[((const uint32_t*)(comp + c.offOfs))[blockIdx.x] + rank];
-    else { const uint32_t p = code == 0u ? 0u : (code == 1u ? 0x55555555u : (code == 2u ? 0xAAAAAAAAu : 0xFFFFFFFFu)); v = make_uint4(p, p, p, p); }
-    out[u] = v;
+    for (uint32_t j = blockIdx.x; j < numOmms; j += gridDim.x) {
+        const uint32_t item = order[j];
+        uint8_t* dst = arrayData + dstOfs[j];
+        const uint32_t n = sizes[j];
+        if (!active[item]) {   // uniform item: constant pattern, computed locally
+            const uint32_t st = (uint32_t)(31 - __clz((int)stateMask[item]));
+            uint32_t usedBits = (1u << (2u * level[item])) * (uint32_t)bits; if (usedBits > 8u) usedBits = 8u;
+            uint32_t pat = 0;
+            for (uint32_t b = 0; b < usedBits; b += (uint32_t)bits) pat |= st << b;
+            for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) dst[k] = (uint8_t)pat;
+            continue;
+        }
+        const uint8_t* comp = streams + (uint64_t)owner[item] * streamPitch;
+        const uint32_t* ofs = (const uint32_t*)(comp + c.offOfs);
+        const uint4* raw = (const uint4*)(comp + c.offRaw);
+        const uint64_t c0 = cofs[j], c1 = c0 + n;
+        for (uint64_t B = c0 / (16u * kCodecBlock); B * (16u * kCodecBlock) < c1; ++B) {   // (block-uniform bounds: every thread takes part in the ballots)
+            const uint64_t u = B * kCodecBlock + threadIdx.x;
+            const bool live = u < c.units;
+            const uint32_t code = live ? (comp[c.offCodes + u / 2u] >> ((u & 1u) * 4u)) & 15u : 0u;
+            uint32_t total;
+            const uint32_t rank = codec_rank(live && code == 4u, s, total);
+            const uint64_t b0 = u * 16u, b1 = b0 + 16u;   // this unit's bytes of the contribution
+            if (live && b1 > c0 && b0 < c1) {
+                uint4 v;
+                if (code == 4u) v = raw[ofs[B] + rank];
+                else { const uint32_t p = code == 0u ? 0u : (code == 1u ? 0x55555555u : (code == 2u ? 0xAAAAAAAAu : 0xFFFFFFFFu)); v = make_uint4(p, p, p, p); }
+                if (b0 >= c0 && b1 <= c1 && (((uint64_t)(dst + (b0 - c0))) & 15ull) == 0ull) *(uint4*)(dst + (b0 - c0)) = v;
+                else {
+                    const uint64_t lo = b0 > c0 ? b0 : c0, hi = b1 < c1 ? b1 : c1;
+                    for (uint64_t b = lo; b < hi; ++b) {
+                        const uint32_t k = (uint32_t)(b - b0);
+                        const uint32_t w = k < 4u ? v.x : (k < 8u ? v.y : (k < 12u ? v.z : v.w));
+                        dst[b - c0] = (uint8_t)(w >> (8u * (k & 3u)));
+                    }
+                }
+            }
+            __syncthreads();   // (s[] is rewritten by the next codec block)
+        }
+    }
+}
+void launch_shard_scatter_streams(const uint8_t* streams, uint64_t streamPitch, uint64_t contributionBytes, const uint8_t* active, const uint8_t* owner,
+                                  const uint32_t* stateMask, const uint8_t* level, int bits, const uint32_t* order, const uint64_t* cofs, const uint32_t* dstOfs,
+                                  const uint32_t* sizes, uint32_t numOmms, uint8_t* arrayData, hipStream_t stream)
+{
+    if (numOmms == 0) return;
+    const uint32_t grid = numOmms < 262144u ? numOmms : 262144u;
+    hipLaunchKernelGGL(shard_scatter_streams, dim3(grid), dim3(256), 0, stream, streams, streamPitch, codec_layout(contributionBytes), active, owner, stateMask, level, bits,
+                       order, cofs, dstOfs, sizes, numOmms, arrayData);
 }
 size_t shard_codec_scratch_bytes(uint64_t contributionBytes)
 {
@@ -522,13 +572,6 @@ hipError_t run_shard_compress(const uint8_t* contrib, uint64_t contributionBytes
     hipLaunchKernelGGL(shard_codec_finish, dim3(1), dim3(1), 0, stream, c, comp, capBytes, sizeWord);
     return hipGetLastError();
 }
-// comp (a stream of run_shard_compress for a contribution of contributionBytes) -> out
-void launch_shard_expand(const uint8_t* comp, uint64_t contributionBytes, uint8_t* out, hipStream_t stream)
-{
-    const CodecLayout c = codec_layout(contributionBytes);
-    if (c.blocks) hipLaunchKernelGGL(shard_codec_expand, dim3((uint32_t)c.blocks), dim3(256), 0, stream, comp, c, (uint4*)out);
-}
-
 void launch_shard_gather(const uint8_t* states, const uint64_t* stateOfs, const uint8_t* active, const uint8_t* owner, uint32_t rank, const uint32_t* order,
                          const uint64_t* cofs, const uint32_t* sizes, uint32_t numOmms, uint8_t* contrib, hipStream_t stream)
 {

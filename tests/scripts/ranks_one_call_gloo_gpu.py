@@ -1,6 +1,6 @@
 """Several REAL processes, all on GPU 0, run the ONE-CALL sharded bake (ommxShardedBakeRccl) over a communicator made of torch.distributed
 collectives (ommxCommFromCollectives; backend gloo: RCCL refuses two ranks on one GPU).  Everything the library does between its collectives
-at world_size > 1 -- status agreement, metadata merge, codec streams at their rank offsets, expansion, scatter, the raw chunked exchange,
+at world_size > 1 -- status agreement, metadata merge, codec streams at their rank offsets, decoding into the result, the raw chunked exchange,
 the host-tail route, ranks without a share -- runs exactly as under RCCL; only the two transport calls differ.
 usage: python tests/scripts/ranks_one_call_gloo_gpu.py [world] [full]     (full: the metric workload at its full size only -- 1 M triangles, 1.27 GB of blocks)
        python tests/scripts/ranks_one_call_gloo_gpu.py world fuzz LO HI  (the randomized cases LO..HI-1 of test_gpu_parity._fuzz_case -- formats, filters, address modes, mip chains,

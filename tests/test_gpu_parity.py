@@ -556,7 +556,7 @@ def test_cpp_user_of_the_rccl_entry_point(tmp_path):
 @pytest.mark.parametrize("world", [2, 3])
 def test_one_call_sharded_bake_over_caller_collectives(world):
     """ommxShardedBakeRccl at world_size > 1: real processes sharing GPU 0, the library's own sequence (status agreement, metadata merge, codec
-    streams at rank offsets / raw chunks, expansion, scatter, host-tail route, idle ranks) over ommxCommFromCollectives + gloo -- everything
+    streams at rank offsets / raw chunks, scatter, host-tail route, idle ranks) over ommxCommFromCollectives + gloo -- everything
     but the two RCCL calls themselves, which one GPU cannot run with two ranks."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
