@@ -1123,7 +1123,17 @@ void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32
     // (256-byte chunks x 64 items: a full-size launch is faster with them than with 1 KB chunks -- 0.77 vs 1.12 ms for 127 k items, more workgroups per CU
     //  hide the latency)
     if (bytesPerItem >= 256u) { // (powers of two: a multiple of the chunk size)
-        hipLaunchKernelGGL((digest_items_lds<256, 64, false>), dim3((numItems + 63u) / 64u), dim3(256), 0, stream, states, stateOfs, D, 0u, bits, digests);
+        // A launch whose workgroups are all resident at once takes as long as ONE of them: (bytes per item / chunk) round trips to HBM.  That is the case
+        // for the few, long items of the high levels (a level-10 item has 256 KiB of packed states: 1024 round trips of 256 bytes, 5.9 ms for any number
+        // of items up to a chipful -- 6 of the 136 ms of configs[4]) and for every level of a sharded bake's share: those take 1 KiB chunks, a quarter of
+        // the round trips (65.8 KB of LDS, two workgroups per CU).
+        const uint32_t groups = (numItems + 63u) / 64u;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        if (bytesPerItem >= 4096u && groups <= 2u * (uint32_t)cus)
+            hipLaunchKernelGGL((digest_items_lds<1024, 64, false>), dim3(groups), dim3(256), 0, stream, states, stateOfs, D, 0u, bits, digests);
+        else
+            hipLaunchKernelGGL((digest_items_lds<256, 64, false>), dim3(groups), dim3(256), 0, stream, states, stateOfs, D, 0u, bits, digests);
         return;
     }
     const uint32_t threads = numItems * 4u;

@@ -553,6 +553,60 @@ def test_cpp_user_of_the_rccl_entry_point(tmp_path):
     assert r.returncode == 0 and "sharded == single-GPU" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
+@pytest.mark.parametrize("level,fmt,n", [(5, ot.FMT_4STATE, 300), (6, ot.FMT_2STATE, 300), (7, ot.FMT_4STATE, 200), (9, ot.FMT_4STATE, 40), (8, ot.FMT_2STATE, 60),
+                                         (7, ot.FMT_4STATE, 70000)])
+def test_item_digests_are_xxh64_of_the_state_bytes(product, oracle, level, fmt, n):
+    """CalcDigest (bake_cpu_impl.cpp:374-377, 1038-1040): the digest of a work item is XXH64(seed 42) over one byte per micro-triangle with UT folded
+    into UO.  The device has several digest kernels (small items, 256-byte and 1-KiB chunks through LDS, chosen by item size and by how many items a
+    launch has -- the last case forces the many-items form); ranks of a sharded bake may pick different ones for the same level, so each must produce
+    THE hash, not just a consistent one.  The per-item digests are visible in the metadata words of the four-phase sharded API."""
+    import ctypes as C
+    import omm_amd.sharded as sh
+    hip = ot.Hip()
+    oracle.dll.orc_xxh64.restype = C.c_uint64
+    oracle.dll.orc_xxh64.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
+    tex = ot.foliage_texture(17, 1024, 1024, feature=24)
+    uv, ix = ot.random_triangles(900 + level, n, 60.0 / 1024 if n < 1000 else 24.0 / 1024)
+    b = product.create_baker()
+    t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+    d = ot.make_desc(t, uv, ix, level, fmt=fmt, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+    ref = product.bake(b, d, want_stats=False)
+    bits = 2 if fmt == ot.FMT_4STATE else 1
+    want = set()
+    # the blocks of the result -> state bytes -> XXH64
+    M = 4 ** level
+    nbytes = max(1, (M * bits) // 8)
+    for e in range(len(ref.descs)):
+        off = int(ref.descs[e][0])
+        blk = ref.array_data[off:off + nbytes]
+        if bits == 2:
+            st = np.stack([(blk >> (2 * k)) & 3 for k in range(4)], axis=1).reshape(-1)[:M].astype(np.uint8)
+            st[st == 2] = 3
+        else:
+            st = np.unpackbits(blk, bitorder="little")[:M].astype(np.uint8)
+        raw = st.tobytes()
+        want.add(int(oracle.dll.orc_xxh64(raw, len(raw), 42)))
+    assert len(want) > (n // 4 if n < 1000 else 10000), (len(want), len(ref.descs))
+    dll = sh.bind(product.dll)
+    d_uv, d_ix = hip.upload(uv), hip.upload(ix.astype(np.int32))
+    dd = ot.BakeInputDesc.from_buffer_copy(d); dd.texCoords, dd.indexBuffer = d_uv, d_ix
+    h = C.c_void_p()
+    assert dll.ommxShardedBegin(b, C.byref(dd), 0, 1, C.byref(h)) == ot.SUCCESS
+    w, nw = C.c_void_p(), C.c_uint64()
+    assert dll.ommxShardedGetMeta(h, C.byref(w), C.byref(nw)) == ot.SUCCESS
+    words = hip.download(w, 4 * nw.value, np.uint32).reshape(4, -1)      # [mask | known | digest lo | digest hi] x active items (tail_kernels.hip: shard_pack_meta)
+    assert dll.ommxShardedDestroy(h) == ot.SUCCESS
+    assert n < 1000 or words.shape[1] > 2 * 256 * 64, words.shape                  # (the last case: more than two workgroups of 64 items per CU)
+    mixed = (words[0] & (words[0] - 1)) != 0                                  # items with more than one state: the ones that keep a block
+    got = set((words[2][mixed].astype(np.uint64) | (words[3][mixed].astype(np.uint64) << np.uint64(32))).tolist())
+    missing = want - got
+    assert not missing, "%d of %d block hashes are not among the %d item digests" % (len(missing), len(want), len(got))
+    assert got == want or len(got) >= len(want)
+    hip.free(d_uv); hip.free(d_ix)
+    product.destroy_texture(b, t)
+    product.destroy_baker(b)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_one_call_sharded_bake_over_caller_collectives(world):
     """ommxShardedBakeRccl at world_size > 1: real processes sharing GPU 0, the library's own sequence (status agreement, metadata merge, codec
