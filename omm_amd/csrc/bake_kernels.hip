@@ -1114,6 +1114,75 @@ __device__ __forceinline__ void digest_items_lds_body(const uint8_t* __restrict_
     if (live && acc == 0) digests[itemIds[it]] = h;
 }
 
+// The same digest for FEW, LONG items: a launch whose workgroups are all resident at once takes as long as one of them, and one of them takes
+// (stripes per item) x (the instructions of one XXH64 round in one wave, ~400 cycles: unpack the states, two 64-bit multiplies, add, rotate) -- 5.9 ms
+// for the 32 768 stripes of a level-10 item however few there are (6 of the 136 ms of configs[4]; 20 % of an 8-rank share of it), 0.29 ms for a rank's
+// share of level-8 items.  Only `v = rotl(v + x, 31) * P1` is a chain; x = unpack(states) * P2 is not.  So a workgroup of 16 items splits the work:
+// wave 0 runs the 64 chains (item, accumulator) over x values it reads from LDS -- ~100 cycles per round --, the other three waves produce the x of
+// the next 32 stripes and fetch the packed states of the 32 after those, one barrier per 32 stripes:
+//     step k:   wave 0: chain over X[k & 1]      waves 1-3: issue loads of chunk k + 2; X[(k + 1) & 1] <- pack[(k + 1) & 1]; pack[k & 1] <- the loaded chunk
+constexpr int DL_ITEMS = 16, DL_STRIPES = 32;
+__global__ __launch_bounds__(256) void digest_items_chain(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs, const uint32_t* __restrict__ itemIds,
+                                                          uint32_t numItems, uint32_t level, uint32_t bits, uint64_t* __restrict__ digests)
+{
+    __shared__ uint32_t s_pack[2][DL_ITEMS][64 + 1];            // packed states of DL_STRIPES stripes per item: 4 * bits bytes per stripe, <= 256 bytes
+    __shared__ uint64_t s_x[2][DL_STRIPES][DL_ITEMS * 4];       // x[stripe][item * 4 + accumulator]
+    __shared__ const uint8_t* s_ptr[DL_ITEMS];
+    const uint32_t tid = threadIdx.x, first = blockIdx.x * DL_ITEMS;
+    if (tid < (uint32_t)DL_ITEMS) s_ptr[tid] = first + tid < numItems ? states + stateOfs[itemIds[first + tid]] : nullptr;
+    const uint32_t M = 1u << (2 * level);
+    const uint32_t chunkBytes = 4u * bits * DL_STRIPES, quads = chunkBytes / 16u;   // 256 or 128 bytes per item and step
+    const uint32_t steps = ((M * bits) >> 3) / chunkBytes;                          // (the launcher checks: a multiple, >= 2)
+    const bool chain = tid < 64u;
+    const uint32_t lt = tid - 64u;                                                  // loader / producer index 0 .. 191
+    uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = r0;
+    auto fetch = [&](uint32_t step) {
+        const uint32_t k0 = lt, k1 = lt + 192u;
+        if (k0 < DL_ITEMS * quads) { const uint8_t* src = s_ptr[k0 / quads]; r0 = src ? *(const uint4*)(src + (size_t)step * chunkBytes + (k0 % quads) * 16u) : make_uint4(0u, 0u, 0u, 0u); }
+        if (k1 < DL_ITEMS * quads) { const uint8_t* src = s_ptr[k1 / quads]; r1 = src ? *(const uint4*)(src + (size_t)step * chunkBytes + (k1 % quads) * 16u) : make_uint4(0u, 0u, 0u, 0u); }
+    };
+    auto stash = [&](uint32_t buf) {
+        const uint32_t k0 = lt, k1 = lt + 192u;
+        if (k0 < DL_ITEMS * quads) { uint32_t* d = &s_pack[buf][k0 / quads][(k0 % quads) * 4u]; d[0] = r0.x; d[1] = r0.y; d[2] = r0.z; d[3] = r0.w; }
+        if (k1 < DL_ITEMS * quads) { uint32_t* d = &s_pack[buf][k1 / quads][(k1 % quads) * 4u]; d[0] = r1.x; d[1] = r1.y; d[2] = r1.z; d[3] = r1.w; }
+    };
+    auto produce = [&](uint32_t buf) {
+        for (uint32_t e = lt; e < DL_STRIPES * DL_ITEMS * 4u; e += 192u) {
+            const uint32_t st = e >> 6, la = e & 63u, il = la >> 2, acc = la & 3u;
+            const uint32_t piece = bits == 2 ? (uint32_t)((const uint16_t*)s_pack[buf][il])[4u * st + acc] : (uint32_t)((const uint8_t*)s_pack[buf][il])[4u * st + acc];
+            s_x[buf][st][la] = expand8(piece, bits) * XP2;
+        }
+    };
+    __syncthreads();
+    if (!chain) { fetch(0); stash(0); }
+    __syncthreads();
+    if (!chain) { if (steps > 1u) fetch(1); produce(0); if (steps > 1u) stash(1); }
+    __syncthreads();
+    const uint32_t acc = tid & 3u;
+    const uint64_t seed = 42;
+    uint64_t v = acc == 0 ? seed + XP1 + XP2 : (acc == 1 ? seed + XP2 : (acc == 2 ? seed : seed - XP1));
+    for (uint32_t k = 0; k < steps; ++k) {
+        if (chain) {
+            #pragma unroll 8
+            for (uint32_t st = 0; st < (uint32_t)DL_STRIPES; ++st) { v += s_x[k & 1u][st][tid]; v = rotl64(v, 31); v *= XP1; }
+        } else {
+            if (k + 2u < steps) fetch(k + 2u);
+            if (k + 1u < steps) produce((k + 1u) & 1u);
+            if (k + 2u < steps) stash(k & 1u);
+        }
+        __syncthreads();
+    }
+    if (!chain) return;
+    const uint32_t l0 = tid & ~3u;
+    const uint64_t v1 = __shfl(v, l0), v2 = __shfl(v, l0 + 1), v3 = __shfl(v, l0 + 2), v4 = __shfl(v, l0 + 3);
+    uint64_t h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+    h = xxh_merge(h, v1); h = xxh_merge(h, v2); h = xxh_merge(h, v3); h = xxh_merge(h, v4);
+    h += (uint64_t)M;
+    h = xxh_avalanche(h);
+    const uint32_t it = first + (tid >> 2);
+    if (it < numItems && acc == 0) digests[itemIds[it]] = h;
+}
+
 void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
                    uint64_t* digests, hipStream_t stream, const uint8_t* only, int want)
 {
@@ -1122,18 +1191,13 @@ void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32
     DigestLists D; memset(&D, 0, sizeof D); D.ids = itemIds; D.count = numItems; D.level = level; D.only = only; D.want = want;
     // (256-byte chunks x 64 items: a full-size launch is faster with them than with 1 KB chunks -- 0.77 vs 1.12 ms for 127 k items, more workgroups per CU
     //  hide the latency)
+    // few, long items (every workgroup resident at once: 16 384 items fill the chip, twice that still gains): the split form above
+    if (bytesPerItem >= 1024u && numItems <= 32768u && only == nullptr) {
+        hipLaunchKernelGGL(digest_items_chain, dim3((numItems + DL_ITEMS - 1u) / DL_ITEMS), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests);
+        return;
+    }
     if (bytesPerItem >= 256u) { // (powers of two: a multiple of the chunk size)
-        // A launch whose workgroups are all resident at once takes as long as ONE of them: (bytes per item / chunk) round trips to HBM.  That is the case
-        // for the few, long items of the high levels (a level-10 item has 256 KiB of packed states: 1024 round trips of 256 bytes, 5.9 ms for any number
-        // of items up to a chipful -- 6 of the 136 ms of configs[4]) and for every level of a sharded bake's share: those take 1 KiB chunks, a quarter of
-        // the round trips (65.8 KB of LDS, two workgroups per CU).
-        const uint32_t groups = (numItems + 63u) / 64u;
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-        if (bytesPerItem >= 4096u && groups <= 2u * (uint32_t)cus)
-            hipLaunchKernelGGL((digest_items_lds<1024, 64, false>), dim3(groups), dim3(256), 0, stream, states, stateOfs, D, 0u, bits, digests);
-        else
-            hipLaunchKernelGGL((digest_items_lds<256, 64, false>), dim3(groups), dim3(256), 0, stream, states, stateOfs, D, 0u, bits, digests);
+        hipLaunchKernelGGL((digest_items_lds<256, 64, false>), dim3((numItems + 63u) / 64u), dim3(256), 0, stream, states, stateOfs, D, 0u, bits, digests);
         return;
     }
     const uint32_t threads = numItems * 4u;

@@ -557,8 +557,8 @@ def test_cpp_user_of_the_rccl_entry_point(tmp_path):
                                          (7, ot.FMT_4STATE, 70000)])
 def test_item_digests_are_xxh64_of_the_state_bytes(product, oracle, level, fmt, n):
     """CalcDigest (bake_cpu_impl.cpp:374-377, 1038-1040): the digest of a work item is XXH64(seed 42) over one byte per micro-triangle with UT folded
-    into UO.  The device has several digest kernels (small items, 256-byte and 1-KiB chunks through LDS, chosen by item size and by how many items a
-    launch has -- the last case forces the many-items form); ranks of a sharded bake may pick different ones for the same level, so each must produce
+    into UO.  The device has several digest kernels (small items; 256-byte chunks through LDS; for few, long items a form that splits the round into a chain wave and
+    three producer waves -- chosen by item size and by how many items a launch has, the last case forces the many-items form); ranks of a sharded bake may pick different ones for the same level, so each must produce
     THE hash, not just a consistent one.  The per-item digests are visible in the metadata words of the four-phase sharded API."""
     import ctypes as C
     import omm_amd.sharded as sh
