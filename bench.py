@@ -231,6 +231,34 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if one_call:
+        # one untimed probe bake: if the one-call entry fails on ANY rank (all ranks learn it), fall back together -- first to the same call over the
+        # process group's collectives, then to the caller-driven four-call path -- instead of ending the run without a result line
+        for attempt in range(2):
+            ok = 1
+            try:
+                prod.dll.ommxDestroyDeviceBakeResult(step())
+            except (RuntimeError, AssertionError) as e:
+                ok = 0
+                print("bench: rank %d: %s" % (rank, e), file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                break
+            if native:
+                if rank == 0:
+                    print("bench: ommxShardedBakeRccl failed with the library's own communicator: the same call over torch.distributed's collectives instead", file=sys.stderr)
+                native = False
+                prod.dll.ommxRcclCommDestroy(comm)
+                borrowed = shard.CollectivesComm(prod.dll, torch, dist, rank, world)
+                comm = borrowed.handle
+                entry_n = "ommxShardedBakeRccl over the process group's collectives (ommxCommFromCollectives)"
+            else:
+                if rank == 0:
+                    print("bench: the one-call entry failed: caller-driven four-call path instead", file=sys.stderr)
+                one_call = False
+                entry_n = "ommxSharded* + torch.distributed"
+                break
     if world > 1:
         # communicator set-up (seconds, once per process) is not part of a bake: force it before any step, whatever --warmup says
         w0 = torch.zeros(4, dtype=torch.int32, device="cuda")
