@@ -619,6 +619,22 @@ def test_one_call_sharded_bake_over_caller_collectives(world):
     assert r.returncode == 0 and "one-call sharded bake over caller collectives ok" in r.stdout, r.stdout[-4000:]
 
 
+@pytest.mark.parametrize("ranks", [1, 4, 7])
+def test_cpp_user_of_caller_collectives_threads_as_ranks(tmp_path, ranks):
+    """examples/sharded_threads.cpp: a C++ program makes a communicator out of two functions of its own (ommxCommFromCollectives: a barrier plus
+    device-to-device copies between threads) and runs the one-call sharded bake with several ranks as threads of ONE process on one GPU -- each rank its
+    own baker, all bakes in flight at once -- and compares every rank's result byte for byte with ommxBakeDevice."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "omm_amd", "lib")
+    exe = str(tmp_path / "sharded_threads")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-Wall", "-Wextra", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "sharded_threads.cpp"), "-o", exe,
+                        "-L" + lib_dir, "-lomm-lib", "-Wl,-rpath," + lib_dir, "-lpthread"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "warning" not in r.stderr, r.stderr[-3000:]
+    r = subprocess.run([exe, str(ranks)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "all == single-GPU" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def test_torch_distributed_plumbing_one_rank_nccl():
     """omm_amd/sharded.py over a real (1-rank) RCCL process group: raw-pointer tensor views, all_reduce, all_gather_into_tensor, and a
     sharded bake compared with ommCpuBake (the multi-rank exchange itself is covered by test_sharded_bake_equals_single_gpu and the gloo test)."""
