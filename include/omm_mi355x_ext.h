@@ -62,7 +62,7 @@ typedef enum ommxBakerKnob {
                                            states stream, one range per 32 MiB, at most 24 */
     ommxBakerKnob_GenericPass      = 3, /* where micro-triangles that span several texels (asset-sized triangles) are classified: 1 = inside the persistent
                                            classification launch, one lane each; 2 = queued and classified by a second launch, eight lanes each (not for streamed
-                                           or sharded bakes); 0 = automatic: 2 when the texels under the triangles outweigh the micro-triangles */
+                                           bakes); 0 = automatic: 2 when the texels under the triangles outweigh the micro-triangles */
     ommxBakerKnob_MAX_NUM          = 4
 } ommxBakerKnob;
 OMM_MI355X_API ommResult ommxSetBakerKnob(ommBaker baker, ommxBakerKnob knob, uint64_t value);

@@ -63,6 +63,7 @@ def worker(rank, world, port, outdir, full):
             if kw.get("levels") is not None:
                 keep.append(torch.from_numpy(kw["levels"]).cuda()); dd.subdivisionLevels = keep[2].data_ptr()
             prod.set_knob(b, ot.KNOB_SHARD_CHUNK_BYTES, (0, 256, 4096)[seed % 3])
+            prod.set_knob(b, ot.KNOB_GENERIC_PASS, (seed // 3) % 3)      # (where the micro-triangles of several texels are classified: automatic / inline / deferred)
             res = ot.device_result_to_host(prod, hip, sh.sharded_bake_rccl(prod.dll, b, C.byref(dd), comm.handle))
             if not res.same_as(ref):
                 bad += 1
