@@ -58,8 +58,8 @@ __device__ __forceinline__ uint32_t early_range(uint32_t leadPos, uint32_t ownPo
 }
 // Deferred generic pass (asset-sized triangles: micro-triangles of several texels).  The persistent launch queues the micro-triangles that need the
 // generic texel loops instead of walking them itself -- entry = {item | degenerate << 30, level << 24 | micro-triangle index}, their packed state left 0 --
-// and classify_generic() classifies them afterwards, eight lanes per micro-triangle, and ORs the states in.  *count may exceed capacity: a tile that did not
-// fit walked its micro-triangles itself and took its reservation back.
+// and classify_generic() classifies them afterwards, eight lanes per micro-triangle, and ORs the states in.  *count <= capacity always: a tile whose
+// micro-triangles do not fit (reservation by compare-and-swap) walks them itself.
 struct GenericQueue { uint2* entries; uint32_t* count; uint32_t capacity; };
 struct ClassifyChunks {
     uint32_t count;
@@ -75,8 +75,9 @@ struct ClassifyChunks {
 };
 hipError_t launch_classify(const ClassifyParams& P, const ItemArrays& A, const uint32_t* activeIds, const uint32_t first[kNumLevels], const uint32_t count[kNumLevels],
                            void* queue, uint32_t* queueCtl, uint32_t numCUs, hipStream_t stream, const ClassifyChunks* chunks = nullptr);
-// level-0 hierarchical query per work item: uniform items get stateMask = 1 << state and active = 0
-void launch_triage(const ClassifyParams& P, const float* uv, const SetupCounters* counters, uint32_t maxItems, uint32_t* stateMask, uint8_t* active, hipStream_t stream);
+// level-0 hierarchical query per work item (summed-area table, then the curve-free-region test): uniform items get stateMask = 1 << state and active = 0
+void launch_triage(const ClassifyParams& P, const float* uv, const uint8_t* level, const uint8_t* degenerate, const SetupCounters* counters, uint32_t maxItems,
+                   uint32_t* stateMask, uint8_t* active, hipStream_t stream);
 // XXH64(seed 42) of the 3-state byte stream of each listed item -> digests[item]
 // (only != null: the listed items with (only[item] != 0) == (want != 0))
 void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,

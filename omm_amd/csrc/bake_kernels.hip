@@ -36,6 +36,19 @@ namespace ommx {
 //        3. states are packed LSB-first into 32-bit words (coalesced stores) and the tile's state mask is OR-reduced
 //           for the uniform-OMM ("special index") detection.
 // ------------------------------------------------------------------------------------------------
+// curve-free-region test (region_curve.h) of the 64-groups inside the persistent kernel: inlined, or as a call with a register allocation of its own
+// (measured on the metric configuration: 15.55 vs 15.60 ms -- the same; inlined it needs 40 bytes per lane less scratch)
+#ifndef OMMX_RC_CALL
+#define OMMX_RC_CALL 0
+#endif
+#if OMMX_RC_CALL
+#define OMMX_RC_GROUP_TEST region_curve_state_call
+#else
+#define OMMX_RC_GROUP_TEST region_curve_state_impl
+#endif
+#ifndef OMMX_RC_LEVELS   // bit 0: items, bit 1: tiles, bit 2: 64-groups (A/B builds; the product ships all three)
+#define OMMX_RC_LEVELS 7
+#endif
 constexpr int BLOCK = 256;
 constexpr int GROUP = 64;
 
@@ -58,25 +71,30 @@ __device__ __forceinline__ TexWindow no_window()
     return W;
 }
 
-__global__ __launch_bounds__(256) void triage_items(ClassifyParams P, const float* __restrict__ uv, const SetupCounters* __restrict__ counters,
-                                                    uint32_t* __restrict__ stateMask, uint8_t* __restrict__ active)
+__global__ __launch_bounds__(256) void triage_items(ClassifyParams P, const float* __restrict__ uv, const uint8_t* __restrict__ level, const uint8_t* __restrict__ degenerate,
+                                                    const SetupCounters* __restrict__ counters, uint32_t* __restrict__ stateMask, uint8_t* __restrict__ active)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= counters->numItems) return;
     int st = -1;
-    if (P.useCoarse) {
-        const float* t = uv + 6ull * i;
-        const MicroTri whole = micro_triangle(t, 0u, 0u);
-        st = region_state<ModeDynamic>(P, whole, item_max_abs(t), no_window());
+    const float* t = uv + 6ull * i;
+    const MicroTri whole = micro_triangle(t, 0u, 0u);
+    const float maxAbs = item_max_abs(t);
+    if (P.useCoarse) st = region_state<ModeDynamic>(P, whole, maxAbs, no_window());
+    // small triangles in a mixed neighbourhood that the level curve does not reach (region_curve.h): uniform as well
+    if ((OMMX_RC_LEVELS & 1) && st < 0 && region_curve_applies(P) && !degenerate[i]) {
+        const DevMip& m = P.mips[0];
+        st = region_curve_state<ModeDynamic>(P, P.texIsFp32 != 0, rc_shape(t, m.fw, m.fh, m.w, m.h, level[i]), whole, maxAbs);
     }
     stateMask[i] = st >= 0 ? (1u << st) : 0u;
     active[i] = st >= 0 ? 0 : 1;
 }
 
-void launch_triage(const ClassifyParams& P, const float* uv, const SetupCounters* counters, uint32_t maxItems, uint32_t* stateMask, uint8_t* active, hipStream_t stream)
+void launch_triage(const ClassifyParams& P, const float* uv, const uint8_t* level, const uint8_t* degenerate, const SetupCounters* counters, uint32_t maxItems,
+                   uint32_t* stateMask, uint8_t* active, hipStream_t stream)
 {
     if (maxItems == 0) return;
-    hipLaunchKernelGGL(triage_items, dim3((maxItems + 255u) / 256u), dim3(256), 0, stream, P, uv, counters, stateMask, active);
+    hipLaunchKernelGGL(triage_items, dim3((maxItems + 255u) / 256u), dim3(256), 0, stream, P, uv, level, degenerate, counters, stateMask, active);
 }
 
 // index narrowing (bake_cpu_impl.cpp:1872-1902) for results that stay on the device
@@ -145,6 +163,11 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
         const MicroTri sub = micro_triangle(uv, tileInItem, level - TILE_LOG4);
         r = region_rect<ModeDynamic>(P, sub, maxAbs);
         if (P.useCoarse) st = region_state<ModeDynamic>(P, sub, maxAbs, no_window());
+        // a tile in a mixed neighbourhood that the level curve does not reach (region_curve.h): settled like a uniform one
+        if ((OMMX_RC_LEVELS & 2) && st < 0 && region_curve_applies(P) && !A.degenerate[item]) {
+            const DevMip& m = P.mips[0];
+            st = region_curve_state<ModeDynamic>(P, P.texIsFp32 != 0, rc_shape(uv, m.fw, m.fh, m.w, m.h, level), sub, maxAbs);
+        }
     }
     // ---- open tiles: wave-compacted append, section by section (a wave sees one section, two at a range boundary, early items apart) ----
     // (the tiles of early items go to the staging list with their range in bits 16..21 of word 1; early_tiles_scatter orders them by range)
@@ -223,8 +246,15 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     auto defer_generic = [&](uint32_t n, uint32_t itemWord, uint32_t level, uint32_t base) -> bool {
         if (!DEFER || !SLICED || n == 0u) return false;
         if (threadIdx.x == 0) {
-            const uint32_t b = atomicAdd(G.count, n);
-            if ((uint64_t)b + n <= (uint64_t)G.capacity) s_gbase = b; else { s_gbase = 0xFFFFFFFFu; atomicSub(G.count, n); }
+            // reserve by compare-and-swap: the count only ever advances by reservations that fit (an add that is taken back when it does not fit lets a
+            // concurrent workgroup see an inflated count, fail spuriously, or succeed at a base that the final count no longer covers)
+            uint32_t b = __hip_atomic_load(G.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), got = 0xFFFFFFFFu;
+            while ((uint64_t)b + n <= (uint64_t)G.capacity) {
+                const uint32_t prev = atomicCAS(G.count, b, b + n);
+                if (prev == b) { got = b; break; }
+                b = prev;
+            }
+            s_gbase = got;
         }
         __syncthreads();
         const uint32_t gb = s_gbase;
@@ -313,6 +343,10 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         // fine_single_texel's FINITE precondition: |uv| <= 16384 bounds every pixel coordinate by 2^30 (size <= 65536) and excludes NaN;
         // items outside it (and degenerate ones) take the generic path
         uFast = fastFine && !uDegenerate && uMaxAbs <= 16384.f;
+        // the curve-free-region test of the groups (phase 0c): the item's shape bounds, once per tile
+        const bool uCurve = (OMMX_RC_LEVELS & 4) && region_curve_applies(P) && !uDegenerate;
+        RcShape uShape; uShape.ok = 0;
+        if (uCurve) { const DevMip& m0 = P.mips[0]; uShape = rc_shape(uUv, m0.fw, m0.fh, m0.w, m0.h, level); }
         {
             // ---- phase 0b: LDS window = every texel / SAT entry this tile can touch ----
             // (the tile's texel rectangle was computed by triage_tiles: region_rect of its sub-triangle)
@@ -337,11 +371,14 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 }
                 windowOk = true;
             }
-            // ---- phase 0c: one query per 64-micro-triangle group (wave 1), straight from the global SAT while the other waves fill the window ----
+            // ---- phase 0c: one query per 64-micro-triangle group (wave 1), straight from the global SAT while the other waves fill the window; a group the
+            //      table leaves open is then asked whether the level curve can reach it at all (region_curve.h: texels from L2) -- settled if not ----
             if (coarse) {
                 if (tid >= 64 && tid < 64 + TILE / GROUP) { // (4096-tile: 64 groups = all of wave 1; 1024-tile: 16 of its lanes)
                     const uint32_t g = tid - 64;
-                    const int gs = region_state_ex<MD>(P, micro_triangle(uUv, (base >> 6) + g, level - 3), uMaxAbs, no_window());
+                    const MicroTri gsub = micro_triangle(uUv, (base >> 6) + g, level - 3);
+                    int gs = region_state_ex<MD>(P, gsub, uMaxAbs, no_window());
+                    if (gs < 0 && uCurve) { const int cs = OMMX_RC_GROUP_TEST(rc_tex<MD>(P, FP32), uShape, gsub.lo.x, gsub.lo.y, gsub.hi.x, gsub.hi.y, uMaxAbs); gs = cs >= 0 ? cs : gs; }
                     s_group[g] = gs;
                     s_gdec[g] = bird_group((base >> 6) + g, level - 3).word;
                     const unsigned long long open = __ballot(gs < 0), allOpen = __ballot(gs == kRegionAllOpen);
@@ -349,7 +386,16 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                     if (gs == kRegionAllOpen) s_olist[__popcll(allOpen & ((1ull << g) - 1ull))] = (uint16_t)g;
                     if (g == 0) { s_gcount = (uint32_t)__popcll(open); s_ocount = (uint32_t)__popcll(allOpen); }
                 }
-            } else if (tid < (uint32_t)(TILE / GROUP)) { s_group[tid] = -1; s_glist[tid] = (uint16_t)tid; s_gdec[tid] = bird_group((base >> 6) + tid, level - 3).word; if (tid == 0) { s_gcount = (uint32_t)(TILE / GROUP); s_ocount = 0; } }
+            } else if (tid < (uint32_t)(TILE / GROUP)) {   // no summed-area table: every group is open unless the level curve cannot reach it
+                const uint32_t g = tid;
+                int gs = -1;
+                if (uCurve) { const MicroTri gsub = micro_triangle(uUv, (base >> 6) + g, level - 3); gs = OMMX_RC_GROUP_TEST(rc_tex<MD>(P, FP32), uShape, gsub.lo.x, gsub.lo.y, gsub.hi.x, gsub.hi.y, uMaxAbs); }
+                s_group[g] = gs;
+                s_gdec[g] = bird_group((base >> 6) + g, level - 3).word;
+                const unsigned long long open = __ballot(gs < 0);
+                if (gs < 0) s_glist[__popcll(open & ((1ull << g) - 1ull))] = (uint16_t)g;
+                if (g == 0) { s_gcount = (uint32_t)__popcll(open); s_ocount = 0; }
+            }
             __syncthreads();
             if (windowOk) { const DevMip& m0 = P.mips[0]; W.tex = (lds_float*)s_wtex; W.sat = (lds_u32*)s_wsat; W.base = m0.texels; W.sx = r.sx; W.sy = r.sy; W.w = ww; W.h = wh; } // (SAT part is only read when coarse is on)
         }

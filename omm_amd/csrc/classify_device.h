@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "bake_types.h"
+#include "region_curve.h"
 
 namespace ommx {
 
@@ -763,6 +764,55 @@ template <class MD>
 __device__ __forceinline__ int region_state_ex(const ClassifyParams& P, const MicroTri& sub, float maxAbs, const TexWindow& W)
 {
     return region_state_impl<MD, true>(P, sub, maxAbs, W);
+}
+
+// ---- hierarchical shortcut of the FINE pass: a bird-curve sub-triangle the level curve provably cannot reach (region_curve.h) ----
+// `sub` is an ancestor (any level <= N, the micro-triangle itself included) of micro-triangles of a NON-DEGENERATE work item with the vertices `uv` and the
+// subdivision level `level`; `sh` = rc_shape() of that item.  Returns the state every descendant ends with -- whichever of the reference's passes classifies
+// it: the votes of ResampleFine all fall on one side of the cutoff, and a descendant that ResampleCoarse resolves has all its texels on that side --
+// or -1.  Independent of the summed-area table: it also culls bakes of textures without one.  Texels come from HBM / L2 (at most 5 x 5 per call).
+__device__ __forceinline__ bool region_curve_applies(const ClassifyParams& P) { return P.filterLinear != 0 && P.mipCount == 1 && P.noFine == 0; }
+struct RcTex { const void* texels; int w, h; float fw, fh; int addr, pow2, fp32; float cutoff; int stateGT, stateLE; };   // what the test reads of ClassifyParams
+template <class MD>
+__device__ __forceinline__ RcTex rc_tex(const ClassifyParams& P, bool fp32)
+{
+    const DevMip& m = P.mips[0];
+    RcTex t; t.texels = m.texels; t.w = m.w; t.h = m.h; t.fw = m.fw; t.fh = m.fh; t.addr = MD::addr(P); t.pow2 = MD::pow2(P); t.fp32 = fp32 ? 1 : 0;
+    t.cutoff = P.cutoff; t.stateGT = P.stateGT; t.stateLE = P.stateLE;
+    return t;
+}
+__device__ __forceinline__ int region_curve_state_impl(const RcTex& T, const RcShape& sh, float lox, float loy, float hix, float hiy, float maxAbs)
+{
+    if (!sh.ok) return -1;
+    const RcFrame f = rc_frame(lox, loy, hix, hiy, maxAbs, T.fw, T.fh, T.w, T.h, T.addr, T.pow2);
+    if (!f.ok) return -1;
+    int sign = 0;
+    for (int j = 0; j < f.ny; ++j)
+        for (int i = 0; i < f.nx; ++i) {
+            const size_t i00 = (size_t)(f.sx + i) + (size_t)(f.sy + j) * (size_t)T.w, i01 = i00 + (size_t)T.w;
+            float g00, g10, g01, g11;
+            if (T.fp32) { const float* t = (const float*)T.texels; g00 = t[i00]; g10 = t[i00 + 1]; g01 = t[i01]; g11 = t[i01 + 1]; }
+            else { const uint8_t* t = (const uint8_t*)T.texels; g00 = (float)t[i00] * (1.f / 255.f); g10 = (float)t[i00 + 1] * (1.f / 255.f); g01 = (float)t[i01] * (1.f / 255.f); g11 = (float)t[i01 + 1] * (1.f / 255.f); }
+            const int c = rc_cell(&sh, g00, g10, g01, g11, T.cutoff, f.bx0 - (float)i, f.bx1 - (float)i, f.by0 - (float)j, f.by1 - (float)j);
+            if (c == 0) return -1;
+            if (c == 2) continue;
+            if (sign != 0 && sign != c) return -1;
+            sign = c;
+        }
+    if (sign == 0) return -1;
+    const int st = sign > 0 ? T.stateGT : T.stateLE;
+    return st == 3 ? -1 : st;   // (as region_state(): the value the reference's fine pass would revisit is not shortcut)
+}
+template <class MD>
+__device__ __forceinline__ int region_curve_state(const ClassifyParams& P, bool fp32, const RcShape& sh, const MicroTri& sub, float maxAbs)
+{
+    return region_curve_state_impl(rc_tex<MD>(P, fp32), sh, sub.lo.x, sub.lo.y, sub.hi.x, sub.hi.y, maxAbs);
+}
+// the same as a real call: inside the persistent classify_tiles kernel the test runs once per 64-group in ONE wave of the tile's set-up phase, and inlined it
+// costs the whole kernel registers (25 -> 49 spilled VGPRs); as a callee it has an allocation of its own
+__device__ __attribute__((noinline)) int region_curve_state_call(RcTex T, RcShape sh, float lox, float loy, float hix, float hiy, float maxAbs)
+{
+    return region_curve_state_impl(T, sh, lox, loy, hix, hiy, maxAbs);
 }
 
 // ---- fine pass of a micro-triangle whose conservative raster covers ONE texel of mip 0 (Linear filter, non-degenerate item) ----

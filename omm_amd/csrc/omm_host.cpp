@@ -555,7 +555,7 @@ struct ShardCtx {
     int ev[5] = { -1, -1, -1, -1, -1 };   // HIP event marks of Begin: setup | triage | classify | digest
     // exchange buffers: carved from the session's arenas (tables: dMeta .. dTotals; xchg: contribution + gather staging), nothing to free
     uint32_t* dMeta = nullptr; uint8_t* dOwner = nullptr; uint64_t *dCofs = nullptr, *dTotals = nullptr; uint8_t *dContrib = nullptr, *dGathered = nullptr;
-    uint8_t *dComp = nullptr, *dGatherComp = nullptr; uint32_t* dCompSize = nullptr; uint64_t compCap = 0;   // block exchange codec (RCCL path): own stream, all ranks' streams, own size word
+    uint8_t *dComp = nullptr, *dGatherComp = nullptr, *dCodecScratch = nullptr; uint32_t* dCompSize = nullptr; uint64_t compCap = 0; size_t codecScratchBytes = 0;   // block exchange codec (RCCL path): own stream, all ranks' streams, own size word, count / scan scratch
     uint64_t totals[kMaxRanks]; uint64_t strideBytes = 0;
 };
 
@@ -815,7 +815,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     P.noFine = (flags & (1u << 9)) != 0;   // DisableFineClassification (bake_cpu_impl.cpp:45,822-823)
 
     // ---- level-0 hierarchical query per item + compaction of the items that need per-micro-triangle work; ONE sync ----
-    launch_triage(P, dUv, dCounters, maxItems, dMask, dActive, stream);
+    launch_triage(P, dUv, dLevel, dDegen, dCounters, maxItems, dMask, dActive, stream);
     if (!HIP_OK(run_prep(dItemIds, dActive, dLevel, bits, maxItems, dCounters, dActiveIds, dStateOfs, dScratch, scratchBytes, stream)) ||
         !HIP_OK(hipMemcpyAsync(&hc, dCounters, sizeof hc, hipMemcpyDeviceToHost, stream)) || !HIP_OK(hipStreamSynchronize(stream)))
         return L.failure("[Failure] - device work-list compaction failed");
@@ -865,7 +865,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             ok = ok && HIP_OK(hipMemcpyAsync(dItemIds, itemIds.data(), (size_t)U * 4, hipMemcpyHostToDevice, stream));
         }
         if (T) ok = ok && HIP_OK(hipMemcpyAsync(dTriToItem, triToItem.data(), (size_t)T * 4, hipMemcpyHostToDevice, stream));
-        launch_triage(P, dUv, dCounters, maxItems, dMask, dActive, stream);
+        launch_triage(P, dUv, dLevel, dDegen, dCounters, maxItems, dMask, dActive, stream);
         ok = ok && HIP_OK(run_prep(dItemIds, dActive, dLevel, bits, maxItems, dCounters, dActiveIds, dStateOfs, dScratch, scratchBytes, stream));
         ok = ok && HIP_OK(hipMemcpyAsync(&hc, dCounters, sizeof hc, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipStreamSynchronize(stream));
         if (!ok) return L.failure("[Failure] - serial work-item setup failed");
@@ -1894,11 +1894,14 @@ ommResult sharded_tail(ShardedBake* sb)
     const size_t gatherBytes = c.asyncBegin ? (size_t)c.strideBytes * c.world + 4096 : 0;
     // (RCCL path) the contributions cross the links as codec streams of at most half their size: this rank's and the gathered ones
     c.compCap = c.asyncBegin ? pad256((size_t)(c.strideBytes / 2) + 4096) : 0;
-    const size_t codecBytes = c.asyncBegin ? (size_t)c.compCap * (c.world + 1) + 256 : 0;
+    // (the codec's count / scan scratch grows with the contribution -- one word per 4 KiB of it plus rocPRIM's -- while the bake's own scratch block is sized
+    //  from the triangle count: a few large blocks, level 10 and up, need more than that, so it comes from this arena)
+    c.codecScratchBytes = c.asyncBegin ? pad256(shard_codec_scratch_bytes(c.strideBytes)) : 0;
+    const size_t codecBytes = c.asyncBegin ? (size_t)c.compCap * (c.world + 1) + 1024 + c.codecScratchBytes : 0;
     if (!sb->ses.set->xchg.reserve((size_t)c.strideBytes + 256 + gatherBytes + codecBytes)) return L.failure("[Failure] - out of device memory for the shard contribution");
     c.dContrib = sb->ses.set->xchg.take<uint8_t>((size_t)c.strideBytes);
     c.dGathered = gatherBytes ? sb->ses.set->xchg.take<uint8_t>(gatherBytes) : nullptr;
-    if (codecBytes) { c.dComp = sb->ses.set->xchg.take<uint8_t>((size_t)c.compCap); c.dGatherComp = sb->ses.set->xchg.take<uint8_t>((size_t)c.compCap * c.world); c.dCompSize = sb->ses.set->xchg.take<uint32_t>(1); }
+    if (codecBytes) { c.dComp = sb->ses.set->xchg.take<uint8_t>((size_t)c.compCap); c.dGatherComp = sb->ses.set->xchg.take<uint8_t>((size_t)c.compCap * c.world); c.dCompSize = sb->ses.set->xchg.take<uint32_t>(1); c.dCodecScratch = sb->ses.set->xchg.take<uint8_t>(c.codecScratchBytes); }
     // (the padding behind this rank's blocks travels too: zeros, which the codec folds away)
     if (c.strideBytes > c.totals[c.rank] && !HIP_OK(hipMemsetAsync(c.dContrib + c.totals[c.rank], 0, (size_t)(c.strideBytes - c.totals[c.rank]), stream))) return L.failure("[Failure] - device memset failed");
     launch_shard_gather(c.dStates, c.dStateOfs, c.dActive, c.dOwner, c.rank, c.to.order, c.dCofs, c.to.sizes, c.counts.numOmms, c.dContrib, stream);
@@ -2149,7 +2152,7 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
             bool ok = arrayData != nullptr && sb->ses.open_comm() && HIP_OK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
             // the contribution as a codec stream (tail_kernels.hip "block exchange codec"); the agreement on the ranks' status carries the stream sizes:
             // MAX over the ranks = what every rank sends (the all-gather needs equal counts), or "one of them does not shrink" = everybody sends raw
-            ok = ok && HIP_OK(run_shard_compress(c.dContrib, c.strideBytes, c.dComp, c.compCap, c.dCompSize, c.dScratch, c.scratchBytes, stream));
+            ok = ok && HIP_OK(run_shard_compress(c.dContrib, c.strideBytes, c.dComp, c.compCap, c.dCompSize, c.dCodecScratch, c.codecScratchBytes, stream));
             uint32_t maxUnits = 0;
             ok = rccl_agree_max(rc, stream, ok, c.dCompSize, &maxUnits, L, "allocation of the result") && ok;
             if (!ok) { if (ready) (void)hipEventDestroy(ready); return false; }

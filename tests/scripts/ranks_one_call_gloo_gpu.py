@@ -89,6 +89,9 @@ def worker(rank, world, port, outdir, full):
     ok = case("levels 5..7, codec streams", foliage, uv, ix, 7, levels=lv, expect="codec")
     uv8, ix8 = ot.random_triangles(811, 8000, 8.0 / 1024)
     ok = case("level 8, codec streams", foliage, uv8, ix8, 8, expect="codec") and ok
+    # few, large blocks (256 KiB each): the codec's count / scan scratch outgrows the bake's own scratch block, which is sized from the triangle count
+    uv10, ix10 = ot.random_triangles(813, 300, 0.02)
+    ok = case("level 10, few large blocks, codec streams", foliage, uv10, ix10, 10, expect="codec") and ok
     uvn, ixn = ot.random_triangles(812, 400, 0.3)
     ok = case("noise, raw exchange in many chunks", noise, uvn, ixn, 6, chunk=4096, expect="raw") and ok
     ok = case("noise, raw exchange in one chunk", noise, uvn, ixn, 6, expect="raw") and ok
