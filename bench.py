@@ -50,7 +50,8 @@ class BakeTimings(C.Structure):
                 ("stateBytes", C.c_uint64), ("triageMs", C.c_float), ("activeItems", C.c_uint32), ("fineMicroTriangles", C.c_uint64), ("setupMs", C.c_float),
                 ("streamChunks", C.c_uint32), ("streamedBytes", C.c_uint64), ("streamTailMs", C.c_float),
                 ("openTiles", C.c_uint32), ("openTileMicroTriangles", C.c_uint64), ("streamEarlyItems", C.c_uint32), ("persistentMs", C.c_float),
-                ("genericMs", C.c_float), ("genericMicroTriangles", C.c_uint64), ("exchangeBytes", C.c_uint64), ("contributionBytes", C.c_uint64)]
+                ("genericMs", C.c_float), ("genericMicroTriangles", C.c_uint64), ("exchangeBytes", C.c_uint64), ("contributionBytes", C.c_uint64),
+                ("streamPreviewMs", C.c_float), ("streamFirstCopyMs", C.c_float), ("streamLastCopyMs", C.c_float), ("streamRangeReadyMs", C.c_float * 32)]
 
 
 def source_hash():
@@ -359,6 +360,8 @@ def main():
                                 "micro_triangles_per_s": micro_tris / (host_ms * 1e-3),
                                 "stream": {"ranges": int(host_tms[-1].streamChunks), "streamed_bytes": int(host_tms[-1].streamedBytes), "exposed_copy_ms": havg("streamTailMs"),
                                            "early_items": int(host_tms[-1].streamEarlyItems),
+                                           "preview_ms": havg("streamPreviewMs"), "first_copy_issued_ms": havg("streamFirstCopyMs"), "last_copy_issued_ms": havg("streamLastCopyMs"),
+                                           "range_ready_ms": [round(float(np.mean([t.streamRangeReadyMs[k] for t in host_tms])), 3) for k in range(min(32, int(host_tms[-1].streamChunks) + 1))],
                                            "note": "ranges > 0: finished OMM blocks cross PCIe (SDMA) straight to their final arrayData offsets while the ONE persistent classification "
                                                    "launch is still running, one copy per range of work items; exposed = from the end of the classification to the last byte on the "
                                                    "host; early_items = possible duplicates, classified with an earlier range than their own; ranges == 0: one copy after the bake "

@@ -45,8 +45,18 @@ typedef struct ommxBakeTimings {
     uint64_t exchangeBytes;    /* ommxShardedBakeRccl: bytes every rank put on the wire in the block all-gather (the contributions travel as unit codes + raw
                                   units; a contribution that does not shrink below half its size travels as it is) */
     uint64_t contributionBytes; /* ... and the size of a rank's (padded) contribution before that */
+    /* (round 4; read them through ommxGetLastBakeTimingsSized) streamed ommCpuBake, wall clock in ms since the bake's device work was first enqueued: */
+    float    streamPreviewMs;      /* HIP events around the level-5 preview of the items of level >= 6 (the possible-duplicate search in front of the classification) */
+    float    streamFirstCopyMs;    /* the first range's blocks are placed and their copy is issued */
+    float    streamLastCopyMs;     /* the last range's copy is issued */
+    float    streamRangeReadyMs[32]; /* range k placed (its event seen by the host thread, which then issues its copy) */
 } ommxBakeTimings;
 
+/* ommxBakeTimings only ever grows at its END.  ommxGetLastBakeTimingsSized copies min(outBytes, the library's size) bytes and zeros the rest of `out`, so a
+ * caller and a library built from different versions of this header stay compatible; *libraryBytes (optional) <- the library's sizeof(ommxBakeTimings).
+ * ommxGetLastBakeTimings is the same call with the size of THIS header's struct baked in at the caller's compile time -- use it only when header and
+ * library are built together (it was the only form until round 4, when the struct had already grown twice: an ABI break for older callers). */
+OMM_MI355X_API ommResult ommxGetLastBakeTimingsSized(ommBaker baker, void* out, size_t outBytes, size_t* libraryBytes);
 OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings* out);
 
 /* ---- per-baker knobs ----

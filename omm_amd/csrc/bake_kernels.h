@@ -58,9 +58,9 @@ __device__ __forceinline__ uint32_t early_range(uint32_t leadPos, uint32_t ownPo
 }
 // Deferred generic pass (asset-sized triangles: micro-triangles of several texels).  The persistent launch queues the micro-triangles that need the
 // generic texel loops instead of walking them itself -- entry = {item | degenerate << 30, level << 24 | micro-triangle index}, their packed state left 0 --
-// and classify_generic() classifies them afterwards, eight lanes per micro-triangle, and ORs the states in.  *count <= capacity always: a tile whose
-// micro-triangles do not fit (reservation by compare-and-swap) walks them itself.
-struct GenericQueue { uint2* entries; uint32_t* count; uint32_t capacity; };
+// and classify_generic() classifies them afterwards, eight lanes per micro-triangle, and ORs the states in.  *count only grows and may exceed capacity: a tile
+// whose reservation does not fit walks its micro-triangles itself and fills the part of the reservation that lies inside the queue with null entries (x == ~0).
+struct GenericQueue { uint2* entries; unsigned long long* count; uint32_t capacity; };
 struct ClassifyChunks {
     uint32_t count;
     void (*after)(void* user, uint32_t chunk, const ClassifySegment* segs, uint32_t numSegs, bool last);
@@ -95,7 +95,9 @@ void launch_digest_lists(const uint8_t* states, const uint64_t* stateOfs, const 
 size_t sat_scratch_bytes(int w, int h);
 void launch_sat_build(const void* texels, int fp32, uint32_t* sat, uint32_t* scratch, int w, int h, float cutoff, hipStream_t stream);
 // active[item] == 0: the item has no stored states (settled by triage); its block is the constant pattern of its single state
-void launch_gather_omms(const uint8_t* states, const uint64_t* stateOfs, const uint8_t* active, const uint32_t* stateMask, const uint8_t* level, int bits,
+// storeBits: packing of `states` (== bits, except a 2-state bake without fine pass, whose states are kept in 2 bits: the gather then packs them to 1 bit by
+// the reference's rule, byte[i >> 3] |= state << (i & 7) truncated to the byte, bake_cpu_impl.cpp:1811)
+void launch_gather_omms(const uint8_t* states, const uint64_t* stateOfs, const uint8_t* active, const uint32_t* stateMask, const uint8_t* level, int bits, int storeBits,
                         const uint32_t* order, const uint32_t* dstOfs, const uint32_t* sizes, uint32_t numOmms, uint8_t* arrayData, hipStream_t stream);
 void launch_write_indices(const int32_t* triToItem, const uint32_t* rep, const int32_t* itemValue, uint32_t numTris, int32_t unresolved,
                           int32_t* out, hipStream_t stream);
@@ -168,7 +170,9 @@ hipError_t run_stream_segment(const StreamSegment& g, uint32_t numActive, void* 
 void launch_stream_publish(const unsigned long long* cursor, unsigned long long* hostSlot, hipStream_t stream);
 // `stream` does not pass until sections [first, first + n) of the 4096-tile queue are complete (every block in them classified and visible); the stream
 // must already be ordered behind the tile triage.  ctl: the streamed result's control words (a wait that gives up sets the violation word)
-void launch_stream_wait_sections(const uint32_t* queueCtl, uint32_t first, uint32_t n, uint32_t* ctl, hipStream_t stream);
+// timeoutSeconds: give up after that long (at least 4 s; the caller scales it with the estimated duration of the classification: a contended GPU or a profiler
+// must not turn a long first range into a discarded stream)
+void launch_stream_wait_sections(const uint32_t* queueCtl, uint32_t first, uint32_t n, uint32_t* ctl, double timeoutSeconds, hipStream_t stream);
 // preview of the items of level >= 6 (tail_kernels.hip "preview"): prepare -> launch_classify() of the items as ONE level-5 class into the preview buffers -> flags
 constexpr uint32_t kPreviewLevel = 5, kPreviewSlotBytes = 256;   // 1024 micro-triangles x 2 bits
 void launch_stream_preview_prepare(const uint32_t* ids, uint32_t n, const float* uv, float texW, float texH, float* uv2, uint64_t* ofs2, uint8_t* early, hipStream_t stream);

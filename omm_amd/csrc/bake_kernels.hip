@@ -46,6 +46,9 @@ namespace ommx {
 #else
 #define OMMX_RC_GROUP_TEST region_curve_state_impl
 #endif
+#ifndef OMMX_RC_MICRO    // the per-micro-triangle form of the test in front of the single-texel pass (phase 2a-1)
+#define OMMX_RC_MICRO 0
+#endif
 #ifndef OMMX_RC_LEVELS   // bit 0: items, bit 1: tiles, bit 2: 64-groups (A/B builds; the product ships all three)
 #define OMMX_RC_LEVELS 7
 #endif
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                                                         uint32_t numItems, uint32_t levelArg, uint64_t numTiles,
                                                         const uint4* __restrict__ tileQueue, uint32_t* __restrict__ queueCtl, uint32_t numSections, GenericQueue G)
 {
-    __shared__ uint32_t s_gbase;                 // DEFER: first entry of this tile's reservation in the generic queue (0xFFFFFFFF: none, walk inline)
+    __shared__ unsigned long long s_gbase;       // DEFER: first entry of this tile's reservation in the generic queue
     __shared__ uint8_t  s_state[TILE];
     __shared__ uint16_t s_queue[TILE];
     __shared__ int      s_group[TILE / GROUP];
@@ -246,19 +249,17 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     auto defer_generic = [&](uint32_t n, uint32_t itemWord, uint32_t level, uint32_t base) -> bool {
         if (!DEFER || !SLICED || n == 0u) return false;
         if (threadIdx.x == 0) {
-            // reserve by compare-and-swap: the count only ever advances by reservations that fit (an add that is taken back when it does not fit lets a
-            // concurrent workgroup see an inflated count, fail spuriously, or succeed at a base that the final count no longer covers)
-            uint32_t b = __hip_atomic_load(G.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), got = 0xFFFFFFFFu;
-            while ((uint64_t)b + n <= (uint64_t)G.capacity) {
-                const uint32_t prev = atomicCAS(G.count, b, b + n);
-                if (prev == b) { got = b; break; }
-                b = prev;
-            }
-            s_gbase = got;
+            // One atomicAdd per tile and no way back: the count only grows (an add that is taken back lets a concurrent workgroup fail spuriously or succeed
+            // at a base the final count no longer covers; a compare-and-swap loop on one word collapses under 1536 workgroups -- measured: 7 us per tile).  A
+            // reservation that does not fit is given up, and the part of it that lies inside the queue is filled with null entries below.
+            s_gbase = atomicAdd(G.count, (unsigned long long)n);   // (64 bits: the reservations of a large bake that overflows the queue must not wrap)
         }
         __syncthreads();
-        const uint32_t gb = s_gbase;
-        if (gb == 0xFFFFFFFFu) return false;
+        const unsigned long long gb = s_gbase;
+        if (gb + n > (unsigned long long)G.capacity) {
+            for (unsigned long long q = gb + threadIdx.x; q < (unsigned long long)G.capacity; q += BLOCK) G.entries[q] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);   // (classify_generic skips these)
+            return false;
+        }
         for (uint32_t q = threadIdx.x; q < n; q += BLOCK) {
             const uint32_t i = s_queue[q];
             G.entries[gb + q] = make_uint2(itemWord & 0x7FFFFFFFu, (level << 24) | (base + i));
@@ -324,11 +325,11 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     const bool coarse = P.useCoarse != 0;
 
     // block-uniform item data of a sliced tile
-    uint32_t uItem = 0; float uUv[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }; float uMaxAbs = 0.f; bool uDegenerate = false, uFast = false;
+    uint32_t uItem = 0; float uUv[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }; float uMaxAbs = 0.f, uUx = 0.f, uUy = 0.f; bool uDegenerate = false, uFast = false;
     TexWindow W = no_window();
     if (tid == 0) { s_qcount = 0; s_mask = 0; s_known = 0; s_pending = 0; s_fine = 0; }
     // the single-texel fast pass (fine_single_texel) covers Linear filtering of one mip on non-degenerate items; everything else is generic
-    const bool fastFine = SLICED && P.filterLinear != 0 && P.mipCount == 1 && !P.noFine;
+    const bool fastFine = SLICED && P.filterLinear != 0 && P.mipCount == 1 && !P.noFine && P.altKernel == 0;
     // micro-triangle i (0 .. TILE) of a sliced tile through the split bird decode: group word + table entry instead of the full decode
     auto tile_micro_triangle = [&](uint32_t i) {
         BirdGroup bg; bg.word = s_gdec[SLICED ? i >> 6 : 0u];
@@ -344,6 +345,12 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         // items outside it (and degenerate ones) take the generic path
         uFast = fastFine && !uDegenerate && uMaxAbs <= 16384.f;
         // the curve-free-region test of the groups (phase 0c): the item's shape bounds, once per tile
+        {   // rounding unit of the item's raster coordinates, per axis (region_curve.h)
+            const DevMip& m0 = P.mips[0];
+            uUx = m0.fw * __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(uUv[0]), __builtin_fabsf(uUv[2])), __builtin_fabsf(uUv[4])) * 5.9604645e-8f;
+            uUy = m0.fh * __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(uUv[1]), __builtin_fabsf(uUv[3])), __builtin_fabsf(uUv[5])) * 5.9604645e-8f;
+        }
+        (void)uUx; (void)uUy;   // (read by the per-micro-triangle form only: OMMX_RC_MICRO)
         const bool uCurve = (OMMX_RC_LEVELS & 4) && region_curve_applies(P) && !uDegenerate;
         RcShape uShape; uShape.ok = 0;
         if (uCurve) { const DevMip& m0 = P.mips[0]; uShape = rc_shape(uUv, m0.fw, m0.fh, m0.w, m0.h, level); }
@@ -469,6 +476,54 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
             const uint32_t gcount = s_gcount, ocount = s_ocount;
             uint32_t qn2 = 0, en = 0, pend = 0;
             const uint32_t units = ocount + ((qn + 63u) >> 6);
+#if OMMX_RC_MICRO
+            // ---- phase 2a-1: the curve-free-region test per micro-triangle (micro_curve_state: ~100 instructions): most of them are clear of the level curve
+            //      of their cell and are done; the others (0xFD) are compacted into s_queue and take the full straight-line pass below ----
+            uint32_t full = 0;
+            for (uint32_t k = tid >> 6; k < units; k += BLOCK / 64) {   // (k is wave-uniform)
+                uint32_t i; bool live = true;
+                if (k < ocount) i = (uint32_t)s_olist[k] * 64u + (tid & 63u);
+                else { const uint32_t q = (k - ocount) * 64u + (tid & 63u); live = q < qn; i = live ? (uint32_t)s_queue[q] : 0u; }
+                if (live) {
+                    const int st = micro_curve_state<FP32, MD>(P, tile_micro_triangle(i), uUx, uUy, W);
+                    s_state[i] = (uint8_t)(st < 0 ? 0xFD : st);
+                    full |= st < 0 ? 1u : 0u;
+                }
+            }
+            if (tid == 0 && ocount) s_fine = ocount * 64u;
+            if (__ballot(full != 0) != 0ull && (tid & 63u) == 0) atomicOr(&s_pending, 4u);
+            __syncthreads();
+            uint32_t qf = 0;
+            if (s_pending & 4u) {   // (block-uniform)
+                if (tid == 0) s_qcount = 0;
+                __syncthreads();
+                for (uint32_t k = tid >> 6; k < gcount; k += BLOCK / 64) {
+                    const uint32_t i = s_glist[k] * 64u + (tid & 63u);
+                    const unsigned long long vf = __ballot(s_state[i] == 0xFDu);
+                    if (vf) {
+                        const uint32_t lane = tid & 63u;
+                        uint32_t bf = 0;
+                        if (lane == 0) bf = atomicAdd(&s_qcount, (uint32_t)__popcll(vf));
+                        bf = __shfl(bf, 0);
+                        if ((vf >> lane) & 1ull) s_queue[bf + __popcll(vf & ((1ull << lane) - 1ull))] = (uint16_t)i;
+                    }
+                }
+                __syncthreads();
+                qf = s_qcount;
+                if (tid == 0) s_pending = 0;   // (re-used by the pass below; every thread has read it: the barrier above)
+            }
+            // ---- phase 2a-2: the full single-texel pass of what is left, densely ----
+            for (uint32_t q0 = 0; q0 < qf; q0 += BLOCK) {
+                const uint32_t q = q0 + tid;
+                if (q < qf) {
+                    const uint32_t i = s_queue[q];
+                    const int st = fine_single_texel<FP32, MD>(P, tile_micro_triangle(i), W);   // state | kNeedsEdges + hints | -1
+                    s_state[i] = (uint8_t)(st < 0 ? 0xFF : st);
+                    pend |= st < 0 ? 1u : ((st & kNeedsEdges) ? 2u : 0u);
+                }
+            }
+            __syncthreads();   // (s_pending was cleared by thread 0 behind the compaction barrier: order it before the votes below)
+#else
             for (uint32_t k = tid >> 6; k < units; k += BLOCK / 64) {   // (k is wave-uniform)
                 uint32_t i; bool live = true;
                 if (k < ocount) i = (uint32_t)s_olist[k] * 64u + (tid & 63u);
@@ -480,6 +535,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 }
             }
             if (tid == 0 && ocount) s_fine = ocount * 64u;
+#endif
             const unsigned long long anyGeneric = __ballot((pend & 1u) != 0), anyEdges = __ballot((pend & 2u) != 0);
             if ((tid & 63u) == 0 && (anyGeneric | anyEdges)) atomicOr(&s_pending, (anyGeneric ? 1u : 0u) | (anyEdges ? 2u : 0u));
             __syncthreads();
@@ -753,17 +809,18 @@ __device__ __forceinline__ int generic_two_phase(const ClassifyParams& P, const 
 template <bool FP32, class MD>
 __global__ __launch_bounds__(256) void classify_generic(ClassifyParams P, ItemArrays A, GenericQueue G)
 {
-    const uint32_t n = *G.count < G.capacity ? *G.count : G.capacity;
+    const uint32_t n = *G.count < (unsigned long long)G.capacity ? (uint32_t)*G.count : G.capacity;
     const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * 256u + threadIdx.x) >> 6, waves = (gridDim.x * 256u) >> 6;
     const uint32_t bits = (uint32_t)P.format;
     for (uint32_t e0 = wave * 64u; e0 < n; e0 += waves * 64u) {   // (wave-uniform)
         const uint32_t e = e0 + lane;
-        const bool live = e < n;
-        const uint2 ent = live ? G.entries[e] : make_uint2(0u, 0u);
+        bool live = e < n;
+        uint2 ent = live ? G.entries[e] : make_uint2(0u, 0u);
+        if (ent.x == 0xFFFFFFFFu) { live = false; ent = make_uint2(0u, 0u); }   // (null entry: the inside part of a reservation that did not fit)
         const uint32_t item = ent.x & 0x3FFFFFFFu;
         const bool degenerate = ((ent.x >> 30) & 1u) != 0u;
         int state = 0;
-        const bool serial = P.mipCount != 1 || degenerate;      // (wave-uniform in practice: mip chains are a bake property, degenerate items are rare)
+        const bool serial = P.mipCount != 1 || degenerate || (P.filterLinear && P.altKernel);   // (wave-uniform in practice: mip chains and the alternative kernel are bake properties, degenerate items are rare)
         if (__ballot(live && serial) != 0ull) {
             if (live) state = fine_state<FP32, MD>(P, micro_triangle(A.uv + 6ull * item, ent.y & 0xFFFFFFu, ent.y >> 24), degenerate, no_window());
         } else if (P.filterLinear) state = generic_two_phase<FP32, 0, MD>(P, A.uv, item, ent.y, live);
@@ -1341,7 +1398,7 @@ void launch_sat_build(const void* texels, int fp32, uint32_t* sat, uint32_t* scr
 // were settled by triage (only emitted when special indices are disabled) are written as their constant pattern
 __global__ __launch_bounds__(256) void tail_gather_omms(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs,
                                                         const uint8_t* __restrict__ active, const uint32_t* __restrict__ stateMask,
-                                                        const uint8_t* __restrict__ level, int bits,
+                                                        const uint8_t* __restrict__ level, int bits, int storeBits,
                                                         const uint32_t* __restrict__ order, const uint32_t* __restrict__ dstOfs,
                                                         const uint32_t* __restrict__ sizes, uint32_t numOmms, uint8_t* __restrict__ arrayData)
 {
@@ -1358,6 +1415,15 @@ __global__ __launch_bounds__(256) void tail_gather_omms(const uint8_t* __restric
             continue;
         }
         const uint8_t* src = states + stateOfs[item];
+        if (storeBits != bits) {   // 2-bit states -> the reference's 1-bit packing of a 2-state bake: byte |= (uint8_t)(state << (i & 7)), states 0 / 1 / 3
+            const uint32_t M = 1u << (2u * level[item]);
+            for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+                uint32_t v = 0;
+                for (uint32_t j = 0; j < 8u && 8u * k + j < M; ++j) { const uint32_t u = 8u * k + j; v |= ((uint32_t)(src[u >> 2] >> ((u & 3u) << 1)) & 3u) << j; }
+                dst[k] = (uint8_t)v;
+            }
+            continue;
+        }
         if (n >= 16u) {
             const uint4* s4 = (const uint4*)src; uint4* d4 = (uint4*)dst;
             for (uint32_t k = threadIdx.x; k < n / 16u; k += blockDim.x) d4[k] = s4[k];
@@ -1367,12 +1433,12 @@ __global__ __launch_bounds__(256) void tail_gather_omms(const uint8_t* __restric
     }
 }
 
-void launch_gather_omms(const uint8_t* states, const uint64_t* stateOfs, const uint8_t* active, const uint32_t* stateMask, const uint8_t* level, int bits,
+void launch_gather_omms(const uint8_t* states, const uint64_t* stateOfs, const uint8_t* active, const uint32_t* stateMask, const uint8_t* level, int bits, int storeBits,
                         const uint32_t* order, const uint32_t* dstOfs, const uint32_t* sizes, uint32_t numOmms, uint8_t* arrayData, hipStream_t stream)
 {
     if (numOmms == 0) return;
     const uint32_t grid = numOmms < 65536u * 4u ? numOmms : 65536u * 4u;
-    hipLaunchKernelGGL(tail_gather_omms, dim3(grid), dim3(256), 0, stream, states, stateOfs, active, stateMask, level, bits, order, dstOfs, sizes, numOmms, arrayData);
+    hipLaunchKernelGGL(tail_gather_omms, dim3(grid), dim3(256), 0, stream, states, stateOfs, active, stateMask, level, bits, storeBits, order, dstOfs, sizes, numOmms, arrayData);
 }
 
 // index buffer: triangle -> unique work item -> dedup representative -> special index or descriptor slot

@@ -35,6 +35,9 @@ struct ClassifyParams {
     int   wantKnownCount;     // rejectionThreshold > 0
     int   noFine;             // internal flag DisableFineClassification (bake_cpu_impl.cpp:45,822-823): ResampleFine is skipped, whatever the coarse pass
                               // left unresolved keeps the initial state UnknownOpaque (:427)
+    int   altKernel;          // internal flags DisableLevelLineIntersection (bit 8) / + EnableAABBTesting (bit 7), bake_cpu_impl.cpp:44-45,915-966: 0 = the level-line
+                              // kernel; 1 = ConservativeBilinearKernel over the micro-triangle's raster; 2 = the same over the two triangles of its bounding box
+                              // (Linear filter only; no centre vote, mip 0 only)
     int   pow2Dispatch;       // SizeIsPow2() of mip 0: the template flag of the reference's kernels (bake_cpu_impl.cpp:299);
                               // TextureImpl::Bilinear alone uses the per-mip flag (texture_impl.cpp:266)
 };

@@ -9,6 +9,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "bake_types.h"
+#define OMMX_RC_RCP(x) __builtin_amdgcn_rcpf(x)
+#define OMMX_RC_KUB 1.000002f
+#define OMMX_RC_KLB 0.999998f
 #include "region_curve.h"
 
 namespace ommx {
@@ -549,6 +552,26 @@ __device__ __forceinline__ void nearest_texel(const ClassifyParams& P, const Dev
     vote(P.cutoff < alpha, above, below);
 }
 
+// bake_kernels_cpu.h:404-452 (ConservativeBilinearKernel, the reference's alternative to the level-line kernel behind internal flag bit 8): the four texels of
+// the cell at int(pixel + 0.5) -- a conversion that truncates towards zero, so negative pixels take the cell one further in -- vote by their extremes
+template <bool FP32, class MD>
+__device__ __forceinline__ void conservative_bilinear_texel(const ClassifyParams& P, const DevMip& m, int px, int py, uint32_t& above, uint32_t& below, const TexWindow& W)
+{
+    const int ix = cvt_trunc_x86((float)px + 0.5f), iy = cvt_trunc_x86((float)py + 0.5f);
+    const int x0 = tex_coord(MD::addr(P), MD::pow2(P), ix, m.w, m.log2w), y0 = tex_coord(MD::addr(P), MD::pow2(P), iy, m.h, m.log2h);
+    const int x1 = tex_coord(MD::addr(P), MD::pow2(P), ix + 1, m.w, m.log2w), y1 = tex_coord(MD::addr(P), MD::pow2(P), iy + 1, m.h, m.log2h);
+    float gx, gy, gz, gw;   // 00, 01, 11, 10
+    if (MD::addr(P) == 3) {
+        gx = load_texel_border<FP32>(m, x0, y0, P.borderAlpha, W); gy = load_texel_border<FP32>(m, x0, y1, P.borderAlpha, W);
+        gz = load_texel_border<FP32>(m, x1, y1, P.borderAlpha, W); gw = load_texel_border<FP32>(m, x1, y0, P.borderAlpha, W);
+    } else {
+        gx = load_texel<FP32>(m, x0, y0, W); gy = load_texel<FP32>(m, x0, y1, W); gz = load_texel<FP32>(m, x1, y1, W); gw = load_texel<FP32>(m, x1, y0, W);
+    }
+    const float mn = std_min(std_min(std_min(gx, gy), gz), gw), mx = std_max(std_max(std_max(gx, gy), gz), gw);
+    above += (P.cutoff < mx) ? 1u : 0u;
+    below += (P.cutoff > mn) ? 1u : 0u;
+}
+
 // ---- conservative rasterisation of one micro-triangle (util/cpu_raster.h:20-52,117-124,277-383) ----
 struct EdgeEq { float nx, ny, c, bias; };
 __device__ __forceinline__ EdgeEq edge_eq(V2 p, V2 q)
@@ -567,7 +590,7 @@ __device__ __forceinline__ float eval_cons(const EdgeEq& e, float sx, float sy)
     return ev + bx * 1.f + by * 1.f;
 }
 
-// KIND: 0 = level-line (linear filter), 1 = nearest vote
+// KIND: 0 = level-line (linear filter), 1 = nearest vote, 2 = ConservativeBilinearKernel (internal flag bit 8)
 template <bool FP32, int KIND, class MD>
 __device__ __forceinline__ void raster_micro_triangle(const ClassifyParams& P, const DevMip& m, const MicroTri& t, float off,
                                                       uint32_t& above, uint32_t& below, const TexWindow& W)
@@ -608,7 +631,8 @@ __device__ __forceinline__ void raster_micro_triangle(const ClassifyParams& P, c
         const bool inside = eval_cons(e0, sx, sy) < 0.f && eval_cons(e1, sx, sy) < 0.f && eval_cons(e2, sx, sy) < 0.f;
             if (inside) {
                 if (KIND == 0) level_line_texel<FP32, false, MD>(P, m, t, x, y, above, below, W);
-                else nearest_texel<FP32, MD>(P, m, x, y, above, below, W);
+                else if (KIND == 1) nearest_texel<FP32, MD>(P, m, x, y, above, below, W);
+                else conservative_bilinear_texel<FP32, MD>(P, m, x, y, above, below, W);
                 if (!countsMatter && above != 0 && below != 0) return;
                 wasInside = true;
             } else if (wasInside) break;
@@ -771,7 +795,7 @@ __device__ __forceinline__ int region_state_ex(const ClassifyParams& P, const Mi
 // subdivision level `level`; `sh` = rc_shape() of that item.  Returns the state every descendant ends with -- whichever of the reference's passes classifies
 // it: the votes of ResampleFine all fall on one side of the cutoff, and a descendant that ResampleCoarse resolves has all its texels on that side --
 // or -1.  Independent of the summed-area table: it also culls bakes of textures without one.  Texels come from HBM / L2 (at most 5 x 5 per call).
-__device__ __forceinline__ bool region_curve_applies(const ClassifyParams& P) { return P.filterLinear != 0 && P.mipCount == 1 && P.noFine == 0; }
+__device__ __forceinline__ bool region_curve_applies(const ClassifyParams& P) { return P.filterLinear != 0 && P.mipCount == 1 && P.noFine == 0 && P.altKernel == 0; }
 struct RcTex { const void* texels; int w, h; float fw, fh; int addr, pow2, fp32; float cutoff; int stateGT, stateLE; };   // what the test reads of ClassifyParams
 template <class MD>
 __device__ __forceinline__ RcTex rc_tex(const ClassifyParams& P, bool fp32)
@@ -813,6 +837,31 @@ __device__ __forceinline__ int region_curve_state(const ClassifyParams& P, bool 
 __device__ __attribute__((noinline)) int region_curve_state_call(RcTex T, RcShape sh, float lox, float loy, float hix, float hiy, float maxAbs)
 {
     return region_curve_state_impl(T, sh, lox, loy, hix, hiy, maxAbs);
+}
+
+// The curve-free-region test for ONE micro-triangle that lies in one texel cell, from its own vertices (region_curve.h: rc_shape_micro): the answer of
+// fine_single_texel() + single_texel_edges() below -- a pure state -- for ~100 instructions instead of ~550 when the level curve of the cell stays clear of the
+// micro-triangle, -1 otherwise (more than one cell, a shape the bounds do not cover, the curve too close).  FINITE precondition as fine_single_texel().
+// ux, uy: rounding unit of the item's raster coordinates (size x largest |uv| of the axis x 2^-24).
+template <bool FP32, class MD>
+__device__ __forceinline__ int micro_curve_state(const ClassifyParams& P, const MicroTri& t, float ux, float uy, const TexWindow& W)
+{
+    const DevMip& m = P.mips[0];
+    const float lox = __builtin_fminf(__builtin_fminf(t.p0.x, t.p1.x), t.p2.x), loy = __builtin_fminf(__builtin_fminf(t.p0.y, t.p1.y), t.p2.y);
+    const float hix = __builtin_fmaxf(__builtin_fmaxf(t.p0.x, t.p1.x), t.p2.x), hiy = __builtin_fmaxf(__builtin_fmaxf(t.p0.y, t.p1.y), t.p2.y);
+    // cells the rasteriser and the centre vote can touch: [floor(lo * size - 0.5), floor(hi * size - 0.5)] (monotone in the vertex, so the box corners do)
+    const float fx0 = __builtin_floorf(lox * m.fw - 0.5f), fy0 = __builtin_floorf(loy * m.fh - 0.5f);
+    const float fx1 = __builtin_floorf(hix * m.fw - 0.5f), fy1 = __builtin_floorf(hiy * m.fh - 0.5f);
+    const bool oneCell = (fx0 == fx1) & (fy0 == fy1);
+    float g00, g01, g11, g10;
+    fetch_cell<FP32, MD>(P, m, MD::pow2(P), (int)fx0, (int)fy0, W, g00, g01, g11, g10);
+    const float pfx = fx0 + 0.5f, pfy = fy0 + 0.5f;
+    const float r0x = m.fw * t.p0.x - pfx, r0y = m.fh * t.p0.y - pfy, r1x = m.fw * t.p1.x - pfx, r1y = m.fh * t.p1.y - pfy, r2x = m.fw * t.p2.x - pfx, r2y = m.fh * t.p2.y - pfy;
+    const RcShape sh = rc_shape_micro(r0x, r0y, r1x, r1y, r2x, r2y, ux, uy);
+    const int c = rc_cell(&sh, g00, g10, g01, g11, P.cutoff, __builtin_fminf(__builtin_fminf(r0x, r1x), r2x), __builtin_fmaxf(__builtin_fmaxf(r0x, r1x), r2x),
+                          __builtin_fminf(__builtin_fminf(r0y, r1y), r2y), __builtin_fmaxf(__builtin_fmaxf(r0y, r1y), r2y));
+    const int st = c > 0 ? P.stateGT : P.stateLE;
+    return (oneCell & (sh.ok != 0) & ((c == 1) | (c == -1)) & (st != 3)) ? st : -1;
 }
 
 // ---- fine pass of a micro-triangle whose conservative raster covers ONE texel of mip 0 (Linear filter, non-degenerate item) ----
@@ -933,6 +982,17 @@ template <bool FP32, class MD>
 __device__ __forceinline__ int fine_state(const ClassifyParams& P, const MicroTri& t, bool degenerate, const TexWindow& W)
 {
     uint32_t above = 0, below = 0;
+    if (P.filterLinear && P.altKernel) {   // bake_cpu_impl.cpp:915-966: no centre vote, mip 0 only, degenerate items like the others
+        const DevMip& m = P.mips[0];
+        if (P.altKernel == 2) {            // EnableAABBTesting: the two triangles of the micro-triangle's bounding box
+            MicroTri t0, t1;
+            t0.p0 = t.lo; t0.p1 = mk2(t.hi.x, t.lo.y); t0.p2 = mk2(t.lo.x, t.hi.y); finish_tri(t0);
+            t1.p0 = t.hi; t1.p1 = mk2(t.hi.x, t.lo.y); t1.p2 = mk2(t.lo.x, t.hi.y); finish_tri(t1);
+            raster_micro_triangle<FP32, 2, MD>(P, m, t0, -0.5f, above, below, W);
+            raster_micro_triangle<FP32, 2, MD>(P, m, t1, -0.5f, above, below, W);
+        } else raster_micro_triangle<FP32, 2, MD>(P, m, t, -0.5f, above, below, W);
+        return state_from_coverage(P, above, below);
+    }
     for (int mip = 0; mip < P.mipCount; ++mip) {
         const DevMip& m = P.mips[mip];
         if (P.filterLinear) {

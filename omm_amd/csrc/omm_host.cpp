@@ -229,14 +229,16 @@ struct HostPool {
 // (the baker's result pool); anything else keeps to hipMemcpyAsync.
 struct SdmaCopier {
     hsa_agent_t gpu{ 0 }, cpu{ 0 }; hsa_signal_t sig{ 0 }; bool ok = false; int64_t pending = 0;
-    struct Find { int wantOrdinal, seen; uint32_t wantBdf; bool haveBdf; hsa_agent_t gpu, cpu; bool gotGpu, gotCpu; };
+    struct Find { int wantOrdinal, seen; uint32_t wantBdf, wantDomain; bool haveBdf; hsa_agent_t gpu, cpu; bool gotGpu, gotCpu; };
     static hsa_status_t visit(hsa_agent_t a, void* u) {
         Find& f = *(Find*)u; hsa_device_type_t t;
         if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
         if (t == HSA_DEVICE_TYPE_CPU && !f.gotCpu) { f.cpu = a; f.gotCpu = true; }
         if (t == HSA_DEVICE_TYPE_GPU) {
             uint32_t bdf = 0; const bool hb = hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) == HSA_STATUS_SUCCESS;
-            const bool match = f.haveBdf && hb ? (bdf & 0xFFFFu) == f.wantBdf : f.seen == f.wantOrdinal;
+            // (bus / device / function alone is not unique on hosts with several PCI domains: the domain has to agree too, where the runtime reports it)
+            uint32_t dom = 0; const bool hd = hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &dom) == HSA_STATUS_SUCCESS;
+            const bool match = f.haveBdf && hb ? (bdf & 0xFFFFu) == f.wantBdf && (!hd || dom == f.wantDomain) : f.seen == f.wantOrdinal;
             if (match && !f.gotGpu) { f.gpu = a; f.gotGpu = true; }
             f.seen++;
         }
@@ -246,7 +248,7 @@ struct SdmaCopier {
         if (hsa_init() != HSA_STATUS_SUCCESS) return false;   // (reference counted: HIP holds the runtime open already)
         Find f; memset(&f, 0, sizeof f); f.wantOrdinal = hipDevice;
         char bus[32] = { 0 };
-        if (hipDeviceGetPCIBusId(bus, sizeof bus, hipDevice) == hipSuccess) { unsigned dom = 0, b = 0, d = 0, fn = 0; if (sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &fn) == 4) { f.wantBdf = (b << 8) | (d << 3) | fn; f.haveBdf = true; } }
+        if (hipDeviceGetPCIBusId(bus, sizeof bus, hipDevice) == hipSuccess) { unsigned dom = 0, b = 0, d = 0, fn = 0; if (sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &fn) == 4) { f.wantBdf = (b << 8) | (d << 3) | fn; f.wantDomain = dom; f.haveBdf = true; } }
         if (hsa_iterate_agents(visit, &f) != HSA_STATUS_SUCCESS || !f.gotGpu || !f.gotCpu) { (void)hsa_shut_down(); return false; }
         gpu = f.gpu; cpu = f.cpu;
         if (hsa_signal_create(0, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) { (void)hsa_shut_down(); return false; }
@@ -300,10 +302,10 @@ struct Baker {
 
 // HIP events on the bake's own stream (torch / the caller never see this stream)
 struct EventTimer {
-    hipStream_t s; hipEvent_t ev[16]; int n = 0;
+    hipStream_t s; hipEvent_t ev[24]; int n = 0;
     explicit EventTimer(hipStream_t st) : s(st) { for (auto& e : ev) e = nullptr; }
     ~EventTimer() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
-    int mark() { if (n >= 16) return -1; if (hipEventCreate(&ev[n]) != hipSuccess) return -1; (void)hipEventRecord(ev[n], s); return n++; }
+    int mark() { if (n >= 24) return -1; if (hipEventCreate(&ev[n]) != hipSuccess) return -1; (void)hipEventRecord(ev[n], s); return n++; }
     float ms(int a, int b) const { float v = 0.f; if (a < 0 || b < 0 || hipEventElapsedTime(&v, ev[a], ev[b]) != hipSuccess) return 0.f; return v; }
 };
 inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -585,6 +587,7 @@ struct StreamCtx {   // what the hook behind a classification launch needs
     uint64_t* digests; unsigned long long* cursor; uint8_t* stage; uint64_t* placed; uint32_t* ctl; unsigned long long* hostCursor; hipEvent_t* events; uint32_t numEvents, recorded; bool ok;
     const uint32_t* queueCtl; bool paired;                 // paired: two queue sections per range (bake_kernels.h: ClassifyChunks)
     const uint32_t* earlyList; uint32_t earlyCapacity; const uint8_t* itemLevel;   // the early class ordered by the range it is classified with (ctl: start / count per range)
+    double waitSeconds;   // how long the placement stream waits for a range before it gives the stream up (scaled with the estimated classification time)
 };
 // in front of the persistent launch: the placement stream starts behind the tile triage (the section tails are final from here on)
 void stream_mark_hook(void* user)
@@ -600,7 +603,7 @@ void stream_hook(void* user, uint32_t chunk, const ClassifySegment* segs, uint32
     StreamCtx& c = *(StreamCtx*)user;
     if (chunk >= c.numEvents) { c.ok = false; return; }
     if (last) c.ok = c.ok && hipEventRecord(c.fences[1], c.stream) == hipSuccess && hipStreamWaitEvent(c.place, c.fences[1], 0) == hipSuccess;   // (the lower levels: behind everything)
-    else launch_stream_wait_sections(c.queueCtl, c.paired ? 2u * chunk : chunk, c.paired ? 2u : 1u, c.ctl, c.place);
+    else launch_stream_wait_sections(c.queueCtl, c.paired ? 2u * chunk : chunk, c.paired ? 2u : 1u, c.ctl, c.waitSeconds, c.place);
     // CalcDigest (bake_cpu_impl.cpp:1038-1040).  A range of the levels >= 6: its own items (the early ones among them have their digest from this range
     // or an earlier one) and, in the same launch, the early items classified WITH this range -- the families that start in it, wherever their members lie --,
     // which then enter the table ahead of the range's placement
@@ -723,6 +726,10 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     const Texture& tex = *untag<Texture>(d.texture);
     const uint32_t T = d.indexCount / 3u;
     const int bits = (int)d.format;
+    // DisableFineClassification with the 2-state format (internal flag bit 9): unresolved micro-triangles keep UnknownOpaque (3), which has no 1-bit form -- the
+    // reference digests the unpacked states and ORs `3 << (i & 7)` into the packed bytes (bake_cpu_impl.cpp:1811).  The states are therefore kept in the
+    // 2-bit packing up to the final gather, which applies that rule (launch_gather_omms: storeBits != bits).
+    const int storeBits = (bits == 1 && (flags & (1u << 9))) ? 2 : bits;
     const uint32_t maxItems = T ? T : 1;
 
     // ---- device layout (worst case: every triangle is its own work item) ----
@@ -760,6 +767,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     if (arena->used > arena->cap) return L.failure("[Failure] - internal error: the working-set layout exceeds its reservation");
 
     // ---- SetupWorkItems (bake_cpu_impl.cpp:589-660) on the device ----
+    const double coreT0 = now_ms();
     const int e0 = et.mark();
     SetupParams S; memset(&S, 0, sizeof S);
     S.texCoords = din.texCoords; S.indices = din.indices; S.perTriLevels = din.perTriLevels;
@@ -808,15 +816,16 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     P.texIsFp32 = tex.format == ommCpuTextureFormat_FP32;
     P.addrMode = d.runtimeSamplerDesc.addressingMode;
     P.filterLinear = d.runtimeSamplerDesc.filter == ommTextureFilterMode_Linear;
-    P.format = bits; P.promotion = d.unknownStatePromotion; P.stateGT = d.alphaCutoffGreater; P.stateLE = d.alphaCutoffLessEqual;
+    P.format = storeBits; P.promotion = d.unknownStatePromotion; P.stateGT = d.alphaCutoffGreater; P.stateLE = d.alphaCutoffLessEqual;
     P.useCoarse = tex.mips[0].sat != nullptr && P.mipCount == 1 && P.filterLinear;
     P.cutoff = d.alphaCutoff; P.borderAlpha = d.runtimeSamplerDesc.borderAlpha;
     P.wantKnownCount = d.rejectionThreshold > 0.f;
     P.noFine = (flags & (1u << 9)) != 0;   // DisableFineClassification (bake_cpu_impl.cpp:45,822-823)
+    P.altKernel = (flags & (1u << 8)) ? ((flags & (1u << 7)) ? 2 : 1) : 0;   // DisableLevelLineIntersection (+ EnableAABBTesting), bake_cpu_impl.cpp:44-45,915-966
 
     // ---- level-0 hierarchical query per item + compaction of the items that need per-micro-triangle work; ONE sync ----
     launch_triage(P, dUv, dLevel, dDegen, dCounters, maxItems, dMask, dActive, stream);
-    if (!HIP_OK(run_prep(dItemIds, dActive, dLevel, bits, maxItems, dCounters, dActiveIds, dStateOfs, dScratch, scratchBytes, stream)) ||
+    if (!HIP_OK(run_prep(dItemIds, dActive, dLevel, storeBits, maxItems, dCounters, dActiveIds, dStateOfs, dScratch, scratchBytes, stream)) ||
         !HIP_OK(hipMemcpyAsync(&hc, dCounters, sizeof hc, hipMemcpyDeviceToHost, stream)) || !HIP_OK(hipStreamSynchronize(stream)))
         return L.failure("[Failure] - device work-list compaction failed");
 
@@ -866,7 +875,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         }
         if (T) ok = ok && HIP_OK(hipMemcpyAsync(dTriToItem, triToItem.data(), (size_t)T * 4, hipMemcpyHostToDevice, stream));
         launch_triage(P, dUv, dLevel, dDegen, dCounters, maxItems, dMask, dActive, stream);
-        ok = ok && HIP_OK(run_prep(dItemIds, dActive, dLevel, bits, maxItems, dCounters, dActiveIds, dStateOfs, dScratch, scratchBytes, stream));
+        ok = ok && HIP_OK(run_prep(dItemIds, dActive, dLevel, storeBits, maxItems, dCounters, dActiveIds, dStateOfs, dScratch, scratchBytes, stream));
         ok = ok && HIP_OK(hipMemcpyAsync(&hc, dCounters, sizeof hc, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipStreamSynchronize(stream));
         if (!ok) return L.failure("[Failure] - serial work-item setup failed");
     }
@@ -885,6 +894,8 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             L.msg(ommMessageSeverity_PerfWarning, buf);
         }
     }
+    if ((flags & (1u << 7)) && !(flags & (1u << 8)))   // bake_cpu_impl.cpp:718-719 (ResampleCoarse is the first to look, behind the workload validation)
+        return L.invalid("[Invalid Arg] - EnableAABBTesting can't be used without also setting DisableLevelLineIntersection");
     // rank ranges of the per-level active lists (single GPU: every range is the whole level group)
     ShardBounds bounds; memset(&bounds, 0, sizeof bounds);
     bounds.rank = sh ? sh->rank : 0; bounds.world = sh ? sh->world : 1;
@@ -900,7 +911,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     // ---- streamed result (ommCpuBake)?  Worth it when the packed states are large enough for the copy to matter ----
     uint32_t streamChunks = 0; const uint32_t numActiveAll = hc.activeStart[kNumLevels];
     uint8_t* hostArray = nullptr; unsigned long long* hCursor = nullptr; bool hostPinned = false;
-    if (so && numActiveAll && !(flags & (1u << 1)) && !hc.collision) {   // (with special indices disabled every uniform item is a block too: the plain path handles that)
+    if (so && numActiveAll && !(flags & (1u << 1)) && !hc.collision && !P.altKernel && storeBits == bits) {   // (with special indices disabled every uniform item is a block too: the plain path handles that)
         uint32_t k = so->chunksWanted;
         if (!so->forced) {
             // >= 64 MiB of packed states: one range per 32 MiB, at most 24 (measured at 1.27 GB: 8 / 16 / 24 / 32 ranges = 38.4 / 36.7 / 36.2 / 36.2 ms)
@@ -925,7 +936,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         const uint64_t mode = baker.knob(ommxBakerKnob_GenericPass);
         const bool wanted = mode == 2 || (mode == 0 && 4e-9 * (double)hc.workload > 2.5e-10 * microAll);
         if (wanted && !streamChunks && !(sh && sh->mergeStates) && !ht && numActiveAll) {
-            genericCapacity = hc.stateBytes * 8ull / (uint64_t)bits;            // every micro-triangle of every active item ...
+            genericCapacity = hc.stateBytes * 8ull / (uint64_t)storeBits;            // every micro-triangle of every active item ...
             if (genericCapacity > (256ull << 20)) genericCapacity = 256ull << 20;   // ... at most 2 GB of entries (a tile that finds no room walks its micro-triangles itself)
         }
     }
@@ -961,6 +972,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     StreamCtx sc; ClassifyChunks cc; memset(&cc, 0, sizeof cc); cc.count = 1;
     MarkCtx mk; mk.et = &et; mk.mark = -1; mk.markGeneric = -1;
     const bool noDedup = (flags & (1u << 3)) != 0;
+    int pv0 = -1, pv1 = -1;   // HIP event marks around the preview of a streamed bake
     if (streamChunks) {
         bool oks = HIP_OK(hipMemsetAsync(dPlaced, 0xFF, (size_t)maxItems * 8, stream)) && HIP_OK(hipMemsetAsync(dCursor, 0, 8, stream)) && HIP_OK(hipMemsetAsync(dStreamCtl, 0, sizeof(uint32_t) * kStreamCtlWords, stream));
         oks = oks && HIP_OK(run_stream_begin(dActiveIds, numActiveAll, dUv, dLevel, dScratch, scratchBytes, stream));
@@ -973,9 +985,11 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         sc.proto.rejectionThreshold = d.rejectionThreshold; sc.proto.bits = bits; sc.proto.disableDedup = noDedup ? 1 : 0;
         cc.count = streamChunks; cc.after = stream_hook; cc.mark = stream_mark_hook; cc.user = &sc; cc.early = nullptr; sc.queueCtl = dQueueCtl;
         sc.paired = streamChunks > 1; sc.earlyList = nullptr; sc.earlyCapacity = 0; sc.itemLevel = dLevel;
+        sc.waitSeconds = 4.0 + 100.0 * 1e-3 * (2.5e-10 * microAll + 4e-9 * (double)hc.workload);   // (100 x the estimate of the whole classification, never below 4 s)
         // preview (tail_kernels.hip): level-5 classification of the items of level >= 6 into buffers of its own; items that share their preview are classified early
         const uint32_t first6 = hc.activeStart[6], count6 = numActiveAll - hc.activeStart[6];
         if (count6 && streamChunks > 1) {
+            pv0 = et.mark();
             ClassifyParams P2 = P; P2.format = 2; P2.promotion = 1; P2.wantKnownCount = 0; P2.noFine = 0;
             ItemArrays A2 = A; A2.uv = dUv2; A2.stateOfs = dOfs2; A2.states = dStates2; A2.stateMask = dMask2; A2.fineCount = dFine2;   // (its level-line statistic goes nowhere)
             bool okp = HIP_OK(hipMemsetAsync(dEarly, 0, maxItems, stream)) && HIP_OK(hipMemsetAsync(dMask2, 0, (size_t)maxItems * 4, stream));
@@ -992,11 +1006,12 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             okp = okp && HIP_OK(run_stream_preview_flags(dActiveIds + first6, count6, first6, numActiveAll, dStates2, dLevel, dEarly, dStreamCtl, dScratch, scratchBytes, dEarlyLead, dEarlyList, plan, stream));
             if (!okp) return L.failure("[Failure] - could not set up the streamed result");
             cc.early = dEarly; cc.earlyLead = dEarlyLead; cc.earlyStage = dStage; sc.proto.early = dEarly; sc.earlyList = dEarlyList; sc.earlyCapacity = count6;
+            pv1 = et.mark();
         }
     } else { cc.mark = mark_hook; cc.user = &mk; cc.early = nullptr; }   // (HIP event in front of the persistent launch of the levels >= 6)
     if (dGeneric) {
         if (!HIP_OK(hipMemsetAsync(dGeneric, 0, 256, stream))) return L.failure("[Failure] - device memset failed");
-        cc.generic.count = (uint32_t*)dGeneric; cc.generic.entries = (uint2*)(dGeneric + 256); cc.generic.capacity = (uint32_t)genericCapacity;
+        cc.generic.count = (unsigned long long*)dGeneric; cc.generic.entries = (uint2*)(dGeneric + 256); cc.generic.capacity = (uint32_t)genericCapacity;
         cc.markGeneric = mark_generic_hook;   // (cc.user is the MarkCtx: a deferred pass and a streamed result exclude each other)
     }
     if (!HIP_OK(launch_classify(P, A, dActiveIds, lvlFirst, lvlCount, dTileQueue, dQueueCtl, device_cu_count(), stream, &cc))) return L.failure("[Failure] - kernel launch failed");
@@ -1010,7 +1025,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     // ---- CalcDigest (bake_cpu_impl.cpp:1038-1040): active items here, uniform ones from the table in the tail ----
     if (!noDedup && !streamChunks)   // (a streamed bake computed them range by range)
         for (int l = 0; l < kNumLevels; ++l)
-            launch_digest(dStates, dStateOfs, dActiveIds + bounds.b[l][bounds.rank], bounds.b[l][bounds.rank + 1] - bounds.b[l][bounds.rank], (uint32_t)l, (uint32_t)bits, dDigests, stream);
+            launch_digest(dStates, dStateOfs, dActiveIds + bounds.b[l][bounds.rank], bounds.b[l][bounds.rank + 1] - bounds.b[l][bounds.rank], (uint32_t)l, (uint32_t)storeBits, dDigests, stream);
     if (!HIP_OK(hipGetLastError())) return L.failure("[Failure] - kernel launch failed");
     const int e3 = et.mark();
     // ---- streamed result: everything is enqueued; follow the classification launches and send what each one placed ----
@@ -1021,11 +1036,15 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         for (uint32_t k = 0; k < sc.recorded; ++k) {
             if (!HIP_OK(hipEventSynchronize(chunkEvents.ev[k]))) return L.failure("[Failure] - the classification failed");
             if (k + 1u == sc.recorded) so->classifyEndMs = now_ms();
+            if (k < 32u) tm.streamRangeReadyMs[k] = (float)(now_ms() - coreT0);
             const uint64_t cur = *(volatile unsigned long long*)(hCursor + k);
             if (cur > sent) {
-                const bool okc = cur <= hc.stateBytes && (useSdma ? sdma.copy_to_host(hostArray + sent, dStage + sent, (size_t)(cur - sent))
-                                                                  : HIP_OK(hipMemcpyAsync(hostArray + sent, dStage + sent, (size_t)(cur - sent), hipMemcpyDeviceToHost, so->copyStream)));
+                // (a copy the DMA engine refuses goes through the HIP runtime instead of failing the bake)
+                const bool okc = cur <= hc.stateBytes && ((useSdma && sdma.copy_to_host(hostArray + sent, dStage + sent, (size_t)(cur - sent)))
+                                                          || HIP_OK(hipMemcpyAsync(hostArray + sent, dStage + sent, (size_t)(cur - sent), hipMemcpyDeviceToHost, so->copyStream)));
                 if (!okc) return L.failure("[Failure] - device to host transfer of the bake result failed");
+                if (sent == 0) tm.streamFirstCopyMs = (float)(now_ms() - coreT0);
+                tm.streamLastCopyMs = (float)(now_ms() - coreT0);
                 sent = cur;
             }
         }
@@ -1085,7 +1104,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         if (!streamed) R.arrayData = (uint8_t*)R.dev_alloc((size_t)counts.arrayDataSize);
         ok = R.descs != nullptr && (streamed || R.arrayData != nullptr);
         if (ok) {
-            if (!streamed) launch_gather_omms(dStates, dStateOfs, dActive, dMask, dLevel, bits, dOrder, dDstOfs, dSizes, E, R.arrayData, stream);
+            if (!streamed) launch_gather_omms(dStates, dStateOfs, dActive, dMask, dLevel, bits, storeBits, dOrder, dDstOfs, dSizes, E, R.arrayData, stream);
             launch_write_descs(dOrder, dDstOfs, dLevel, bits, E, R.descs, stream);
         }
     }
@@ -1105,7 +1124,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     uint32_t queueTails[2] = { 0u, 0u };   // open tiles of the two tile sizes (statistics)
     uint32_t hostCtl[kClassifyCtlWords]; memset(hostCtl, 0, sizeof hostCtl);
     if (hc.activeStart[kNumLevels]) ok = ok && HIP_OK(hipMemcpyAsync(hostCtl, dQueueCtl, sizeof hostCtl, hipMemcpyDeviceToHost, stream));
-    uint32_t genericCount = 0;
+    unsigned long long genericCount = 0;
     if (dGeneric) ok = ok && HIP_OK(hipMemcpyAsync(&genericCount, dGeneric, sizeof genericCount, hipMemcpyDeviceToHost, stream));
     const int e5 = et.mark();
     ok = ok && HIP_OK(hipStreamSynchronize(stream));
@@ -1116,6 +1135,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     memcpy(fineSlots.data(), span.data() + ((const uint8_t*)dFine - (const uint8_t*)dArrayHist), sizeof(unsigned long long) * fineSlots.size());
 
     tm.uploadMs = 0.f; tm.hostSetupMs = 0.f; tm.setupMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.digestMs = et.ms(e2, e3);
+    tm.streamPreviewMs = pv0 >= 0 ? et.ms(pv0, pv1) : 0.f;
     tm.tailMs = et.ms(e3, e4); tm.gatherMs = et.ms(e4, e5); tm.persistentMs = mk.mark >= 0 ? et.ms(mk.mark, mk.markGeneric >= 0 ? mk.markGeneric : e2) : 0.f;
     tm.genericMs = mk.markGeneric >= 0 ? et.ms(mk.markGeneric, e2) : 0.f; tm.genericMicroTriangles = genericCount < genericCapacity ? genericCount : genericCapacity;
     for (int k = 0; k < kFineSlots; ++k) fineCount += fineSlots[(size_t)k * kFineStride];
@@ -1133,20 +1153,19 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
 
 inline bool wants_host_tail(const ommCpuBakeInputDesc& d) { return ((uint32_t)d.bakeFlags & ((1u << 4) | (1u << 10))) != 0 || d.maxArrayDataSize != 0xFFFFFFFFu; }
 
-ommResult scope_fences(const Baker& baker, const ommCpuBakeInputDesc& d, bool formatsOnHost, bool hostTailOk = true)
+ommResult scope_fences(const Baker& baker, const ommCpuBakeInputDesc& d, bool formatsOnHost, bool hostTailOk = true, bool plainEntry = true)
 {
     const Logger& L = baker.log;
     const uint32_t flags = (uint32_t)d.bakeFlags;
     if (wants_host_tail(d) && !hostTailOk) // the serial reducers run on the host over the merged states: not in the caller-driven four-phase protocol
         { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - near-duplicate merging / maxArrayDataSize budgets are available through ommCpuBake, ommxBakeDevice and ommxShardedBakeRccl, not through ommxShardedBegin/Tail/Finish"); return ommResult_NOT_IMPLEMENTED; }
-    // internal flags (bake_cpu_impl.cpp:43-48): DisableFineClassification (9), the brute-force near-duplicate search (10) and EnableEdgeHeuristic (11)
-    // are honoured; the two switches of the reference's alternative ConservativeBilinearKernel (7, 8) are not built
-    if ((flags & ((1u << 7) | (1u << 8))) != 0)
-        { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - internal bake flags EnableAABBTesting / DisableLevelLineIntersection (bits 7, 8) are not supported"); return ommResult_NOT_IMPLEMENTED; }
+    // internal flags (bake_cpu_impl.cpp:43-48): EnableAABBTesting (7) / DisableLevelLineIntersection (8) select the reference's ConservativeBilinearKernel
+    // (ClassifyParams::altKernel), DisableFineClassification (9), the brute-force near-duplicate search (10) and EnableEdgeHeuristic (11) are honoured
     // without the fine pass unresolved micro-triangles keep the state UnknownOpaque (3), which the reference ORs into ONE bit of a 2-state block together with
-    // its neighbour's (bake_cpu_impl.cpp:1811) while digesting the unpacked value: not reproducible from packed states
-    if ((flags & (1u << 9)) != 0 && d.format == ommFormat_OC1_2_State)
-        { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - internal bake flag DisableFineClassification (bit 9) is supported for OC1_4_State only"); return ommResult_NOT_IMPLEMENTED; }
+    // its neighbour's (bake_cpu_impl.cpp:1811) while digesting the unpacked value: bake_core keeps such a bake in the 2-bit packing up to the final gather --
+    // on the two single-device entry points; not where blocks travel between ranks or to the host tail in their packed form
+    if ((flags & (1u << 9)) != 0 && d.format == ommFormat_OC1_2_State && (!plainEntry || wants_host_tail(d)))
+        { L.msg(ommMessageSeverity_Fatal, "[Not Implemented] - internal bake flag DisableFineClassification (bit 9) with OC1_2_State is supported by ommCpuBake / ommxBakeDevice without near-duplicate merging or a size budget"); return ommResult_NOT_IMPLEMENTED; }
     if (d.formats) { // the reference sizes its arrays from the global format only (bake_cpu_impl.cpp:1763-1772): mixed formats corrupt its heap
         if (!formatsOnHost) return L.failure("[Failure] - per-triangle formats are not supported on the device-resident entry point");
         for (uint32_t i = 0; i < d.indexCount / 3u; ++i)
@@ -1795,6 +1814,13 @@ struct RcclComm {
     }
     const char* error_string(int code) const { return custom ? "the caller's collective reported a failure" : (rccl().getErrorString ? rccl().getErrorString(code) : "RCCL error"); }
 };
+// The two status words and the stream of idle ranks are set up when the communicator is made (on the device that is current then), so that a rank
+// that has run out of device memory later can still take part in every agreement; rccl_agree() only allocates if that did not succeed.
+void rccl_prepare_status(RcclComm* c)
+{
+    if (!c->dStatus && !HIP_OK(hipMalloc((void**)&c->dStatus, 2 * sizeof(uint32_t)))) { c->dStatus = nullptr; (void)hipGetLastError(); }
+    if (!c->statusStream && !HIP_OK(hipStreamCreateWithFlags(&c->statusStream, hipStreamNonBlocking))) { c->statusStream = nullptr; (void)hipGetLastError(); }
+}
 // A rank-local failure (out of memory, mostly) must not leave the other ranks waiting in the next collective: before every data collective each rank
 // contributes its status to a one-element MIN all-reduce and all of them go on, or none.  `stream`: the bake's stream (idle ranks: the communicator's own).
 bool rccl_agree(RcclComm* rc, hipStream_t stream, bool mineOk, const Logger& L, const char* stage)
@@ -1852,7 +1878,7 @@ ommResult sharded_checks(ommBaker baker, const ommCpuBakeInputDesc* desc, Baker*
         return ommResult_FAILURE;
     ommResult r = validate_desc(*b, *desc);
     if (r != ommResult_SUCCESS) return r;
-    r = scope_fences(*b, *desc, false, hostTailOk);
+    r = scope_fences(*b, *desc, false, hostTailOk, false);
     if (r != ommResult_SUCCESS) return r;
     *outB = b;
     return ommResult_SUCCESS;
@@ -2048,6 +2074,7 @@ OMM_MI355X_API ommResult ommxRcclCommInitRank(const void* id, size_t idBytes, ui
     if (!c) return ommResult_FAILURE;
     if (rccl().commInitRank(&c->comm, (int)worldSize, uid, (int)rank) != 0) { delete c; return ommResult_FAILURE; }
     c->owned = true; c->rank = (int)rank; c->world = (int)worldSize;
+    rccl_prepare_status(c);
     *outComm = (ommxRcclComm)c;
     return ommResult_SUCCESS;
 }
@@ -2060,6 +2087,7 @@ OMM_MI355X_API ommResult ommxRcclCommWrap(void* ncclComm, ommxRcclComm* outComm)
     if (!c) return ommResult_FAILURE;
     c->comm = ncclComm; c->owned = false;
     if (rccl().commCount(c->comm, &c->world) != 0 || rccl().commUserRank(c->comm, &c->rank) != 0 || c->world < 1 || c->world > kMaxRanks) { delete c; return ommResult_INVALID_ARGUMENT; }
+    rccl_prepare_status(c);
     *outComm = (ommxRcclComm)c;
     return ommResult_SUCCESS;
 }
@@ -2071,6 +2099,7 @@ OMM_MI355X_API ommResult ommxCommFromCollectives(const ommxCollectives* collecti
     RcclComm* c = new (std::nothrow) RcclComm();
     if (!c) return ommResult_FAILURE;
     c->custom = true; c->user = *collectives; c->rank = (int)rank; c->world = (int)worldSize;
+    rccl_prepare_status(c);
     *outComm = (ommxRcclComm)c;
     return ommResult_SUCCESS;
 }
@@ -2222,14 +2251,22 @@ OMM_MI355X_API ommResult ommxSetBakerKnob(ommBaker baker, ommxBakerKnob knob, ui
     return ommResult_SUCCESS;
 }
 
-OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings* out)
+OMM_MI355X_API ommResult ommxGetLastBakeTimingsSized(ommBaker baker, void* out, size_t outBytes, size_t* libraryBytes)
 {
+    if (libraryBytes) *libraryBytes = sizeof(ommxBakeTimings);
     if (baker == 0 || out == nullptr || tag_of(baker) != kCpuBaker) return ommResult_INVALID_ARGUMENT;
     Baker* b = untag<Baker>(baker);
     std::lock_guard<std::mutex> g(b->timingsMu);
     if (!b->haveTimings) return ommResult_FAILURE;
-    *out = b->timings;
+    // the struct only ever grows at its end: a caller built against an older header gets the prefix it knows, one built against a newer header zeros
+    const size_t n = outBytes < sizeof(ommxBakeTimings) ? outBytes : sizeof(ommxBakeTimings);
+    memcpy(out, &b->timings, n);
+    if (outBytes > n) memset((uint8_t*)out + n, 0, outBytes - n);
     return ommResult_SUCCESS;
+}
+OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings* out)
+{
+    return ommxGetLastBakeTimingsSized(baker, out, sizeof(ommxBakeTimings), nullptr);
 }
 
 #include "serialize.inc"

@@ -929,20 +929,21 @@ hipError_t run_stream_segment(const StreamSegment& g, uint32_t numActive, void* 
 // Holds the placement stream until sections [first, first + n) of the tile queue are complete: done == tail (bake_kernels.hip: classify_tiles).  One lane, asleep
 // between two looks.  The tail is final (the stream was fenced behind the tile triage); a count that never arrives -- it cannot, short of a fault in
 // the classification launch -- ends the wait after ~4 s of the 100 MHz wall clock with the violation word set, which discards the streamed result.
-__global__ void stream_wait_sections(const uint32_t* __restrict__ queueCtl, uint32_t first, uint32_t n, uint32_t* __restrict__ ctl)
+__global__ void stream_wait_sections(const uint32_t* __restrict__ queueCtl, uint32_t first, uint32_t n, uint32_t* __restrict__ ctl, unsigned long long timeoutTicks)
 {
     const uint64_t t0 = wall_clock64();
     for (uint32_t sec = first; sec < first + n; ++sec) {
         const uint32_t want = __hip_atomic_load(queueCtl + kSecTails + sec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (__hip_atomic_load(queueCtl + kSecDone + sec, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want) {
             __builtin_amdgcn_s_sleep(64);
-            if (wall_clock64() - t0 > 400000000ull) { atomicOr(ctl + 1, 1u); return; }
+            if (wall_clock64() - t0 > timeoutTicks) { atomicOr(ctl + 1, 1u); return; }   // (100 MHz ticks; the host scales it with the size of the bake)
         }
     }
 }
-void launch_stream_wait_sections(const uint32_t* queueCtl, uint32_t first, uint32_t n, uint32_t* ctl, hipStream_t stream)
+void launch_stream_wait_sections(const uint32_t* queueCtl, uint32_t first, uint32_t n, uint32_t* ctl, double timeoutSeconds, hipStream_t stream)
 {
-    hipLaunchKernelGGL(stream_wait_sections, dim3(1), dim3(1), 0, stream, queueCtl, first, n, ctl);
+    const double ticks = (timeoutSeconds < 4.0 ? 4.0 : (timeoutSeconds > 3600.0 ? 3600.0 : timeoutSeconds)) * 1e8;
+    hipLaunchKernelGGL(stream_wait_sections, dim3(1), dim3(1), 0, stream, queueCtl, first, n, ctl, (unsigned long long)ticks);
 }
 void launch_stream_publish(const unsigned long long* cursor, unsigned long long* hostSlot, hipStream_t stream)
 {

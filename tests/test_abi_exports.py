@@ -273,3 +273,20 @@ def test_baker_knobs_are_per_baker_state_not_environment():
     lib.destroy_baker(b)
     undefined = subprocess.check_output(["nm", "-D", "--undefined-only", path], text=True)
     assert "getenv" not in undefined.split()
+
+
+def test_timings_struct_of_the_extension_header_matches_its_python_mirror():
+    """ommxBakeTimings (include/omm_mi355x_ext.h) only ever grows at its end; ommxGetLastBakeTimingsSized reports the library's size of it, which must be
+    the size of bench.py's ctypes mirror (a mirror that lags behind the header would read garbage through the unsized getter)."""
+    import bench
+    dll = C.CDLL(ot.product_path())
+    dll.ommxGetLastBakeTimingsSized.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib = ot.Lib("product")
+    b = lib.create_baker()
+    n = C.c_size_t(0)
+    tm = bench.BakeTimings()
+    r = dll.ommxGetLastBakeTimingsSized(b, C.byref(tm), C.sizeof(tm), C.byref(n))
+    assert r == ot.FAILURE            # no bake yet on this baker
+    assert n.value == C.sizeof(bench.BakeTimings), (n.value, C.sizeof(bench.BakeTimings))
+    assert dll.ommxGetLastBakeTimingsSized(None, C.byref(tm), C.sizeof(tm), None) == ot.INVALID_ARGUMENT
+    lib.destroy_baker(b)

@@ -1276,7 +1276,7 @@ def test_internal_flags_no_fine_pass_and_edge_heuristic(product, oracle):
     """Internal bake flags (bake_cpu_impl.cpp:43-48).  Bit 9 (DisableFineClassification) skips ResampleFine: what the summed-area pass leaves
     unresolved keeps the initial UnknownOpaque -- the reference's own "everything but the fine pass" timing switch; bit 11 (EnableEdgeHeuristic)
     selects the edge-length level heuristic for every triangle (glibc log2f on the host).  Bits 7 / 8 (the alternative conservative-bilinear
-    kernel) stay NOT_IMPLEMENTED."""
+    kernel): test_internal_flags_conservative_bilinear_kernel."""
     tex = ot.foliage_texture(3, 512, 512, feature=24)
     uv, ix = ot.random_triangles(31, 600, 0.05)
     lv = (2 + ot.hash_u32(np.arange(600) + 3) % 7).astype(np.uint8)          # levels 2..8: both tile sizes and the small-item launches
@@ -1288,13 +1288,33 @@ def test_internal_flags_no_fine_pass_and_edge_heuristic(product, oracle):
     lv2 = np.where(ot.hash_u32(np.arange(600) + 9) % 3 == 0, 0xF, lv).astype(np.uint8)
     both(product, oracle, [tex], uv, ix, 9, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, dyn_scale=2.0, flags=ot.FLAG_THREADS | (1 << 11))
     both(product, oracle, [tex], uv, ix, 9, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, dyn_scale=0.7, levels=lv2, flags=ot.FLAG_THREADS | (1 << 11) | (1 << 9))
-    b = product.create_baker()
-    t = product.create_texture(b, [tex], alpha_cutoff=0.5)
-    for bit in (7, 8):
-        product.bake(b, ot.make_desc(t, uv, ix, 4, addr=ot.WRAP, flags=ot.FLAG_THREADS | (1 << bit)), expect=ot.NOT_IMPLEMENTED)
-    product.bake(b, ot.make_desc(t, uv, ix, 4, addr=ot.WRAP, flags=ot.FLAG_THREADS | (1 << 9), fmt=ot.FMT_2STATE), expect=ot.NOT_IMPLEMENTED)   # (state 3 has no 1-bit form)
-    product.destroy_texture(b, t)
-    product.destroy_baker(b)
+    # bit 9 with the 2-state format: unresolved micro-triangles keep UnknownOpaque (3), which the reference digests unpacked and ORs into the 1-bit packing as
+    # `3 << (i & 7)` (bake_cpu_impl.cpp:1811) -- every level (blocks of less than a byte included), special indices on and off, dedup on and off
+    lv3 = (ot.hash_u32(np.arange(600) + 5) % 9).astype(np.uint8)             # levels 0..8
+    for sat in (True, False):
+        for extra in (0, ot.FLAG_NO_SPECIAL, ot.FLAG_NO_DEDUP):
+            both(product, oracle, [tex], uv, ix, 8, sat=sat, addr=ot.WRAP, fmt=ot.FMT_2STATE, promo=ot.PROMO_FORCE_OPAQUE, levels=lv3, flags=ot.FLAG_THREADS | (1 << 9) | extra)
+    both(product, oracle, [noise_u8()], uv, ix, 6, addr=ot.CLAMP, fmt=ot.FMT_2STATE, promo=ot.PROMO_NEAREST, rejection=0.4, flags=ot.FLAG_THREADS | (1 << 9))
+
+
+def test_internal_flags_conservative_bilinear_kernel(product, oracle):
+    """Internal bake flags bit 8 (DisableLevelLineIntersection: ConservativeBilinearKernel over the micro-triangle's raster, bake_kernels_cpu.h:404-452,
+    bake_cpu_impl.cpp:941-966) and bits 7 + 8 (EnableAABBTesting: the same kernel over the two triangles of the micro-triangle's bounding box, :915-940): no
+    centre vote, mip 0 only; the summed-area pass in front of it as usual.  Bit 7 alone is an invalid argument (:718-719)."""
+    tex = ot.foliage_texture(3, 512, 512, feature=24)
+    texf = ot.value_noise(8, 300, 200, octaves=3, base_cell=16).astype(np.float32)
+    uv, ix = ot.random_triangles(41, 500, 0.05)
+    uv[3 * 40:3 * 44, :] = uv[3 * 40:3 * 44, :1] * np.float32(0.5) + np.float32(0.25)          # degenerate triangles (all three vertices on a line x == y)
+    lv = (ot.hash_u32(np.arange(500) + 13) % 9).astype(np.uint8)                               # levels 0..8
+    for bits in ((1 << 8), (1 << 7) | (1 << 8)):
+        for sat in (True, False):
+            both(product, oracle, [tex], uv, ix, 8, sat=sat, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv, flags=ot.FLAG_THREADS | bits)
+        both(product, oracle, [tex], uv - np.float32(0.3), ix, 6, addr=ot.MIRROR, promo=ot.PROMO_NEAREST, fmt=ot.FMT_2STATE, flags=ot.FLAG_THREADS | bits)   # negative pixels: int(x + 0.5) truncates towards zero
+        both(product, oracle, [texf], uv * np.float32(1.7) - np.float32(0.2), ix, 5, sat=False, addr=ot.BORDER, border_alpha=0.7, promo=ot.PROMO_FORCE_TRANSPARENT, flags=ot.FLAG_THREADS | bits)
+        both(product, oracle, [texf], uv, ix, 7, addr=ot.CLAMP, promo=ot.PROMO_NEAREST, levels=lv, flags=ot.FLAG_THREADS | bits, knobs=[(ot.KNOB_GENERIC_PASS, 2)])
+        both(product, oracle, [tex], uv, ix, 6, addr=ot.WRAP, filt=ot.NEAREST, promo=ot.PROMO_FORCE_OPAQUE, flags=ot.FLAG_THREADS | bits)      # (the Nearest filter ignores both bits)
+        both(product, oracle, [tex], uv, ix, 7, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, flags=ot.FLAG_THREADS | bits | (1 << 9))            # (bit 9 wins: no fine pass at all)
+    both(product, oracle, [tex], uv, ix, 5, addr=ot.WRAP, flags=ot.FLAG_THREADS | (1 << 7), expect=ot.INVALID_ARGUMENT)
 
 
 @pytest.mark.parametrize("chunks", [1, 3, 7])
