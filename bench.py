@@ -8,10 +8,10 @@ XXH64 dedup, spatial sort, pack, index buffer).  Default workload = BASELINE.jso
 micro-triangles span several texels); the driver's line is the default, c2.
 
 Prints ONE JSON line (rank 0):
-  value / ms_per_step   micro-triangles of all unique work items / wall time of a step through ommxBakeDevice -- the ommCpuBake contract with
-                        the UV / index inputs and the result arrays resident in HBM (the bench contract: inputs resident when the clock starts)
-  bake_wall_time_ms     the SAME bake through the SDK entry point proper, ommCpuBake: host arrays in, host arrays out, PCIe inclusive
-                        (SURVEY.md section 8d metric 2), averaged over the same --steps after the same --warmup; details under host_api
+  value / ms_per_step   micro-triangles of all unique work items / wall time of a step through ommCpuBake, the SDK entry point: host arrays in, host
+  = bake_wall_time_ms   arrays out, PCIe inclusive (SURVEY.md section 8d defines both metrics on it); K timed steps after W warm-up steps; details: host_api
+  device_resident       the SAME bake through ommxBakeDevice (UV / index inputs and result arrays resident in HBM), same steps and warm-up.
+                        (N > 1 GPUs: the sharded device-resident entry is the headline -- there is no multi-GPU host-array entry point.)
   roofline              what limits the dominant kernel (classify_tiles): VALU issue slots; roofline_hbm = the HBM view on the units the
                         launch really processes; cpu_baseline = the oracle (port of the reference CPU baker) on the host cores, same run
 """
@@ -107,14 +107,21 @@ def micro_triangles_of(lib, baker, desc):
     return int(tm.microTriangles)
 
 
-def cpu_baseline(tex, uv, ix, lv, kw, sample, sat=True, micro_tris=None, grow=True):
+def oracle_timings(orc):
+    tm = (C.c_double * 8)()
+    orc.dll.oracle_ommxGetLastBakeTimings(tm)
+    return {"setup_s": tm[0], "coarse_s": tm[1], "fine_s": tm[2], "tail_s": tm[3], "sum_s": tm[4], "fine_micro_triangles": tm[5], "micro_triangles": tm[6], "threads": int(tm[7])}
+
+
+def cpu_baseline(tex, uv, ix, lv, kw, sample, sat=True, grow=True, sweep=True):
     """The oracle (bit-exact restatement of the reference CPU baker, OpenMP over work items like the reference) timed on a bounded sample
     of the same triangle stream: the reference needs 2 * 4^N bytes per work item (131 GB at the full metric configuration).
-    Two runs: the whole bake, and the same bake with the reference's own DisableFineClassification switch (internal flag bit 9,
-    bake_cpu_impl.cpp:45) = everything except ResampleFine; the difference is the fine pass alone, the kernel-vs-kernel figure."""
+    One run at all hardware threads on a sample that grows until it is >= 8 s of CPU work, with the oracle's own phase clocks (set-up, ResampleCoarse,
+    ResampleFine, serial tail: oracle_ommxGetLastBakeTimings) -- and, since the reference's loop structure does not scale to 256 threads, the same bake of a
+    quarter of the sample at 16 and 64 threads: `value` is the best of the three rates."""
     cores, host = host_info()
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     orc = ot.Lib("oracle")
+    orc.dll.oracle_ommxSetThreads(0)
     b = orc.create_baker()
     t = orc.create_texture(b, [tex], alpha_cutoff=0.5 if sat else -1.0)
     n = min(sample, ix.size // 3)
@@ -126,17 +133,28 @@ def cpu_baseline(tex, uv, ix, lv, kw, sample, sat=True, micro_tris=None, grow=Tr
         dt = time.time() - t0
         if dt >= 8.0 or n >= ix.size // 3 or not grow: break
         n = min(ix.size // 3, int(n * min(16.0, 12.0 / max(dt, 1e-3))) + 1)
-    d9 = desc_for(t, suv, six, slv, kw, extra_flags=1 << 9)
-    t0 = time.time()
-    orc.bake(b, d9, want_stats=False)
-    dt9 = time.time() - t0
+    ph = oracle_timings(orc)
+    threads = {str(ph["threads"]): {"micro_triangles_per_s": ph["micro_triangles"] / dt, "sample_triangles": n, "seconds": dt}}
+    if sweep:
+        nq = max(1, n // 4)
+        quv, qix, qlv = wl.subset(uv, ix, lv, 0, nq)
+        for th in (64, 16):
+            if th >= cores: continue
+            orc.dll.oracle_ommxSetThreads(th)
+            t0 = time.time()
+            orc.bake(b, desc_for(t, quv, qix, qlv, kw), want_stats=False)
+            dq = time.time() - t0
+            threads[str(th)] = {"micro_triangles_per_s": oracle_timings(orc)["micro_triangles"] / dq, "sample_triangles": nq, "seconds": dq}
+        orc.dll.oracle_ommxSetThreads(0)
     orc.destroy_texture(b, t)
     orc.destroy_baker(b)
-    out = {"unit": "micro-triangles/s", "cores": cores, "kind": "port", "host": host,
-           "sample_triangles": n, "seconds": dt, "seconds_without_fine_pass": dt9,
-           "note": "same loop structure as the reference (static-schedule OpenMP over work items, serial tail): with many threads the whole-bake figure is dominated by the serial "
-                   "tail; `fine_pass_only` = micro-triangles / (whole bake - the same bake with the reference's DisableFineClassification flag) isolates ResampleFine"}
-    return out, res, (suv, six, slv), dt, dt9
+    best = max(threads, key=lambda k: threads[k]["micro_triangles_per_s"])
+    out = {"unit": "micro-triangles/s", "value": threads[best]["micro_triangles_per_s"], "cores": int(best), "kind": "port", "host": host,
+           "host_threads": cores, "threads_sweep": threads, "best_threads": int(best),
+           "sample_triangles": n, "seconds": dt, "phases_at_all_threads_s": {k: ph[k] for k in ("setup_s", "coarse_s", "fine_s", "tail_s")},
+           "note": "same loop structure as the reference (static-schedule OpenMP over work items, serial set-up and tail); `cores` = the thread count of the best run; "
+                   "the phases are the oracle's own wall clocks of the all-threads run"}
+    return out, res, (suv, six, slv), dt, ph
 
 
 def main():
@@ -152,6 +170,8 @@ def main():
     ap.add_argument("--sat-off-sample", type=int, default=50000, help="c2 only: triangles of the SAT-off (no coarse pass) GPU measurement; CPU uses 1/20 of it (0 = skip)")
     ap.add_argument("--generic-pass", type=int, default=0, help="ommxBakerKnob_GenericPass (0 = library default, 1 = inside the persistent launch, 2 = deferred pass)")
     ap.add_argument("--stream-chunks", type=int, default=0, help="ommxBakerKnob_StreamChunks for the ommCpuBake measurement (0 = library default)")
+    ap.add_argument("--concurrent", type=int, default=0, help="also measure K host threads baking concurrently on ONE baker through ommCpuBake (bakes/s for 1, 4, .. K threads; "
+                                                              "the reference documents caller-level parallelism as a first-class strategy, docs/integration_guide.md:434)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     tris = args.tris or cfg["tris"]
@@ -319,7 +339,11 @@ def main():
         host_ms = (time.perf_counter() - t1) / host_steps * 1e3
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
+        dev_ms = elapsed / args.steps * 1e3
+        # headline: the SDK entry point itself (SURVEY.md section 8d defines both metrics on ommCpuBake); the device-resident entry is the named secondary.
+        # N > 1 (and runs that skip the host bakes) have only the device-resident entry.
+        headline_host = host_ms is not None and world == 1
+        ms_per_step = host_ms if headline_host else dev_ms
         avg = lambda f, ts=tms: float(np.mean([getattr(t, f) for t in ts]))
         classify_ms = avg("classifyMs")
         persistent_ms = avg("persistentMs") or classify_ms
@@ -332,26 +356,29 @@ def main():
         t_last = tms[-1]
         bits = 2
         line = {
-            "metric": "micro-triangles classified/sec (whole node)", "value": micro_tris / (elapsed / args.steps),
-            "unit": "micro-triangles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "metric": "micro-triangles classified/sec (whole node)", "value": micro_tris / (ms_per_step * 1e-3),
+            "unit": "micro-triangles/s", "n_gpus": world, "steps": host_steps if headline_host else args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["what"] % tris, "name": args.config,
-                       "entry": (entry_n if world > 1 else "ommxBakeDevice") + " (ommCpuBake contract, UV/index inputs and result arrays resident in HBM)",
+                       "entry": "ommCpuBake (the SDK entry point: host arrays in, host arrays out, PCIe inclusive)" if headline_host else
+                                (entry_n if world > 1 else "ommxBakeDevice") + " (ommCpuBake contract, UV/index inputs and result arrays resident in HBM)",
                        "sharding": ("active work items partitioned over ranks; RCCL all-reduce of item metadata + all-gather of the OMM blocks as codec streams "
                                     "(%d of %d contribution bytes per rank on the wire)" % (int(tms[-1].exchangeBytes), int(tms[-1].contributionBytes))) if world > 1 else "none",
                        "result": result_info, "unique_items": int(t_last.uniqueItems), "active_items": int(t_last.activeItems),
                        "open_tiles": int(t_last.openTiles), "fine_micro_triangles": int(t_last.fineMicroTriangles),
                        "generic_pass_micro_triangles": int(t_last.genericMicroTriangles)},
-            # `value` / `ms_per_step`: device-resident entry (the bench contract: inputs resident in HBM when the clock starts).
-            # `bake_wall_time_ms`: the SDK call a drop-in user makes, ommCpuBake, host arrays in and out, PCIe inclusive -- same steps, same warm-up.
-            "value_entry": "ommxBakeDevice" if world == 1 else ("ommxShardedBakeRccl" if one_call else "ommxSharded* + torch.distributed"),
-            "bake_wall_time_ms": host_ms if host_ms is not None else ms_per_step,
-            "bake_wall_time_entry": "ommCpuBake (host arrays in/out, PCIe inclusive)" if host_ms is not None else "ommxBakeDevice (ommCpuBake was not timed in this run)",
-            "rates": {"all_work_items": micro_tris / (elapsed / args.steps),
+            # `value` / `ms_per_step` / `bake_wall_time_ms`: the SDK call a drop-in user makes, ommCpuBake, host arrays in and out, PCIe inclusive (SURVEY.md
+            # section 8d defines both metrics on it).  `device_resident`: the same bake through ommxBakeDevice (inputs and result arrays in HBM), same steps.
+            "value_entry": "ommCpuBake" if headline_host else ("ommxBakeDevice" if world == 1 else ("ommxShardedBakeRccl" if one_call else "ommxSharded* + torch.distributed")),
+            "bake_wall_time_ms": ms_per_step,
+            "bake_wall_time_entry": "ommCpuBake (host arrays in/out, PCIe inclusive)" if headline_host else "device-resident entry (ommCpuBake was not timed in this run)",
+            "device_resident": {"entry": "ommxBakeDevice" if world == 1 else entry_n, "ms_per_bake": dev_ms, "micro_triangles_per_s": micro_tris / (dev_ms * 1e-3), "bakes": args.steps,
+                                "note": "the ommCpuBake contract with the UV / index inputs and the result arrays resident in HBM (no PCIe in the timed region)"},
+            "rates": {"all_work_items": micro_tris / (ms_per_step * 1e-3),
                       "open_tiles_only": float(t_last.openTileMicroTriangles) / ((tiles_ms + generic_ms) * 1e-3) if tiles_ms + generic_ms > 0 else None,
-                      "fine_pass_only": float(t_last.fineMicroTriangles) / (classify_ms * 1e-3) if classify_ms > 0 else None,
-                      "note": "`value` counts 4^level micro-triangles for every unique work item like the reference's loop does; most items are settled by one summed-area-table "
-                              "query (hierarchical culling), so the rate over the micro-triangles of the tiles that reach classify_tiles and over those that reach the level-line pass are given too"},
+                      "note": "`value` counts 4^level micro-triangles for every unique work item like the reference's loop does; most of them are settled by hierarchical queries "
+                              "(summed-area table, curve-free regions) without per-micro-triangle work, so the rate over the micro-triangles of the tiles that reach classify_tiles "
+                              "(device-resident bake, kernel time) is given too; the fine pass alone: fine_pass_only, measured on the CPU baseline's sample on both sides"},
             "phases_ms": {k: avg(k) for k in ("uploadMs", "setupMs", "triageMs", "classifyMs", "persistentMs", "genericMs", "digestMs", "tailMs", "gatherMs", "downloadMs", "totalMs")},
         }
         if host_ms is not None:
@@ -395,7 +422,9 @@ def main():
         if world == 1 and default_workload and os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("source_sha256_16") == source_hash() and tj.get("kernel", "classify_tiles") == dom_kernel:
-                src = "profiles/%s_pmc.md (separate rocprofv3 --pmc passes of `%s`; %s; sources %s)" % (tj.get("tag"), tj.get("command"), tj.get("corrections"), tj.get("source_sha256_16"))
+                src = ("profiles/%s_pmc.md -- NOT counters of this run: separate rocprofv3 --pmc passes of `%s`, collected %s on %s; %s; per-launch counts are deterministic for the "
+                       "workload and are used only when the hash of omm_amd/csrc matches (%s)") % (tj.get("tag"), tj.get("command"), tj.get("collected_utc", "in an earlier round"),
+                                                                                                 tj.get("collected_on", "a gpurun lease"), tj.get("corrections"), tj.get("source_sha256_16"))
                 roof_hbm["traffic"] = tj.get("traffic_bytes_per_launch")
                 roof_hbm["traffic_source"] = src
                 valu = tj.get("valu_wave_instructions_per_launch"); hz = tj.get("shader_clock_hz")
@@ -417,22 +446,51 @@ def main():
             gb = 2.0 * result_info["arrayDataBytes"] + 8.0 * result_info["descs"] + 8.0 * result_info["triangles"]
             line["roofline_streaming"] = {"bound": "hbm", "kernel": "tail_gather_omms (+ narrow_indices)", "achieved": gb / (gather_ms * 1e-3) / 1e9,
                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / (gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if world == 1 and args.concurrent > 0:
+            # K caller threads share one baker and one texture (the SDK allows concurrent ommCpuBake calls on a baker: docs/integration_guide.md:434); every
+            # thread bakes the same desc through ommCpuBake + ommCpuDestroyBakeResult; ctypes releases the GIL for the duration of a call
+            import threading
+            per_thread = max(4, int(min(400, 2000.0 / max(ms_per_step, 0.05))))
+            cc = {}
+            ks = sorted(set(k for k in (1, 4, 16, args.concurrent) if k <= args.concurrent))
+            for K in ks:
+                def work():
+                    for _ in range(per_thread):
+                        r, out = prod.bake_raw(baker, host_desc)
+                        assert r == ot.SUCCESS
+                        prod.fn("ommCpuDestroyBakeResult")(out)
+                ths = [threading.Thread(target=work) for _ in range(K)]
+                tc = time.perf_counter()
+                for t_ in ths: t_.start()
+                for t_ in ths: t_.join()
+                dtc = time.perf_counter() - tc
+                cc[str(K)] = {"bakes_per_s": K * per_thread / dtc, "ms_per_bake_per_thread": dtc / per_thread * 1e3, "bakes": K * per_thread}
+            line["concurrent_bakes"] = {"entry": "ommCpuBake from K threads on one baker", "threads": cc,
+                                        "scaling_vs_one_thread": {k: v["bakes_per_s"] / cc[str(ks[0])]["bakes_per_s"] for k, v in cc.items()}}
         if world == 1 and args.create_texture and args.config == "c2":
             line["create_texture_ms"] = {"entry": "ommCpuCreateTexture, UNORM8 + alphaCutoff (H2D + device summed-area table)", "4096": create_texture_ms(prod, baker, 4096, 1234),
                                          "8192": create_texture_ms(prod, baker, 8192, 1234)}
         if cpu_sample > 0 and world == 1:
-            cb, cpu_res, (suv, six, slv), dt, dt9 = cpu_baseline(tex, uv, ix, lv, kw, cpu_sample)
+            cb, cpu_res, (suv, six, slv), dt, ph = cpu_baseline(tex, uv, ix, lv, kw, cpu_sample)
             # correctness gate of the same run: the HIP library bakes the CPU sample, byte-for-byte comparison
-            gpu_res = prod.bake(baker, desc_for(th, suv, six, slv, kw), want_stats=False)
+            sdesc = desc_for(th, suv, six, slv, kw)
+            gpu_res = prod.bake(baker, sdesc, want_stats=False)
             assert gpu_res.same_as(cpu_res), "GPU result differs from the CPU baseline on its sample: " + gpu_res.diff(cpu_res)
-            mt = micro_triangles_of(prod, baker, None)
-            cb["value"] = mt / dt
-            cb["fine_pass_only"] = mt / (dt - dt9) if dt - dt9 > 0.05 * dt else None   # (None: the fine pass is within the noise of the two runs)
-            cb["sample"] = "first %d triangles of the same seeded stream (%.3g micro-triangles), SAT on, %.1f s (%.1f s without the fine pass)" % (cb["sample_triangles"], mt, dt, dt9)
+            # the fine pass alone, SAME numerator on both sides: the micro-triangles of the sample that enter ResampleFine (counted by the oracle) over the
+            # oracle's own clock around ResampleFine, and over the GPU's classification time (HIP events) of the same sample, second bake (warm)
+            prod.bake(baker, sdesc, want_stats=False)
+            stm = BakeTimings(); prod.dll.ommxGetLastBakeTimings(baker, C.byref(stm))
+            cb["sample"] = "first %d triangles of the same seeded stream (%.3g micro-triangles), SAT on, %.1f s at %d threads" % (cb["sample_triangles"], ph["micro_triangles"], dt, ph["threads"])
             line["cpu_baseline"] = cb
-            line["speedup_vs_cpu_baseline"] = {"whole_bake_device_entry": line["value"] / cb["value"],
-                                               "whole_bake_ommCpuBake": (micro_tris / (host_ms * 1e-3)) / cb["value"] if host_ms else None,
-                                               "note": "whole-bake ratios include the hierarchical SAT shortcut and the baseline's serial tail; sat_off (c2) is the kernel-vs-kernel pair"}
+            line["fine_pass_only"] = {"numerator": "micro-triangles of the CPU sample that enter ResampleFine (coarse pass left them UnknownOpaque): %.4g" % ph["fine_micro_triangles"],
+                                      "cpu_micro_triangles_per_s": ph["fine_micro_triangles"] / ph["fine_s"] if ph["fine_s"] > 0 else None,
+                                      "cpu_seconds": ph["fine_s"], "cpu_threads": ph["threads"],
+                                      "gpu_micro_triangles_per_s": ph["fine_micro_triangles"] / (stm.classifyMs * 1e-3) if stm.classifyMs > 0 else None,
+                                      "gpu_classify_ms": float(stm.classifyMs),
+                                      "note": "GPU time = all classification kernels of the sample's bake (triage of tiles, persistent launch), which also do the coarse pass"}
+            line["speedup_vs_cpu_baseline"] = {"whole_bake_ommCpuBake": (micro_tris / (host_ms * 1e-3)) / cb["value"] if host_ms else None,
+                                               "whole_bake_device_entry": (micro_tris / (dev_ms * 1e-3)) / cb["value"],
+                                               "note": "whole-bake ratios include the hierarchical shortcuts and the baseline's serial set-up and tail; fine_pass_only and sat_off (c2) are the kernel-vs-kernel pairs"}
             line["parity_vs_cpu_baseline"] = "bit-exact on the CPU sample (arrayData %d B, %d descs, index buffer, histograms, index format)" % (gpu_res.array_data.size, len(gpu_res.descs))
             # second texture mode (no summed-area table: every micro-triangle takes the level-line pass), bounded samples on both sides
             if args.sat_off_sample > 0 and args.config == "c2":
@@ -446,11 +504,10 @@ def main():
                 gpu_dt = time.perf_counter() - t2
                 gmt = micro_triangles_of(prod, baker, None)
                 kc = min(max(args.sat_off_sample // 20, 200), ks)
-                cb2, cpu_res2, (cuv, cix, clv), dt2, _ = cpu_baseline(tex, uv, ix, lv, kw, kc, sat=False, grow=False)
+                cb2, cpu_res2, (cuv, cix, clv), dt2, ph2 = cpu_baseline(tex, uv, ix, lv, kw, kc, sat=False, grow=False, sweep=False)
                 gpu_res2 = prod.bake(baker, desc_for(th2, cuv, cix, clv, kw), want_stats=False)
                 assert gpu_res2.same_as(cpu_res2), "SAT-off GPU result differs from the CPU baseline: " + gpu_res2.diff(cpu_res2)
-                cb2["value"] = micro_triangles_of(prod, baker, None) / dt2
-                cb2["sample"] = "first %d triangles, SAT off, %.1f s" % (kc, dt2)
+                cb2["sample"] = "first %d triangles, SAT off, %.1f s at %d threads" % (kc, dt2, ph2["threads"])
                 prod.destroy_texture(baker, th2)
                 line["sat_off"] = {"entry": "ommCpuBake (host arrays, PCIe inclusive), texture without alphaCutoff", "gpu_micro_triangles_per_s": gmt / gpu_dt,
                                    "gpu_sample": "first %d triangles, %.1f ms" % (ks, gpu_dt * 1e3), "cpu_baseline": cb2, "speedup": (gmt / gpu_dt) / cb2["value"], "parity": "bit-exact on the CPU sample"}

@@ -806,12 +806,69 @@ __device__ __forceinline__ int generic_two_phase(const ClassifyParams& P, const 
     return state_from_coverage(P, above, below);
 }
 
+// a wave's classified entries: state ORed into the packed word the persistent launch left 0; item mask / known count with one atomic per item and wave
+// (the entries of a wave mostly share their item)
+__device__ __forceinline__ void generic_commit(const ClassifyParams& P, const ItemArrays& A, bool live, uint32_t item, uint32_t index, int state)
+{
+    const uint32_t lane = threadIdx.x & 63u, bits = (uint32_t)P.format;
+    if (live) {
+        const uint64_t bit = (uint64_t)index * bits;
+        atomicOr((uint32_t*)(A.states + A.stateOfs[item]) + (bit >> 5), (uint32_t)state << (uint32_t)(bit & 31u));
+    }
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t it0 = (uint32_t)__shfl((int)item, leader);
+        const unsigned long long same = __ballot(live && item == it0) & todo;
+        todo &= ~same;
+        uint32_t mask = 0;
+        #pragma unroll
+        for (int s = 0; s < 4; ++s) if (__ballot(live && item == it0 && state == s) & same) mask |= 1u << s;
+        const uint32_t known = (uint32_t)__popcll(__ballot(live && item == it0 && state < 2) & same);
+        if ((int)lane == leader) { atomicOr(&A.stateMask[it0], mask); if (P.wantKnownCount && known) atomicAdd(&A.knownCount[it0], known); }
+    }
+}
+
+// First stage of the deferred generic pass: most queued micro-triangles straddle a cell boundary NEXT to the level curve without being reached by it.  The
+// curve-free-region test (micro_curve_state_cells: up to 2 x 2 cells, ~300 instructions, no texel walk) settles those; the rest is compacted for the walk.
+template <bool FP32, class MD>
+__global__ __launch_bounds__(256) void generic_cull(ClassifyParams P, ItemArrays A, GenericQueue G)
+{
+    const uint32_t n = *G.count < (unsigned long long)G.capacity ? (uint32_t)*G.count : G.capacity;
+    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * 256u + threadIdx.x) >> 6, waves = (gridDim.x * 256u) >> 6;
+    const bool applies = region_curve_applies(P);
+    for (uint32_t e0 = wave * 64u; e0 < n; e0 += waves * 64u) {   // (wave-uniform)
+        const uint32_t e = e0 + lane;
+        bool live = e < n;
+        uint2 ent = live ? G.entries[e] : make_uint2(0u, 0u);
+        if (ent.x == 0xFFFFFFFFu) { live = false; ent = make_uint2(0u, 0u); }   // (null entry)
+        const uint32_t item = ent.x & 0x3FFFFFFFu;
+        const bool degenerate = ((ent.x >> 30) & 1u) != 0u;
+        int state = -1;
+        if (live && applies && !degenerate) {
+            const float* uv = A.uv + 6ull * item;
+            const DevMip& m = P.mips[0];
+            const float ux = m.fw * __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(uv[0]), __builtin_fabsf(uv[2])), __builtin_fabsf(uv[4])) * 5.9604645e-8f;
+            const float uy = m.fh * __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(uv[1]), __builtin_fabsf(uv[3])), __builtin_fabsf(uv[5])) * 5.9604645e-8f;
+            state = micro_curve_state_cells<FP32, MD>(P, micro_triangle(uv, ent.y & 0xFFFFFFu, ent.y >> 24), ux, uy, item_max_abs(uv));
+        }
+        generic_commit(P, A, live && state >= 0, item, ent.y & 0xFFFFFFu, state);
+        const bool keep = live && state < 0;
+        const unsigned long long kb = __ballot(keep);
+        if (kb) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(G.count2, (unsigned long long)__popcll(kb));
+            base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0);
+            if (keep) G.entries2[base + __popcll(kb & ((1ull << lane) - 1ull))] = ent;
+        }
+    }
+}
+
 template <bool FP32, class MD>
 __global__ __launch_bounds__(256) void classify_generic(ClassifyParams P, ItemArrays A, GenericQueue G)
 {
     const uint32_t n = *G.count < (unsigned long long)G.capacity ? (uint32_t)*G.count : G.capacity;
     const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * 256u + threadIdx.x) >> 6, waves = (gridDim.x * 256u) >> 6;
-    const uint32_t bits = (uint32_t)P.format;
     for (uint32_t e0 = wave * 64u; e0 < n; e0 += waves * 64u) {   // (wave-uniform)
         const uint32_t e = e0 + lane;
         bool live = e < n;
@@ -825,23 +882,7 @@ __global__ __launch_bounds__(256) void classify_generic(ClassifyParams P, ItemAr
             if (live) state = fine_state<FP32, MD>(P, micro_triangle(A.uv + 6ull * item, ent.y & 0xFFFFFFu, ent.y >> 24), degenerate, no_window());
         } else if (P.filterLinear) state = generic_two_phase<FP32, 0, MD>(P, A.uv, item, ent.y, live);
         else state = generic_two_phase<FP32, 1, MD>(P, A.uv, item, ent.y, live);
-        if (live) {
-            const uint64_t bit = (uint64_t)(ent.y & 0xFFFFFFu) * bits;
-            atomicOr((uint32_t*)(A.states + A.stateOfs[item]) + (bit >> 5), (uint32_t)state << (uint32_t)(bit & 31u));
-        }
-        // item mask / known count: one atomic per item and wave (the entries of a wave mostly share their item)
-        unsigned long long todo = __ballot(live);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const uint32_t it0 = (uint32_t)__shfl((int)item, leader);
-            const unsigned long long same = __ballot(live && item == it0) & todo;
-            todo &= ~same;
-            uint32_t mask = 0;
-            #pragma unroll
-            for (int s = 0; s < 4; ++s) if (__ballot(live && item == it0 && state == s) & same) mask |= 1u << s;
-            const uint32_t known = (uint32_t)__popcll(__ballot(live && item == it0 && state < 2) & same);
-            if ((int)lane == leader) { atomicOr(&A.stateMask[it0], mask); if (P.wantKnownCount && known) atomicAdd(&A.knownCount[it0], known); }
-        }
+        generic_commit(P, A, live, item, ent.y & 0xFFFFFFu, state);
     }
 }
 
@@ -935,7 +976,7 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
     const TileSections& S = plan.ranges; const uint32_t K = S.n;
     const bool paired = K > 1u;   // (two sections per range; the queue holds a second copy of the levels >= 6 for the odd ones: classify_queue_records)
     const bool deferred = chunks.generic.entries != nullptr && chunks.after == nullptr;
-    GenericQueue noGeneric; noGeneric.entries = nullptr; noGeneric.count = nullptr; noGeneric.capacity = 0;
+    GenericQueue noGeneric; memset(&noGeneric, 0, sizeof noGeneric);
     uint4* q1024 = queue + (plan.totalBig * (paired ? 2u : 1u)) * kTileRecordWords;
     TileSections one; memset(&one, 0, sizeof one); one.n = 1;
     // ---- sliced items, step 1: tile triage of both tile sizes (settled tiles are final after it, open ones are queued) ----
@@ -982,7 +1023,12 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
     // ---- deferred generic pass: the micro-triangles of several texels that the persistent launches queued instead of walking ----
     if (deferred) {
         if (chunks.markGeneric) chunks.markGeneric(chunks.user);
-        hipLaunchKernelGGL((classify_generic<FP32, MD>), dim3(numCUs * 8u), dim3(256), 0, stream, P, A, chunks.generic);
+        GenericQueue walk = chunks.generic;
+        if (chunks.generic.entries2) {   // stage 1: the curve-free-region test; stage 2 walks what it leaves
+            hipLaunchKernelGGL((generic_cull<FP32, MD>), dim3(numCUs * 8u), dim3(256), 0, stream, P, A, chunks.generic);
+            walk.entries = chunks.generic.entries2; walk.count = chunks.generic.count2;
+        }
+        hipLaunchKernelGGL((classify_generic<FP32, MD>), dim3(numCUs * 8u), dim3(256), 0, stream, P, A, walk);
     }
     for (uint32_t k = 0; k < K; ++k) {
         if (chunks.after) {   // the work items of this range, as segments of the per-level active lists, in the order of the final result

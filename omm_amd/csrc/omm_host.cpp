@@ -642,7 +642,7 @@ void setup_on_host(const ommCpuBakeInputDesc& d, uint32_t flags, const Texture& 
     for (uint32_t i = 0; i < triCount; ++i) {
         const HostTri t = fetch_triangle(d, i);
         const int32_t lvl = level_for_primitive(d, flags, i, t, tex.mips[0].w, tex.mips[0].h);
-        if (lvl == 0xE || tri_invalid(t)) { numDisabled++; continue; }
+        if (lvl == 0xE || tri_invalid(t) || ((flags & (1u << 8)) && tri_degenerate(t))) { numDisabled++; continue; }   // (:563-575: degenerate triangles are invalid without the level-line kernel)
         UvKey key;
         for (int k = 0; k < 6; ++k) { const float f = t.p[k] == 0.f ? 0.f : t.p[k]; memcpy(&key.k[k], &f, 4); }
         key.k[6] = (uint32_t)lvl; key.k[7] = (uint32_t)d.format;
@@ -776,6 +776,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     S.globalLevel = d.maxSubdivisionLevel; S.dynScale = d.dynamicSubdivisionScale; S.edgeHeuristic = (flags & (1u << 11)) != 0;   // (EnableEdgeHeuristic, bake_cpu_impl.cpp:48,547)
     S.texW = tex.mips[0].w; S.texH = tex.mips[0].h; S.disableDedup = (flags & (1u << 3)) != 0;
     S.wantWorkload = 1;   // (also the input of the two shape decisions below: streamed result, deferred generic pass)
+    S.degenerateInvalid = (flags & (1u << 8)) != 0;
     const bool checkWorkload = ((flags & (1u << 5)) != 0) || d.maxWorkloadSize != 0xFFFFFFFFFFFFFFFFull;
     S.keyMask = ~0ull;
     if (const uint64_t kb = baker.knob(ommxBakerKnob_SetupKeyBits)) S.keyMask = (1ull << kb) - 1ull;   // (tests: forced key collisions)
@@ -940,7 +941,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             if (genericCapacity > (256ull << 20)) genericCapacity = 256ull << 20;   // ... at most 2 GB of entries (a tile that finds no room walks its micro-triangles itself)
         }
     }
-    const size_t genericBytes = genericCapacity ? pad256((size_t)genericCapacity * 8) + 256 : 0;
+    const size_t genericBytes = genericCapacity ? 2 * pad256((size_t)genericCapacity * 8) + 256 : 0;   // count words (256 B), the queue, the queue of what generic_cull leaves
     if (!statesArena->reserve(stateBytes + queueBytes + ctlBytes + (streamChunks ? stateBytes : 0) + genericBytes)) return L.failure("[Failure] - out of device memory for the packed micro-triangle states");
     uint8_t* dStates = statesArena->base;
     void* dTileQueue = statesArena->base + stateBytes; uint32_t* dQueueCtl = (uint32_t*)(statesArena->base + stateBytes + queueBytes);
@@ -1012,6 +1013,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     if (dGeneric) {
         if (!HIP_OK(hipMemsetAsync(dGeneric, 0, 256, stream))) return L.failure("[Failure] - device memset failed");
         cc.generic.count = (unsigned long long*)dGeneric; cc.generic.entries = (uint2*)(dGeneric + 256); cc.generic.capacity = (uint32_t)genericCapacity;
+        cc.generic.count2 = (unsigned long long*)(dGeneric + 128); cc.generic.entries2 = (uint2*)(dGeneric + 256 + pad256((size_t)genericCapacity * 8));
         cc.markGeneric = mark_generic_hook;   // (cc.user is the MarkCtx: a deferred pass and a streamed result exclude each other)
     }
     if (!HIP_OK(launch_classify(P, A, dActiveIds, lvlFirst, lvlCount, dTileQueue, dQueueCtl, device_cu_count(), stream, &cc))) return L.failure("[Failure] - kernel launch failed");

@@ -111,6 +111,28 @@ OMMX_RC_FN RcShape rc_shape_micro(float r0x, float r0y, float r1x, float r1y, fl
     return s;
 }
 
+/* rc_shape_micro() without its restriction to edges that are clearly not vertical.  TestEdgeHyperbolaIntersection (bake_kernels_cpu.h:144-238) takes its
+ * vertical-edge branch exactly when |dx| < 1e-6 -- decided on the same fp32 value as here -- and that branch has the smallest residual of the three (5.2 e S);
+ * every other edge has |slope| <= dymax / max(dxmin, 1e-6), which is what the residual bounds of rc_cell() need.  Axis-aligned work items (quads split into
+ * two right triangles: their micro-triangles have one edge whose dx is 0 or a few roundings) are the case this serves. */
+OMMX_RC_FN RcShape rc_shape_micro_any(float r0x, float r0y, float r1x, float r1y, float r2x, float r2y, float ux, float uy)
+{
+    RcShape s; s.Kub = 0.f; s.Klb = 0.f; s.rhoX = 0.f; s.rhoY = 0.f; s.ok = 0;
+    const float e0x = r1x - r0x, e0y = r1y - r0y, e1x = r2x - r1x, e1y = r2y - r1y, e2x = r0x - r2x, e2y = r0y - r2y;
+    const float ax0 = rc_abs(e0x), ax1 = rc_abs(e1x), ax2 = rc_abs(e2x), ay0 = rc_abs(e0y), ay1 = rc_abs(e1y), ay2 = rc_abs(e2y);
+    const float dxmin = rc_min(rc_min(ax0, ax1), ax2), dxmax = rc_max(rc_max(ax0, ax1), ax2);
+    const float dymin = rc_min(rc_min(ay0, ay1), ay2), dymax = rc_max(rc_max(ay0, ay1), ay2);
+    const float c1 = e0x * e1y, c2 = e0y * e1x;
+    const float dX = 2.f * ux, dY = 2.f * uy;
+    const float twoA = rc_abs(c1 - c2) - 4e-7f * (rc_abs(c1) + rc_abs(c2)) - (dX * (ay0 + ay1) + dY * (ax0 + ax1)) - 2.f * dX * dY;
+    const float L2 = rc_max(rc_max(e0x * e0x + e0y * e0y, e1x * e1x + e1y * e1y), e2x * e2x + e2y * e2y) * 1.00001f + 3.f * rc_max(dX, dY) * (dxmax + dymax) + 2.f * dX * dY;
+    const int ok = (ux <= 1e-3f) & (uy <= 1e-3f) & (dxmax <= 1.f) & (dymax <= 1.f) & (twoA >= 0.005f * L2);
+    s.Kub = dymax * OMMX_RC_RCP(rc_max(dxmin, 1e-6f)) * OMMX_RC_KUB; s.Klb = dymin * OMMX_RC_RCP(rc_max(dxmax, 1e-30f)) * OMMX_RC_KLB;
+    s.rhoX = 6e-3f + 4.f * ux + 0.015625f; s.rhoY = 6e-3f + 4.f * uy + 0.015625f;
+    s.ok = ok;
+    return s;
+}
+
 /* Wrap addressing of util/texture.h:34-45 (the only mode whose cells may leave [0, size)); other modes: identity, interior only */
 OMMX_RC_FN int rc_wrap(int pow2, int x, int size) { return pow2 ? (int)((uint32_t)x & (uint32_t)(size - 1)) : (int)((uint32_t)x % (uint32_t)size); }
 

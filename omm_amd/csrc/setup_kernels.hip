@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void setup_fetch(SetupParams S, float* __restr
     // util/geometry.h:44-47
     const float area0 = 0.5f * __builtin_fabsf(p[0] * (p[3] - p[5]) + p[2] * (p[5] - p[1]) + p[4] * (p[1] - p[3]));
     const bool degenerate = (double)area0 < 1e-9;
+    invalid |= S.degenerateInvalid && degenerate;   // GetIsInvalid (bake_cpu_impl.cpp:563-575): without the level-line kernel degenerate triangles are not baked at all
     // ---- GetSubdivisionLevelForPrimitive (bake_cpu_impl.cpp:542-560) ----
     uint32_t level; bool pending = false;
     if (S.perTriLevels && S.perTriLevels[t] <= 12) level = S.perTriLevels[t];

@@ -22,6 +22,9 @@ ommResult oracle_ommCpuGetBakeResultDesc(ommCpuBakeResult r, const ommCpuBakeRes
 ommResult oracle_ommDebugGetStats(ommBaker baker, const ommCpuBakeResultDesc* res, ommDebugStats* out);
 ommResult oracle_ommDebugGetStats2(ommBaker baker, ommCpuBakeResult res, ommDebugStats* out);
 const float* oracle_bake_result_areas(ommCpuBakeResult r);
+/* bench support: phase wall times of the last bake (see omm_oracle.c) and the OpenMP thread count of the following ones */
+void oracle_ommxGetLastBakeTimings(double out[8]);
+void oracle_ommxSetThreads(int n);
 
 /* unit-level probes used by tests */
 void     orc_index2bary(uint32_t index, uint32_t level, float uv[6]);

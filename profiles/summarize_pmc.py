@@ -166,7 +166,9 @@ def main():
         out += ["", "raw counters: " + ", ".join("%s=%.4g" % kv for kv in sorted(c.items()))]
     open(os.path.join(root, tag + "_pmc.md"), "w").write("\n".join(out) + "\n")
     ck = [r for r in rows if r[0] == KERNEL]
+    import socket, time
     js = {"tag": tag, "command": cmd, "kernel": KSHORT, "source_sha256_16": lib_stamp(),
+          "collected_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "collected_on": "gpurun lease, host " + socket.gethostname(),
           "read_bytes_per_launch": ck[0][2] if ck else None, "written_bytes_per_launch": ck[0][3] if ck else None,
           "traffic_bytes_per_launch": (ck[0][2] + ck[0][3]) if ck else None, "corrections": "FETCH_SIZE KiB x2 (gfx950), WRITE_SIZE KiB x1", **summary}
     json.dump(js, open(os.path.join(root, tag + "_hbm_traffic.json"), "w"), indent=1)

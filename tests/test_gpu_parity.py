@@ -959,9 +959,13 @@ def test_bench_contract_small():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["bake_wall_time_entry"].startswith("ommCpuBake") and d["bake_wall_time_ms"] > 0 and d["host_api"]["stream"]["ranges"] == 3 and d["value_entry"] == "ommxBakeDevice"
-    fpo = d["cpu_baseline"]["fine_pass_only"]       # (None when the pair of CPU timings differs by less than its noise)
-    assert (fpo is None or fpo > 0) and d["roofline"]["bound"] == "hbm"      # (the issue-slot roofline needs the PMC summary of the full-size workload)
+    # the headline is the SDK entry point itself; the device-resident entry is the named secondary
+    assert d["bake_wall_time_entry"].startswith("ommCpuBake") and d["bake_wall_time_ms"] == d["ms_per_step"] > 0 and d["host_api"]["stream"]["ranges"] == 3 and d["value_entry"] == "ommCpuBake"
+    assert d["device_resident"]["entry"] == "ommxBakeDevice" and 0 < d["device_resident"]["ms_per_bake"] and d["device_resident"]["micro_triangles_per_s"] > 0
+    fpo = d["fine_pass_only"]                       # the same numerator on both sides: the sample's micro-triangles that enter ResampleFine, counted by the oracle
+    assert fpo["cpu_micro_triangles_per_s"] > 0 and fpo["gpu_micro_triangles_per_s"] > 0
+    assert d["cpu_baseline"]["best_threads"] == d["cpu_baseline"]["cores"] and str(d["cpu_baseline"]["best_threads"]) in d["cpu_baseline"]["threads_sweep"]
+    assert d["roofline"]["bound"] == "hbm"          # (the issue-slot roofline needs the PMC summary of the full-size workload)
     for cfgname in ("c1", "c4", "cards"):
         o2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", cfgname, "--tris", "1500", "--steps", "1", "--warmup", "1", "--cpu-sample", "200",
                              "--host-api-steps", "1"], capture_output=True, text=True, timeout=600)
