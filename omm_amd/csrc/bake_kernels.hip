@@ -922,8 +922,17 @@ void classify_plan(const uint32_t first[kNumLevels], const uint32_t count[kNumLe
     if (ranges > kMaxStreamRanges) ranges = kMaxStreamRanges;
     const uint32_t K = plan->totalBig ? (ranges ? ranges : 1u) : 0u;
     TileSections& S = plan->ranges; S.n = K;
+    // (round 4: the classification of the metric workload is now faster than the PCIe copy of its result, so the copy engine is the critical pipe and what
+    //  counts is how early its FIRST piece is ready: the first ranges are small -- a quarter, a half, three quarters of the others --, the rest equal)
+#ifndef OMMX_STREAM_RAMP
+#define OMMX_STREAM_RAMP 1
+#endif
+    double wsum = 0.0, wacc = 0.0;
+    auto weight = [&](uint32_t k) { return (OMMX_STREAM_RAMP && K >= 8u && k < 3u) ? 0.25 * (double)(k + 1u) : 1.0; };
+    for (uint32_t k = 0; k < K; ++k) wsum += weight(k);
     for (uint32_t k = 1; k <= K; ++k) {
-        uint64_t t = plan->totalBig * k / K;
+        wacc += weight(k - 1u);
+        uint64_t t = k == K ? plan->totalBig : (uint64_t)((double)plan->totalBig * (wacc / wsum));
         if (k < K) {
             const TileLevels& L = plan->big; uint32_t g = 0;
             while (g + 1 < L.n && t >= L.tileStart[g + 1]) ++g;

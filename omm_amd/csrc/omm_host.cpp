@@ -581,6 +581,8 @@ struct StreamOut {
     // out
     bool used = false, fellBack = false; uint32_t chunks = 0; uint64_t streamedBytes = 0;
     double classifyEndMs = 0, lastByteMs = 0;
+    SdmaCopier sdma;   // copies in flight when bake_core returns: the caller queues its small read-backs behind the bake, THEN waits for these (finish())
+    bool finish() { bool ok = true; if (copyStream) ok = hipStreamSynchronize(copyStream) == hipSuccess; ok = sdma.wait() && ok; lastByteMs = now_ms(); return ok; }
 };
 struct StreamCtx {   // what the hook behind a classification launch needs
     hipStream_t stream, place; hipEvent_t* fences; const uint32_t* activeIds; uint32_t numActive; StreamSegment proto; void* scratch; size_t scratchBytes;
@@ -1032,7 +1034,8 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     const int e3 = et.mark();
     // ---- streamed result: everything is enqueued; follow the classification launches and send what each one placed ----
     uint64_t sent = 0;
-    SdmaCopier sdma;   // (its destructor waits for copies in flight: error paths included)
+    SdmaCopier localSdma;   // (ommCpuBake: StreamOut's; its destructor waits for copies in flight: error paths included)
+    SdmaCopier& sdma = so ? so->sdma : localSdma;
     if (streamChunks) {
         const bool useSdma = hostPinned && sdma.open(so->device);
         for (uint32_t k = 0; k < sc.recorded; ++k) {
@@ -1093,6 +1096,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             return L.failure("[Failure] - could not verify the streamed result");
         streamed = hctl[2] == 0u && sent == R.arrayDataSize;
         if (!streamed) {
+            (void)so->finish();   // (the caller is about to overwrite the host array with the ordinary copy: nothing of the discarded stream may still be landing in it)
             char buf[256];
             snprintf(buf, sizeof buf, "[Perf Warning] - the streamed result was discarded (%u blocks placed / %u expected, %llu bytes / %llu expected, duplicate owned by a later range: %u): "
                      "falling back to one copy after the bake", hctl[0], E, (unsigned long long)sent, (unsigned long long)R.arrayDataSize, hctl[1]);
@@ -1130,7 +1134,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     if (dGeneric) ok = ok && HIP_OK(hipMemcpyAsync(&genericCount, dGeneric, sizeof genericCount, hipMemcpyDeviceToHost, stream));
     const int e5 = et.mark();
     ok = ok && HIP_OK(hipStreamSynchronize(stream));
-    if (streamChunks) { ok = HIP_OK(hipStreamSynchronize(so->copyStream)) && ok; ok = sdma.wait() && ok; so->lastByteMs = now_ms(); }
+    // (a streamed result may still be on its way to the host: the caller queues its small read-backs first and then waits, StreamOut::finish)
     if (!ok) return L.failure("[Failure] - could not materialise the bake result on the device");
     memcpy(R.hist, span.data(), sizeof(uint32_t) * kNumLevels);
     memcpy(R.hist + kNumLevels, span.data() + ((const uint8_t*)dIndexHist - (const uint8_t*)dArrayHist), sizeof(uint32_t) * kNumLevels);
@@ -1356,7 +1360,6 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
         ok = ok && res->descs;
         if (!so.used) ok = ok && HIP_OK(hipMemcpyAsync(res->arrayData, R.arrayData, (size_t)R.arrayDataSize, hipMemcpyDeviceToHost, stream));
         ok = ok && HIP_OK(hipMemcpyAsync(res->descs, R.descs, sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, hipMemcpyDeviceToHost, stream));
-        if (so.used) tm.streamTailMs = (float)(so.lastByteMs - so.classifyEndMs);
     }
     res->index = (int32_t*)baker.mem.allocate(sizeof(int32_t) * (size_t)(T ? T : 1), 16);
     res->triArea = (float*)baker.mem.allocate(sizeof(float) * (size_t)(T ? T : 1), 16);
@@ -1366,6 +1369,7 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     if (ok && T) ok = HIP_OK(hipMemcpyAsync(res->triArea, R.triAreaScratch, sizeof(float) * (size_t)T, hipMemcpyDeviceToHost, stream));
     const int d1 = et.mark();
     ok = ok && HIP_OK(hipStreamSynchronize(stream));
+    if (so.chunks) { ok = so.finish() && ok; if (so.used) tm.streamTailMs = (float)(so.lastByteMs - so.classifyEndMs); }   // (the last streamed bytes arrive while the small arrays above are read back)
     if (!ok) { return L.failure("[Failure] - device to host transfer of the bake result failed"); }
 
     // histograms: format {2-state, 4-state} x level ascending, non-zero entries only (:1833-1850); one global format here
