@@ -60,12 +60,7 @@ __device__ __forceinline__ uint32_t early_range(uint32_t leadPos, uint32_t ownPo
 // generic texel loops instead of walking them itself -- entry = {item | degenerate << 30, level << 24 | micro-triangle index}, their packed state left 0 --
 // and classify_generic() classifies them afterwards, eight lanes per micro-triangle, and ORs the states in.  *count only grows and may exceed capacity: a tile
 // whose reservation does not fit walks its micro-triangles itself and fills the part of the reservation that lies inside the queue with null entries (x == ~0).
-struct GenericQueue {
-    uint2* entries; unsigned long long* count; uint32_t capacity;
-    // second stage: generic_cull() asks the curve-free-region test about every queued micro-triangle (region_curve.h), writes the states of those the level
-    // curve cannot reach and compacts the others into entries2 (*count2 <= capacity), which classify_generic() then walks
-    uint2* entries2; unsigned long long* count2;
-};
+struct GenericQueue { uint2* entries; unsigned long long* count; uint32_t capacity; };
 struct ClassifyChunks {
     uint32_t count;
     void (*after)(void* user, uint32_t chunk, const ClassifySegment* segs, uint32_t numSegs, bool last);

@@ -46,9 +46,6 @@ namespace ommx {
 #else
 #define OMMX_RC_GROUP_TEST region_curve_state_impl
 #endif
-#ifndef OMMX_RC_MICRO    // the per-micro-triangle form of the test in front of the single-texel pass (phase 2a-1)
-#define OMMX_RC_MICRO 0
-#endif
 #ifndef OMMX_RC_LEVELS   // bit 0: items, bit 1: tiles, bit 2: 64-groups (A/B builds; the product ships all three)
 #define OMMX_RC_LEVELS 7
 #endif
@@ -325,7 +322,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     const bool coarse = P.useCoarse != 0;
 
     // block-uniform item data of a sliced tile
-    uint32_t uItem = 0; float uUv[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }; float uMaxAbs = 0.f, uUx = 0.f, uUy = 0.f; bool uDegenerate = false, uFast = false;
+    uint32_t uItem = 0; float uUv[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }; float uMaxAbs = 0.f; bool uDegenerate = false, uFast = false;
     TexWindow W = no_window();
     if (tid == 0) { s_qcount = 0; s_mask = 0; s_known = 0; s_pending = 0; s_fine = 0; }
     // the single-texel fast pass (fine_single_texel) covers Linear filtering of one mip on non-degenerate items; everything else is generic
@@ -345,12 +342,6 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         // items outside it (and degenerate ones) take the generic path
         uFast = fastFine && !uDegenerate && uMaxAbs <= 16384.f;
         // the curve-free-region test of the groups (phase 0c): the item's shape bounds, once per tile
-        {   // rounding unit of the item's raster coordinates, per axis (region_curve.h)
-            const DevMip& m0 = P.mips[0];
-            uUx = m0.fw * __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(uUv[0]), __builtin_fabsf(uUv[2])), __builtin_fabsf(uUv[4])) * 5.9604645e-8f;
-            uUy = m0.fh * __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(uUv[1]), __builtin_fabsf(uUv[3])), __builtin_fabsf(uUv[5])) * 5.9604645e-8f;
-        }
-        (void)uUx; (void)uUy;   // (read by the per-micro-triangle form only: OMMX_RC_MICRO)
         const bool uCurve = (OMMX_RC_LEVELS & 4) && region_curve_applies(P) && !uDegenerate;
         RcShape uShape; uShape.ok = 0;
         if (uCurve) { const DevMip& m0 = P.mips[0]; uShape = rc_shape(uUv, m0.fw, m0.fh, m0.w, m0.h, level); }
@@ -476,54 +467,6 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
             const uint32_t gcount = s_gcount, ocount = s_ocount;
             uint32_t qn2 = 0, en = 0, pend = 0;
             const uint32_t units = ocount + ((qn + 63u) >> 6);
-#if OMMX_RC_MICRO
-            // ---- phase 2a-1: the curve-free-region test per micro-triangle (micro_curve_state: ~100 instructions): most of them are clear of the level curve
-            //      of their cell and are done; the others (0xFD) are compacted into s_queue and take the full straight-line pass below ----
-            uint32_t full = 0;
-            for (uint32_t k = tid >> 6; k < units; k += BLOCK / 64) {   // (k is wave-uniform)
-                uint32_t i; bool live = true;
-                if (k < ocount) i = (uint32_t)s_olist[k] * 64u + (tid & 63u);
-                else { const uint32_t q = (k - ocount) * 64u + (tid & 63u); live = q < qn; i = live ? (uint32_t)s_queue[q] : 0u; }
-                if (live) {
-                    const int st = micro_curve_state<FP32, MD>(P, tile_micro_triangle(i), uUx, uUy, W);
-                    s_state[i] = (uint8_t)(st < 0 ? 0xFD : st);
-                    full |= st < 0 ? 1u : 0u;
-                }
-            }
-            if (tid == 0 && ocount) s_fine = ocount * 64u;
-            if (__ballot(full != 0) != 0ull && (tid & 63u) == 0) atomicOr(&s_pending, 4u);
-            __syncthreads();
-            uint32_t qf = 0;
-            if (s_pending & 4u) {   // (block-uniform)
-                if (tid == 0) s_qcount = 0;
-                __syncthreads();
-                for (uint32_t k = tid >> 6; k < gcount; k += BLOCK / 64) {
-                    const uint32_t i = s_glist[k] * 64u + (tid & 63u);
-                    const unsigned long long vf = __ballot(s_state[i] == 0xFDu);
-                    if (vf) {
-                        const uint32_t lane = tid & 63u;
-                        uint32_t bf = 0;
-                        if (lane == 0) bf = atomicAdd(&s_qcount, (uint32_t)__popcll(vf));
-                        bf = __shfl(bf, 0);
-                        if ((vf >> lane) & 1ull) s_queue[bf + __popcll(vf & ((1ull << lane) - 1ull))] = (uint16_t)i;
-                    }
-                }
-                __syncthreads();
-                qf = s_qcount;
-                if (tid == 0) s_pending = 0;   // (re-used by the pass below; every thread has read it: the barrier above)
-            }
-            // ---- phase 2a-2: the full single-texel pass of what is left, densely ----
-            for (uint32_t q0 = 0; q0 < qf; q0 += BLOCK) {
-                const uint32_t q = q0 + tid;
-                if (q < qf) {
-                    const uint32_t i = s_queue[q];
-                    const int st = fine_single_texel<FP32, MD>(P, tile_micro_triangle(i), W);   // state | kNeedsEdges + hints | -1
-                    s_state[i] = (uint8_t)(st < 0 ? 0xFF : st);
-                    pend |= st < 0 ? 1u : ((st & kNeedsEdges) ? 2u : 0u);
-                }
-            }
-            __syncthreads();   // (s_pending was cleared by thread 0 behind the compaction barrier: order it before the votes below)
-#else
             for (uint32_t k = tid >> 6; k < units; k += BLOCK / 64) {   // (k is wave-uniform)
                 uint32_t i; bool live = true;
                 if (k < ocount) i = (uint32_t)s_olist[k] * 64u + (tid & 63u);
@@ -535,7 +478,6 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 }
             }
             if (tid == 0 && ocount) s_fine = ocount * 64u;
-#endif
             const unsigned long long anyGeneric = __ballot((pend & 1u) != 0), anyEdges = __ballot((pend & 2u) != 0);
             if ((tid & 63u) == 0 && (anyGeneric | anyEdges)) atomicOr(&s_pending, (anyGeneric ? 1u : 0u) | (anyEdges ? 2u : 0u));
             __syncthreads();
@@ -829,41 +771,6 @@ __device__ __forceinline__ void generic_commit(const ClassifyParams& P, const It
     }
 }
 
-// First stage of the deferred generic pass: most queued micro-triangles straddle a cell boundary NEXT to the level curve without being reached by it.  The
-// curve-free-region test (micro_curve_state_cells: up to 2 x 2 cells, ~300 instructions, no texel walk) settles those; the rest is compacted for the walk.
-template <bool FP32, class MD>
-__global__ __launch_bounds__(256) void generic_cull(ClassifyParams P, ItemArrays A, GenericQueue G)
-{
-    const uint32_t n = *G.count < (unsigned long long)G.capacity ? (uint32_t)*G.count : G.capacity;
-    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * 256u + threadIdx.x) >> 6, waves = (gridDim.x * 256u) >> 6;
-    const bool applies = region_curve_applies(P);
-    for (uint32_t e0 = wave * 64u; e0 < n; e0 += waves * 64u) {   // (wave-uniform)
-        const uint32_t e = e0 + lane;
-        bool live = e < n;
-        uint2 ent = live ? G.entries[e] : make_uint2(0u, 0u);
-        if (ent.x == 0xFFFFFFFFu) { live = false; ent = make_uint2(0u, 0u); }   // (null entry)
-        const uint32_t item = ent.x & 0x3FFFFFFFu;
-        const bool degenerate = ((ent.x >> 30) & 1u) != 0u;
-        int state = -1;
-        if (live && applies && !degenerate) {
-            const float* uv = A.uv + 6ull * item;
-            const DevMip& m = P.mips[0];
-            const float ux = m.fw * __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(uv[0]), __builtin_fabsf(uv[2])), __builtin_fabsf(uv[4])) * 5.9604645e-8f;
-            const float uy = m.fh * __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(uv[1]), __builtin_fabsf(uv[3])), __builtin_fabsf(uv[5])) * 5.9604645e-8f;
-            state = micro_curve_state_cells<FP32, MD>(P, micro_triangle(uv, ent.y & 0xFFFFFFu, ent.y >> 24), ux, uy, item_max_abs(uv));
-        }
-        generic_commit(P, A, live && state >= 0, item, ent.y & 0xFFFFFFu, state);
-        const bool keep = live && state < 0;
-        const unsigned long long kb = __ballot(keep);
-        if (kb) {
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(G.count2, (unsigned long long)__popcll(kb));
-            base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0);
-            if (keep) G.entries2[base + __popcll(kb & ((1ull << lane) - 1ull))] = ent;
-        }
-    }
-}
-
 template <bool FP32, class MD>
 __global__ __launch_bounds__(256) void classify_generic(ClassifyParams P, ItemArrays A, GenericQueue G)
 {
@@ -1032,12 +939,7 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
     // ---- deferred generic pass: the micro-triangles of several texels that the persistent launches queued instead of walking ----
     if (deferred) {
         if (chunks.markGeneric) chunks.markGeneric(chunks.user);
-        GenericQueue walk = chunks.generic;
-        if (chunks.generic.entries2) {   // stage 1: the curve-free-region test; stage 2 walks what it leaves
-            hipLaunchKernelGGL((generic_cull<FP32, MD>), dim3(numCUs * 8u), dim3(256), 0, stream, P, A, chunks.generic);
-            walk.entries = chunks.generic.entries2; walk.count = chunks.generic.count2;
-        }
-        hipLaunchKernelGGL((classify_generic<FP32, MD>), dim3(numCUs * 8u), dim3(256), 0, stream, P, A, walk);
+        hipLaunchKernelGGL((classify_generic<FP32, MD>), dim3(numCUs * 8u), dim3(256), 0, stream, P, A, chunks.generic);
     }
     for (uint32_t k = 0; k < K; ++k) {
         if (chunks.after) {   // the work items of this range, as segments of the per-level active lists, in the order of the final result

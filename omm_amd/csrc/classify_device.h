@@ -9,9 +9,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "bake_types.h"
-#define OMMX_RC_RCP(x) __builtin_amdgcn_rcpf(x)
-#define OMMX_RC_KUB 1.000002f
-#define OMMX_RC_KLB 0.999998f
 #include "region_curve.h"
 
 namespace ommx {
@@ -195,12 +192,6 @@ struct TexWindow {
     const void*     base;  // texels of mip 0 (the window belongs to that mip only)
     int sx, sy, w, h;
 };
-
-__device__ __forceinline__ TexWindow no_window_tex()
-{
-    TexWindow W; W.tex = (lds_float*)0; W.sat = (lds_u32*)0; W.base = nullptr; W.sx = W.sy = 0; W.w = W.h = 0;
-    return W;
-}
 
 // texture_impl.h:178-202
 template <bool FP32>
@@ -843,67 +834,6 @@ __device__ __forceinline__ int region_curve_state(const ClassifyParams& P, bool 
 __device__ __attribute__((noinline)) int region_curve_state_call(RcTex T, RcShape sh, float lox, float loy, float hix, float hiy, float maxAbs)
 {
     return region_curve_state_impl(T, sh, lox, loy, hix, hiy, maxAbs);
-}
-
-// The curve-free-region test for ONE micro-triangle that lies in one texel cell, from its own vertices (region_curve.h: rc_shape_micro): the answer of
-// fine_single_texel() + single_texel_edges() below -- a pure state -- for ~100 instructions instead of ~550 when the level curve of the cell stays clear of the
-// micro-triangle, -1 otherwise (more than one cell, a shape the bounds do not cover, the curve too close).  FINITE precondition as fine_single_texel().
-// ux, uy: rounding unit of the item's raster coordinates (size x largest |uv| of the axis x 2^-24).
-template <bool FP32, class MD>
-__device__ __forceinline__ int micro_curve_state(const ClassifyParams& P, const MicroTri& t, float ux, float uy, const TexWindow& W)
-{
-    const DevMip& m = P.mips[0];
-    const float lox = __builtin_fminf(__builtin_fminf(t.p0.x, t.p1.x), t.p2.x), loy = __builtin_fminf(__builtin_fminf(t.p0.y, t.p1.y), t.p2.y);
-    const float hix = __builtin_fmaxf(__builtin_fmaxf(t.p0.x, t.p1.x), t.p2.x), hiy = __builtin_fmaxf(__builtin_fmaxf(t.p0.y, t.p1.y), t.p2.y);
-    // cells the rasteriser and the centre vote can touch: [floor(lo * size - 0.5), floor(hi * size - 0.5)] (monotone in the vertex, so the box corners do)
-    const float fx0 = __builtin_floorf(lox * m.fw - 0.5f), fy0 = __builtin_floorf(loy * m.fh - 0.5f);
-    const float fx1 = __builtin_floorf(hix * m.fw - 0.5f), fy1 = __builtin_floorf(hiy * m.fh - 0.5f);
-    const bool oneCell = (fx0 == fx1) & (fy0 == fy1);
-    float g00, g01, g11, g10;
-    fetch_cell<FP32, MD>(P, m, MD::pow2(P), (int)fx0, (int)fy0, W, g00, g01, g11, g10);
-    const float pfx = fx0 + 0.5f, pfy = fy0 + 0.5f;
-    const float r0x = m.fw * t.p0.x - pfx, r0y = m.fh * t.p0.y - pfy, r1x = m.fw * t.p1.x - pfx, r1y = m.fh * t.p1.y - pfy, r2x = m.fw * t.p2.x - pfx, r2y = m.fh * t.p2.y - pfy;
-    const RcShape sh = rc_shape_micro(r0x, r0y, r1x, r1y, r2x, r2y, ux, uy);
-    const int c = rc_cell(&sh, g00, g10, g01, g11, P.cutoff, __builtin_fminf(__builtin_fminf(r0x, r1x), r2x), __builtin_fmaxf(__builtin_fmaxf(r0x, r1x), r2x),
-                          __builtin_fminf(__builtin_fminf(r0y, r1y), r2y), __builtin_fmaxf(__builtin_fmaxf(r0y, r1y), r2y));
-    const int st = c > 0 ? P.stateGT : P.stateLE;
-    return (oneCell & (sh.ok != 0) & ((c == 1) | (c == -1)) & (st != 3)) ? st : -1;
-}
-
-// The curve-free-region test for ONE micro-triangle of at most a texel in size that may straddle cell boundaries (up to 2 x 2 cells), any address mode, texels
-// from HBM / L2: what the deferred generic pass asks before it walks the texels of a raster box (bake_kernels.hip: generic_cull).  -1: walk.
-template <bool FP32, class MD>
-__device__ __forceinline__ int micro_curve_state_cells(const ClassifyParams& P, const MicroTri& t, float ux, float uy, float maxAbs)
-{
-    const DevMip& m = P.mips[0];
-    if (!(maxAbs <= 16384.f)) return -1;   // (FINITE: every conversion below stays in the int range)
-    const float lox = __builtin_fminf(__builtin_fminf(t.p0.x, t.p1.x), t.p2.x), loy = __builtin_fminf(__builtin_fminf(t.p0.y, t.p1.y), t.p2.y);
-    const float hix = __builtin_fmaxf(__builtin_fmaxf(t.p0.x, t.p1.x), t.p2.x), hiy = __builtin_fmaxf(__builtin_fmaxf(t.p0.y, t.p1.y), t.p2.y);
-    const float fx0 = __builtin_floorf(lox * m.fw - 0.5f), fy0 = __builtin_floorf(loy * m.fh - 0.5f);
-    const float fx1 = __builtin_floorf(hix * m.fw - 0.5f), fy1 = __builtin_floorf(hiy * m.fh - 0.5f);
-    const int nx = (int)(fx1 - fx0) + 1, ny = (int)(fy1 - fy0) + 1;
-    if (!(nx >= 1 && nx <= 2 && ny >= 1 && ny <= 2)) return -1;
-    const float pfx = fx0 + 0.5f, pfy = fy0 + 0.5f;
-    const float r0x = m.fw * t.p0.x - pfx, r0y = m.fh * t.p0.y - pfy, r1x = m.fw * t.p1.x - pfx, r1y = m.fh * t.p1.y - pfy, r2x = m.fw * t.p2.x - pfx, r2y = m.fh * t.p2.y - pfy;
-    const RcShape sh = rc_shape_micro_any(r0x, r0y, r1x, r1y, r2x, r2y, ux, uy);
-    if (!sh.ok) return -1;
-    const float bx0 = __builtin_fminf(__builtin_fminf(r0x, r1x), r2x), bx1 = __builtin_fmaxf(__builtin_fmaxf(r0x, r1x), r2x);
-    const float by0 = __builtin_fminf(__builtin_fminf(r0y, r1y), r2y), by1 = __builtin_fmaxf(__builtin_fmaxf(r0y, r1y), r2y);
-    const int X0 = (int)fx0, Y0 = (int)fy0;
-    int sign = 0;
-    for (int j = 0; j < ny; ++j)
-        for (int i = 0; i < nx; ++i) {
-            float g00, g01, g11, g10;
-            fetch_cell<FP32, MD>(P, m, MD::pow2(P), X0 + i, Y0 + j, no_window_tex(), g00, g01, g11, g10);
-            const int c = rc_cell(&sh, g00, g10, g01, g11, P.cutoff, bx0 - (float)i, bx1 - (float)i, by0 - (float)j, by1 - (float)j);
-            if (c == 0) return -1;
-            if (c == 2) continue;
-            if (sign != 0 && sign != c) return -1;
-            sign = c;
-        }
-    if (sign == 0) return -1;
-    const int st = sign > 0 ? P.stateGT : P.stateLE;
-    return st == 3 ? -1 : st;
 }
 
 // ---- fine pass of a micro-triangle whose conservative raster covers ONE texel of mip 0 (Linear filter, non-degenerate item) ----

@@ -943,7 +943,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             if (genericCapacity > (256ull << 20)) genericCapacity = 256ull << 20;   // ... at most 2 GB of entries (a tile that finds no room walks its micro-triangles itself)
         }
     }
-    const size_t genericBytes = genericCapacity ? 2 * pad256((size_t)genericCapacity * 8) + 256 : 0;   // count words (256 B), the queue, the queue of what generic_cull leaves
+    const size_t genericBytes = genericCapacity ? pad256((size_t)genericCapacity * 8) + 256 : 0;
     if (!statesArena->reserve(stateBytes + queueBytes + ctlBytes + (streamChunks ? stateBytes : 0) + genericBytes)) return L.failure("[Failure] - out of device memory for the packed micro-triangle states");
     uint8_t* dStates = statesArena->base;
     void* dTileQueue = statesArena->base + stateBytes; uint32_t* dQueueCtl = (uint32_t*)(statesArena->base + stateBytes + queueBytes);
@@ -1015,7 +1015,6 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     if (dGeneric) {
         if (!HIP_OK(hipMemsetAsync(dGeneric, 0, 256, stream))) return L.failure("[Failure] - device memset failed");
         cc.generic.count = (unsigned long long*)dGeneric; cc.generic.entries = (uint2*)(dGeneric + 256); cc.generic.capacity = (uint32_t)genericCapacity;
-        cc.generic.count2 = (unsigned long long*)(dGeneric + 128); cc.generic.entries2 = (uint2*)(dGeneric + 256 + pad256((size_t)genericCapacity * 8));
         cc.markGeneric = mark_generic_hook;   // (cc.user is the MarkCtx: a deferred pass and a streamed result exclude each other)
     }
     if (!HIP_OK(launch_classify(P, A, dActiveIds, lvlFirst, lvlCount, dTileQueue, dQueueCtl, device_cu_count(), stream, &cc))) return L.failure("[Failure] - kernel launch failed");

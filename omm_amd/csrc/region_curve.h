@@ -43,14 +43,6 @@ OMMX_RC_FN float rc_max(float a, float b) { return a < b ? b : a; }
 OMMX_RC_FN int rc_trunc(float f) { return (f >= -2147483648.f && f < 2147483648.f) ? (int)f : (int)0x80000000; }   /* cvttss2si */
 OMMX_RC_FN float rc_floor(float f) { return __builtin_floorf(f); }
 
-/* reciprocal used for the two slope bounds of rc_shape_micro(): the device takes v_rcp_f32 (1 ulp) and widens by 2e-6; the audit build of the oracle
- * divides exactly and widens by 1.5e-6, i.e. stays on the permissive side of anything the device can compute: whatever the device settles, the audit settles */
-#ifndef OMMX_RC_RCP
-#define OMMX_RC_RCP(x) (1.f / (x))
-#define OMMX_RC_KUB 1.0000015f
-#define OMMX_RC_KLB 0.9999985f
-#endif
-
 #define OMMX_RC_MAX_CELLS 4   /* cells per axis a sub-triangle may touch (5 x 5 texels) */
 
 /* Slope and shape bounds shared by every micro-triangle of a work item (uv: its six floats; level: its subdivision level; w, h: texture size). */
@@ -86,50 +78,6 @@ OMMX_RC_FN RcShape rc_shape(const float* uv, float fw, float fh, int w, int h, u
     s.Kub = (dymax / dxmin) * 1.00001f; s.Klb = (dymin / dxmax) * 0.99999f;
     s.rhoX = 6e-3f + 22.f * ux + 0.015625f; s.rhoY = 6e-3f + 22.f * uy + 0.015625f;
     s.ok = 1;
-    return s;
-}
-
-/* The same bounds for ONE micro-triangle from its own fp32 vertices r0, r1, r2 (coordinates of the cell it lies in, exactly the values the level-line kernel
- * computes, bake_kernels_cpu.h:378-379): nothing has to be allowed for the rounding of OTHER micro-triangles, so this form applies to every work item, also
- * to those whose micro-triangles are smaller than the rounding of their vertices.  ux, uy as in rc_shape().  Point-in-triangle runs on the UV-space
- * vertices, whose scaled differences are within 2 u of the differences used here (one rounding of size x p per vertex when the size is not a power of two). */
-OMMX_RC_FN RcShape rc_shape_micro(float r0x, float r0y, float r1x, float r1y, float r2x, float r2y, float ux, float uy)
-{
-    RcShape s; s.Kub = 0.f; s.Klb = 0.f; s.rhoX = 0.f; s.rhoY = 0.f; s.ok = 0;
-    const float e0x = r1x - r0x, e0y = r1y - r0y, e1x = r2x - r1x, e1y = r2y - r1y, e2x = r0x - r2x, e2y = r0y - r2y;
-    const float ax0 = rc_abs(e0x), ax1 = rc_abs(e1x), ax2 = rc_abs(e2x), ay0 = rc_abs(e0y), ay1 = rc_abs(e1y), ay2 = rc_abs(e2y);
-    const float dxmin = rc_min(rc_min(ax0, ax1), ax2), dxmax = rc_max(rc_max(ax0, ax1), ax2);
-    const float dymin = rc_min(rc_min(ay0, ay1), ay2), dymax = rc_max(rc_max(ay0, ay1), ay2);
-    const float c1 = e0x * e1y, c2 = e0y * e1x;
-    const float dX = 2.f * ux, dY = 2.f * uy;
-    const float twoA = rc_abs(c1 - c2) - 4e-7f * (rc_abs(c1) + rc_abs(c2)) - (dX * (ay0 + ay1) + dY * (ax0 + ax1)) - 2.f * dX * dY;
-    const float L2 = rc_max(rc_max(e0x * e0x + e0y * e0y, e1x * e1x + e1y * e1y), e2x * e2x + e2y * e2y) * 1.00001f + 3.f * rc_max(dX, dY) * (dxmax + dymax) + 2.f * dX * dY;
-    const int ok = (ux <= 1e-3f) & (uy <= 1e-3f) & (dxmin >= 1e-4f) & (dxmax <= 1.f) & (dymax <= 1.f) & (twoA >= 0.005f * L2);
-    s.Kub = dymax * OMMX_RC_RCP(dxmin) * OMMX_RC_KUB; s.Klb = dymin * OMMX_RC_RCP(dxmax) * OMMX_RC_KLB;
-    s.rhoX = 6e-3f + 4.f * ux + 0.015625f; s.rhoY = 6e-3f + 4.f * uy + 0.015625f;
-    s.ok = ok;
-    return s;
-}
-
-/* rc_shape_micro() without its restriction to edges that are clearly not vertical.  TestEdgeHyperbolaIntersection (bake_kernels_cpu.h:144-238) takes its
- * vertical-edge branch exactly when |dx| < 1e-6 -- decided on the same fp32 value as here -- and that branch has the smallest residual of the three (5.2 e S);
- * every other edge has |slope| <= dymax / max(dxmin, 1e-6), which is what the residual bounds of rc_cell() need.  Axis-aligned work items (quads split into
- * two right triangles: their micro-triangles have one edge whose dx is 0 or a few roundings) are the case this serves. */
-OMMX_RC_FN RcShape rc_shape_micro_any(float r0x, float r0y, float r1x, float r1y, float r2x, float r2y, float ux, float uy)
-{
-    RcShape s; s.Kub = 0.f; s.Klb = 0.f; s.rhoX = 0.f; s.rhoY = 0.f; s.ok = 0;
-    const float e0x = r1x - r0x, e0y = r1y - r0y, e1x = r2x - r1x, e1y = r2y - r1y, e2x = r0x - r2x, e2y = r0y - r2y;
-    const float ax0 = rc_abs(e0x), ax1 = rc_abs(e1x), ax2 = rc_abs(e2x), ay0 = rc_abs(e0y), ay1 = rc_abs(e1y), ay2 = rc_abs(e2y);
-    const float dxmin = rc_min(rc_min(ax0, ax1), ax2), dxmax = rc_max(rc_max(ax0, ax1), ax2);
-    const float dymin = rc_min(rc_min(ay0, ay1), ay2), dymax = rc_max(rc_max(ay0, ay1), ay2);
-    const float c1 = e0x * e1y, c2 = e0y * e1x;
-    const float dX = 2.f * ux, dY = 2.f * uy;
-    const float twoA = rc_abs(c1 - c2) - 4e-7f * (rc_abs(c1) + rc_abs(c2)) - (dX * (ay0 + ay1) + dY * (ax0 + ax1)) - 2.f * dX * dY;
-    const float L2 = rc_max(rc_max(e0x * e0x + e0y * e0y, e1x * e1x + e1y * e1y), e2x * e2x + e2y * e2y) * 1.00001f + 3.f * rc_max(dX, dY) * (dxmax + dymax) + 2.f * dX * dY;
-    const int ok = (ux <= 1e-3f) & (uy <= 1e-3f) & (dxmax <= 1.f) & (dymax <= 1.f) & (twoA >= 0.005f * L2);
-    s.Kub = dymax * OMMX_RC_RCP(rc_max(dxmin, 1e-6f)) * OMMX_RC_KUB; s.Klb = dymin * OMMX_RC_RCP(rc_max(dxmax, 1e-30f)) * OMMX_RC_KLB;
-    s.rhoX = 6e-3f + 4.f * ux + 0.015625f; s.rhoY = 6e-3f + 4.f * uy + 0.015625f;
-    s.ok = ok;
     return s;
 }
 
