@@ -69,13 +69,20 @@ typedef enum ommxBakerKnob {
     ommxBakerKnob_StreamChunks     = 2, /* ommCpuBake: number of ranges (of work items, in the order of the result) whose finished OMM blocks are copied to
                                            their place in the host array while the following ranges are being classified; a value (1..32) forces streaming
                                            whatever the size of the bake (1 = classify everything, then one copy).  Default: bakes with >= 64 MiB of packed
-                                           states stream, one range per 32 MiB, at most 24 */
+                                           states stream, one range per 32 MiB, at most 32 */
     ommxBakerKnob_GenericPass      = 3, /* where micro-triangles that span several texels (asset-sized triangles) are classified: 1 = inside the persistent
                                            classification launch, one lane each; 2 = queued and classified by a second launch, eight lanes each (not for streamed
                                            bakes); 0 = automatic: 2 when the texels under the triangles outweigh the micro-triangles */
-    ommxBakerKnob_MAX_NUM          = 4
+    ommxBakerKnob_RetainMemory     = 4, /* what a baker keeps between bakes.  0 / default: the working set of a bake (device arenas, streams), up to six idle device result
+                                           blocks and up to two idle PINNED host blocks for arrayData (a fresh 1.3 GB host block costs more in page faults and munmap than the
+                                           PCIe copy of its contents) stay with the baker until it is destroyed; 1: nothing is retained -- every block goes back to the system
+                                           when the result that uses it is destroyed.  For pipelines that create many bakers, or bake rarely.  See also ommxTrimBaker. */
+    ommxBakerKnob_MAX_NUM          = 5
 } ommxBakerKnob;
 OMM_MI355X_API ommResult ommxSetBakerKnob(ommBaker baker, ommxBakerKnob knob, uint64_t value);
+/* Gives every idle pooled block of the baker back to the system now: pinned host blocks, device result blocks, device working sets of finished bakes.  Results
+ * that are still alive keep their memory.  Safe to call at any time from any thread; the next bake allocates again. */
+OMM_MI355X_API ommResult ommxTrimBaker(ommBaker baker);
 
 /* ---- device-resident bake ----
  * Same contract as ommCpuBake (include/omm_mi355x.h; reference omm.h:574) except for where the bulk data lives:

@@ -922,7 +922,10 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
     // this launch pending and lets nothing else in -- measured with device time stamps: the one-lane wait kernel of the first range then starts 24 ms late,
     // when the first of these workgroups exits.  Half a workgroup per CU less than full is the measured optimum (metric configuration, ms per ommCpuBake, by
     // workgroups held back: 0 / 16: 52.7, 64: 34.6 .. 37.7 (unstable), 96: 34.9, 128: 34.8, 192: 35.4, 256: 35.4; configs[4]: 64: 145, 128: 148, 256: 155).
-    const uint64_t want = (uint64_t)numCUs * OMMX_CLASSIFY_WAVES - (chunks.after ? numCUs / 2u : 0u);
+#ifndef OMMX_STREAM_HOLDBACK   // workgroups a streamed bake's persistent launch leaves free, in eighths of the CU count (4 = half a workgroup per CU)
+#define OMMX_STREAM_HOLDBACK 4
+#endif
+    const uint64_t want = (uint64_t)numCUs * OMMX_CLASSIFY_WAVES - (chunks.after ? numCUs * OMMX_STREAM_HOLDBACK / 8u : 0u);
     if (plan.totalSmall) {
         const dim3 cg((uint32_t)(plan.totalSmall < want ? plan.totalSmall : want)), cb(BLOCK);
         if (deferred) hipLaunchKernelGGL((classify_tiles<FP32, true, 1024, MD, true>), cg, cb, 0, stream, P, A, (const uint32_t*)nullptr, 0u, 0u, (uint64_t)0, (const uint4*)q1024, ctl1024, 1u, chunks.generic);

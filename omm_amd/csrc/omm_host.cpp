@@ -131,13 +131,15 @@ struct ArenaPool {
         { std::lock_guard<std::mutex> g(mu); if (!idle.empty()) { std::unique_ptr<ArenaSet> a = std::move(idle.back()); idle.pop_back(); return a; } }
         return std::unique_ptr<ArenaSet>(new ArenaSet());
     }
-    void release(std::unique_ptr<ArenaSet> a) { std::lock_guard<std::mutex> g(mu); if (idle.size() < 2) idle.push_back(std::move(a)); }   // (else freed here)
+    std::atomic<bool> retain{ true };
+    void release(std::unique_ptr<ArenaSet> a) { std::lock_guard<std::mutex> g(mu); if (retain.load() && idle.size() < 2) idle.push_back(std::move(a)); }   // (else freed here)
+    void trim() { std::vector<std::unique_ptr<ArenaSet>> drop; { std::lock_guard<std::mutex> g(mu); drop.swap(idle); } }   // (freed outside the lock)
 };
 
 // ---- device blocks of bake results, reused across bakes (hipMalloc / hipFree of a 1.3 GB block are synchronous and cost ~1 ms) ----
 struct DevPool {
     struct Blk { void* p; size_t cap; bool used; };
-    std::mutex mu; std::vector<Blk> blks;
+    std::mutex mu; std::vector<Blk> blks; std::atomic<bool> retain{ true };
     ~DevPool() { for (auto& b : blks) (void)hipFree(b.p); }
     void* acquire(size_t bytes) {
         if (bytes == 0) bytes = 1;
@@ -159,7 +161,7 @@ struct DevPool {
     void release(void* p) {
         if (!p) return;
         { std::lock_guard<std::mutex> g(mu); for (auto& b : blks) if (b.p == p) b.used = false; }
-        trim(6);                                      // at most two idle result sets (arrayData, descs, index)
+        trim(retain.load() ? 6 : 0);                  // at most two idle result sets (arrayData, descs, index)
     }
     void trim(size_t keepIdle) {
         std::lock_guard<std::mutex> g(mu);
@@ -178,7 +180,7 @@ struct DevPool {
 // pages) and pre-faulted by a few threads.  User-supplied allocators are always honoured as given.
 struct HostPool {
     struct Blk { void* p; size_t cap; bool used; bool pinned; };
-    std::mutex mu; std::vector<Blk> blks;
+    std::mutex mu; std::vector<Blk> blks; std::atomic<bool> retain{ true };
     static constexpr size_t kMinBytes = 8u << 20, kHuge = 2u << 20;
     static void drop(const Blk& b) { if (b.pinned) (void)hipHostFree(b.p); else free(b.p); }
     ~HostPool() { for (auto& b : blks) drop(b); }
@@ -216,8 +218,13 @@ struct HostPool {
         std::lock_guard<std::mutex> g(mu);
         size_t freeBlocks = 0;
         for (auto& b : blks) { if (b.p == p) b.used = false; if (!b.used) freeBlocks++; }
-        for (size_t i = 0; i < blks.size() && freeBlocks > 2; ) // keep at most two idle blocks
-            if (!blks[i].used && blks[i].p != p) { drop(blks[i]); blks.erase(blks.begin() + (long)i); freeBlocks--; } else ++i;
+        const size_t keep = retain.load() ? 2 : 0;
+        for (size_t i = 0; i < blks.size() && freeBlocks > keep; ) // keep at most two idle blocks (none: ommxBakerKnob_RetainMemory = 1)
+            if (!blks[i].used && (blks[i].p != p || keep == 0)) { drop(blks[i]); blks.erase(blks.begin() + (long)i); freeBlocks--; } else ++i;
+    }
+    void trim() {
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < blks.size(); ) if (!blks[i].used) { drop(blks[i]); blks.erase(blks.begin() + (long)i); } else ++i;
     }
 };
 
@@ -917,8 +924,8 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     if (so && numActiveAll && !(flags & (1u << 1)) && !hc.collision && !P.altKernel && storeBits == bits) {   // (with special indices disabled every uniform item is a block too: the plain path handles that)
         uint32_t k = so->chunksWanted;
         if (!so->forced) {
-            // >= 64 MiB of packed states: one range per 32 MiB, at most 24 (measured at 1.27 GB: 8 / 16 / 24 / 32 ranges = 38.4 / 36.7 / 36.2 / 36.2 ms)
-            k = hc.stateBytes >= (64ull << 20) ? (uint32_t)(hc.stateBytes >> 25) : 0u; if (k > 24u) k = 24u;
+            // >= 64 MiB of packed states: one range per 32 MiB, at most 32 (round 3, classification-bound, at 1.27 GB: 8 / 16 / 24 / 32 ranges = 38.4 / 36.7 / 36.2 / 36.2 ms)
+            k = hc.stateBytes >= (64ull << 20) ? (uint32_t)(hc.stateBytes >> 25) : 0u; if (k > kMaxStreamRanges) k = kMaxStreamRanges;   // (round 4, copy-bound: 12 / 16 / 24 / 32 ranges = 32.4 / 31.8 / 31.0 / 30.9 ms)
             // ... and only when the copy is worth hiding.  Streaming costs the classification about a quarter of its time (5 instead of 6 workgroups per CU,
             // the placement kernels next to it) and saves at most the copy (~57 GB/s over PCIe).  The classification time is estimated from the two
             // quantities that drive it: micro-triangles (sub-texel ones, mostly culled: 2.5e-10 ms each -- 27 ms for 6.5e10, 128 ms for 6.0e11 measured) and
@@ -2252,7 +2259,23 @@ OMM_MI355X_API ommResult ommxSetBakerKnob(ommBaker baker, ommxBakerKnob knob, ui
     if (knob == ommxBakerKnob_ShardChunkBytes && value != 0 && value < 256) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_StreamChunks && value > kMaxStreamRanges) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_GenericPass && value > 2) return ommResult_INVALID_ARGUMENT;
+    if (knob == ommxBakerKnob_RetainMemory) {
+        if (value > 1) return ommResult_INVALID_ARGUMENT;
+        Baker* bk = untag<Baker>(baker);
+        const bool keep = value == 0;
+        bk->hostPool->retain.store(keep); bk->devPool->retain.store(keep); bk->arenas->retain.store(keep);
+        if (!keep) { const DeviceScope onBakersDevice(bk->device.load()); bk->hostPool->trim(); bk->devPool->trim(0); bk->arenas->trim(); }
+    }
     untag<Baker>(baker)->knobs[knob].store(value);
+    return ommResult_SUCCESS;
+}
+
+OMM_MI355X_API ommResult ommxTrimBaker(ommBaker baker)
+{
+    if (baker == 0 || tag_of(baker) != kCpuBaker) return ommResult_INVALID_ARGUMENT;
+    Baker* b = untag<Baker>(baker);
+    const DeviceScope onBakersDevice(b->device.load());
+    b->hostPool->trim(); b->devPool->trim(0); b->arenas->trim();
     return ommResult_SUCCESS;
 }
 

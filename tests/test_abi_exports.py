@@ -268,6 +268,9 @@ def test_baker_knobs_are_per_baker_state_not_environment():
     assert dll.ommxSetBakerKnob(b, ot.KNOB_STREAM_CHUNKS, 33) == ot.INVALID_ARGUMENT     # at most 32 ranges (two queue sections each)
     assert dll.ommxSetBakerKnob(b, ot.KNOB_GENERIC_PASS, 2) == ot.SUCCESS
     assert dll.ommxSetBakerKnob(b, ot.KNOB_GENERIC_PASS, 3) == ot.INVALID_ARGUMENT
+    assert dll.ommxSetBakerKnob(b, ot.KNOB_RETAIN_MEMORY, 1) == ot.SUCCESS and dll.ommxSetBakerKnob(b, ot.KNOB_RETAIN_MEMORY, 2) == ot.INVALID_ARGUMENT
+    dll.ommxTrimBaker.argtypes = [C.c_void_p]
+    assert dll.ommxTrimBaker(b) == ot.SUCCESS and dll.ommxTrimBaker(None) == ot.INVALID_ARGUMENT
     assert dll.ommxSetBakerKnob(b, 99, 1) == ot.INVALID_ARGUMENT
     assert dll.ommxSetBakerKnob(None, ot.KNOB_STREAM_CHUNKS, 3) == ot.INVALID_ARGUMENT
     lib.destroy_baker(b)

@@ -1321,6 +1321,31 @@ def test_internal_flags_conservative_bilinear_kernel(product, oracle):
     both(product, oracle, [tex], uv, ix, 5, addr=ot.WRAP, flags=ot.FLAG_THREADS | (1 << 7), expect=ot.INVALID_ARGUMENT)
 
 
+def test_baker_memory_retention_knob_and_trim(product, oracle):
+    """ommxBakerKnob_RetainMemory = 1: the baker keeps no idle working set, device result block or pinned host block between bakes; ommxTrimBaker gives the
+    idle ones back at once.  Results stay valid (they own their blocks) and later bakes allocate again: same bytes as the oracle throughout."""
+    import ctypes
+    tex = ot.foliage_texture(9, 512, 512, feature=24)
+    uv, ix = ot.random_triangles(77, 1500, 0.03)
+    product.dll.ommxTrimBaker.argtypes = [ctypes.c_void_p]
+    ref = both(product, oracle, [tex], uv, ix, 7, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+    b = product.create_baker()
+    t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+    d = ot.make_desc(t, uv, ix, 7, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
+    assert product.bake(b, d).same_as(ref)
+    assert product.dll.ommxTrimBaker(b) == ot.SUCCESS
+    assert product.bake(b, d).same_as(ref)
+    product.set_knob(b, ot.KNOB_RETAIN_MEMORY, 1)
+    for _ in range(3):
+        assert product.bake(b, d).same_as(ref)
+    product.set_knob(b, ot.KNOB_STREAM_CHUNKS, 3)          # (a streamed result takes its pinned block from the pool and hands it straight back)
+    assert product.bake(b, d).same_as(ref)
+    product.set_knob(b, ot.KNOB_RETAIN_MEMORY, 0)
+    assert product.bake(b, d).same_as(ref)
+    product.destroy_texture(b, t)
+    product.destroy_baker(b)
+
+
 @pytest.mark.parametrize("chunks", [1, 3, 7])
 def test_streamed_result_of_ommCpuBake(product, oracle, chunks):
     """ommCpuBake sends finished OMM blocks to the host while the classification is still running: the active items are sorted into the order of
