@@ -338,6 +338,13 @@ def main():
             prod.fn("ommCpuDestroyBakeResult")(out)
         host_ms = (time.perf_counter() - t1) / host_steps * 1e3
 
+    comm_info = None
+    if comm is not None:   # what the communicator itself says about its size: a SCALE line proves that the collectives really ran over N ranks
+        cr, cw = C.c_uint32(0), C.c_uint32(0)
+        prod.dll.ommxRcclCommInfo.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        if prod.dll.ommxRcclCommInfo(comm, C.byref(cr), C.byref(cw)) == ot.SUCCESS:
+            comm_info = {"kind": "RCCL communicator made by the library (ncclCommCount / ncclCommUserRank)" if native else "caller collectives over torch.distributed (%s)" % dist.get_backend(),
+                         "ranks": int(cw.value), "this_rank": int(cr.value)}
     if rank == 0:
         dev_ms = elapsed / args.steps * 1e3
         # headline: the SDK entry point itself (SURVEY.md section 8d defines both metrics on ommCpuBake); the device-resident entry is the named secondary.
@@ -356,6 +363,7 @@ def main():
         t_last = tms[-1]
         bits = 2
         line = {
+            "communicator": comm_info,
             "metric": "micro-triangles classified/sec (whole node)", "value": micro_tris / (ms_per_step * 1e-3),
             "unit": "micro-triangles/s", "n_gpus": world, "steps": host_steps if headline_host else args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

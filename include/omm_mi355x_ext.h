@@ -140,6 +140,9 @@ OMM_MI355X_API ommResult ommxRcclGetUniqueId(void* outId, size_t idBytes);
 OMM_MI355X_API ommResult ommxRcclCommInitRank(const void* id, size_t idBytes, uint32_t rank, uint32_t worldSize, ommxRcclComm* outComm);
 OMM_MI355X_API ommResult ommxRcclCommWrap(void* ncclComm, ommxRcclComm* outComm);
 OMM_MI355X_API ommResult ommxRcclCommDestroy(ommxRcclComm comm);
+/* rank and size as the communicator itself reports them (a wrapped or library-made RCCL communicator: ncclCommUserRank / ncclCommCount asked again at the
+ * time of the call; a communicator of caller collectives: the values it was made with) */
+OMM_MI355X_API ommResult ommxRcclCommInfo(ommxRcclComm comm, uint32_t* outRank, uint32_t* outWorldSize);
 OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInputDesc* deviceDesc, ommxRcclComm comm, ommxDeviceBakeResult* outResult);
 
 /* ---- the one-call sharded bake over a transport of the caller (MPI with device pointers, torch.distributed, a test harness) ----

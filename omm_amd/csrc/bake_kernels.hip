@@ -376,7 +376,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                     const uint32_t g = tid - 64;
                     const MicroTri gsub = micro_triangle(uUv, (base >> 6) + g, level - 3);
                     int gs = region_state_ex<MD>(P, gsub, uMaxAbs, no_window());
-                    if (gs < 0 && uCurve) { const int cs = OMMX_RC_GROUP_TEST(rc_tex<MD>(P, FP32), uShape, gsub.lo.x, gsub.lo.y, gsub.hi.x, gsub.hi.y, uMaxAbs); gs = cs >= 0 ? cs : gs; }
+                    if (gs < 0 && uCurve) { const int cs = OMMX_RC_GROUP_TEST(rc_tex<MD>(P, FP32), uShape, gsub.lo.x, gsub.lo.y, gsub.hi.x, gsub.hi.y, uMaxAbs); gs = (cs >= 0 || (cs <= -kRegionEdgeFreeBase && uFast)) ? cs : gs; }
                     s_group[g] = gs;
                     s_gdec[g] = bird_group((base >> 6) + g, level - 3).word;
                     const unsigned long long open = __ballot(gs < 0), allOpen = __ballot(gs == kRegionAllOpen);
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
             } else if (tid < (uint32_t)(TILE / GROUP)) {   // no summed-area table: every group is open unless the level curve cannot reach it
                 const uint32_t g = tid;
                 int gs = -1;
-                if (uCurve) { const MicroTri gsub = micro_triangle(uUv, (base >> 6) + g, level - 3); gs = OMMX_RC_GROUP_TEST(rc_tex<MD>(P, FP32), uShape, gsub.lo.x, gsub.lo.y, gsub.hi.x, gsub.hi.y, uMaxAbs); }
+                if (uCurve) { const MicroTri gsub = micro_triangle(uUv, (base >> 6) + g, level - 3); const int cs = OMMX_RC_GROUP_TEST(rc_tex<MD>(P, FP32), uShape, gsub.lo.x, gsub.lo.y, gsub.hi.x, gsub.hi.y, uMaxAbs); gs = (cs >= 0 || (cs <= -kRegionEdgeFreeBase && uFast)) ? cs : -1; }
                 s_group[g] = gs;
                 s_gdec[g] = bird_group((base >> 6) + g, level - 3).word;
                 const unsigned long long open = __ballot(gs < 0);
@@ -415,6 +415,23 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         // one wave = one 64-group; gs (wave-uniform) is < 0 here: kRegionAllOpen or kRegionUnknown
         auto phase1_group = [&](uint32_t i, int gs) {
             bool unresolved = false;
+            if (gs <= -kRegionEdgeFreeBase) {
+                // the group lies in one cell whose level curve cannot reach it (region_curve.h), but the work item is too thin / too small against the rounding of
+                // its vertices for the corner bound: every micro-triangle has the state of that side unless PointInTriangle puts one of the cell's wrong-side corners
+                // inside it -- four cross-product tests per lane instead of the whole single-texel pass; the (rare) exceptions are queued for that pass
+                const uint32_t code = (uint32_t)(-gs - kRegionEdgeFreeBase);
+                if (i < count) {
+                    const DevMip& m0 = P.mips[0];
+                    const MicroTri t = tile_micro_triangle(i);
+                    const float pfx = __builtin_floorf(t.p0.x * m0.fw - 0.5f) + 0.5f, pfy = __builtin_floorf(t.p0.y * m0.fh - 0.5f) + 0.5f;   // the cell of the group = of every vertex in it
+                    const float ipx = pfx * m0.rw, ipy = pfy * m0.rh;
+                    const bool in0 = point_in_triangle_flat(t, ipx, ipy), in1 = point_in_triangle_flat(t, ipx, ipy + m0.rh);
+                    const bool in2 = point_in_triangle_flat(t, ipx + m0.rw, ipy + m0.rh), in3 = point_in_triangle_flat(t, ipx + m0.rw, ipy);
+                    const uint32_t in = (in0 ? 1u : 0u) | (in1 ? 2u : 0u) | (in2 ? 4u : 0u) | (in3 ? 8u : 0u);
+                    unresolved = (in & code & 15u) != 0u;
+                    s_state[i] = (uint8_t)((code & 16u) ? P.stateGT : P.stateLE);
+                }
+            } else
             if (gs == kRegionAllOpen) { // the whole group is unresolved by construction: no per-micro-triangle SAT test
                 if (uFast) return;   // phase 2a takes the group as a whole, it needs no queue entries
                 unresolved = i < count;   // (phase 2 writes the state of every queued micro-triangle)

@@ -757,6 +757,8 @@ __device__ __forceinline__ TexRect region_rect(const ClassifyParams& P, const Mi
     return r;
 }
 
+constexpr int kRegionEdgeFreeBase = 0x100;   // region_curve_state(): -(base + 16 above + mask) = "inside ONE cell, every vote on that side except, possibly, the
+                                             // corner votes of the cell corners in `mask` (wrong side): test PointInTriangle for those per micro-triangle"
 constexpr int kRegionUnknown = -1;     // descendants must be tested one by one
 constexpr int kRegionAllOpen = -2;     // EVERY descendant stays unresolved in the coarse pass (region_state_ex only)
 
@@ -807,7 +809,7 @@ __device__ __forceinline__ int region_curve_state_impl(const RcTex& T, const RcS
     if (!sh.ok) return -1;
     const RcFrame f = rc_frame(lox, loy, hix, hiy, maxAbs, T.fw, T.fh, T.w, T.h, T.addr, T.pow2);
     if (!f.ok) return -1;
-    int sign = 0;
+    int sign = 0; uint32_t wrong = 0;
     for (int j = 0; j < f.ny; ++j)
         for (int i = 0; i < f.nx; ++i) {
             const size_t i00 = (size_t)(f.sx + i) + (size_t)(f.sy + j) * (size_t)T.w, i01 = i00 + (size_t)T.w;
@@ -819,10 +821,18 @@ __device__ __forceinline__ int region_curve_state_impl(const RcTex& T, const RcS
             if (c == 2) continue;
             if (sign != 0 && sign != c) return -1;
             sign = c;
+            // corners of this cell whose texel is on the other side, in the order the level-line kernel tests them: (x, y), (x, y+1), (x+1, y+1), (x+1, y)
+            const uint32_t above = (T.cutoff < g00 ? 1u : 0u) | (T.cutoff < g01 ? 2u : 0u) | (T.cutoff < g11 ? 4u : 0u) | (T.cutoff < g10 ? 8u : 0u);
+            wrong = c > 0 ? (~above & 15u) : above;
         }
     if (sign == 0) return -1;
     const int st = sign > 0 ? T.stateGT : T.stateLE;
-    return st == 3 ? -1 : st;   // (as region_state(): the value the reference's fine pass would revisit is not shortcut)
+    if (st == 3) return -1;   // (as region_state(): the value the reference's fine pass would revisit is not shortcut)
+    if (sh.fat) return st;
+    // the corner bound does not hold for this work item (RcShape::fat): edges and centre vote are settled, the corner votes of the other side are not.  For
+    // a sub-triangle inside ONE cell the caller can finish the job per micro-triangle (PointInTriangle of the cell's wrong-side corners): kRegionEdgeFree code
+    if (f.nx != 1 || f.ny != 1) return -1;
+    return -(kRegionEdgeFreeBase + (sign > 0 ? 16 : 0) + (int)wrong);
 }
 template <class MD>
 __device__ __forceinline__ int region_curve_state(const ClassifyParams& P, bool fp32, const RcShape& sh, const MicroTri& sub, float maxAbs)

@@ -2116,6 +2116,16 @@ OMM_MI355X_API ommResult ommxCommFromCollectives(const ommxCollectives* collecti
     return ommResult_SUCCESS;
 }
 
+OMM_MI355X_API ommResult ommxRcclCommInfo(ommxRcclComm comm, uint32_t* outRank, uint32_t* outWorldSize)
+{
+    if (comm == 0 || outRank == nullptr || outWorldSize == nullptr) return ommResult_INVALID_ARGUMENT;
+    RcclComm* c = (RcclComm*)comm;
+    int rank = c->rank, world = c->world;
+    if (!c->custom && c->comm && rccl().ok() && (rccl().commCount(c->comm, &world) != 0 || rccl().commUserRank(c->comm, &rank) != 0)) return ommResult_FAILURE;
+    *outRank = (uint32_t)rank; *outWorldSize = (uint32_t)world;
+    return ommResult_SUCCESS;
+}
+
 OMM_MI355X_API ommResult ommxRcclCommDestroy(ommxRcclComm comm)
 {
     if (comm == 0) return ommResult_INVALID_ARGUMENT;

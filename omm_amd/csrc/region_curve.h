@@ -34,7 +34,7 @@
 #define OMMX_RC_FN static inline
 #endif
 
-typedef struct RcShape { float Kub, Klb, rhoX, rhoY; int ok; } RcShape;                 /* per work item (level included) */
+typedef struct RcShape { float Kub, Klb, rhoX, rhoY; int ok, fat; } RcShape;            /* per work item (level included).  ok: the edge / centre-vote bounds hold; fat: the corner (point-in-triangle) bound too */
 typedef struct RcFrame { int X0, Y0, sx, sy, nx, ny, ok; float bx0, bx1, by0, by1; } RcFrame;   /* per sub-triangle: cells [X0, X0 + nx) x [Y0, Y0 + ny) */
 
 OMMX_RC_FN float rc_abs(float v) { return v < 0.f ? -v : v; }
@@ -48,7 +48,7 @@ OMMX_RC_FN float rc_floor(float f) { return __builtin_floorf(f); }
 /* Slope and shape bounds shared by every micro-triangle of a work item (uv: its six floats; level: its subdivision level; w, h: texture size). */
 OMMX_RC_FN RcShape rc_shape(const float* uv, float fw, float fh, int w, int h, uint32_t level)
 {
-    RcShape s; s.Kub = 0.f; s.Klb = 0.f; s.rhoX = 0.f; s.rhoY = 0.f; s.ok = 0;
+    RcShape s; s.Kub = 0.f; s.Klb = 0.f; s.rhoX = 0.f; s.rhoY = 0.f; s.ok = 0; s.fat = 0;
     /* u: bound of ONE rounding of a raster-space coordinate of this item (2^-24 relative), per axis */
     const float mx = rc_max(rc_max(rc_abs(uv[0]), rc_abs(uv[2])), rc_abs(uv[4])), my = rc_max(rc_max(rc_abs(uv[1]), rc_abs(uv[3])), rc_abs(uv[5]));
     const float ux = fw * mx * 5.9604645e-8f, uy = fh * my * 5.9604645e-8f;
@@ -64,7 +64,10 @@ OMMX_RC_FN RcShape rc_shape(const float* uv, float fw, float fh, int w, int h, u
     const float ax0 = rc_abs(ex0), ax1 = rc_abs(ex1), ax2 = rc_abs(ex2), ay0 = rc_abs(ey0), ay1 = rc_abs(ey1), ay2 = rc_abs(ey2);
     const float dxmin = rc_min(rc_min(ax0, ax1), ax2) * 0.99999f - dX, dxmax = rc_max(rc_max(ax0, ax1), ax2) * 1.00001f + dX;
     const float dymin = rc_max(rc_min(rc_min(ay0, ay1), ay2) * 0.99999f - dY, 0.f), dymax = rc_max(rc_max(ay0, ay1), ay2) * 1.00001f + dY;
-    if (!(dxmin >= 2e-4f && dxmax <= 1.f && dymax <= 1.f)) return s;
+    if (!(dxmax <= 1.f && dymax <= 1.f)) return s;
+    /* (no lower bound on dxmin: an edge whose |dx| is below 1e-6 takes TestEdgeHyperbolaIntersection's vertical branch -- decided on the same fp32 value --
+     *  whose residual is the smallest of the three; every other edge has |slope| <= dymax / 1e-6.  The bounds of rc_cell() hold for any slope bound; a large
+     *  one only makes them weak.) */
     /* smallest angle: sin >= 2 A / Lmax^2, both on the pessimistic side of that perturbation (|cross(e + d, e' + d') - cross(e, e')| <= dX (|ey| + |ey'|) + dY (|ex| + |ex'|) + 2 dX dY) */
     const float c1 = ex0 * ey1, c2 = ey0 * ex1;
     const float twoA = rc_abs(c1 - c2) - 4e-7f * (rc_abs(c1) + rc_abs(c2));
@@ -74,8 +77,11 @@ OMMX_RC_FN RcShape rc_shape(const float* uv, float fw, float fh, int w, int h, u
     const float q01 = dX * (ay0 + ay1) + dY * (ax0 + ax1), q12 = dX * (ay1 + ay2) + dY * (ax1 + ax2), q20 = dX * (ay2 + ay0) + dY * (ax2 + ax0);
     const float twoAlb = twoA - rc_min(rc_min(q01, q12), q20) * 1.0001f - 2.f * dX * dY;
     const float L2ub = L2 + 3.f * dl * (dxmax + dymax) + 2.f * dl * dl;
-    if (!(twoAlb >= 0.005f * L2ub)) return s;
-    s.Kub = (dymax / dxmin) * 1.00001f; s.Klb = (dymin / dxmax) * 0.99999f;
+    /* without that lower bound on the angles (thin work items; micro-triangles smaller than the rounding of their vertices) only the corner votes are open: the
+     * edge tests and the centre vote do not depend on it.  Such a work item gets the weaker verdict of region_curve.h's callers: "every vote is on side s unless
+     * PointInTriangle puts a cell corner of the OTHER side inside the micro-triangle", which the caller then evaluates per micro-triangle. */
+    s.fat = twoAlb >= 0.005f * L2ub;
+    s.Kub = (dymax / rc_max(dxmin, 1e-6f)) * 1.00001f; s.Klb = (dymin / dxmax) * 0.99999f;
     s.rhoX = 6e-3f + 22.f * ux + 0.015625f; s.rhoY = 6e-3f + 22.f * uy + 0.015625f;
     s.ok = 1;
     return s;
@@ -129,14 +135,22 @@ OMMX_RC_FN int rc_cell(const RcShape* sh, float g00, float g10, float g01, float
     const float Mb = 2.5f * (1.f + Kub) * 1.000001f;
     const float C1b = (ac * Kub + ad * Mb + ab) * 1.000001f;
     const float C2b = (aa + ac * Mb) * 1.000001f;
-    const float c0lb = rc_max(ad * Klb * 0.999999f, 0.999999e-6f);
     const float rest = 1.0001e-6f + E * (9.1f * C2b + 8.1f * C1b + 6.1f * ad * Kub + 2.02f * (ac + ad) * (Kub + 1.f)) + 66.f * E * S + 1e-30f;
+    /* the quadratic branch's ill-conditioning term e C1(k)^2 / |c0(k)| of an edge of slope k, |c0| = |hd| k >= 1e-6 in that branch, C1(k) = |hc| k + |hd| 2.5 (1 + k) + |hb|:
+     * convex in k above k* = 1e-6 / |hd|, so over the slopes [max(Klb, k*), Kub] the work item's edges can have it is largest at an end (curve_excluded() of
+     * classify_device.h uses the cruder C1(Kub)^2 / (|hd| Klb), which needs Klb > 0: useless when an edge may be horizontal) */
+    float G = 0.f;
+    if (ad * Kub > 0.999999e-6f) {
+        const float klo = rc_min(rc_max(Klb, 1.000001e-6f / ad), Kub);
+        const float c1lo = (ac * klo + ad * 2.5f * (1.f + klo) + ab) * 1.000002f;
+        G = rc_max(c1lo * c1lo / rc_max(ad * klo * 0.999999f, 0.999999e-6f), C1b * C1b / rc_max(ad * Kub * 0.999999f, 0.999999e-6f));
+    }
     const float cv = 16.f * E * (rc_abs(g00) + rc_abs(g10) + rc_abs(g01) + rc_abs(g11) + rc_abs(cutoff));
     const float gy0 = ha + hc * y0, hy0 = hb + hd * y0, gy1 = ha + hc * y1, hy1 = hb + hd * y1;
     const float f00 = gy0 + x0 * hy0, f10 = gy0 + x1 * hy0, f01 = gy1 + x0 * hy1, f11 = gy1 + x1 * hy1;
     const float fmn = rc_min(rc_min(f00, f10), rc_min(f01, f11)), fmx = rc_max(rc_max(f00, f10), rc_max(f01, f11));
     const float F = rc_max(fmn, -fmx) - rest - cv;
-    const int pass = (F > 0.f) & (F * c0lb > 1.01f * E * C1b * C1b) & (!flat | (F > 2e-5f));
+    const int pass = (F > 1.01f * E * G) & (!flat | (F > 2e-5f));
     return pass ? (fmn > 0.f ? 1 : -1) : 0;
 }
 

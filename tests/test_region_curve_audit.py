@@ -4,7 +4,10 @@ of the oracle includes that header as it is, evaluates the test for EVERY sub-tr
 kernels use, and all the others) and compares a verdict "all descendants have the pure state s" with the states the reference algorithm produced for them.
 counters (oracle/omm_oracle.c: audit_region_item): [0] sub-triangles tested, [1] settled, [2] micro-triangles under settled sub-triangles, [3] micro-triangles
 whose reference state differs (must be 0), [4] / [5] work items whose shape admits the test / all, [6] / [7] = [1] / [2] for sub-triangles whose cells hold
-texels on both sides of the cutoff (what the summed-area table cannot settle)."""
+texels on both sides of the cutoff (what the summed-area table cannot settle); work items without the corner bound (thin ones, or micro-triangles smaller
+than the rounding of their vertices: RcShape::fat == 0) get the weaker verdict "pure state unless PointInTriangle puts a wrong-side cell corner inside":
+[8] sub-triangles with that verdict, [9] descendants it covers, [10] descendants left to the full pass (a wrong-side corner inside), [11] covered ones whose
+reference state differs (must be 0)."""
 import ctypes as C
 import os
 import subprocess
@@ -31,7 +34,7 @@ def audit():
 
 
 def counters(lib):
-    return [lib.dll.orc_audit_region_counter(i) for i in range(8)]
+    return [lib.dll.orc_audit_region_counter(i) for i in range(12)]
 
 
 def test_region_verdicts_on_the_bench_workloads(audit):
@@ -49,7 +52,8 @@ def test_region_verdicts_on_the_bench_workloads(audit):
     c = counters(audit)
     assert c[0] > 10_000_000 and c[4] > 1000, c
     assert c[6] > 100_000 and c[7] > 1_000_000, c      # settled where the texels around the sub-triangle are NOT all on one side
-    assert c[3] == 0, c
+    assert c[8] > 1_000_000 and c[9] > 10_000_000, c   # the weaker verdict (no corner bound): configs[4]'s level-9 / 10 items are all of that kind
+    assert c[3] == 0 and c[11] == 0, c
 
 
 def test_region_verdicts_on_adversarial_inputs(audit):
@@ -91,4 +95,4 @@ def test_region_verdicts_on_adversarial_inputs(audit):
     audit.destroy_baker(b)
     c = counters(audit)
     assert c[0] > 500_000 and c[1] > 400_000 and c[6] > 2_000, tuple(c)
-    assert c[3] == 0, c
+    assert c[3] == 0 and c[11] == 0, c
