@@ -640,29 +640,19 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
 
 // ------------------------------------------------------------------------------------------------
 // Deferred generic pass.  Micro-triangles that span several texels (asset-sized triangles) walk the texels of their raster box (conservative
-// raster + level-line kernel / nearest vote per texel: fine_state).  Inside classify_tiles one lane walks one box: neighbouring boxes differ in
-// size by orders of magnitude, two thirds of the walks end at their first mixed texel after a handful of visits and the rest visit every texel
-// under the triangle, so a fifth of the lanes does useful work (profiles/r03_v3_cards_pmc.md).  Here the walk has two phases per wave of 64
-// queued micro-triangles:
-//   A  one lane per micro-triangle, at most OMMX_GENERIC_SOLO (12) visits of texels under the triangle: settles the short walks at full width;
-//   B  the unfinished walks, eight at a time, EIGHT lanes each: texel k of the box goes to lane k mod 8 from where phase A stopped, the counters
-//      are combined with two wave ballots after every round, and a sub-group stops as soon as both are non-zero (when the promotion does not
-//      look at the counts) -- the early exit of the serial walk at a granularity of eight texels.
-// (Eight lanes per walk from the start -- the first form -- took as long as the serial walk: it pays 8 x for every short walk what it gains on
-// the long ones.)  The result depends on the two counters only through (above != 0, below != 0) or, for the Nearest promotion, their totals
-// (state_from_coverage), and every texel of the box is visited at most once: same state as the serial walk.  Mip chains and degenerate items
-// take the serial fine_state().  The state is ORed into the packed word the persistent launch left 0; item mask / known count are folded per wave.
+// raster + level-line kernel / nearest vote per texel: fine_state).  Inside classify_tiles one lane walks one box in lockstep with 63 others:
+// neighbouring boxes differ in size by orders of magnitude, two thirds of the walks end at their first mixed texel after a handful of visits
+// and the rest visit every texel under the triangle, so a fifth of the lanes does useful work (profiles/r03_v3_cards_pmc.md).  Here the walks
+// are queue entries and a lane that finishes one takes the next (generic_refill / generic_walks below); every texel of a box is visited at most
+// once, in row-major order, with the serial loop's early exit: same state.  Mip chains, the alternative kernel and degenerate items take the
+// serial fine_state().  The state is ORed into the packed word the persistent launch left 0; item mask / known count are folded per wave.
+// (Round 3's form -- 12 visits one lane per walk, then eight lanes per unfinished walk -- took 36.9 ms where this one takes 28.8.)
 // ------------------------------------------------------------------------------------------------
-#ifndef OMMX_GENERIC_SOLO
-#define OMMX_GENERIC_SOLO 12   // measured on the cards workload (generic pass alone): 2 / 4 / 8 / 12 / 24 / 64 / unbounded = 43.4 / 39.4 / 37.6 / 37.1 / 38.3 / 41.3 / 46.6 ms
-#endif
 struct RasterBox { EdgeEq e0, e1, e2; int minx, miny, xend, yend; uint32_t w, cnt; };   // texels [minx, xend) x [miny, yend), row-major index k < cnt
 struct TexelCursor { int x, y; };
 __device__ __forceinline__ TexelCursor cursor_at(const RasterBox& B, uint32_t k) { TexelCursor c; c.x = B.minx + (int)(k % B.w); c.y = B.miny + (int)(k / B.w); return c; }
 __device__ __forceinline__ bool cursor_live(const RasterBox& B, const TexelCursor& c) { return c.y < B.yend; }
 __device__ __forceinline__ void cursor_step(const RasterBox& B, TexelCursor& c) { if (++c.x == B.xend) { c.x = B.minx; ++c.y; } }
-__device__ __forceinline__ void cursor_step8(const RasterBox& B, TexelCursor& c) { c.x += 8; while (c.x >= B.xend && c.y < B.yend) { c.x -= (int)B.w; ++c.y; } }
-__device__ __forceinline__ uint32_t cursor_index(const RasterBox& B, const TexelCursor& c) { return c.y >= B.yend ? B.cnt : (uint32_t)(c.y - B.miny) * B.w + (uint32_t)(c.x - B.minx); }
 __device__ __forceinline__ RasterBox raster_box(const DevMip& m, const MicroTri& t, float off)
 {
     // same set-up as raster_micro_triangle (classify_device.h): winding, raster-space vertices, box
@@ -701,70 +691,6 @@ __device__ __forceinline__ void texel_vote(const ClassifyParams& P, const DevMip
     if (KIND == 0) level_line_texel<FP32, false, MD>(P, m, t, c.x, c.y, above, below, no_window());
     else nearest_texel<FP32, MD>(P, m, c.x, c.y, above, below, no_window());
 }
-// sum of a counter over the 8 lanes of a sub-group
-__device__ __forceinline__ uint32_t sum8(uint32_t v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
-
-template <bool FP32, int KIND, class MD>
-__device__ __forceinline__ int generic_two_phase(const ClassifyParams& P, const float* __restrict__ uvAll, uint32_t item, uint32_t levelWord, bool live)
-{
-    const DevMip& m = P.mips[0];
-    const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, sg = lane >> 3;
-    const bool countsMatter = P.promotion == 0;
-    const float off = KIND == 0 ? -0.5f : 0.f;
-    uint32_t above = 0, below = 0, k = 0;
-    bool finished = !live;
-    {   // ---- phase A: one lane per micro-triangle ----
-        const MicroTri t = micro_triangle(uvAll + 6ull * item, levelWord & 0xFFFFFFu, levelWord >> 24);
-        if (KIND == 0 && live) vote(P.cutoff < bilinear<FP32, MD>(P, m, t.p0, no_window()), above, below);
-        const RasterBox B = raster_box(m, t, off);
-        TexelCursor c = cursor_at(B, 0u);   // (no integer division per texel: the cursor steps)
-        for (uint32_t visits = 0; !finished && visits < (uint32_t)OMMX_GENERIC_SOLO; ++visits) {
-            while (cursor_live(B, c) && !texel_under(B, c)) cursor_step(B, c);
-            if (!cursor_live(B, c)) { finished = true; break; }
-            texel_vote<FP32, KIND, MD>(P, m, t, c, above, below);
-            cursor_step(B, c);
-            if (!countsMatter && above != 0 && below != 0) finished = true;
-        }
-        if (!finished) { while (cursor_live(B, c) && !texel_under(B, c)) cursor_step(B, c); if (!cursor_live(B, c)) finished = true; }
-        k = cursor_index(B, c);
-    }
-    // ---- phase B: the unfinished walks, eight at a time, eight lanes each ----
-    unsigned long long pending = __ballot(!finished);
-    while (pending) {
-        unsigned long long mine = pending;
-        for (uint32_t q = 0; q < sg; ++q) mine &= mine - 1ull;               // drop the sg lowest set bits: this sub-group takes the next one
-        const int src = mine ? __ffsll((long long)mine) - 1 : -1;
-        const bool work = src >= 0;
-        const int from = work ? src : (int)lane;
-        const uint32_t it2 = (uint32_t)__shfl((int)item, from), lw2 = (uint32_t)__shfl((int)levelWord, from), k0 = (uint32_t)__shfl((int)k, from);
-        const uint32_t a0 = (uint32_t)__shfl((int)above, from), b0 = (uint32_t)__shfl((int)below, from);
-        const MicroTri t = micro_triangle(uvAll + 6ull * it2, lw2 & 0xFFFFFFu, lw2 >> 24);
-        const RasterBox B = raster_box(m, t, off);
-        uint32_t la = sub == 0u ? a0 : 0u, lb = sub == 0u ? b0 : 0u;          // (lane 0 of the sub-group carries the walk's counters so far)
-        const uint32_t shift = lane & 56u;
-        bool done = !work;
-        TexelCursor c = cursor_at(B, k0 + sub < B.cnt ? k0 + sub : 0u); if (k0 + sub >= B.cnt) c.y = B.yend;
-        for (;;) {
-            while (!done && cursor_live(B, c) && !texel_under(B, c)) cursor_step8(B, c);
-            const bool go = !done && cursor_live(B, c);
-            if (__ballot(go) == 0ull) break;
-            if (go) { texel_vote<FP32, KIND, MD>(P, m, t, c, la, lb); cursor_step8(B, c); }
-            if (!countsMatter) {   // the sub-group has seen both sides: the state is final
-                const unsigned long long ba = __ballot(la != 0), bb = __ballot(lb != 0);
-                if (((ba >> shift) & 0xFFull) != 0ull && ((bb >> shift) & 0xFFull) != 0ull) done = true;
-            }
-        }
-        const uint32_t ta = sum8(la), tb = sum8(lb);
-        // hand the totals back to the lanes that own the walks: owner of the r-th set bit <- sub-group r
-        const uint32_t rank = (uint32_t)__popcll(pending & ((1ull << lane) - 1ull));
-        const bool owner = ((pending >> lane) & 1ull) != 0ull && rank < 8u;
-        const uint32_t ra = (uint32_t)__shfl((int)ta, (int)((owner ? rank : 0u) * 8u)), rb = (uint32_t)__shfl((int)tb, (int)((owner ? rank : 0u) * 8u));
-        if (owner) { above = ra; below = rb; finished = true; }
-        for (int q = 0; q < 8 && pending; ++q) pending &= pending - 1ull;
-    }
-    return state_from_coverage(P, above, below);
-}
-
 // a wave's classified entries: state ORed into the packed word the persistent launch left 0; item mask / known count with one atomic per item and wave
 // (the entries of a wave mostly share their item)
 __device__ __forceinline__ void generic_commit(const ClassifyParams& P, const ItemArrays& A, bool live, uint32_t item, uint32_t index, int state)
@@ -788,24 +714,215 @@ __device__ __forceinline__ void generic_commit(const ClassifyParams& P, const It
     }
 }
 
+// ---- the refill form ----
+// A wave that runs 64 walks in lockstep has two thirds of its lanes finished after two visits, waiting for its longest walk.  Here a lane that finishes
+// gets the next queued micro-triangle: a wave pulls chunks of
+// OMMX_GENERIC_CHUNK entries from a cursor next to the queue's count word, and whenever OMMX_GENERIC_REFILL lanes are idle they commit their states together
+// (generic_commit folds the item masks per wave), take the next entries and set them up (micro-triangle, centre vote, raster box) in one dense round; every
+// other iteration is one visit -- skip to the next covered texel, vote -- for all lanes that hold a walk.  Same visits in the same order per walk as the
+// serial loop, with its early exit: same state.
+#ifndef OMMX_GENERIC_REFILL
+#define OMMX_GENERIC_REFILL 16
+#endif
+#ifndef OMMX_GENERIC_CHUNK
+#define OMMX_GENERIC_CHUNK 1024u
+#endif
+template <bool FP32, int KIND, class MD>
+__device__ __forceinline__ void generic_refill(const ClassifyParams& P, const ItemArrays& A, const GenericQueue& G, uint32_t n)
+{
+    const DevMip& m = P.mips[0];
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool countsMatter = P.promotion == 0;
+    const float off = KIND == 0 ? -0.5f : 0.f;
+    unsigned long long* const cursorWord = G.count + 1;
+    uint32_t chunkNext = 0, chunkEnd = 0;   // (wave-uniform)
+    bool drained = false;                   // (wave-uniform) no entries left in the queue
+    bool have = false, result = false;      // this lane: holds an unfinished walk / a finished one that is not committed yet
+    uint32_t item = 0, levelWord = 0, above = 0, below = 0;
+    int direct = -1;                        // state of a degenerate item's micro-triangle (serial fine_state), or -1
+    MicroTri t; t.p0 = t.p1 = t.p2 = mk2(0.f, 0.f);
+    RasterBox B = raster_box(m, t, off);
+    TexelCursor c = cursor_at(B, 0u);
+    for (;;) {
+        const unsigned long long busy = __ballot(have);
+        const uint32_t idle = 64u - (uint32_t)__popcll(busy);
+        if ((!drained && idle >= (uint32_t)OMMX_GENERIC_REFILL) || busy == 0ull) {
+            generic_commit(P, A, result, item, levelWord & 0xFFFFFFu, direct >= 0 ? direct : state_from_coverage(P, above, below));
+            result = false;
+            if (drained) { if (busy == 0ull) break; }
+            else {
+                if (chunkNext == chunkEnd) {
+                    unsigned long long start = 0;
+                    if (lane == 0u) start = atomicAdd(cursorWord, (unsigned long long)OMMX_GENERIC_CHUNK);
+                    start = (unsigned long long)__shfl((long long)start, 0);
+                    if (start >= (unsigned long long)n) drained = true;
+                    else { chunkNext = (uint32_t)start; chunkEnd = start + OMMX_GENERIC_CHUNK < (unsigned long long)n ? (uint32_t)start + OMMX_GENERIC_CHUNK : n; }
+                }
+                if (!drained) {
+                    const uint32_t avail = chunkEnd - chunkNext, take = idle < avail ? idle : avail;
+                    const uint32_t rank = (uint32_t)__popcll(~busy & ((1ull << lane) - 1ull));
+                    bool get = !have && rank < take;
+                    uint2 ent = get ? G.entries[chunkNext + rank] : make_uint2(0u, 0u);
+                    chunkNext += take;
+                    if (ent.x == 0xFFFFFFFFu) get = false;   // (null entry: the inside part of a reservation that did not fit)
+                    const bool degenerate = get && ((ent.x >> 30) & 1u) != 0u;
+                    if (get) { item = ent.x & 0x3FFFFFFFu; levelWord = ent.y; above = 0; below = 0; direct = -1; }
+                    if (__ballot(degenerate) != 0ull) {   // (rare: degenerate items take the serial form)
+                        if (degenerate) { direct = fine_state<FP32, MD>(P, micro_triangle(A.uv + 6ull * item, levelWord & 0xFFFFFFu, levelWord >> 24), true, no_window()); result = true; get = false; }
+                    }
+                    if (get) {
+                        t = micro_triangle(A.uv + 6ull * item, levelWord & 0xFFFFFFu, levelWord >> 24);
+                        if (KIND == 0) vote(P.cutoff < bilinear<FP32, MD>(P, m, t.p0, no_window()), above, below);
+                        B = raster_box(m, t, off);
+                        c = cursor_at(B, 0u);
+                        have = true;
+                    }
+                }
+            }
+            continue;
+        }
+        if (have) {   // one visit
+            while (cursor_live(B, c) && !texel_under(B, c)) cursor_step(B, c);
+            if (!cursor_live(B, c)) { have = false; result = true; }
+            else {
+                texel_vote<FP32, KIND, MD>(P, m, t, c, above, below);
+                cursor_step(B, c);
+                if (!countsMatter && above != 0 && below != 0) { have = false; result = true; }
+            }
+        }
+    }
+}
+
+// ---- the level-line walks (Linear filter) in the refill form, with the cheap cells passed in an inner loop ----
+// Most cells of a long walk are cheap: flat (no edge can cross a constant patch: the reference votes by the first texel) and with all four texels on a side
+// the walk has already seen -- when only (any vote above, any vote below) counts, such a cell changes nothing.  Every lane advances to its next cell that
+// needs work (corner votes: its texels are not all on a seen side; edge tests: it is not flat), a few rounds of fetch + compare, and then the wave does the
+// corner votes and the three edge tests for those cells together.  Rows are left at the first texel that is not under the triangle after one that was: the
+// texels under the conservative triangle form an interval in every row (each edge function is monotone in x, in fp32 too).
+#ifndef OMMX_GENERIC_ADVANCE
+#define OMMX_GENERIC_ADVANCE 4   // rounds of advancing per round of cell work
+#endif
 template <bool FP32, class MD>
-__global__ __launch_bounds__(256) void classify_generic(ClassifyParams P, ItemArrays A, GenericQueue G)
+__device__ __forceinline__ void generic_walks(const ClassifyParams& P, const ItemArrays& A, const GenericQueue& G, uint32_t n)
+{
+    const DevMip& m = P.mips[0];
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool countsMatter = P.promotion == 0;
+    unsigned long long* const cursorWord = G.count + 1;
+    uint32_t chunkNext = 0, chunkEnd = 0;   // (wave-uniform)
+    bool drained = false;                   // (wave-uniform)
+    bool have = false, result = false, rowSeen = false;
+    uint32_t item = 0, levelWord = 0, above = 0, below = 0;
+    int direct = -1;
+    MicroTri t; t.p0 = t.p1 = t.p2 = mk2(0.f, 0.f);
+    RasterBox B = raster_box(m, t, -0.5f);
+    TexelCursor c = cursor_at(B, 0u);
+    for (;;) {
+        const unsigned long long busy = __ballot(have);
+        const uint32_t idle = 64u - (uint32_t)__popcll(busy);
+        if ((!drained && idle >= (uint32_t)OMMX_GENERIC_REFILL) || busy == 0ull) {
+            generic_commit(P, A, result, item, levelWord & 0xFFFFFFu, direct >= 0 ? direct : state_from_coverage(P, above, below));
+            result = false;
+            if (drained) break;   // (busy == 0)
+            if (chunkNext == chunkEnd) {
+                unsigned long long start = 0;
+                if (lane == 0u) start = atomicAdd(cursorWord, (unsigned long long)OMMX_GENERIC_CHUNK);
+                start = (unsigned long long)__shfl((long long)start, 0);
+                if (start >= (unsigned long long)n) drained = true;
+                else { chunkNext = (uint32_t)start; chunkEnd = start + OMMX_GENERIC_CHUNK < (unsigned long long)n ? (uint32_t)start + OMMX_GENERIC_CHUNK : n; }
+            }
+            if (!drained) {
+                const uint32_t avail = chunkEnd - chunkNext, take = idle < avail ? idle : avail;
+                const uint32_t rank = (uint32_t)__popcll(~busy & ((1ull << lane) - 1ull));
+                bool get = !have && rank < take;
+                uint2 ent = get ? G.entries[chunkNext + rank] : make_uint2(0u, 0u);
+                chunkNext += take;
+                if (ent.x == 0xFFFFFFFFu) get = false;   // (null entry: the inside part of a reservation that did not fit)
+                const bool degenerate = get && ((ent.x >> 30) & 1u) != 0u;
+                if (get) { item = ent.x & 0x3FFFFFFFu; levelWord = ent.y; above = 0; below = 0; direct = -1; }
+                if (__ballot(degenerate) != 0ull) {   // (rare: degenerate items take the serial form)
+                    if (degenerate) { direct = fine_state<FP32, MD>(P, micro_triangle(A.uv + 6ull * item, levelWord & 0xFFFFFFu, levelWord >> 24), true, no_window()); result = true; get = false; }
+                }
+                if (get) {
+                    t = micro_triangle(A.uv + 6ull * item, levelWord & 0xFFFFFFu, levelWord >> 24);
+                    vote(P.cutoff < bilinear<FP32, MD>(P, m, t.p0, no_window()), above, below);
+                    B = raster_box(m, t, -0.5f);
+                    c = cursor_at(B, 0u); rowSeen = false;
+                    have = true;
+                }
+            }
+            continue;
+        }
+        // ---- advance: every walking lane to its next cell that needs work ----
+        bool cell = false, corners = false;
+        float ha = 0.f, hb = 0.f, hc = 0.f, hd = 0.f, pfx = 0.f, pfy = 0.f;
+        uint32_t obits = 0;
+        for (int round = 0; round < OMMX_GENERIC_ADVANCE; ++round) {
+            if (have && !cell) {
+                while (cursor_live(B, c) && !texel_under(B, c)) { if (rowSeen) { c.x = B.minx; ++c.y; rowSeen = false; } else cursor_step(B, c); }
+                if (!cursor_live(B, c)) { have = false; result = true; }
+                else {
+                    rowSeen = true;
+                    pfx = (float)c.x + 0.5f; pfy = (float)c.y + 0.5f;
+                    float gx, gy, gz, gw;   // 00, 01, 11, 10
+                    fetch_cell<FP32, MD>(P, m, MD::pow2(P), c.x, c.y, no_window(), gx, gy, gz, gw);
+                    const bool o0 = P.cutoff < gx, o1 = P.cutoff < gy, o2 = P.cutoff < gz, o3 = P.cutoff < gw;
+                    hb = gw - gx; hc = gy - gx; hd = gx + gz - gy - gw; ha = gx - P.cutoff;
+                    const bool flat = near_zero(hb, 1e-6f) & near_zero(hc, 1e-6f) & near_zero(hd, 1e-6f);
+                    const bool seen = !countsMatter & (o0 == o1) & (o1 == o2) & (o2 == o3) & (o0 ? above != 0 : below != 0);
+                    corners = !seen;
+                    cell = !seen | !flat;
+                    obits = (o0 ? 1u : 0u) | (o1 ? 2u : 0u) | (o2 ? 4u : 0u) | (o3 ? 8u : 0u) | (flat ? 16u : 0u);
+                    cursor_step(B, c);
+                    if (c.x == B.minx) rowSeen = false;   // (the step wrapped into the next row)
+                }
+            }
+            if (__ballot(have && !cell) == 0ull || __popcll(__ballot(cell)) >= 48) break;
+        }
+        // ---- the cells that need work: bake_kernels_cpu.h:241-399 ----
+        if (cell) {
+            const bool o0 = (obits & 1u) != 0u, o1 = (obits & 2u) != 0u, o2 = (obits & 4u) != 0u, o3 = (obits & 8u) != 0u, flat = (obits & 16u) != 0u;
+            bool both = false;
+            if (corners) {
+                const float ipx = pfx * m.rw, ipy = pfy * m.rh;
+                const bool in0 = point_in_triangle_flat(t, ipx, ipy), in1 = point_in_triangle_flat(t, ipx, ipy + m.rh);
+                const bool in2 = point_in_triangle_flat(t, ipx + m.rw, ipy + m.rh), in3 = point_in_triangle_flat(t, ipx + m.rw, ipy);
+                const bool isO = (in0 & o0) | (in1 & o1) | (in2 & o2) | (in3 & o3), isT = (in0 & !o0) | (in1 & !o1) | (in2 & !o2) | (in3 & !o3);
+                above += isO ? 1u : 0u; below += isT ? 1u : 0u;
+                both = isO & isT;
+                if (flat & !both) vote(o0, above, below);
+            }
+            if (!flat & !both & (countsMatter | !(above != 0 && below != 0))) {
+                const V2 q0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy), q1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy), q2 = mk2(m.fw * t.p2.x - pfx, m.fh * t.p2.y - pfy);
+                const bool x0 = edge_crosses_level_curve(q0, q1, ha, hb, hc, hd), x1 = edge_crosses_level_curve(q1, q2, ha, hb, hc, hd), x2 = edge_crosses_level_curve(q2, q0, ha, hb, hc, hd);
+                if (x0 | x1 | x2) { above += 1; below += 1; }
+            }
+            if (!countsMatter && above != 0 && below != 0) { have = false; result = true; }
+        }
+    }
+}
+
+#ifndef OMMX_GENERIC_WAVES
+#define OMMX_GENERIC_WAVES 6
+#endif
+template <bool FP32, class MD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OMMX_GENERIC_WAVES, OMMX_GENERIC_WAVES))) void classify_generic(ClassifyParams P, ItemArrays A, GenericQueue G)
 {
     const uint32_t n = *G.count < (unsigned long long)G.capacity ? (uint32_t)*G.count : G.capacity;
     const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * 256u + threadIdx.x) >> 6, waves = (gridDim.x * 256u) >> 6;
-    for (uint32_t e0 = wave * 64u; e0 < n; e0 += waves * 64u) {   // (wave-uniform)
+    if (P.mipCount == 1 && !(P.filterLinear && P.altKernel)) {
+        if (P.filterLinear) generic_walks<FP32, MD>(P, A, G, n);
+        else generic_refill<FP32, 1, MD>(P, A, G, n);
+        return;
+    }
+    for (uint32_t e0 = wave * 64u; e0 < n; e0 += waves * 64u) {   // (wave-uniform) mip chains / the alternative kernel: the serial form per entry
         const uint32_t e = e0 + lane;
         bool live = e < n;
         uint2 ent = live ? G.entries[e] : make_uint2(0u, 0u);
         if (ent.x == 0xFFFFFFFFu) { live = false; ent = make_uint2(0u, 0u); }   // (null entry: the inside part of a reservation that did not fit)
         const uint32_t item = ent.x & 0x3FFFFFFFu;
-        const bool degenerate = ((ent.x >> 30) & 1u) != 0u;
         int state = 0;
-        const bool serial = P.mipCount != 1 || degenerate || (P.filterLinear && P.altKernel);   // (wave-uniform in practice: mip chains and the alternative kernel are bake properties, degenerate items are rare)
-        if (__ballot(live && serial) != 0ull) {
-            if (live) state = fine_state<FP32, MD>(P, micro_triangle(A.uv + 6ull * item, ent.y & 0xFFFFFFu, ent.y >> 24), degenerate, no_window());
-        } else if (P.filterLinear) state = generic_two_phase<FP32, 0, MD>(P, A.uv, item, ent.y, live);
-        else state = generic_two_phase<FP32, 1, MD>(P, A.uv, item, ent.y, live);
+        if (live) state = fine_state<FP32, MD>(P, micro_triangle(A.uv + 6ull * item, ent.y & 0xFFFFFFu, ent.y >> 24), ((ent.x >> 30) & 1u) != 0u, no_window());
         generic_commit(P, A, live, item, ent.y & 0xFFFFFFu, state);
     }
 }
