@@ -230,6 +230,22 @@ __device__ __forceinline__ void fetch_cell(const ClassifyParams& P, const DevMip
         }
     }
 #endif
+    // outside the window: the two texels of a row are neighbours in memory unless the address mode folds the cell at a seam -- one load per row
+    // (the deferred generic pass does nothing but such fetches: classify_generic 28.6 -> 27.8 ms)
+    if (MD::addr(P) != 3 && x1 == x0 + 1) {
+        const size_t i0 = (size_t)x0 + (size_t)y0 * (size_t)m.w, i1 = (size_t)x0 + (size_t)y1 * (size_t)m.w;
+        if (FP32) {
+            typedef float __attribute__((ext_vector_type(2), aligned(4))) f32x2u;
+            const f32x2u r0 = *(const f32x2u*)((const float*)m.texels + i0), r1 = *(const f32x2u*)((const float*)m.texels + i1);
+            g00 = r0.x; g10 = r0.y; g01 = r1.x; g11 = r1.y;
+        } else {
+            typedef uint16_t __attribute__((aligned(1))) u16u;
+            const uint32_t r0 = *(const u16u*)((const uint8_t*)m.texels + i0), r1 = *(const u16u*)((const uint8_t*)m.texels + i1);
+            g00 = (float)(r0 & 0xFFu) * (1.f / 255.f); g10 = (float)(r0 >> 8) * (1.f / 255.f);
+            g01 = (float)(r1 & 0xFFu) * (1.f / 255.f); g11 = (float)(r1 >> 8) * (1.f / 255.f);
+        }
+        return;
+    }
     if (MD::addr(P) == 3) {
         g00 = load_texel_border<FP32>(m, x0, y0, P.borderAlpha, W); g01 = load_texel_border<FP32>(m, x0, y1, P.borderAlpha, W);
         g11 = load_texel_border<FP32>(m, x1, y1, P.borderAlpha, W); g10 = load_texel_border<FP32>(m, x1, y0, P.borderAlpha, W);
