@@ -126,7 +126,7 @@ void launch_narrow_indices(const int32_t* in, uint32_t n, int bytesPerIndex, voi
 // first copy; section 2k + 1 = the tiles of EARLY items of later ranges whose family starts in range k, in the queue's second copy ([total, 2 total)),
 // ordered by range with a staging pass (early_tiles_*).
 // record = 3 x uint4 (everything a tile's workgroup needs, in ONE memory round trip):
-//   [0] x = item | degenerate << 30 | rectOk << 31, y = tile in item | level << 24, z = sx | sy << 16, w = ex | ey << 16 (addressed texel rectangle)
+//   [0] x = item | degenerate << 30 | rectOk << 31, y = tile in item | level << 24 | no-single-texel-micro-triangle << 31, z = sx | sy << 16, w = ex | ey << 16 (addressed texel rectangle)
 //   [1] the item's uv[0..3]      [2] uv[4], uv[5], address of the tile's packed states (lo, hi)
 constexpr uint32_t kTileRecordWords = 3;   // uint4 per record (bake_kernels.h: kTileRecordBytes)
 template <int TILE>
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
     if (t < S.n) queueCtl[kSecBases + stride * t] = S.cut[t];   // (the persistent launch walks the sections by these; the odd ones: early_tiles_bases)
     const uint32_t lane = threadIdx.x & 63u;
     const bool live = t < L.tileStart[L.n];
-    uint32_t sec = 0; bool isEarly = false;
+    uint32_t sec = 0; bool isEarly = false, bigMicro = false;
     int st = -1; uint32_t item = 0, tileInItem = 0, level = TILE_LOG4; TexRect r; r.sx = r.sy = r.ex = r.ey = 0; r.ok = false;
     float uvv[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
     const uint32_t bits = (uint32_t)P.format, tileBytes = (uint32_t)TILE * bits / 8u;
@@ -160,6 +160,14 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
         #pragma unroll
         for (int q = 0; q < 6; ++q) uvv[q] = uv[q];
         const float maxAbs = item_max_abs(uv);
+        {   // every micro-triangle of an item has the item's bounding-box extents / 2^level (up to rounding): wider or taller than a texel means that no raster box
+            // is one texel, i.e. the single-texel pass of classify_tiles would send all of them to the generic path anyway (asset-sized triangles: it is skipped)
+            const DevMip& m0 = P.mips[0];
+            const float ls = __uint_as_float((127u - level) << 23);
+            const float ex = (std_max(std_max(uv[0], uv[2]), uv[4]) - std_min(std_min(uv[0], uv[2]), uv[4])) * m0.fw * ls;
+            const float ey = (std_max(std_max(uv[1], uv[3]), uv[5]) - std_min(std_min(uv[1], uv[3]), uv[5])) * m0.fh * ls;
+            bigMicro = ex > 1.01f || ey > 1.01f;
+        }
         const MicroTri sub = micro_triangle(uv, tileInItem, level - TILE_LOG4);
         r = region_rect<ModeDynamic>(P, sub, maxAbs);
         if (P.useCoarse) st = region_state<ModeDynamic>(P, sub, maxAbs, no_window());
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
         if (open && key == k0) {
             uint4* rec = ((k0 & 1u) ? earlyStage : queue) + (size_t)kTileRecordWords * (wbase + __popcll(ob & ((1ull << lane) - 1ull)));
             const unsigned long long dst = (unsigned long long)(A.states + A.stateOfs[item] + (size_t)tileInItem * tileBytes);
-            rec[0] = make_uint4(item | (A.degenerate[item] ? 0x40000000u : 0u) | (r.ok ? 0x80000000u : 0u), tileInItem | (level << 24) | ((k0 & 1u) ? (k0 >> 1) << 16 : 0u),
+            rec[0] = make_uint4(item | (A.degenerate[item] ? 0x40000000u : 0u) | (r.ok ? 0x80000000u : 0u), tileInItem | (level << 24) | (bigMicro ? 0x80000000u : 0u) | ((k0 & 1u) ? (k0 >> 1) << 16 : 0u),
                                 (uint32_t)r.sx | ((uint32_t)r.sy << 16), (uint32_t)r.ex | ((uint32_t)r.ey << 16));
             rec[1] = make_uint4(__float_as_uint(uvv[0]), __float_as_uint(uvv[1]), __float_as_uint(uvv[2]), __float_as_uint(uvv[3]));
             rec[2] = make_uint4(__float_as_uint(uvv[4]), __float_as_uint(uvv[5]), (uint32_t)dst, (uint32_t)(dst >> 32));
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         rec = rp[0]; rec1 = rp[1]; rec2 = rp[2];   // three independent loads: one round trip for item, rectangle, UVs and output address
         rec.x = uniform_u32(rec.x); rec.y = uniform_u32(rec.y); rec.z = uniform_u32(rec.z); rec.w = uniform_u32(rec.w);
         if (tid == 0) { uint32_t sec = s_nsec; nextPos = next_record(sec); s_nsec = sec; }   // consumed at the end of this tile
-        level = rec.y >> 24;
+        level = (rec.y >> 24) & 0x7Fu;
         // a sliced tile implies 4^level >= TILE; without the hint clang hoists micro_triangle()'s level-0 branch (three loop-invariant
         // vertices) out of the phase-1/2 loops and keeps them in VGPRs for the whole kernel
         __builtin_assume(level >= TILE_LOG4);
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         uDegenerate = ((rec.x >> 30) & 1u) != 0u;
         // fine_single_texel's FINITE precondition: |uv| <= 16384 bounds every pixel coordinate by 2^30 (size <= 65536) and excludes NaN;
         // items outside it (and degenerate ones) take the generic path
-        uFast = fastFine && !uDegenerate && uMaxAbs <= 16384.f;
+        uFast = fastFine && !uDegenerate && uMaxAbs <= 16384.f && (rec.y >> 31) == 0u;   // (bit 31: no micro-triangle of the item fits in one texel, triage_tiles)
         // the curve-free-region test of the groups (phase 0c): the item's shape bounds, once per tile
         const bool uCurve = (OMMX_RC_LEVELS & 4) && region_curve_applies(P) && !uDegenerate;
         RcShape uShape; uShape.ok = 0;
@@ -845,7 +853,7 @@ __device__ __forceinline__ void generic_walks(const ClassifyParams& P, const Ite
                 }
                 if (get) {
                     t = micro_triangle(A.uv + 6ull * item, levelWord & 0xFFFFFFu, levelWord >> 24);
-                    vote(P.cutoff < bilinear<FP32, MD>(P, m, t.p0, no_window()), above, below);
+                    vote(P.cutoff < bilinear<FP32, MD, true>(P, m, t.p0, no_window()), above, below);
                     B = raster_box(m, t, -0.5f);
                     c = cursor_at(B, 0u); rowSeen = false;
                     have = true;
@@ -865,7 +873,7 @@ __device__ __forceinline__ void generic_walks(const ClassifyParams& P, const Ite
                     rowSeen = true;
                     pfx = (float)c.x + 0.5f; pfy = (float)c.y + 0.5f;
                     float gx, gy, gz, gw;   // 00, 01, 11, 10
-                    fetch_cell<FP32, MD>(P, m, MD::pow2(P), c.x, c.y, no_window(), gx, gy, gz, gw);
+                    fetch_cell<FP32, MD, true>(P, m, MD::pow2(P), c.x, c.y, no_window(), gx, gy, gz, gw);
                     const bool o0 = P.cutoff < gx, o1 = P.cutoff < gy, o2 = P.cutoff < gz, o3 = P.cutoff < gw;
                     hb = gw - gx; hc = gy - gx; hd = gx + gz - gy - gw; ha = gx - P.cutoff;
                     const bool flat = near_zero(hb, 1e-6f) & near_zero(hc, 1e-6f) & near_zero(hd, 1e-6f);

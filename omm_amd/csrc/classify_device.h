@@ -214,7 +214,7 @@ __device__ __forceinline__ float load_texel_border(const DevMip& m, int x, int y
 // the reference does (GatherTexCoord4, util/texture.h:130-148).  When the whole cell lies in the tile's LDS window -- where
 // addressing is a pure translation, which is re-checked here through x1 == x0 + 1, y1 == y0 + 1 -- the four values come from one
 // index computation; otherwise every texel goes through load_texel() / the border rule on its own.
-template <bool FP32, class MD>
+template <bool FP32, class MD, bool PAIRS = false>
 __device__ __forceinline__ void fetch_cell(const ClassifyParams& P, const DevMip& m, int pow2, int px, int py, const TexWindow& W,
                                            float& g00, float& g01, float& g11, float& g10)
 {
@@ -232,7 +232,8 @@ __device__ __forceinline__ void fetch_cell(const ClassifyParams& P, const DevMip
 #endif
     // outside the window: the two texels of a row are neighbours in memory unless the address mode folds the cell at a seam -- one load per row
     // (the deferred generic pass does nothing but such fetches: classify_generic 28.6 -> 27.8 ms)
-    if (MD::addr(P) != 3 && x1 == x0 + 1) {
+    // (PAIRS: only where the caller asks for it -- in the persistent kernel the extra path costs more registers than the rare fetch outside the window saves)
+    if (PAIRS && MD::addr(P) != 3 && x1 == x0 + 1) {
         const size_t i0 = (size_t)x0 + (size_t)y0 * (size_t)m.w, i1 = (size_t)x0 + (size_t)y1 * (size_t)m.w;
         if (FP32) {
             typedef float __attribute__((ext_vector_type(2), aligned(4))) f32x2u;
@@ -284,14 +285,14 @@ __device__ __forceinline__ uint32_t sat_sum(const DevMip& m, int sx, int sy, int
 
 // texture_impl.cpp:261-278 (centre vote).  Border texels take borderAlpha (the reference reads out of
 // bounds there -- documented fence).
-template <bool FP32, class MD>
+template <bool FP32, class MD, bool PAIRS = false>
 __device__ __forceinline__ float bilinear(const ClassifyParams& P, const DevMip& m, V2 p, const TexWindow& W)
 {
     const float px = p.x * m.fw - 0.5f, py = p.y * m.fh - 0.5f;
     const float fx = __builtin_floorf(px), fy = __builtin_floorf(py);
     const int ix = cvt_trunc_x86(fx), iy = cvt_trunc_x86(fy);
     float a, b, c, d; // 00, 01, 10, 11 (the sentinel of Border addressing reads borderAlpha: documented fence)
-    fetch_cell<FP32, MD>(P, m, m.pow2, ix, iy, W, a, b, d, c);
+    fetch_cell<FP32, MD, PAIRS>(P, m, m.pow2, ix, iy, W, a, b, d, c);
     const float wx = px - fx, wy = py - fy;
     const float ac = a * (1.f - wx) + c * wx;
     const float bd = b * (1.f - wx) + d * wx;
