@@ -1474,7 +1474,7 @@ def test_micro_triangles_of_several_texels(product, oracle, generic_pass):
     """Micro-triangles that span several texels (asset-sized triangles: the shape of the reference's Leaflet KATs at production size): the generic
     texel-loop path (conservative raster + level-line kernel per texel) with every promotion.  Quads of 40 .. 700 texels at levels 6 .. 9,
     Clamp / Wrap / Mirror / Border, UNORM8 and FP32, SAT on and off, 2-state.  Both homes of that path (ommxBakerKnob_GenericPass): inside the
-    persistent classification launch, one lane per micro-triangle, and the deferred pass (bake_kernels.hip: classify_generic), eight lanes each."""
+    persistent classification launch, one lane per micro-triangle, and the deferred pass (bake_kernels.hip: classify_generic), whose lanes pull walks from a queue."""
     import workloads as wl
     knobs = [(ot.KNOB_GENERIC_PASS, generic_pass)]
     tex8 = ot.foliage_texture(77, 1024, 1024, feature=48)
@@ -1502,6 +1502,37 @@ def test_micro_triangles_of_several_texels(product, oracle, generic_pass):
     both(product, oracle, mips[:3], uv, ix, 7, sat=False, addr=ot.CLAMP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv, knobs=knobs)
     uvd = uv.copy().reshape(-1, 2); uvd[ix[3::18]] = uvd[ix[4::18]]          # every sixth triangle collapses onto an edge
     both(product, oracle, [tex8], uvd, ix, 7, addr=ot.CLAMP, promo=ot.PROMO_FORCE_OPAQUE, knobs=knobs)
+
+
+def test_texel_walk_shapes(product, oracle):
+    """The walks of the deferred pass leave a row at the first texel that is not under the triangle after one that was, and pass cells that cannot change
+    the state: shapes that stress both -- thin slivers in every direction (rows with a single covered texel, rows with none), triangles whose boxes are
+    hundreds of texels wide and a few high, UV offsets far from the origin and below zero (Wrap / Mirror), a non-power-of-two FP32 texture, 0 / 1 noise
+    (no flat cells next to each other), a constant texture (only flat cells) -- against the oracle, every promotion."""
+    knobs = [(ot.KNOB_GENERIC_PASS, 2)]
+    rng = np.random.RandomState(5)
+    n = 60
+    c = rng.rand(n, 2).astype(np.float32) * np.float32(0.8) + np.float32(0.1)
+    ang = rng.rand(n).astype(np.float32) * np.float32(2 * np.pi)
+    ln = (np.float32(0.05) + rng.rand(n).astype(np.float32) * np.float32(0.25)); th = ln * np.float32(0.002) * (1 + (np.arange(n) % 7)).astype(np.float32)
+    d = np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32); o = np.stack([-d[:, 1], d[:, 0]], 1)
+    tri = np.stack([c - d * ln[:, None], c + d * ln[:, None], c + o * th[:, None]], 1).astype(np.float32)
+    tri[::9, 1, 1] = tri[::9, 0, 1]                                   # exactly horizontal long edge
+    tri[1::9, 1, 0] = tri[1::9, 0, 0]                                 # exactly vertical long edge
+    uv = np.ascontiguousarray(tri.reshape(-1, 2)); ix = np.arange(3 * n, dtype=np.uint32)
+    tex8 = ot.foliage_texture(21, 512, 512, feature=24)
+    texf = ot.value_noise(3, 300, 200, octaves=3, base_cell=20).astype(np.float32)
+    noise = (rng.rand(256, 256) > 0.5).astype(np.float32)
+    const = np.full((128, 128), 0.75, np.float32)
+    for promo in (ot.PROMO_FORCE_OPAQUE, ot.PROMO_FORCE_TRANSPARENT, ot.PROMO_NEAREST):
+        both(product, oracle, [tex8], uv, ix, 6, addr=ot.CLAMP, promo=promo, knobs=knobs)
+    both(product, oracle, [tex8], uv + np.float32(37.0), ix, 7, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, knobs=knobs)
+    both(product, oracle, [tex8], uv - np.float32(2.5), ix, 6, addr=ot.MIRROR, promo=ot.PROMO_NEAREST, knobs=knobs)
+    both(product, oracle, [texf], uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_TRANSPARENT, knobs=knobs)
+    both(product, oracle, [texf], uv * np.float32(2.0) - np.float32(0.5), ix, 5, addr=ot.BORDER, promo=ot.PROMO_FORCE_OPAQUE, border_alpha=0.2, sat=False, knobs=knobs)
+    both(product, oracle, [noise], uv, ix, 6, addr=ot.CLAMP, promo=ot.PROMO_FORCE_OPAQUE, knobs=knobs)
+    both(product, oracle, [noise], uv, ix, 5, addr=ot.WRAP, promo=ot.PROMO_NEAREST, fmt=ot.FMT_2STATE, sat=False, knobs=knobs)
+    both(product, oracle, [const], uv, ix, 6, addr=ot.MIRROR_ONCE, promo=ot.PROMO_FORCE_OPAQUE, sat=False, knobs=knobs)
 
 
 def test_near_duplicate_merge_and_budget_at_scale(product, oracle):
