@@ -71,7 +71,7 @@ typedef enum ommxBakerKnob {
                                            whatever the size of the bake (1 = classify everything, then one copy).  Default: bakes with >= 64 MiB of packed
                                            states stream, one range per 32 MiB, at most 32 */
     ommxBakerKnob_GenericPass      = 3, /* where micro-triangles that span several texels (asset-sized triangles) are classified: 1 = inside the persistent
-                                           classification launch, one lane each; 2 = queued and classified by a second launch, eight lanes each (not for streamed
+                                           classification launch, one lane each; 2 = queued and classified by a second launch whose lanes pull them as their walks end (not for streamed
                                            bakes); 0 = automatic: 2 when the texels under the triangles outweigh the micro-triangles */
     ommxBakerKnob_RetainMemory     = 4, /* what a baker keeps between bakes.  0 / default: the working set of a bake (device arenas, streams), up to six idle device result
                                            blocks and up to two idle PINNED host blocks for arrayData (a fresh 1.3 GB host block costs more in page faults and munmap than the

@@ -651,7 +651,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
 // raster + level-line kernel / nearest vote per texel: fine_state).  Inside classify_tiles one lane walks one box in lockstep with 63 others:
 // neighbouring boxes differ in size by orders of magnitude, two thirds of the walks end at their first mixed texel after a handful of visits
 // and the rest visit every texel under the triangle, so a fifth of the lanes does useful work (profiles/r03_v3_cards_pmc.md).  Here the walks
-// are queue entries and a lane that finishes one takes the next (generic_refill / generic_walks below); every texel of a box is visited at most
+// are queue entries and a lane that finishes one takes the next (generic_walks below); every texel of a box is visited at most
 // once, in row-major order, with the serial loop's early exit: same state.  Mip chains, the alternative kernel and degenerate items take the
 // serial fine_state().  The state is ORed into the packed word the persistent launch left 0; item mask / known count are folded per wave.
 // (Round 3's form -- 12 visits one lane per walk, then eight lanes per unfinished walk -- took 36.9 ms where this one takes 28.8.)
@@ -690,15 +690,6 @@ __device__ __forceinline__ bool texel_under(const RasterBox& B, const TexelCurso
     const float sx = (float)c.x, sy = (float)c.y;
     return eval_cons(B.e0, sx, sy) < 0.f && eval_cons(B.e1, sx, sy) < 0.f && eval_cons(B.e2, sx, sy) < 0.f;
 }
-// the vote of a covered texel: level-line kernel (linear filter) or nearest sample.  (Splitting the level-line kernel once more -- cell fetch and corner
-// votes first, the three edge tests for the lanes that need them in a second round -- was measured and is slower, 51.8 vs 38.9 ms on the cards
-// workload: in a smooth alpha texture nearly every covered texel needs its edge tests, so the second round gathers nothing and the cell is fetched twice.)
-template <bool FP32, int KIND, class MD>
-__device__ __forceinline__ void texel_vote(const ClassifyParams& P, const DevMip& m, const MicroTri& t, const TexelCursor& c, uint32_t& above, uint32_t& below)
-{
-    if (KIND == 0) level_line_texel<FP32, false, MD>(P, m, t, c.x, c.y, above, below, no_window());
-    else nearest_texel<FP32, MD>(P, m, c.x, c.y, above, below, no_window());
-}
 // a wave's classified entries: state ORed into the packed word the persistent launch left 0; item mask / known count with one atomic per item and wave
 // (the entries of a wave mostly share their item)
 __device__ __forceinline__ void generic_commit(const ClassifyParams& P, const ItemArrays& A, bool live, uint32_t item, uint32_t index, int state)
@@ -722,113 +713,55 @@ __device__ __forceinline__ void generic_commit(const ClassifyParams& P, const It
     }
 }
 
-// ---- the refill form ----
+// ---- the walks ----
 // A wave that runs 64 walks in lockstep has two thirds of its lanes finished after two visits, waiting for its longest walk.  Here a lane that finishes
-// gets the next queued micro-triangle: a wave pulls chunks of
-// OMMX_GENERIC_CHUNK entries from a cursor next to the queue's count word, and whenever OMMX_GENERIC_REFILL lanes are idle they commit their states together
-// (generic_commit folds the item masks per wave), take the next entries and set them up (micro-triangle, centre vote, raster box) in one dense round; every
-// other iteration is one visit -- skip to the next covered texel, vote -- for all lanes that hold a walk.  Same visits in the same order per walk as the
-// serial loop, with its early exit: same state.
+// gets the next queued micro-triangle: a wave pulls chunks of OMMX_GENERIC_CHUNK entries from a cursor next to the queue's count word, and whenever
+// OMMX_GENERIC_REFILL lanes are idle they commit their states together (generic_commit folds the item masks per wave), take the next entries and set them
+// up (micro-triangle, centre vote, raster box) in one round.  Same visits in the same order per walk as the serial loop, with its early exit: same state.
+// Rows are left at the first texel that is not under the triangle after one that was: the texels under the conservative triangle form an interval in
+// every row (each edge function is monotone in x, in fp32 too).
+// KIND 0, the level-line kernel (Linear filter): most cells of a long walk are cheap -- flat (no edge can cross a constant patch: the reference votes by the
+// first texel) and with all four texels on a side the walk has already seen; when only (any vote above, any vote below) counts, such a cell changes nothing.
+// Every lane advances to its next cell that needs work (corner votes: its texels are not all on a seen side; edge tests: it is not flat), a few rounds of
+// fetch + compare, and then the wave does the corner votes and the three edge tests for those cells together.  KIND 1, Nearest: every covered texel votes
+// with its sample.
 #ifndef OMMX_GENERIC_REFILL
-#define OMMX_GENERIC_REFILL 16
+#define OMMX_GENERIC_REFILL 16   // measured on the cards workload: 8 / 16 / 32 = 30.2 / 29.0 / 31.1 ms
 #endif
 #ifndef OMMX_GENERIC_CHUNK
 #define OMMX_GENERIC_CHUNK 1024u
 #endif
+#ifndef OMMX_GENERIC_ADVANCE
+#define OMMX_GENERIC_ADVANCE 4   // rounds of advancing per round of cell work (1 / 4 / 8: 28.6 / 28.8 / 31.2 ms)
+#endif
 template <bool FP32, int KIND, class MD>
-__device__ __forceinline__ void generic_refill(const ClassifyParams& P, const ItemArrays& A, const GenericQueue& G, uint32_t n)
+__device__ __forceinline__ void generic_walks(const ClassifyParams& P, const ItemArrays& A, const GenericQueue& G, uint32_t n)
 {
     const DevMip& m = P.mips[0];
     const uint32_t lane = threadIdx.x & 63u;
     const bool countsMatter = P.promotion == 0;
     const float off = KIND == 0 ? -0.5f : 0.f;
     unsigned long long* const cursorWord = G.count + 1;
-    uint32_t chunkNext = 0, chunkEnd = 0;   // (wave-uniform)
+    uint32_t chunkNext = 0, chunkEnd = 0;   // (wave-uniform) the chunk of the queue this wave works on
     bool drained = false;                   // (wave-uniform) no entries left in the queue
     bool have = false, result = false;      // this lane: holds an unfinished walk / a finished one that is not committed yet
+    bool rowSeen = false;                   // a texel of the cursor's row was under the triangle
     uint32_t item = 0, levelWord = 0, above = 0, below = 0;
     int direct = -1;                        // state of a degenerate item's micro-triangle (serial fine_state), or -1
     MicroTri t; t.p0 = t.p1 = t.p2 = mk2(0.f, 0.f);
     RasterBox B = raster_box(m, t, off);
     TexelCursor c = cursor_at(B, 0u);
+    // to the next texel under the triangle; false: the box is exhausted
+    auto next_covered = [&]() -> bool {
+        while (cursor_live(B, c) && !texel_under(B, c)) { if (rowSeen) { c.x = B.minx; ++c.y; rowSeen = false; } else cursor_step(B, c); }
+        return cursor_live(B, c);
+    };
+    auto step = [&]() { rowSeen = true; cursor_step(B, c); if (c.x == B.minx) rowSeen = false; };   // (c.x == minx: the step wrapped into the next row)
     for (;;) {
         const unsigned long long busy = __ballot(have);
         const uint32_t idle = 64u - (uint32_t)__popcll(busy);
         if ((!drained && idle >= (uint32_t)OMMX_GENERIC_REFILL) || busy == 0ull) {
-            generic_commit(P, A, result, item, levelWord & 0xFFFFFFu, direct >= 0 ? direct : state_from_coverage(P, above, below));
-            result = false;
-            if (drained) { if (busy == 0ull) break; }
-            else {
-                if (chunkNext == chunkEnd) {
-                    unsigned long long start = 0;
-                    if (lane == 0u) start = atomicAdd(cursorWord, (unsigned long long)OMMX_GENERIC_CHUNK);
-                    start = (unsigned long long)__shfl((long long)start, 0);
-                    if (start >= (unsigned long long)n) drained = true;
-                    else { chunkNext = (uint32_t)start; chunkEnd = start + OMMX_GENERIC_CHUNK < (unsigned long long)n ? (uint32_t)start + OMMX_GENERIC_CHUNK : n; }
-                }
-                if (!drained) {
-                    const uint32_t avail = chunkEnd - chunkNext, take = idle < avail ? idle : avail;
-                    const uint32_t rank = (uint32_t)__popcll(~busy & ((1ull << lane) - 1ull));
-                    bool get = !have && rank < take;
-                    uint2 ent = get ? G.entries[chunkNext + rank] : make_uint2(0u, 0u);
-                    chunkNext += take;
-                    if (ent.x == 0xFFFFFFFFu) get = false;   // (null entry: the inside part of a reservation that did not fit)
-                    const bool degenerate = get && ((ent.x >> 30) & 1u) != 0u;
-                    if (get) { item = ent.x & 0x3FFFFFFFu; levelWord = ent.y; above = 0; below = 0; direct = -1; }
-                    if (__ballot(degenerate) != 0ull) {   // (rare: degenerate items take the serial form)
-                        if (degenerate) { direct = fine_state<FP32, MD>(P, micro_triangle(A.uv + 6ull * item, levelWord & 0xFFFFFFu, levelWord >> 24), true, no_window()); result = true; get = false; }
-                    }
-                    if (get) {
-                        t = micro_triangle(A.uv + 6ull * item, levelWord & 0xFFFFFFu, levelWord >> 24);
-                        if (KIND == 0) vote(P.cutoff < bilinear<FP32, MD>(P, m, t.p0, no_window()), above, below);
-                        B = raster_box(m, t, off);
-                        c = cursor_at(B, 0u);
-                        have = true;
-                    }
-                }
-            }
-            continue;
-        }
-        if (have) {   // one visit
-            while (cursor_live(B, c) && !texel_under(B, c)) cursor_step(B, c);
-            if (!cursor_live(B, c)) { have = false; result = true; }
-            else {
-                texel_vote<FP32, KIND, MD>(P, m, t, c, above, below);
-                cursor_step(B, c);
-                if (!countsMatter && above != 0 && below != 0) { have = false; result = true; }
-            }
-        }
-    }
-}
-
-// ---- the level-line walks (Linear filter) in the refill form, with the cheap cells passed in an inner loop ----
-// Most cells of a long walk are cheap: flat (no edge can cross a constant patch: the reference votes by the first texel) and with all four texels on a side
-// the walk has already seen -- when only (any vote above, any vote below) counts, such a cell changes nothing.  Every lane advances to its next cell that
-// needs work (corner votes: its texels are not all on a seen side; edge tests: it is not flat), a few rounds of fetch + compare, and then the wave does the
-// corner votes and the three edge tests for those cells together.  Rows are left at the first texel that is not under the triangle after one that was: the
-// texels under the conservative triangle form an interval in every row (each edge function is monotone in x, in fp32 too).
-#ifndef OMMX_GENERIC_ADVANCE
-#define OMMX_GENERIC_ADVANCE 4   // rounds of advancing per round of cell work
-#endif
-template <bool FP32, class MD>
-__device__ __forceinline__ void generic_walks(const ClassifyParams& P, const ItemArrays& A, const GenericQueue& G, uint32_t n)
-{
-    const DevMip& m = P.mips[0];
-    const uint32_t lane = threadIdx.x & 63u;
-    const bool countsMatter = P.promotion == 0;
-    unsigned long long* const cursorWord = G.count + 1;
-    uint32_t chunkNext = 0, chunkEnd = 0;   // (wave-uniform)
-    bool drained = false;                   // (wave-uniform)
-    bool have = false, result = false, rowSeen = false;
-    uint32_t item = 0, levelWord = 0, above = 0, below = 0;
-    int direct = -1;
-    MicroTri t; t.p0 = t.p1 = t.p2 = mk2(0.f, 0.f);
-    RasterBox B = raster_box(m, t, -0.5f);
-    TexelCursor c = cursor_at(B, 0u);
-    for (;;) {
-        const unsigned long long busy = __ballot(have);
-        const uint32_t idle = 64u - (uint32_t)__popcll(busy);
-        if ((!drained && idle >= (uint32_t)OMMX_GENERIC_REFILL) || busy == 0ull) {
+            // ---- commit what is finished, hand out the next entries ----
             generic_commit(P, A, result, item, levelWord & 0xFFFFFFu, direct >= 0 ? direct : state_from_coverage(P, above, below));
             result = false;
             if (drained) break;   // (busy == 0)
@@ -853,24 +786,33 @@ __device__ __forceinline__ void generic_walks(const ClassifyParams& P, const Ite
                 }
                 if (get) {
                     t = micro_triangle(A.uv + 6ull * item, levelWord & 0xFFFFFFu, levelWord >> 24);
-                    vote(P.cutoff < bilinear<FP32, MD, true>(P, m, t.p0, no_window()), above, below);
-                    B = raster_box(m, t, -0.5f);
+                    if (KIND == 0) vote(P.cutoff < bilinear<FP32, MD, true>(P, m, t.p0, no_window()), above, below);
+                    B = raster_box(m, t, off);
                     c = cursor_at(B, 0u); rowSeen = false;
                     have = true;
                 }
             }
             continue;
         }
-        // ---- advance: every walking lane to its next cell that needs work ----
+        if (KIND == 1) {   // ---- Nearest: one visit ----
+            if (have) {
+                if (!next_covered()) { have = false; result = true; }
+                else {
+                    nearest_texel<FP32, MD>(P, m, c.x, c.y, above, below, no_window());
+                    step();
+                    if (!countsMatter && above != 0 && below != 0) { have = false; result = true; }
+                }
+            }
+            continue;
+        }
+        // ---- level line: every walking lane advances to its next cell that needs work ----
         bool cell = false, corners = false;
         float ha = 0.f, hb = 0.f, hc = 0.f, hd = 0.f, pfx = 0.f, pfy = 0.f;
         uint32_t obits = 0;
         for (int round = 0; round < OMMX_GENERIC_ADVANCE; ++round) {
             if (have && !cell) {
-                while (cursor_live(B, c) && !texel_under(B, c)) { if (rowSeen) { c.x = B.minx; ++c.y; rowSeen = false; } else cursor_step(B, c); }
-                if (!cursor_live(B, c)) { have = false; result = true; }
+                if (!next_covered()) { have = false; result = true; }
                 else {
-                    rowSeen = true;
                     pfx = (float)c.x + 0.5f; pfy = (float)c.y + 0.5f;
                     float gx, gy, gz, gw;   // 00, 01, 11, 10
                     fetch_cell<FP32, MD, true>(P, m, MD::pow2(P), c.x, c.y, no_window(), gx, gy, gz, gw);
@@ -881,8 +823,7 @@ __device__ __forceinline__ void generic_walks(const ClassifyParams& P, const Ite
                     corners = !seen;
                     cell = !seen | !flat;
                     obits = (o0 ? 1u : 0u) | (o1 ? 2u : 0u) | (o2 ? 4u : 0u) | (o3 ? 8u : 0u) | (flat ? 16u : 0u);
-                    cursor_step(B, c);
-                    if (c.x == B.minx) rowSeen = false;   // (the step wrapped into the next row)
+                    step();
                 }
             }
             if (__ballot(have && !cell) == 0ull || __popcll(__ballot(cell)) >= 48) break;
@@ -919,8 +860,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OMMX_GENERI
     const uint32_t n = *G.count < (unsigned long long)G.capacity ? (uint32_t)*G.count : G.capacity;
     const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * 256u + threadIdx.x) >> 6, waves = (gridDim.x * 256u) >> 6;
     if (P.mipCount == 1 && !(P.filterLinear && P.altKernel)) {
-        if (P.filterLinear) generic_walks<FP32, MD>(P, A, G, n);
-        else generic_refill<FP32, 1, MD>(P, A, G, n);
+        if (P.filterLinear) generic_walks<FP32, 0, MD>(P, A, G, n); else generic_walks<FP32, 1, MD>(P, A, G, n);
         return;
     }
     for (uint32_t e0 = wave * 64u; e0 < n; e0 += waves * 64u) {   // (wave-uniform) mip chains / the alternative kernel: the serial form per entry
