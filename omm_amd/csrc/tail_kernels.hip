@@ -516,6 +516,31 @@ __global__ __launch_bounds__(256) void shard_scatter_streams(const uint8_t* __re
         const uint32_t* ofs = (const uint32_t*)(comp + c.offOfs);
         const uint4* raw = (const uint4*)(comp + c.offRaw);
         const uint64_t c0 = cofs[j], c1 = c0 + n;
+        if (((c0 | (uint64_t)n) & (16u * kCodecBlock - 1u)) == 0u && (((uint64_t)dst) & 15ull) == 0ull) {
+            // whole codec blocks (every block of level >= 7 in 4-state: 16 KB = 4 codec blocks), the common case at full size: one WAVE per codec block, no
+            // barrier -- pass k of a wave decodes units 64 k + lane, so every store instruction of the wave writes 1 KB in a row; a raw unit's rank inside
+            // its codec block = the raw units of the earlier passes + those of lower lanes in this pass, from the passes' ballots
+            // (the barrier form below moved the result at 1.5 TB/s: four iterations of load - ballot - barrier per workgroup and block)
+            const uint32_t lane = threadIdx.x & 63u;
+            for (uint64_t B = c0 / (16u * kCodecBlock) + (threadIdx.x >> 6); B * (16u * kCodecBlock) < c1; B += blockDim.x >> 6) {
+                const uint8_t* codes = comp + c.offCodes + B * (kCodecBlock / 2u);
+                const uint4* rawB = raw + ofs[B];
+                uint4* out = (uint4*)(dst + (B * (16u * kCodecBlock) - c0));
+                uint32_t before = 0;
+                #pragma unroll
+                for (uint32_t k = 0; k < kCodecBlock / 64u; ++k) {
+                    const uint32_t u = 64u * k + lane;
+                    const uint32_t code = (codes[u >> 1] >> ((u & 1u) * 4u)) & 15u;
+                    const unsigned long long rb = __ballot(code == 4u);
+                    uint4 v;
+                    if (code == 4u) v = rawB[before + (uint32_t)__popcll(rb & ((1ull << lane) - 1ull))];
+                    else { const uint32_t p = code == 0u ? 0u : (code == 1u ? 0x55555555u : (code == 2u ? 0xAAAAAAAAu : 0xFFFFFFFFu)); v = make_uint4(p, p, p, p); }
+                    out[u] = v;
+                    before += (uint32_t)__popcll(rb);
+                }
+            }
+            continue;   // (block-uniform branch: no thread of this workgroup reaches the barriers below for this block)
+        }
         for (uint64_t B = c0 / (16u * kCodecBlock); B * (16u * kCodecBlock) < c1; ++B) {   // (block-uniform bounds: every thread takes part in the ballots)
             const uint64_t u = B * kCodecBlock + threadIdx.x;
             const bool live = u < c.units;
