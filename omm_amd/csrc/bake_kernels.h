@@ -123,8 +123,8 @@ struct SetupCounters {                                         // one device-res
 };
 size_t setup_scratch_bytes(uint32_t numTris);
 hipError_t run_setup_fetch(const SetupParams& S, void* scratch, size_t scratchBytes, SetupCounters* counters, hipStream_t stream);
-hipError_t copy_pending_to_host(void* scratch, size_t scratchBytes, uint32_t numTris, uint32_t numPending, uint32_t* pendingTris, float* pendingUv, hipStream_t stream);
-hipError_t run_setup_fix_pending(const SetupParams& S, void* scratch, size_t scratchBytes, const uint32_t* pendingTris, const uint8_t* levels, uint32_t numPending, hipStream_t stream);
+hipError_t copy_pending_to_host(void* scratch, size_t scratchBytes, uint32_t numTris, uint32_t numPending, uint32_t* pendingTris, float* pendingUv, void* tmp, hipStream_t stream);
+hipError_t run_setup_fix_pending(const SetupParams& S, void* scratch, size_t scratchBytes, const uint32_t* pendingTris, const uint8_t* levels, uint32_t numPending, void* tmp, hipStream_t stream);
 hipError_t run_setup_items(const SetupParams& S, void* scratch, size_t scratchBytes, SetupCounters* counters, float* itemUv, uint8_t* itemLevel,
                            uint8_t* itemDegenerate, int32_t* triToItem, uint32_t* itemIds, float* triArea /* per triangle UV area, or null */, hipStream_t stream);
 

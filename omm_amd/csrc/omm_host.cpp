@@ -799,13 +799,21 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             return L.failure("[Failure] - device work-item setup failed");
         if (hc.numPending) {
             std::vector<uint32_t> pend(hc.numPending); std::vector<float> puv((size_t)hc.numPending * 6); std::vector<uint8_t> plv(hc.numPending);
-            if (!HIP_OK(copy_pending_to_host(dScratch, scratchBytes, T, hc.numPending, pend.data(), puv.data(), stream))) return L.failure("[Failure] - device work-item setup failed");
-            for (uint32_t k = 0; k < hc.numPending; ++k) {
-                HostTri t; memcpy(t.p, &puv[(size_t)k * 6], 24);
-                ommCpuBakeInputDesc tmp = d; tmp.subdivisionLevels = nullptr; // per-triangle overrides were already honoured on the device
-                plv[k] = (uint8_t)level_for_primitive(tmp, flags, 0, t, S.texW, S.texH);
+            struct PoolBlock { DevPool* pool; void* p; ~PoolBlock() { if (p) pool->release(p); } } tmp{ baker.devPool.get(), baker.devPool->acquire((size_t)hc.numPending * 24 + 256) };
+            if (!tmp.p) return L.failure("[Failure] - device work-item setup failed");
+            if (!HIP_OK(copy_pending_to_host(dScratch, scratchBytes, T, hc.numPending, pend.data(), puv.data(), tmp.p, stream))) return L.failure("[Failure] - device work-item setup failed");
+            {   // (tiny triangles under dynamic subdivision are degenerate by the tens of thousands -- configs[4]: 1.5 ms of log2f on one thread; four share it)
+                ommCpuBakeInputDesc tmpDesc = d; tmpDesc.subdivisionLevels = nullptr;   // per-triangle overrides were already honoured on the device
+                auto part = [&](uint32_t k0, uint32_t k1) {
+                    for (uint32_t k = k0; k < k1; ++k) { HostTri t; memcpy(t.p, &puv[(size_t)k * 6], 24); plv[k] = (uint8_t)level_for_primitive(tmpDesc, flags, 0, t, S.texW, S.texH); }
+                };
+                const uint32_t n = hc.numPending, ways = n >= 8192u ? 4u : 1u;
+                std::vector<std::thread> helpers;
+                for (uint32_t w = 1; w < ways; ++w) helpers.emplace_back(part, (uint32_t)((uint64_t)n * w / ways), (uint32_t)((uint64_t)n * (w + 1u) / ways));
+                part(0u, (uint32_t)((uint64_t)n / ways));
+                for (auto& h : helpers) h.join();
             }
-            if (!HIP_OK(run_setup_fix_pending(S, dScratch, scratchBytes, pend.data(), plv.data(), hc.numPending, stream))) return L.failure("[Failure] - device work-item setup failed");
+            if (!HIP_OK(run_setup_fix_pending(S, dScratch, scratchBytes, pend.data(), plv.data(), hc.numPending, tmp.p, stream))) return L.failure("[Failure] - device work-item setup failed");
         }
     }
     if (!HIP_OK(run_setup_items(S, dScratch, scratchBytes, dCounters, dUv, dLevel, dDegen, dTriToItem, dItemIds, dTriArea, stream)))

@@ -373,13 +373,14 @@ __global__ __launch_bounds__(256) void setup_scatter_levels(const uint32_t* __re
     if (k < n) triLevel[pending[k]] = levels[k];
 }
 
+// (tmp: device memory of the caller, >= 24 bytes per pending triangle, shared with copy_pending_to_host -- a hipMalloc / hipFree pair here cost a bake with
+//  pending triangles 0.7 ms each)
 hipError_t run_setup_fix_pending(const SetupParams& S, void* scratch, size_t scratchBytes, const uint32_t* pendingTris /*host*/, const uint8_t* levels /*host*/,
-                                 uint32_t numPending, hipStream_t stream)
+                                 uint32_t numPending, void* tmp, hipStream_t stream)
 {
     if (numPending == 0) return hipSuccess;
     SetupScratch s = carve_setup(scratch, scratchBytes, S.numTris);
-    uint8_t* dLevels = nullptr;
-    SETUP_CHECK(hipMalloc((void**)&dLevels, numPending));
+    uint8_t* dLevels = (uint8_t*)tmp;
     hipError_t e = hipMemcpyAsync(dLevels, levels, numPending, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(s.pending, pendingTris, (size_t)numPending * 4, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) {
@@ -388,24 +389,21 @@ hipError_t run_setup_fix_pending(const SetupParams& S, void* scratch, size_t scr
         hipLaunchKernelGGL(setup_rehash_pending, grid, block, 0, stream, S, s.triUv, s.triLevel, s.pending, numPending, s.keysA);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void)hipFree(dLevels);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);   // (the host arrays are the caller's temporaries)
     return e;
 }
 
 hipError_t copy_pending_to_host(void* scratch, size_t scratchBytes, uint32_t numTris, uint32_t numPending, uint32_t* pendingTris /*host*/, float* pendingUv /*host, 6 each*/,
-                                hipStream_t stream)
+                                void* tmp, hipStream_t stream)
 {
     if (numPending == 0) return hipSuccess;
     SetupScratch s = carve_setup(scratch, scratchBytes, numTris);
-    float* dUv = nullptr;
-    SETUP_CHECK(hipMalloc((void**)&dUv, (size_t)numPending * 24));
+    float* dUv = (float*)tmp;
     hipLaunchKernelGGL(setup_gather_pending, dim3((numPending + 255u) / 256u), dim3(256), 0, stream, s.triUv, s.pending, numPending, dUv);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(pendingTris, s.pending, (size_t)numPending * 4, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(pendingUv, dUv, (size_t)numPending * 24, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void)hipFree(dUv);
     return e;
 }
 
