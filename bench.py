@@ -11,7 +11,7 @@ Prints ONE JSON line (rank 0):
   value / ms_per_step   micro-triangles of all unique work items / wall time of a step through ommCpuBake, the SDK entry point: host arrays in, host
   = bake_wall_time_ms   arrays out, PCIe inclusive (SURVEY.md section 8d defines both metrics on it); K timed steps after W warm-up steps; details: host_api
   device_resident       the SAME bake through ommxBakeDevice (UV / index inputs and result arrays resident in HBM), same steps and warm-up.
-                        (N > 1 GPUs: the sharded device-resident entry is the headline -- there is no multi-GPU host-array entry point.)
+                        (N > 1 GPUs: the sharded device-resident entry is the headline; value_same_entry_as_n_gt_1 = the same entry at every N.)
   roofline              what limits the dominant kernel (classify_tiles): VALU issue slots; roofline_hbm = the HBM view on the units the
                         launch really processes; cpu_baseline = the oracle (port of the reference CPU baker) on the host cores, same run
 """
@@ -54,6 +54,15 @@ class BakeTimings(C.Structure):
                 ("streamPreviewMs", C.c_float), ("streamFirstCopyMs", C.c_float), ("streamLastCopyMs", C.c_float), ("streamRangeReadyMs", C.c_float * 32)]
 
 
+def get_timings(lib, baker):
+    """ommxGetLastBakeTimingsSized into this file's mirror of ommxBakeTimings (the unsized symbol only fills the round-3 prefix of the struct)"""
+    tm = BakeTimings()
+    fn = lib.dll.ommxGetLastBakeTimingsSized
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    fn(baker, C.byref(tm), C.sizeof(tm), None)
+    return tm
+
+
 def source_hash():
     """sha256 (16 hex digits) over omm_amd/csrc, the same recipe as profiles/summarize_pmc.py: ties a committed PMC summary to the sources"""
     import hashlib
@@ -91,7 +100,35 @@ def host_info():
     except OSError:
         pass
     cores = multiprocessing.cpu_count()
-    return cores, "%s, %d socket(s), %d hardware threads" % (model, max(1, len(sockets)), cores)
+    eff, why = effective_cpus(cores)
+    return cores, eff, "%s, %d socket(s), %d hardware threads; %d CPUs usable by this process (%s)" % (model, max(1, len(sockets)), cores, eff, why)
+
+
+def effective_cpus(hardware_threads):
+    """CPUs this process can really run on at once: the scheduler affinity mask, capped by the cgroup CPU quota (cpu.max of cgroup v2, cfs quota of v1).
+    A container with a quota of 16 CPUs on a 256-thread host gets 16 CPUs' worth of time however many threads it starts."""
+    n, why = hardware_threads, "no affinity mask or cgroup quota below the hardware threads"
+    try:
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, why = a, "sched_getaffinity"
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n, why = max(1, int(quota + 0.5)), "cgroup cpu quota %.1f" % quota
+    return n, why
 
 
 def desc_for(tex_handle, uv, ix, lv, kw, extra_flags=0):
@@ -102,9 +139,7 @@ def desc_for(tex_handle, uv, ix, lv, kw, extra_flags=0):
 
 def micro_triangles_of(lib, baker, desc):
     """sum of 4^level over the unique work items of a bake (product library: from its timings)"""
-    tm = BakeTimings()
-    lib.dll.ommxGetLastBakeTimings(baker, C.byref(tm))
-    return int(tm.microTriangles)
+    return int(get_timings(lib, baker).microTriangles)
 
 
 def oracle_timings(orc):
@@ -116,12 +151,13 @@ def oracle_timings(orc):
 def cpu_baseline(tex, uv, ix, lv, kw, sample, sat=True, grow=True, sweep=True):
     """The oracle (bit-exact restatement of the reference CPU baker, OpenMP over work items like the reference) timed on a bounded sample
     of the same triangle stream: the reference needs 2 * 4^N bytes per work item (131 GB at the full metric configuration).
-    One run at all hardware threads on a sample that grows until it is >= 8 s of CPU work, with the oracle's own phase clocks (set-up, ResampleCoarse,
-    ResampleFine, serial tail: oracle_ommxGetLastBakeTimings) -- and, since the reference's loop structure does not scale to 256 threads, the same bake of a
-    quarter of the sample at 16 and 64 threads: `value` is the best of the three rates."""
-    cores, host = host_info()
+    The main run uses as many threads as this process has CPUs (affinity mask and cgroup quota: `effective_cpus`, printed next to the hardware threads) on a
+    sample that grows until it is >= 8 s of wall time, with the oracle's own phase clocks (set-up, ResampleCoarse, ResampleFine, serial tail:
+    oracle_ommxGetLastBakeTimings); a quarter of the sample is baked again at twice that many threads and at all hardware threads (oversubscribed when
+    the quota is the limit).  `value` is the best of the rates, `cores` the thread count of that run."""
+    hw, eff, host = host_info()
     orc = ot.Lib("oracle")
-    orc.dll.oracle_ommxSetThreads(0)
+    orc.dll.oracle_ommxSetThreads(eff)
     b = orc.create_baker()
     t = orc.create_texture(b, [tex], alpha_cutoff=0.5 if sat else -1.0)
     n = min(sample, ix.size // 3)
@@ -138,8 +174,7 @@ def cpu_baseline(tex, uv, ix, lv, kw, sample, sat=True, grow=True, sweep=True):
     if sweep:
         nq = max(1, n // 4)
         quv, qix, qlv = wl.subset(uv, ix, lv, 0, nq)
-        for th in (64, 16):
-            if th >= cores: continue
+        for th in sorted(set((min(hw, 2 * eff), hw)) - {eff}):
             orc.dll.oracle_ommxSetThreads(th)
             t0 = time.time()
             orc.bake(b, desc_for(t, quv, qix, qlv, kw), want_stats=False)
@@ -150,10 +185,11 @@ def cpu_baseline(tex, uv, ix, lv, kw, sample, sat=True, grow=True, sweep=True):
     orc.destroy_baker(b)
     best = max(threads, key=lambda k: threads[k]["micro_triangles_per_s"])
     out = {"unit": "micro-triangles/s", "value": threads[best]["micro_triangles_per_s"], "cores": int(best), "kind": "port", "host": host,
-           "host_threads": cores, "threads_sweep": threads, "best_threads": int(best),
-           "sample_triangles": n, "seconds": dt, "phases_at_all_threads_s": {k: ph[k] for k in ("setup_s", "coarse_s", "fine_s", "tail_s")},
+           "host_threads": hw, "effective_cpus": eff, "threads_sweep": threads, "best_threads": int(best),
+           "sample_triangles": n, "seconds": dt, "phases_at_effective_cpus_s": {k: ph[k] for k in ("setup_s", "coarse_s", "fine_s", "tail_s")},
            "note": "same loop structure as the reference (static-schedule OpenMP over work items, serial set-up and tail); `cores` = the thread count of the best run; "
-                   "the phases are the oracle's own wall clocks of the all-threads run"}
+                   "`effective_cpus` = what the affinity mask / cgroup quota let this process use at once (thread counts above it are oversubscribed: they say "
+                   "nothing about how the loops scale on more cores); the phases are the oracle's own wall clocks of the run at effective_cpus threads"}
     return out, res, (suv, six, slv), dt, ph
 
 
@@ -195,7 +231,6 @@ def main():
     tris = ix.size // 3
 
     prod = ot.Lib("product")
-    prod.dll.ommxGetLastBakeTimings.argtypes = [C.c_void_p, C.POINTER(BakeTimings)]
     prod.dll.ommxBakeDevice.argtypes = [C.c_void_p, C.POINTER(ot.BakeInputDesc), C.POINTER(C.c_void_p)]
     prod.dll.ommxGetDeviceBakeResultDesc.argtypes = [C.c_void_p, C.POINTER(C.POINTER(ot.BakeResultDesc))]
     prod.dll.ommxDestroyDeviceBakeResult.argtypes = [C.c_void_p]
@@ -299,9 +334,7 @@ def main():
         if last is not None:
             prod.dll.ommxDestroyDeviceBakeResult(last)
         last = step()
-        tm = BakeTimings()
-        prod.dll.ommxGetLastBakeTimings(baker, C.byref(tm))
-        tms.append(tm)
+        tms.append(get_timings(prod, baker))
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -332,9 +365,7 @@ def main():
         for _ in range(host_steps):
             r, out = prod.bake_raw(baker, host_desc)
             assert r == ot.SUCCESS
-            htm = BakeTimings()
-            prod.dll.ommxGetLastBakeTimings(baker, C.byref(htm))
-            host_tms.append(htm)
+            host_tms.append(get_timings(prod, baker))
             prod.fn("ommCpuDestroyBakeResult")(out)
         host_ms = (time.perf_counter() - t1) / host_steps * 1e3
 
@@ -378,6 +409,10 @@ def main():
             # `value` / `ms_per_step` / `bake_wall_time_ms`: the SDK call a drop-in user makes, ommCpuBake, host arrays in and out, PCIe inclusive (SURVEY.md
             # section 8d defines both metrics on it).  `device_resident`: the same bake through ommxBakeDevice (inputs and result arrays in HBM), same steps.
             "value_entry": "ommCpuBake" if headline_host else ("ommxBakeDevice" if world == 1 else ("ommxShardedBakeRccl" if one_call else "ommxSharded* + torch.distributed")),
+            # A scaling curve over N must compare ONE entry: at N > 1 `value` is the device-resident sharded bake, so the N = 1 line carries the
+            # device-resident single-GPU bake under this key as well (at N > 1 it repeats `value`)
+            "value_same_entry_as_n_gt_1": {"entry": "ommxBakeDevice" if world == 1 else entry_n, "value": micro_tris / (dev_ms * 1e-3), "ms_per_step": dev_ms,
+                                           "note": "the device-resident bake (UV / index inputs and result arrays in HBM): the entry whose sharded form is `value` for n_gpus > 1"},
             "bake_wall_time_ms": ms_per_step,
             "bake_wall_time_entry": "ommCpuBake (host arrays in/out, PCIe inclusive)" if headline_host else "device-resident entry (ommCpuBake was not timed in this run)",
             "device_resident": {"entry": "ommxBakeDevice" if world == 1 else entry_n, "ms_per_bake": dev_ms, "micro_triangles_per_s": micro_tris / (dev_ms * 1e-3), "bakes": args.steps,
@@ -487,7 +522,7 @@ def main():
             # the fine pass alone, SAME numerator on both sides: the micro-triangles of the sample that enter ResampleFine (counted by the oracle) over the
             # oracle's own clock around ResampleFine, and over the GPU's classification time (HIP events) of the same sample, second bake (warm)
             prod.bake(baker, sdesc, want_stats=False)
-            stm = BakeTimings(); prod.dll.ommxGetLastBakeTimings(baker, C.byref(stm))
+            stm = get_timings(prod, baker)
             cb["sample"] = "first %d triangles of the same seeded stream (%.3g micro-triangles), SAT on, %.1f s at %d threads" % (cb["sample_triangles"], ph["micro_triangles"], dt, ph["threads"])
             line["cpu_baseline"] = cb
             line["fine_pass_only"] = {"numerator": "micro-triangles of the CPU sample that enter ResampleFine (coarse pass left them UnknownOpaque): %.4g" % ph["fine_micro_triangles"],

@@ -54,8 +54,8 @@ typedef struct ommxBakeTimings {
 
 /* ommxBakeTimings only ever grows at its END.  ommxGetLastBakeTimingsSized copies min(outBytes, the library's size) bytes and zeros the rest of `out`, so a
  * caller and a library built from different versions of this header stay compatible; *libraryBytes (optional) <- the library's sizeof(ommxBakeTimings).
- * ommxGetLastBakeTimings is the same call with the size of THIS header's struct baked in at the caller's compile time -- use it only when header and
- * library are built together (it was the only form until round 4, when the struct had already grown twice: an ABI break for older callers). */
+ * ommxGetLastBakeTimings is the round-3 symbol: it fills the fields up to and including contributionBytes (the struct as it was then) and never writes
+ * beyond them, whatever the caller's header says -- the fields from streamPreviewMs on are only available through the sized call. */
 OMM_MI355X_API ommResult ommxGetLastBakeTimingsSized(ommBaker baker, void* out, size_t outBytes, size_t* libraryBytes);
 OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings* out);
 

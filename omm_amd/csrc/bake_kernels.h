@@ -58,7 +58,7 @@ __device__ __forceinline__ uint32_t early_range(uint32_t leadPos, uint32_t ownPo
 }
 // Deferred generic pass (asset-sized triangles: micro-triangles of several texels).  The persistent launch queues the micro-triangles that need the
 // generic texel loops instead of walking them itself -- entry = {item | degenerate << 30, level << 24 | micro-triangle index}, their packed state left 0 --
-// and classify_generic() classifies them afterwards -- its lanes take the entries one after the other as their walks end -- and ORs the states in.  count[1] is that launch's cursor.  *count only grows and may exceed capacity: a tile
+// and classify_generic() classifies them afterwards -- its lanes take the entries one after the other as their walks end -- and ORs the states in.  count[1] is that launch's cursor, count[2] the number of micro-triangles it classified (null entries not counted).  *count only grows and may exceed capacity: a tile
 // whose reservation does not fit walks its micro-triangles itself and fills the part of the reservation that lies inside the queue with null entries (x == ~0).
 struct GenericQueue { uint2* entries; unsigned long long* count; uint32_t capacity; };
 struct ClassifyChunks {

@@ -692,7 +692,8 @@ __device__ __forceinline__ bool texel_under(const RasterBox& B, const TexelCurso
 }
 // a wave's classified entries: state ORed into the packed word the persistent launch left 0; item mask / known count with one atomic per item and wave
 // (the entries of a wave mostly share their item)
-__device__ __forceinline__ void generic_commit(const ClassifyParams& P, const ItemArrays& A, bool live, uint32_t item, uint32_t index, int state)
+// returns the number of live entries of the wave (wave-uniform; the caller adds them up for the pass's statistic)
+__device__ __forceinline__ uint32_t generic_commit(const ClassifyParams& P, const ItemArrays& A, bool live, uint32_t item, uint32_t index, int state)
 {
     const uint32_t lane = threadIdx.x & 63u, bits = (uint32_t)P.format;
     if (live) {
@@ -700,6 +701,7 @@ __device__ __forceinline__ void generic_commit(const ClassifyParams& P, const It
         atomicOr((uint32_t*)(A.states + A.stateOfs[item]) + (bit >> 5), (uint32_t)state << (uint32_t)(bit & 31u));
     }
     unsigned long long todo = __ballot(live);
+    const uint32_t committed = (uint32_t)__popcll(todo);
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const uint32_t it0 = (uint32_t)__shfl((int)item, leader);
@@ -711,6 +713,7 @@ __device__ __forceinline__ void generic_commit(const ClassifyParams& P, const It
         const uint32_t known = (uint32_t)__popcll(__ballot(live && item == it0 && state < 2) & same);
         if ((int)lane == leader) { atomicOr(&A.stateMask[it0], mask); if (P.wantKnownCount && known) atomicAdd(&A.knownCount[it0], known); }
     }
+    return committed;
 }
 
 // ---- the walks ----
@@ -744,6 +747,7 @@ __device__ __forceinline__ void generic_walks(const ClassifyParams& P, const Ite
     unsigned long long* const cursorWord = G.count + 1;
     uint32_t chunkNext = 0, chunkEnd = 0;   // (wave-uniform) the chunk of the queue this wave works on
     bool drained = false;                   // (wave-uniform) no entries left in the queue
+    uint32_t classified = 0;                // (wave-uniform) entries this wave has committed: one atomic per wave at the end (count[2], a statistic)
     bool have = false, result = false;      // this lane: holds an unfinished walk / a finished one that is not committed yet
     bool rowSeen = false;                   // a texel of the cursor's row was under the triangle
     uint32_t item = 0, levelWord = 0, above = 0, below = 0;
@@ -762,7 +766,7 @@ __device__ __forceinline__ void generic_walks(const ClassifyParams& P, const Ite
         const uint32_t idle = 64u - (uint32_t)__popcll(busy);
         if ((!drained && idle >= (uint32_t)OMMX_GENERIC_REFILL) || busy == 0ull) {
             // ---- commit what is finished, hand out the next entries ----
-            generic_commit(P, A, result, item, levelWord & 0xFFFFFFu, direct >= 0 ? direct : state_from_coverage(P, above, below));
+            classified += generic_commit(P, A, result, item, levelWord & 0xFFFFFFu, direct >= 0 ? direct : state_from_coverage(P, above, below));
             result = false;
             if (drained) break;   // (busy == 0)
             if (chunkNext == chunkEnd) {
@@ -849,6 +853,7 @@ __device__ __forceinline__ void generic_walks(const ClassifyParams& P, const Ite
             if (!countsMatter && above != 0 && below != 0) { have = false; result = true; }
         }
     }
+    if (lane == 0u && classified) atomicAdd(G.count + 2, (unsigned long long)classified);
 }
 
 #ifndef OMMX_GENERIC_WAVES
@@ -863,6 +868,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OMMX_GENERI
         if (P.filterLinear) generic_walks<FP32, 0, MD>(P, A, G, n); else generic_walks<FP32, 1, MD>(P, A, G, n);
         return;
     }
+    uint32_t classified = 0;
     for (uint32_t e0 = wave * 64u; e0 < n; e0 += waves * 64u) {   // (wave-uniform) mip chains / the alternative kernel: the serial form per entry
         const uint32_t e = e0 + lane;
         bool live = e < n;
@@ -871,8 +877,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OMMX_GENERI
         const uint32_t item = ent.x & 0x3FFFFFFFu;
         int state = 0;
         if (live) state = fine_state<FP32, MD>(P, micro_triangle(A.uv + 6ull * item, ent.y & 0xFFFFFFu, ent.y >> 24), ((ent.x >> 30) & 1u) != 0u, no_window());
-        generic_commit(P, A, live, item, ent.y & 0xFFFFFFu, state);
+        classified += generic_commit(P, A, live, item, ent.y & 0xFFFFFFu, state);
     }
+    if (lane == 0u && classified) atomicAdd(G.count + 2, (unsigned long long)classified);
 }
 
 // ---- launches ----

@@ -807,11 +807,18 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
                 auto part = [&](uint32_t k0, uint32_t k1) {
                     for (uint32_t k = k0; k < k1; ++k) { HostTri t; memcpy(t.p, &puv[(size_t)k * 6], 24); plv[k] = (uint8_t)level_for_primitive(tmpDesc, flags, 0, t, S.texW, S.texH); }
                 };
-                const uint32_t n = hc.numPending, ways = n >= 8192u ? 4u : 1u;
+                // helper threads only with the caller's permission (ommCpuBakeFlags_EnableInternalThreads, omm.h:303: what the reference spends on its OpenMP
+                // loops); a thread that cannot be started (std::system_error: thread limit, cgroup pids) leaves its share to this thread -- nothing escapes the C ABI
+                const uint32_t n = hc.numPending, ways = (n >= 8192u && (flags & (uint32_t)ommCpuBakeFlags_EnableInternalThreads)) ? 4u : 1u;
                 std::vector<std::thread> helpers;
-                for (uint32_t w = 1; w < ways; ++w) helpers.emplace_back(part, (uint32_t)((uint64_t)n * w / ways), (uint32_t)((uint64_t)n * (w + 1u) / ways));
+                uint32_t started = 0;
+                try {
+                    helpers.reserve(ways);
+                    for (uint32_t w = 1; w < ways; ++w) { helpers.emplace_back(part, (uint32_t)((uint64_t)n * w / ways), (uint32_t)((uint64_t)n * (w + 1u) / ways)); started = w; }
+                } catch (...) {}
                 part(0u, (uint32_t)((uint64_t)n / ways));
                 for (auto& h : helpers) h.join();
+                for (uint32_t w = started + 1u; w < ways; ++w) part((uint32_t)((uint64_t)n * w / ways), (uint32_t)((uint64_t)n * (w + 1u) / ways));   // (shares whose thread did not start)
             }
             if (!HIP_OK(run_setup_fix_pending(S, dScratch, scratchBytes, pend.data(), plv.data(), hc.numPending, tmp.p, stream))) return L.failure("[Failure] - device work-item setup failed");
         }
@@ -1144,8 +1151,8 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     uint32_t queueTails[2] = { 0u, 0u };   // open tiles of the two tile sizes (statistics)
     uint32_t hostCtl[kClassifyCtlWords]; memset(hostCtl, 0, sizeof hostCtl);
     if (hc.activeStart[kNumLevels]) ok = ok && HIP_OK(hipMemcpyAsync(hostCtl, dQueueCtl, sizeof hostCtl, hipMemcpyDeviceToHost, stream));
-    unsigned long long genericCount = 0;
-    if (dGeneric) ok = ok && HIP_OK(hipMemcpyAsync(&genericCount, dGeneric, sizeof genericCount, hipMemcpyDeviceToHost, stream));
+    unsigned long long genericWords[3] = { 0, 0, 0 };   // reservations (incl. null padding), the pass's cursor, micro-triangles it classified
+    if (dGeneric) ok = ok && HIP_OK(hipMemcpyAsync(genericWords, dGeneric, sizeof genericWords, hipMemcpyDeviceToHost, stream));
     const int e5 = et.mark();
     ok = ok && HIP_OK(hipStreamSynchronize(stream));
     // (a streamed result may still be on its way to the host: the caller queues its small read-backs first and then waits, StreamOut::finish)
@@ -1157,7 +1164,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     tm.uploadMs = 0.f; tm.hostSetupMs = 0.f; tm.setupMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.digestMs = et.ms(e2, e3);
     tm.streamPreviewMs = pv0 >= 0 ? et.ms(pv0, pv1) : 0.f;
     tm.tailMs = et.ms(e3, e4); tm.gatherMs = et.ms(e4, e5); tm.persistentMs = mk.mark >= 0 ? et.ms(mk.mark, mk.markGeneric >= 0 ? mk.markGeneric : e2) : 0.f;
-    tm.genericMs = mk.markGeneric >= 0 ? et.ms(mk.markGeneric, e2) : 0.f; tm.genericMicroTriangles = genericCount < genericCapacity ? genericCount : genericCapacity;
+    tm.genericMs = mk.markGeneric >= 0 ? et.ms(mk.markGeneric, e2) : 0.f; tm.genericMicroTriangles = genericWords[2];
     for (int k = 0; k < kFineSlots; ++k) fineCount += fineSlots[(size_t)k * kFineStride];
     queueTails[1] = hostCtl[kCtl1024 + kSecTails]; for (uint32_t k = 0; k < kMaxClassifyChunks; ++k) queueTails[0] += hostCtl[kSecTails + k];   // (1024-tile queue; sections of the 4096-tile queue)
     tm.openTiles = queueTails[0] + queueTails[1]; tm.openTileMicroTriangles = (uint64_t)queueTails[0] * 4096u + (uint64_t)queueTails[1] * 1024u;
@@ -1820,6 +1827,7 @@ const RcclApi& rccl()
 struct RcclComm {
     rcclComm_t comm = nullptr; bool owned = false; int rank = 0, world = 1;
     uint32_t* dStatus = nullptr; hipStream_t statusStream = nullptr;   // status agreement (rccl_agree): two device words and a stream for ranks that have no bake stream
+    int statusDevice = -1;                                             // ... and the device they live on (rccl_status_on_device)
     bool custom = false; ommxCollectives user{};                       // ommxCommFromCollectives: the caller's transport instead of RCCL
     // the two collectives of the sharded bake (uint32 all-reduce, byte all-gather), stream-ordered; 0 = success
     int all_reduce(const void* send, void* recv, size_t count, int rcclOp, hipStream_t stream) const
@@ -1838,8 +1846,22 @@ struct RcclComm {
 // that has run out of device memory later can still take part in every agreement; rccl_agree() only allocates if that did not succeed.
 void rccl_prepare_status(RcclComm* c)
 {
+    if (!HIP_OK(hipGetDevice(&c->statusDevice))) { c->statusDevice = -1; (void)hipGetLastError(); }
     if (!c->dStatus && !HIP_OK(hipMalloc((void**)&c->dStatus, 2 * sizeof(uint32_t)))) { c->dStatus = nullptr; (void)hipGetLastError(); }
     if (!c->statusStream && !HIP_OK(hipStreamCreateWithFlags(&c->statusStream, hipStreamNonBlocking))) { c->statusStream = nullptr; (void)hipGetLastError(); }
+}
+// The communicator may have been made before the caller selected the rank's device (ommxCommFromCollectives / ommxRcclCommWrap in front of
+// torch.cuda.set_device): status words and stream of another GPU than the bake's would mix devices inside one collective.  Called under the baker's
+// DeviceScope: anything that lives elsewhere is released and made again here.
+void rccl_status_on_device(RcclComm* c, int device)
+{
+    if (c->statusDevice == device && c->dStatus && c->statusStream) return;
+    if (c->statusDevice != device) {
+        if (c->statusStream) { (void)hipStreamSynchronize(c->statusStream); (void)hipStreamDestroy(c->statusStream); c->statusStream = nullptr; }
+        if (c->dStatus) { (void)hipFree(c->dStatus); c->dStatus = nullptr; }
+        (void)hipGetLastError();
+    }
+    rccl_prepare_status(c);   // (on the current device = `device`)
 }
 // A rank-local failure (out of memory, mostly) must not leave the other ranks waiting in the next collective: before every data collective each rank
 // contributes its status to a one-element MIN all-reduce and all of them go on, or none.  `stream`: the bake's stream (idle ranks: the communicator's own).
@@ -2155,7 +2177,8 @@ OMM_MI355X_API ommResult ommxShardedBakeRccl(ommBaker baker, const ommCpuBakeInp
     RcclComm* rc = (RcclComm*)comm;
     if (!rc->custom && !rccl().ok()) return L.failure(("[Failure] - RCCL is not available: " + rccl().error).c_str());
     return guarded(&L, [&]() -> ommResult {
-        const DeviceScope onBakersDevice(b->bind_device());   // (the communicator must have been created on this device)
+        const DeviceScope onBakersDevice(b->bind_device());
+        rccl_status_on_device(rc, b->bind_device());          // (status words / idle-rank stream on the bake's device, whatever was current when the communicator was made)
         auto nccl_fail = [&](int code, const char* what) {
             char buf[256]; snprintf(buf, sizeof buf, "[Failure] - %s: %s", what, rc->error_string(code));
             return L.failure(buf);
@@ -2312,7 +2335,9 @@ OMM_MI355X_API ommResult ommxGetLastBakeTimingsSized(ommBaker baker, void* out, 
 }
 OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings* out)
 {
-    return ommxGetLastBakeTimingsSized(baker, out, sizeof(ommxBakeTimings), nullptr);
+    // The unsized getter is the round-3 symbol: binaries (and ctypes mirrors) built against that header hold a struct that ends in front of
+    // streamPreviewMs, so this symbol never writes more than that prefix.  Everything newer is read through ommxGetLastBakeTimingsSized.
+    return ommxGetLastBakeTimingsSized(baker, out, offsetof(ommxBakeTimings, streamPreviewMs), nullptr);
 }
 
 #include "serialize.inc"

@@ -28,7 +28,16 @@
 #define OMMX_REGION_CURVE_H
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+/* Bit-exactness of the verdicts between the device code and the audited host compilation rests on both evaluating the SAME fp32 expressions: no FMA
+ * contraction, no fast-math.  Both Makefiles pass -ffp-contract=off (omm_amd/csrc/Makefile, oracle/Makefile); for clang (hipcc: host and device side) the
+ * pragma below pins it in the source as well, whatever flags a different build passes. */
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+#if defined(__FAST_MATH__)
+#error "region_curve.h must not be compiled with -ffast-math: its error bounds assume IEEE fp32 evaluation"
+#endif
+#if defined(__HIPCC__)
 #define OMMX_RC_FN __host__ __device__ static inline
 #else
 #define OMMX_RC_FN static inline

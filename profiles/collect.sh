@@ -8,7 +8,6 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; cd /tmp; export TMPDIR=/tmp
 O=$R/gpurun_out/$tag; mkdir -p $O
 BENCH="python $R/bench.py --config $cfg"
 [ -x $R/profiles/bin/valu_rates ] && [ ! -s $O/valu_rates.json ] && $R/profiles/bin/valu_rates > $O/valu_rates.json 2> $O/valu_rates.err
-timeout 1200 $BENCH > $O/bench.json 2> $O/bench.err
 # (the trace run skips the bench's side bakes -- CPU-baseline parity samples, SAT-off sample, the ommCpuBake steps -- so that every classify_tiles launch in
 #  the stats table is the full workload through the device-resident entry and its average is comparable with roofline.avg_launch_ms)
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- $BENCH --cpu-sample 0 --sat-off-sample 0 --host-api-steps 0 --create-texture 0 > $O/trace.log 2>&1
@@ -23,6 +22,12 @@ pass C4 SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_
 cd $R
 python profiles/summarize_rocprof.py $(find $O/trace -name "*.db" | head -1) > $O/kernel_stats.md 2> $O/kernel_stats.err
 python profiles/summarize_pmc.py $tag $O "python bench.py --config $cfg $PM" > $O/pmc_summary.json 2> $O/pmc_summary.err
+# the bench line comes LAST and reads the counters that were just collected on this very box (round 5: every committed <tag>_<config>_bench.json carries the
+# valu_issue roofline and its traffic figure; bench.py accepts the summary only when its source hash equals the tree's)
+[ -s $O/${tag}_hbm_traffic.json ] && cp $O/${tag}_hbm_traffic.json $R/profiles/pmc_latest_$cfg.json
+cd /tmp
+timeout 1200 $BENCH > $O/bench.json 2> $O/bench.err
+cd $R
 tail -c 900 $O/bench.json; echo; cat $O/pmc_summary.json; head -14 $O/kernel_stats.md
 # only the summaries travel back (gpurun merges at most 64 MiB; the raw trace database and counter CSVs of one configuration are larger than that)
 [ -z "$OMMX_KEEP_RAW" ] && rm -rf $O/trace $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_C1 $O/pmc_C2 $O/pmc_C3 $O/pmc_C4

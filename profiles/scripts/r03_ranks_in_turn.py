@@ -85,7 +85,6 @@ def worker(rank, world, port, outdir, cfg, bakes):
     cbs = (ALLREDUCE(all_reduce), ALLGATHER(all_gather)); table = Collectives(cbs[0], cbs[1], None)
     prod.dll.ommxCommFromCollectives.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     comm = C.c_void_p(); assert prod.dll.ommxCommFromCollectives(C.byref(table), rank, world, C.byref(comm)) == 0
-    prod.dll.ommxGetLastBakeTimings.argtypes = [C.c_void_p, C.POINTER(bench.BakeTimings)]
     prod.dll.ommxDestroyDeviceBakeResult.argtypes = [C.c_void_p]
 
     # single-GPU reference time of the same bake, alone on the GPU (rank 0, the others wait)
@@ -107,7 +106,7 @@ def worker(rank, world, port, outdir, cfg, bakes):
         acquire()
         out = sh.sharded_bake_rccl(prod.dll, b, C.byref(dd), comm)
         release(None)
-        tm = bench.BakeTimings(); prod.dll.ommxGetLastBakeTimings(b, C.byref(tm))
+        tm = bench.get_timings(prod, b)
         prod.dll.ommxDestroyDeviceBakeResult(out)
         if i >= 2:
             runs.append(list(clock["phases"]))

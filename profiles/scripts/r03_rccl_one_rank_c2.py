@@ -20,7 +20,7 @@ if lv is not None:
 comm = sh.rccl_comm(prod.dll, torch, dist, 0, 1)
 for i in range(3):
     t0 = time.perf_counter(); out = sh.sharded_bake_rccl(prod.dll, b, C.byref(dd), comm); dt = time.perf_counter() - t0
-    tm = bench.BakeTimings(); prod.dll.ommxGetLastBakeTimings.argtypes = [C.c_void_p, C.POINTER(bench.BakeTimings)]; prod.dll.ommxGetLastBakeTimings(b, C.byref(tm))
+    tm = bench.get_timings(prod, b)
     print("bake %d: %.2f ms wall; classify %.2f tail %.2f exchange+scatter %.2f ms; contribution %.1f MB -> %.2f MB on the wire (%.1f %%)" %
           (i, dt * 1e3, tm.classifyMs, tm.tailMs, tm.gatherMs, tm.contributionBytes / 1e6, tm.exchangeBytes / 1e6, 100.0 * tm.exchangeBytes / max(1, tm.contributionBytes)))
     res = ot.device_result_to_host(prod, hip, out) if i == 2 else None

@@ -388,8 +388,7 @@ def test_full_size_mixed_levels_config4(product, oracle):
     # device-resident entry, which assembles the result after the classification
     import bench, ctypes
     tm = bench.BakeTimings()
-    product.dll.ommxGetLastBakeTimings.argtypes = [ctypes.c_void_p, ctypes.POINTER(bench.BakeTimings)]
-    product.dll.ommxGetLastBakeTimings(b, ctypes.byref(tm))
+    tm = bench.get_timings(product, b)
     assert tm.streamChunks > 1 and tm.streamedBytes == full.array_data.size, (tm.streamChunks, tm.streamedBytes)
     dev = ot.bake_device(product, ot.Hip(), b, d, uv, ix, levels=lv)
     assert dev.same_as(full), dev.diff(full)
@@ -933,8 +932,7 @@ def test_user_allocator_is_honoured_and_balanced(product):
     before = stats["biggest"]
     r3 = product.bake(b, desc)
     tm = bench.BakeTimings()
-    product.dll.ommxGetLastBakeTimings.argtypes = [C.c_void_p, C.POINTER(bench.BakeTimings)]
-    product.dll.ommxGetLastBakeTimings(b, C.byref(tm))
+    tm = bench.get_timings(product, b)
     assert r3.same_as(r1) and tm.streamChunks == 3 and tm.streamedBytes == r1.array_data.size
     assert stats["biggest"] >= before and stats["biggest"] >= tm.stateBytes >= r1.array_data.size
     product.destroy_texture(b, t)
@@ -1427,8 +1425,7 @@ def test_streamed_result_falls_back_when_a_later_range_owns_the_block(product, o
         t = product.create_texture(b, [tile], alpha_cutoff=0.5)
         res = product.bake(b, ot.make_desc(t, uv, ix, level, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE))
         tm = bench.BakeTimings()
-        product.dll.ommxGetLastBakeTimings.argtypes = [ctypes.c_void_p, ctypes.POINTER(bench.BakeTimings)]
-        product.dll.ommxGetLastBakeTimings(b, ctypes.byref(tm))
+        tm = bench.get_timings(product, b)
         product.destroy_texture(b, t); product.destroy_baker(b)
         assert res.same_as(ref), res.diff(ref)
         assert tm.streamedBytes > 0
@@ -1449,8 +1446,7 @@ def test_both_formats_and_both_generic_passes_at_scale(product):
     d = ot.make_desc(t, uv, ix, lvl, **kw)
     host = product.bake(b, d, want_stats=False)
     tm = bench.BakeTimings()
-    product.dll.ommxGetLastBakeTimings.argtypes = [ctypes.c_void_p, ctypes.POINTER(bench.BakeTimings)]
-    product.dll.ommxGetLastBakeTimings(b, ctypes.byref(tm))
+    tm = bench.get_timings(product, b)
     assert tm.streamChunks > 1 and tm.streamedBytes == host.array_data.size > (64 << 20), (tm.streamChunks, tm.streamedBytes, host.array_data.size)
     dev = ot.bake_device(product, hip, b, d, uv, ix)
     assert dev.same_as(host), dev.diff(host)
@@ -1463,7 +1459,7 @@ def test_both_formats_and_both_generic_passes_at_scale(product):
         b = product.create_baker(); product.set_knob(b, ot.KNOB_GENERIC_PASS, mode)
         t = product.create_texture(b, [tex], alpha_cutoff=0.5)
         results.append(ot.bake_device(product, hip, b, ot.make_desc(t, uv, ix, lvl, levels=lv, **kw), uv, ix, levels=lv))
-        product.dll.ommxGetLastBakeTimings(b, ctypes.byref(tm))
+        tm = bench.get_timings(product, b)
         assert (tm.genericMicroTriangles > 1000000) == (mode == 2), (mode, tm.genericMicroTriangles)
         product.destroy_texture(b, t); product.destroy_baker(b)
     assert results[0].same_as(results[1]), results[0].diff(results[1])
@@ -1554,3 +1550,19 @@ def test_near_duplicate_merge_and_budget_at_scale(product, oracle):
             lib.destroy_texture(b, t); lib.destroy_baker(b)
         assert out[0].same_as(out[1]), out[0].diff(out[1])
         assert len(out[0].descs) > 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 101])
+def test_curve_free_regions_device_against_oracle_on_adversarial_inputs(product, oracle, seed):
+    """The curve-free-region test (region_curve.h) is audited on the HOST compilation of the header (tests/test_region_curve_audit.py); this bakes the audit's
+    adversarial cases -- thin work items (edge-free verdict), textures without a summed-area table, alpha within ulps of the cutoff, FP32 values of +-1000,
+    non-power-of-two sizes, every address mode / promotion, both formats -- through the DEVICE code (items, 4096-tiles and 64-groups all culled) and compares
+    every result array with the oracle: a divergence between the device and the host evaluation of the header (an FMA contraction, a fast-math flag) shows here."""
+    import region_cases
+    want = []
+    region_cases.run(oracle, seed=seed, tri_seed_base=2000 if seed == 11 else 7000 + seed, each=lambda k, r: want.append(r))
+    bad = []
+    region_cases.run(product, seed=seed, tri_seed_base=2000 if seed == 11 else 7000 + seed, each=lambda k, r: (None if r.same_as(want[k]) else bad.append((k, r.diff(want[k])))))
+    assert len(want) == 84 and not bad, bad[:3]
+

@@ -57,42 +57,24 @@ def test_region_verdicts_on_the_bench_workloads(audit):
 
 
 def test_region_verdicts_on_adversarial_inputs(audit):
-    """textures that stress the error bounds (alpha hugging the cutoff, nearly flat patches with a twist around the 1e-6 branch threshold, 0 / 1 noise, FP32
-    values far from [0, 1], a non-power-of-two size), triangles with thin shapes, nearly vertical / horizontal edges, sizes from far below to above a texel,
-    UV offsets, every address mode, 2-state and every promotion"""
+    """textures that stress the error bounds, thin triangles, nearly vertical / horizontal edges, UV offsets, every address mode, 2-state and every promotion
+    (tests/region_cases.py; the GPU suite bakes the same cases on the device and compares the arrays with the oracle)"""
+    import region_cases
     audit.dll.orc_audit_region_reset()
-    rng = np.random.RandomState(11)
-    yy, xx = np.mgrid[0:256, 0:256].astype(np.float32)
-    texs = [
-        (0.5 + 1e-6 * (xx - 128) + 3e-7 * (yy - 128) + 1e-8 * (xx - 128) * (yy - 128)).astype(np.float32),
-        (0.5 + 1e-3 * np.sin(xx * 0.7) * np.cos(yy * 0.9) + 2e-6 * rng.rand(256, 256)).astype(np.float32),
-        (rng.rand(256, 256) > 0.5).astype(np.float32),
-        (0.5 + 0.25 * np.sin(xx * 0.05) + 1e-5 * xx * yy / 256).astype(np.float32),
-        (1000.0 * np.sin(xx * 0.11) * np.cos(yy * 0.07) + 0.5).astype(np.float32),                                  # FP32 alpha far outside [0, 1]
-        (ot.value_noise(5, 300, 200, octaves=3, base_cell=16) * 255).astype(np.uint8),                             # 200 x 300, not a power of two
-        np.where(((xx.astype(np.int32) // 3 + yy.astype(np.int32) // 5) & 1) == 1, np.float32(0.5000001), np.float32(0.4999999)).astype(np.float32),  # steps of 2 ulp
-    ]
-    b = audit.create_baker()
-    case = 0
-    for ti, tx in enumerate(texs):
-        for cutoff in (0.5, -1.0):
-            t = audit.create_texture(b, [tx], alpha_cutoff=cutoff)
-            for ext, level, n in ((0.02, 6, 30), (0.006, 5, 40), (0.05, 8, 6), (0.0015, 3, 60), (0.3, 7, 3), (0.004, 9, 2)):
-                case += 1
-                uv, ix = ot.random_triangles(2000 + case, n, ext)
-                tri = uv.reshape(-1, 3, 2)
-                tri[::4, 1, 0] = tri[::4, 0, 0] + np.float32(1e-7)                       # nearly vertical edge
-                tri[1::4, 2, 1] = tri[1::4, 0, 1]                                         # exactly horizontal edge
-                tri[2::4, 2] = tri[2::4, 0] + (tri[2::4, 1] - tri[2::4, 0]) * np.float32(1.02) + np.float32(ext * 0.01)   # thin sliver
-                off = (0.0, 3.0, -17.0, 900.0)[case % 4]
-                addr = (ot.WRAP, ot.CLAMP, ot.MIRROR, ot.BORDER, ot.MIRROR_ONCE)[case % 5]
-                promo = (ot.PROMO_NEAREST, ot.PROMO_FORCE_OPAQUE, ot.PROMO_FORCE_TRANSPARENT)[case % 3]
-                fmt = ot.FMT_2STATE if case % 7 == 0 else ot.FMT_4STATE
-                d = ot.make_desc(t, (tri.reshape(-1, 2) + np.float32(off)).astype(np.float32), ix, level, addr=addr, promo=promo, fmt=fmt,
-                                 flags=ot.FLAG_THREADS | ot.FLAG_NO_DEDUP)
-                audit.bake(b, d, want_stats=False)
-            audit.destroy_texture(b, t)
-    audit.destroy_baker(b)
+    region_cases.run(audit)
     c = counters(audit)
     assert c[0] > 500_000 and c[1] > 400_000 and c[6] > 2_000, tuple(c)
+    assert c[3] == 0 and c[11] == 0, c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [101, 202, 303])
+def test_region_verdicts_seed_sweep_on_every_lease(audit, seed):
+    """The same audit with other seeds (textures' noise, triangle streams), as part of the GPU suite: every lease of a GPU box re-audits the constants of
+    region_curve.h on inputs the CPU suite has not seen (pure CPU work, a few seconds per seed; marked gpu only for WHERE it runs)."""
+    import region_cases
+    audit.dll.orc_audit_region_reset()
+    region_cases.run(audit, seed=seed, tri_seed_base=7000 + seed)
+    c = counters(audit)
+    assert c[0] > 300_000 and c[1] > 200_000, tuple(c)
     assert c[3] == 0 and c[11] == 0, c
