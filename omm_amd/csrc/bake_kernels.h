@@ -10,7 +10,7 @@ struct SetupCounters;
 
 // classification of the active items of ALL levels: level l = activeIds[first[l] .. first[l] + count[l]).  Items of level >= 5 are cut into
 // tiles; `queue` holds classify_queue_records(count) tile records of kTileRecordBytes, `queueCtl` kClassifyCtlWords words (zeroed here).  numCUs sizes the persistent grid.
-constexpr size_t kTileRecordBytes = 48;
+constexpr size_t kTileRecordBytes = 112;   // 48 bytes of tile data + 64 verdict bytes (one per 64-group: triage_groups)
 uint64_t classify_queue_records(const uint32_t count[kNumLevels], bool sections = false);   // sections: a streamed bake (chunks.count > 1), whose queue holds a second copy of the levels >= 6
 // `queueCtl` (zeroed here): per section k of the 4096-tile queue the words [kSecTails + k] records appended, [kSecHeads + k] records handed out,
 // [kSecBases + k] first record, [kSecDone + k] records whose tiles are finished AND visible device-wide (== tail: the section is complete); the same four

@@ -125,10 +125,23 @@ void launch_narrow_indices(const int32_t* in, uint32_t n, int bytesPerIndex, voi
 // bakes: one section.  Streamed bakes (ommCpuBake) with K ranges: section 2k = the tiles of range k's own items, at records [cut[k], ..) of the queue's
 // first copy; section 2k + 1 = the tiles of EARLY items of later ranges whose family starts in range k, in the queue's second copy ([total, 2 total)),
 // ordered by range with a staging pass (early_tiles_*).
-// record = 3 x uint4 (everything a tile's workgroup needs, in ONE memory round trip):
+// record = 7 x uint4 (everything a tile's workgroup needs, in ONE memory round trip):
 //   [0] x = item | degenerate << 30 | rectOk << 31, y = tile in item | level << 24 | no-single-texel-micro-triangle << 31, z = sx | sy << 16, w = ex | ey << 16 (addressed texel rectangle)
 //   [1] the item's uv[0..3]      [2] uv[4], uv[5], address of the tile's packed states (lo, hi)
-constexpr uint32_t kTileRecordWords = 3;   // uint4 per record (bake_kernels.h: kTileRecordBytes)
+//   [3..6] one verdict byte per 64-group of the tile (triage_groups below; a 1024-tile uses the first 16)
+constexpr uint32_t kTileRecordWords = 7;   // uint4 per record (bake_kernels.h: kTileRecordBytes)
+static_assert(kTileRecordWords * 16u == kTileRecordBytes, "tile record size");
+// verdict byte of a 64-group: 0..3 = every micro-triangle of the group has that state; kGvUnknown = test them one by one; kGvAllOpen = none of them is resolved by
+// the coarse pass; kGvEdgeFree | code = region_curve_state()'s edge-free verdict -(kRegionEdgeFreeBase + code), code = 16 above + mask of the wrong-side corners
+constexpr uint32_t kGvUnknown = 0xFFu, kGvAllOpen = 0xFEu, kGvEdgeFree = 0x80u;
+__device__ __forceinline__ uint32_t group_verdict_byte(int gs)
+{
+    return gs >= 0 ? (uint32_t)gs : (gs == kRegionUnknown ? kGvUnknown : (gs == kRegionAllOpen ? kGvAllOpen : (kGvEdgeFree | ((uint32_t)(-gs - kRegionEdgeFreeBase) & 31u))));
+}
+__device__ __forceinline__ int group_verdict(uint32_t b)
+{
+    return b < 4u ? (int)b : (b == kGvUnknown ? kRegionUnknown : (b == kGvAllOpen ? kRegionAllOpen : -(kRegionEdgeFreeBase + (int)(b & 31u))));
+}
 template <int TILE>
 __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays A, const uint32_t* __restrict__ activeIds, TileLevels L,
                                                     uint4* __restrict__ queue, uint32_t* __restrict__ queueCtl, TileSections S,
@@ -221,6 +234,44 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Group triage (round 5).  Every OPEN tile is asked the two hierarchical questions once more per 64-micro-triangle group (its level-(N - 3) sub-triangles): the
+// summed-area table (region_state_ex: settled / wholly open / undecided) and, for what the table leaves open, the curve-free-region test (region_curve.h:
+// settled / edge-free).  Until round 4 ONE wave of the tile's workgroup did that inside the persistent classify_tiles launch while the other three waited at
+// a barrier, and the test's registers (RcShape, RcTex, the cell loop) were live across the whole kernel -- 160 bytes of scratch per lane.  Here it is a dense
+// pass of its own: lane = (open tile, group), no barriers, no LDS; the verdict bytes land in the tile's record, which the persistent workgroup reads anyway.
+// ------------------------------------------------------------------------------------------------
+template <bool FP32, class MD, int TILE>
+__global__ __launch_bounds__(256) void triage_groups(ClassifyParams P, uint4* __restrict__ queue, const uint32_t* __restrict__ queueCtl, uint32_t numSections)
+{
+    constexpr uint32_t GROUPS = (uint32_t)TILE / 64u, PER_BLOCK = 256u / GROUPS;   // 64 groups: a wave per tile; 16 groups: four tiles per wave
+    const uint32_t g = threadIdx.x % GROUPS, slot = threadIdx.x / GROUPS;
+    const bool coarse = P.useCoarse != 0;
+    const bool fastFine = P.filterLinear != 0 && P.mipCount == 1 && !P.noFine && P.altKernel == 0;
+    const bool curveOn = (OMMX_RC_LEVELS & 4) && region_curve_applies(P);
+    for (uint32_t sec = 0; sec < numSections; ++sec) {
+        const uint32_t base = queueCtl[kSecBases + sec], tail = queueCtl[kSecTails + sec];
+        for (uint32_t r = blockIdx.x * PER_BLOCK + slot; r < tail; r += gridDim.x * PER_BLOCK) {
+            uint4* rec = queue + (size_t)kTileRecordWords * (base + r);
+            const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+            float uv[6] = { __uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x), __uint_as_float(r2.y) };
+            const uint32_t level = (r0.y >> 24) & 0x7Fu, first = (r0.y & 0xFFFFFFu) * (GROUPS);   // first group of the tile in the item's level-(N - 3) enumeration
+            const float maxAbs = item_max_abs(uv);
+            const bool degenerate = ((r0.x >> 30) & 1u) != 0u;
+            const bool fast = fastFine && !degenerate && maxAbs <= 16384.f && (r0.y >> 31) == 0u;   // (= classify_tiles' uFast: only then can it use the edge-free verdict)
+            const MicroTri gsub = micro_triangle(uv, first + g, level - 3u);
+            int gs = coarse ? region_state_ex<MD>(P, gsub, maxAbs, no_window()) : kRegionUnknown;
+            if (gs < 0 && curveOn && !degenerate) {
+                const DevMip& m0 = P.mips[0];
+                const RcShape shape = rc_shape(uv, m0.fw, m0.fh, m0.w, m0.h, level);
+                const int cs = region_curve_state_impl(rc_tex<MD>(P, FP32), shape, gsub.lo.x, gsub.lo.y, gsub.hi.x, gsub.hi.y, maxAbs);
+                gs = (cs >= 0 || (cs <= -kRegionEdgeFreeBase && fast)) ? cs : gs;
+            }
+            ((uint8_t*)(rec + 3))[g] = (uint8_t)group_verdict_byte(gs);
+        }
+    }
+}
+
 constexpr int WIN = 32; // largest LDS texel window edge
 
 // SLICED: 4^level >= TILE, the tile is a slice of ONE work item (block-uniform item data, LDS texel/SAT window).
@@ -250,10 +301,20 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     __shared__ uint32_t s_mask, s_known;
     __shared__ uint32_t s_pending, s_fine;       // single-texel pass: micro-triangles left for the generic pass / level-line statistic
     __shared__ uint32_t s_next;                  // sliced: next tile-queue position of this (persistent) workgroup
+    // tid is re-"defined" (an empty asm the optimizer cannot look through) at the top of every tile and phase: otherwise LICM hoists every cheap value derived
+    // from it -- LDS addresses, lane masks, wave indices, a dozen of them -- out of the persistent tile loop and keeps them alive across all phases, i.e. in
+    // scratch (round 4: 18 scratch stores in front of the loop, reloads in every phase).  Recomputing them costs one or two instructions each.
+    uint32_t tid = threadIdx.x;
+#ifndef OMMX_NO_TID_LAUNDER
+#define OMMX_FRESH_TID() asm volatile("" : "+v"(tid))
+#else
+#define OMMX_FRESH_TID() ((void)0)
+#endif
     // DEFER: hand `n` queued micro-triangles (s_queue[0 .. n)) to the generic queue; false = no room, the caller walks them itself.  Block-uniform.
     auto defer_generic = [&](uint32_t n, uint32_t itemWord, uint32_t level, uint32_t base) -> bool {
         if (!DEFER || !SLICED || n == 0u) return false;
-        if (threadIdx.x == 0) {
+        OMMX_FRESH_TID();
+        if (tid == 0) {
             // One atomicAdd per tile and no way back: the count only grows (an add that is taken back lets a concurrent workgroup fail spuriously or succeed
             // at a base the final count no longer covers; a compare-and-swap loop on one word collapses under 1536 workgroups -- measured: 7 us per tile).  A
             // reservation that does not fit is given up, and the part of it that lies inside the queue is filled with null entries below.
@@ -262,10 +323,10 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         __syncthreads();
         const unsigned long long gb = s_gbase;
         if (gb + n > (unsigned long long)G.capacity) {
-            for (unsigned long long q = gb + threadIdx.x; q < (unsigned long long)G.capacity; q += BLOCK) G.entries[q] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);   // (classify_generic skips these)
+            for (unsigned long long q = gb + tid; q < (unsigned long long)G.capacity; q += BLOCK) G.entries[q] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);   // (classify_generic skips these)
             return false;
         }
-        for (uint32_t q = threadIdx.x; q < n; q += BLOCK) {
+        for (uint32_t q = tid; q < n; q += BLOCK) {
             const uint32_t i = s_queue[q];
             G.entries[gb + q] = make_uint2(itemWord & 0x7FFFFFFFu, (level << 24) | (base + i));
             s_state[i] = (uint8_t)kDeferredState;
@@ -278,7 +339,6 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     __shared__ float    s_wtex[SLICED ? WIN * WIN : 1];
     __shared__ uint32_t s_wsat[SLICED ? (WIN + 1) * (WIN + 1) : 1];
     constexpr uint32_t TILE_LOG4 = TILE == 4096 ? 6u : 5u; // the tile is the level-(N - TILE_LOG4) sub-triangle of its item
-    const uint32_t tid = threadIdx.x;
     // SLICED: persistent workgroups drain the queue of open tiles that triage_tiles filled (all levels >= log4 TILE in one launch);
     // the position of the NEXT tile is fetched while the current one is being classified.
     // The queue is cut into sections (TileSections; queueCtl: SectionCtl words per section), drained one after the other by the SAME launch.  A streamed
@@ -301,6 +361,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         qpos = uniform_u32(s_next);
     }
   for (;;) {
+    OMMX_FRESH_TID();
     uint32_t level = levelArg, tile = 0;
     uint4 rec = make_uint4(0u, 0u, 0u, 0u), rec1 = rec, rec2 = rec;
     uint32_t nextPos = 0;
@@ -349,11 +410,8 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         // fine_single_texel's FINITE precondition: |uv| <= 16384 bounds every pixel coordinate by 2^30 (size <= 65536) and excludes NaN;
         // items outside it (and degenerate ones) take the generic path
         uFast = fastFine && !uDegenerate && uMaxAbs <= 16384.f && (rec.y >> 31) == 0u;   // (bit 31: no micro-triangle of the item fits in one texel, triage_tiles)
-        // the curve-free-region test of the groups (phase 0c): the item's shape bounds, once per tile
-        const bool uCurve = (OMMX_RC_LEVELS & 4) && region_curve_applies(P) && !uDegenerate;
-        RcShape uShape; uShape.ok = 0;
-        if (uCurve) { const DevMip& m0 = P.mips[0]; uShape = rc_shape(uUv, m0.fw, m0.fh, m0.w, m0.h, level); }
         {
+            OMMX_FRESH_TID();
             // ---- phase 0b: LDS window = every texel / SAT entry this tile can touch ----
             // (the tile's texel rectangle was computed by triage_tiles: region_rect of its sub-triangle)
             TexRect r; r.sx = (int)(rec.z & 0xFFFFu); r.sy = (int)(rec.z >> 16); r.ex = (int)(rec.w & 0xFFFFu); r.ey = (int)(rec.w >> 16); r.ok = (rec.x >> 31) != 0u;
@@ -361,46 +419,30 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
             bool windowOk = false;
             if (r.ok && ww <= WIN && wh <= WIN) {
                 const DevMip& m0 = P.mips[0];
-                // 64 x 3 thread grid over the window (no integer division by the run-time width): column = lane, one row per wave and pass;
-                // wave 1 is busy with the group queries below, waves 0, 2, 3 load
+                // 64 x 4 thread grid over the window (no integer division by the run-time width): column = lane, one row per wave and pass
                 const int cx = (int)(tid & 63u);
-                const uint32_t wv = tid >> 6;
-                if (wv != 1u || !coarse)
-                for (int cy = coarse ? (int)(wv == 0u ? 0u : wv - 1u) : (int)wv; cy <= wh; cy += coarse ? 3 : 4) {
+                for (int cy = (int)(tid >> 6); cy <= wh; cy += 4) {
                     const int x = r.sx + cx, y = r.sy + cy;
                     if (cx < ww && cy < wh) {
                         const size_t idx = (size_t)x + (size_t)y * (size_t)m0.w;
                         s_wtex[cx + cy * ww] = FP32 ? ((const float*)m0.texels)[idx] : (float)((const uint8_t*)m0.texels)[idx] * (1.f / 255.f);
                     }
-                    if (m0.sat && cx <= ww) // SAT entry (x-1, y-1); row / column -1 of the table is zero
+                    if (coarse && m0.sat && cx <= ww) // SAT entry (x-1, y-1); row / column -1 of the table is zero
                         s_wsat[cx + cy * (ww + 1)] = (x >= 1 && y >= 1) ? m0.sat[(size_t)(x - 1) + (size_t)(y - 1) * (size_t)m0.w] : 0u;
                 }
                 windowOk = true;
             }
-            // ---- phase 0c: one query per 64-micro-triangle group (wave 1), straight from the global SAT while the other waves fill the window; a group the
-            //      table leaves open is then asked whether the level curve can reach it at all (region_curve.h: texels from L2) -- settled if not ----
-            if (coarse) {
-                if (tid >= 64 && tid < 64 + TILE / GROUP) { // (4096-tile: 64 groups = all of wave 1; 1024-tile: 16 of its lanes)
-                    const uint32_t g = tid - 64;
-                    const MicroTri gsub = micro_triangle(uUv, (base >> 6) + g, level - 3);
-                    int gs = region_state_ex<MD>(P, gsub, uMaxAbs, no_window());
-                    if (gs < 0 && uCurve) { const int cs = OMMX_RC_GROUP_TEST(rc_tex<MD>(P, FP32), uShape, gsub.lo.x, gsub.lo.y, gsub.hi.x, gsub.hi.y, uMaxAbs); gs = (cs >= 0 || (cs <= -kRegionEdgeFreeBase && uFast)) ? cs : gs; }
-                    s_group[g] = gs;
-                    s_gdec[g] = bird_group((base >> 6) + g, level - 3).word;
-                    const unsigned long long open = __ballot(gs < 0), allOpen = __ballot(gs == kRegionAllOpen);
-                    if (gs < 0) s_glist[__popcll(open & ((1ull << g) - 1ull))] = (uint16_t)g;
-                    if (gs == kRegionAllOpen) s_olist[__popcll(allOpen & ((1ull << g) - 1ull))] = (uint16_t)g;
-                    if (g == 0) { s_gcount = (uint32_t)__popcll(open); s_ocount = (uint32_t)__popcll(allOpen); }
-                }
-            } else if (tid < (uint32_t)(TILE / GROUP)) {   // no summed-area table: every group is open unless the level curve cannot reach it
+            // ---- phase 0c: the verdicts of the tile's 64-groups (triage_groups wrote them into the record: summed-area table, then the curve-free-region
+            //      test), their bird-curve decode words and the compacted lists of the groups that are not settled / wholly open ----
+            if (tid < (uint32_t)(TILE / GROUP)) {   // (4096-tile: 64 groups = all of wave 0; 1024-tile: 16 of its lanes)
                 const uint32_t g = tid;
-                int gs = -1;
-                if (uCurve) { const MicroTri gsub = micro_triangle(uUv, (base >> 6) + g, level - 3); const int cs = OMMX_RC_GROUP_TEST(rc_tex<MD>(P, FP32), uShape, gsub.lo.x, gsub.lo.y, gsub.hi.x, gsub.hi.y, uMaxAbs); gs = (cs >= 0 || (cs <= -kRegionEdgeFreeBase && uFast)) ? cs : -1; }
+                const int gs = group_verdict((uint32_t)((const uint8_t*)(tileQueue + (size_t)kTileRecordWords * qpos + 3))[g]);
                 s_group[g] = gs;
                 s_gdec[g] = bird_group((base >> 6) + g, level - 3).word;
-                const unsigned long long open = __ballot(gs < 0);
+                const unsigned long long open = __ballot(gs < 0), allOpen = __ballot(gs == kRegionAllOpen);
                 if (gs < 0) s_glist[__popcll(open & ((1ull << g) - 1ull))] = (uint16_t)g;
-                if (g == 0) { s_gcount = (uint32_t)__popcll(open); s_ocount = 0; }
+                if (gs == kRegionAllOpen) s_olist[__popcll(allOpen & ((1ull << g) - 1ull))] = (uint16_t)g;
+                if (g == 0) { s_gcount = (uint32_t)__popcll(open); s_ocount = (uint32_t)__popcll(allOpen); }
             }
             __syncthreads();
             if (windowOk) { const DevMip& m0 = P.mips[0]; W.tex = (lds_float*)s_wtex; W.sat = (lds_u32*)s_wsat; W.base = m0.texels; W.sx = r.sx; W.sy = r.sy; W.w = ww; W.h = wh; } // (SAT part is only read when coarse is on)
@@ -419,6 +461,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         __syncthreads();
     }
     {
+        OMMX_FRESH_TID();
         // ---- phase 1: per-micro-triangle coarse test in the unsettled groups ----
         // one wave = one 64-group; gs (wave-uniform) is < 0 here: kRegionAllOpen or kRegionUnknown
         auto phase1_group = [&](uint32_t i, int gs) {
@@ -482,6 +525,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         __syncthreads();
 
         // ---- phase 2: fine, dense over the queue ----
+        OMMX_FRESH_TID();
         const uint32_t qn = s_qcount;
         if (tid == 0 && qn) atomicAdd(A.fineCount + (size_t)((blockIdx.x + 7u * blockIdx.y) & (kFineSlots - 1)) * kFineStride, (unsigned long long)qn);
         if (uFast) {
@@ -506,6 +550,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
             const unsigned long long anyGeneric = __ballot((pend & 1u) != 0), anyEdges = __ballot((pend & 2u) != 0);
             if ((tid & 63u) == 0 && (anyGeneric | anyEdges)) atomicOr(&s_pending, (anyGeneric ? 1u : 0u) | (anyEdges ? 2u : 0u));
             __syncthreads();
+            OMMX_FRESH_TID();
             if (s_pending) {   // (block-uniform)
                 if (tid == 0) { s_qcount = 0; s_ecount = 0; }
                 __syncthreads();
@@ -526,6 +571,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 qn2 = s_qcount; en = s_ecount;
             }
             // ---- phase 2b: the edge tests of the micro-triangles that curve_excluded() could not settle, densely ----
+            OMMX_FRESH_TID();
             for (uint32_t q0 = 0; q0 < en; q0 += BLOCK) {
                 const uint32_t q = q0 + tid;
                 if (q < en) {
@@ -534,6 +580,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 }
             }
             // ---- phase 2c: the generic pass for whatever did not fit the single-texel pattern ----
+            OMMX_FRESH_TID();
             if (tid == 0 && s_fine) atomicAdd(A.fineCount + (size_t)((blockIdx.x + 7u * blockIdx.y) & (kFineSlots - 1)) * kFineStride, (unsigned long long)s_fine);
             if (!defer_generic(qn2, rec.x, level, base))
             for (uint32_t q0 = 0; q0 < qn2; q0 += BLOCK) {
@@ -561,6 +608,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     }
 
     // ---- phase 3: pack + per-item summary ----
+    OMMX_FRESH_TID();
     const uint32_t bits = (uint32_t)P.format;          // 1 or 2 bits per micro-triangle
     const uint32_t perWord = 32u / bits;               // micro-triangles per 32-bit word
     if (SLICED) {
@@ -996,6 +1044,18 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
     if (plan.totalSmall)
         hipLaunchKernelGGL((triage_tiles<1024>), dim3((uint32_t)((plan.totalSmall + 255u) / 256u)), dim3(256), 0, stream, P, A, activeIds, plan.small, q1024, ctl1024, one,
                            (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint4*)nullptr);
+    // ---- sliced items, step 1b: group triage of the open tiles (verdict bytes into the records; grid-stride over the sections' device-side counts) ----
+    {
+        const uint32_t cap = numCUs * 16u;   // workgroups (a wave per 4096-tile / four 1024-tiles per wave); the queue's fill is only known on the device
+        if (plan.totalSmall) {
+            const uint64_t need = (plan.totalSmall + 15u) / 16u;
+            hipLaunchKernelGGL((triage_groups<FP32, MD, 1024>), dim3((uint32_t)(need < cap ? need : cap)), dim3(256), 0, stream, P, q1024, (const uint32_t*)ctl1024, 1u);
+        }
+        if (plan.totalBig) {
+            const uint64_t need = (plan.totalBig + 3u) / 4u;
+            hipLaunchKernelGGL((triage_groups<FP32, MD, 4096>), dim3((uint32_t)(need < cap ? need : cap)), dim3(256), 0, stream, P, queue, (const uint32_t*)queueCtl, paired ? 2u * K : K);
+        }
+    }
     // ---- small items: one launch per level ----
     for (uint32_t level = 0; level < 5u; ++level) {
         if (!count[level]) continue;
@@ -1066,6 +1126,10 @@ hipError_t launch_classify(const ClassifyParams& P, const ItemArrays& A, const u
     // the two address-mode/pow2 pairs that real assets use get their own instantiation (the reference has one per pair); the rest is dynamic
     const bool wrapP2 = P.addrMode == 0 && P.pow2Dispatch, clampP2 = P.addrMode == 2 && P.pow2Dispatch;
     uint4* q = (uint4*)queue;
+#ifdef OMMX_ONLY_HOT   // (A/B and resource-usage builds: one instantiation set -- UNORM8 texels, Wrap addressing, power-of-two size -- compiles in a sixth of the time)
+    if (P.texIsFp32 || !wrapP2) return hipErrorNotSupported;
+    launch_classify_md<false, ModeStatic<0, 1>>(P, A, activeIds, first, count, q, queueCtl, numCUs, chunks, stream);
+#else
     if (P.texIsFp32) {
         if (wrapP2) launch_classify_md<true, ModeStatic<0, 1>>(P, A, activeIds, first, count, q, queueCtl, numCUs, chunks, stream);
         else if (clampP2) launch_classify_md<true, ModeStatic<2, 1>>(P, A, activeIds, first, count, q, queueCtl, numCUs, chunks, stream);
@@ -1075,6 +1139,7 @@ hipError_t launch_classify(const ClassifyParams& P, const ItemArrays& A, const u
         else if (clampP2) launch_classify_md<false, ModeStatic<2, 1>>(P, A, activeIds, first, count, q, queueCtl, numCUs, chunks, stream);
         else launch_classify_md<false, ModeDynamic>(P, A, activeIds, first, count, q, queueCtl, numCUs, chunks, stream);
     }
+#endif
     return hipGetLastError();
 }
 

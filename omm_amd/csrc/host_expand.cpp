@@ -1,0 +1,135 @@
+// host_expand.cpp -- see host_expand.h
+#include "host_expand.h"
+#include <emmintrin.h>
+#include <sched.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace ommx {
+
+unsigned effective_cpus()
+{
+    static const unsigned cached = [] {
+        unsigned n = std::thread::hardware_concurrency(); if (n == 0) n = 1;
+        cpu_set_t set; CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0 && (unsigned)a < n) n = (unsigned)a; }
+        double quota = -1.0;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = { 0 }; double per = 0;
+            if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) quota = atof(q) / per;
+            fclose(f);
+        } else {
+            double q = -1, per = 0;
+            if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lf", &q) != 1) q = -1; fclose(fq); }
+            if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lf", &per) != 1) per = 0; fclose(fp); }
+            if (q > 0 && per > 0) quota = q / per;
+        }
+        if (quota > 0 && quota < (double)n) n = (unsigned)(quota + 0.5);
+        return n ? n : 1u;
+    }();
+    return cached;
+}
+
+WorkerPool::WorkerPool(unsigned workers)
+{
+    try {
+        threads_.reserve(workers);
+        for (unsigned k = 0; k < workers; ++k) threads_.emplace_back([this] { loop(); });
+    } catch (...) {}   // (std::system_error: thread limit, cgroup pids -- whatever did start is kept)
+}
+WorkerPool::~WorkerPool()
+{
+    { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+    wake_.notify_all();
+    for (auto& t : threads_) t.join();
+}
+void WorkerPool::loop()
+{
+    uint64_t seen = 0;
+    for (;;) {
+        const std::function<void(uint32_t)>* fn; uint32_t tasks;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            wake_.wait(lk, [&] { return stop_ || generation_ != seen; });
+            if (stop_) return;
+            seen = generation_; fn = fn_; tasks = tasks_;
+        }
+        for (uint32_t t; (t = next_.fetch_add(1, std::memory_order_relaxed)) < tasks; ) (*fn)(t);
+        { std::lock_guard<std::mutex> g(mu_); if (--active_ == 0) done_.notify_all(); }
+    }
+}
+void WorkerPool::run(uint32_t tasks, const std::function<void(uint32_t)>& fn)
+{
+    if (tasks == 0) return;
+    std::lock_guard<std::mutex> one(runMu_);
+    if (threads_.empty() || tasks == 1) { for (uint32_t t = 0; t < tasks; ++t) fn(t); return; }
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        fn_ = &fn; tasks_ = tasks; next_.store(0, std::memory_order_relaxed); active_ = (unsigned)threads_.size(); ++generation_;
+    }
+    wake_.notify_all();
+    for (uint32_t t; (t = next_.fetch_add(1, std::memory_order_relaxed)) < tasks; ) fn(t);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return active_ == 0; });
+    fn_ = nullptr;
+}
+
+HostCodecLayout host_codec_layout(uint64_t paddedBytes)
+{
+    HostCodecLayout c; c.units = paddedBytes / 16u; c.blocks = (c.units + 255u) / 256u; c.offOfs = 16u;
+    c.offCodes = (c.offOfs + 4u * (c.blocks + 1u) + 15u) & ~15ull; c.offRaw = (c.offCodes + (c.units + 1u) / 2u + 15u) & ~15ull;
+    return c;
+}
+
+namespace {
+const uint32_t kPattern[4] = { 0u, 0x55555555u, 0xAAAAAAAAu, 0xFFFFFFFFu };
+template <bool NT> inline void put16(uint8_t* d, __m128i v) { if (NT) _mm_stream_si128((__m128i*)d, v); else _mm_storeu_si128((__m128i*)d, v); }
+template <bool NT>
+void expand(uint8_t* dst, uint64_t dstBytes, const uint8_t* stream, const HostCodecLayout& L, uint64_t b0, uint64_t b1)
+{
+    const uint32_t* ofs = (const uint32_t*)(stream + L.offOfs);
+    for (uint64_t b = b0; b < b1; ++b) {
+        const uint64_t u0 = b * 256u, u1 = u0 + 256u < L.units ? u0 + 256u : L.units;
+        const uint8_t* codes = stream + L.offCodes + u0 / 2u;
+        const uint8_t* raw = stream + L.offRaw + 16ull * ofs[b];
+        uint8_t* d = dst + u0 * 16u;
+        const bool whole = u1 * 16u <= dstBytes && u1 - u0 == 256u;
+        if (whole) {
+            // a block of one repeated state (most of them): 128 equal code bytes 0x00 / 0x11 / 0x22 / 0x33
+            uint64_t w0; memcpy(&w0, codes, 8);
+            bool same = (w0 & 0xCCCCCCCCCCCCCCCCull) == 0 && ((w0 >> 4) & 0x0F0F0F0F0F0F0F0Full) == (w0 & 0x0F0F0F0F0F0F0F0Full) && w0 == (w0 & 0xFF) * 0x0101010101010101ull;
+            for (int k = 1; same && k < 16; ++k) { uint64_t w; memcpy(&w, codes + 8 * k, 8); same = w == w0; }
+            if (same) {
+                const __m128i v = _mm_set1_epi32((int)kPattern[w0 & 3u]);
+                for (int k = 0; k < 256; ++k) put16<NT>(d + 16 * k, v);
+                continue;
+            }
+            for (int k = 0; k < 128; ++k) {
+                const uint32_t two = codes[k], c0 = two & 15u, c1 = two >> 4;
+                __m128i v0, v1;
+                if (c0 < 4u) v0 = _mm_set1_epi32((int)kPattern[c0]); else { v0 = _mm_loadu_si128((const __m128i*)raw); raw += 16; }
+                if (c1 < 4u) v1 = _mm_set1_epi32((int)kPattern[c1]); else { v1 = _mm_loadu_si128((const __m128i*)raw); raw += 16; }
+                put16<NT>(d + 32 * k, v0); put16<NT>(d + 32 * k + 16, v1);
+            }
+            continue;
+        }
+        // the last block of the array: units that end beyond dstBytes are cut
+        for (uint64_t u = u0; u < u1; ++u) {
+            const uint32_t c = (codes[(u - u0) / 2u] >> (4u * (uint32_t)((u - u0) & 1u))) & 15u;
+            uint8_t tmp[16];
+            if (c < 4u) { for (int k = 0; k < 4; ++k) memcpy(tmp + 4 * k, &kPattern[c], 4); } else { memcpy(tmp, raw, 16); raw += 16; }
+            const uint64_t at = u * 16u;
+            if (at >= dstBytes) break;
+            memcpy(dst + at, tmp, at + 16u <= dstBytes ? 16u : (size_t)(dstBytes - at));
+        }
+    }
+    if (NT) _mm_sfence();
+}
+} // namespace
+
+void codec_expand_blocks(uint8_t* dst, uint64_t dstBytes, const uint8_t* stream, const HostCodecLayout& L, uint64_t b0, uint64_t b1)
+{
+    if (((uintptr_t)dst & 15u) == 0) expand<true>(dst, dstBytes, stream, L, b0, b1); else expand<false>(dst, dstBytes, stream, L, b0, b1);
+}
+
+} // namespace ommx

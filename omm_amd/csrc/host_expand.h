@@ -1,0 +1,48 @@
+// host_expand.h -- host side of the compressed result of ommCpuBake: the finished arrayData crosses PCIe as a codec stream (tail_kernels.hip "block
+// exchange codec": one nibble per 16-byte unit = which state it repeats, or "raw") and a few host threads expand it into the caller's array.
+// Plain C++ (no HIP): compiled like host_tail.cpp.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace ommx {
+
+// CPUs this process can run on at once: scheduler affinity capped by the cgroup CPU quota (cpu.max of cgroup v2, the cfs quota of v1); >= 1
+unsigned effective_cpus();
+
+// A baker's helper threads (ommCpuBakeFlags_EnableInternalThreads, omm.h:303: the reference spends that permission on its OpenMP loops).  Threads are
+// started on first use and sleep between calls; run() hands out task indices 0 .. tasks-1 to the workers AND the calling thread and returns when all are done.
+// One run() at a time (concurrent bakes on one baker take turns).  A thread that cannot be started is simply missing: the caller does the work itself.
+class WorkerPool {
+public:
+    explicit WorkerPool(unsigned workers);
+    ~WorkerPool();
+    WorkerPool(const WorkerPool&) = delete; WorkerPool& operator=(const WorkerPool&) = delete;
+    unsigned workers() const { return (unsigned)threads_.size(); }
+    void run(uint32_t tasks, const std::function<void(uint32_t)>& fn);
+private:
+    void loop();
+    std::vector<std::thread> threads_;
+    std::mutex runMu_;                         // one run() at a time
+    std::mutex mu_; std::condition_variable wake_, done_;
+    const std::function<void(uint32_t)>* fn_ = nullptr;
+    uint32_t tasks_ = 0; uint64_t generation_ = 0; unsigned active_ = 0; bool stop_ = false;
+    std::atomic<uint32_t> next_{ 0 };
+};
+
+// Layout of a codec stream (the same arithmetic as tail_kernels.hip: codec_layout): header 16 B | first raw unit of every 256-unit block (uint32, blocks + 1) |
+// one nibble per unit (0..3: 16 bytes of 0x00 / 0x55 / 0xAA / 0xFF, 4: raw) | the raw units
+struct HostCodecLayout { uint64_t units, blocks, offOfs, offCodes, offRaw; };
+HostCodecLayout host_codec_layout(uint64_t paddedBytes);
+
+// Expands codec blocks [b0, b1) of `stream` (layout L) into dst[0 .. dstBytes): block b covers dst bytes [4096 b, 4096 (b + 1)); bytes beyond dstBytes are not
+// written (the device pads the array to a multiple of 256 bytes).  Write-only on dst (non-temporal stores when dst is 16-byte aligned).
+void codec_expand_blocks(uint8_t* dst, uint64_t dstBytes, const uint8_t* stream, const HostCodecLayout& L, uint64_t b0, uint64_t b1);
+
+} // namespace ommx

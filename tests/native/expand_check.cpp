@@ -1,0 +1,54 @@
+// expand_check.cpp -- host side of ommCpuBake's compressed result (omm_amd/csrc/host_expand.cpp) against a scalar model of the device codec
+// (tail_kernels.hip: codec_code / shard_codec_write): random arrays with long constant runs, every size class incl. tails that are not a multiple of 16,
+// unaligned destinations, worker pools of 0 .. 7 threads.  Prints "ok <cases>" or the first mismatch.   (CPU only; built and run by tests/test_host_expand.py)
+#include "../../omm_amd/csrc/host_expand.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+using namespace ommx;
+static uint64_t s = 0x9E3779B97F4A7C15ull;
+static uint64_t rnd() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+int main()
+{
+    int cases = 0;
+    const size_t sizes[] = { 1, 15, 16, 17, 255, 256, 4095, 4096, 4097, 65536 + 3, (1u << 20) + 777, (5u << 20) + 16 };
+    for (size_t bytes : sizes) for (int variant = 0; variant < 4; ++variant) for (unsigned workers : { 0u, 3u, 7u }) {
+        const size_t padded = (bytes + 255) & ~(size_t)255;
+        std::vector<uint8_t> src(padded, 0);
+        // runs of a repeated state byte with raw noise in between (variant 3: all noise = incompressible, variant 0: one state only)
+        static const uint8_t pat[4] = { 0x00, 0x55, 0xAA, 0xFF };
+        for (size_t o = 0; o < padded; ) {
+            size_t len = variant == 0 ? padded : (variant == 3 ? 16 : 16 * (1 + rnd() % (variant == 1 ? 2000 : 40)));
+            if (o + len > padded) len = padded - o;
+            if (variant == 3 || (variant != 0 && rnd() % 8 == 0)) for (size_t k = 0; k < len; ++k) src[o + k] = (uint8_t)rnd();
+            else memset(&src[o], pat[rnd() % 4], len);
+            o += len;
+        }
+        const HostCodecLayout L = host_codec_layout(padded);
+        std::vector<uint8_t> stream(L.offRaw + 16 * L.units + 64, 0xEE);
+        uint32_t* ofs = (uint32_t*)(stream.data() + L.offOfs); uint32_t nraw = 0;
+        for (uint64_t u = 0; u < L.units; ++u) {
+            if (u % 256 == 0) ofs[u / 256] = nraw;
+            uint32_t w[4]; memcpy(w, &src[u * 16], 16);
+            const bool same = w[0] == w[1] && w[0] == w[2] && w[0] == w[3];
+            const uint32_t code = !same ? 4u : (w[0] == 0u ? 0u : (w[0] == 0x55555555u ? 1u : (w[0] == 0xAAAAAAAAu ? 2u : (w[0] == 0xFFFFFFFFu ? 3u : 4u))));
+            uint8_t& c = stream[L.offCodes + u / 2];
+            c = (uint8_t)((u & 1) ? ((c & 0x0F) | (code << 4)) : code);
+            if (code == 4u) { memcpy(&stream[L.offRaw + 16ull * nraw], w, 16); ++nraw; }
+        }
+        ofs[L.blocks] = nraw;
+        for (int misalign = 0; misalign < 2; ++misalign) {
+            std::vector<uint8_t> out(bytes + 64 + 16, 0xCD);
+            uint8_t* base = out.data(); while (((uintptr_t)base & 15u) != (misalign ? 4u : 0u)) ++base;
+            WorkerPool pool(workers);
+            const uint32_t tasks = (uint32_t)((L.blocks + 63) / 64);
+            pool.run(tasks, [&](uint32_t t) { const uint64_t b0 = (uint64_t)t * 64, b1 = b0 + 64 < L.blocks ? b0 + 64 : L.blocks; codec_expand_blocks(base, bytes, stream.data(), L, b0, b1); });
+            if (memcmp(base, src.data(), bytes) != 0) { printf("MISMATCH bytes=%zu variant=%d workers=%u misalign=%d\n", bytes, variant, workers, misalign); return 1; }
+            for (int k = 0; k < 16; ++k) if (base[bytes + k] != 0xCD) { printf("OVERRUN bytes=%zu variant=%d at +%d\n", bytes, variant, k); return 1; }
+            ++cases;
+        }
+    }
+    printf("ok %d effective_cpus %u\n", cases, effective_cpus());
+    return 0;
+}
