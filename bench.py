@@ -51,7 +51,8 @@ class BakeTimings(C.Structure):
                 ("streamChunks", C.c_uint32), ("streamedBytes", C.c_uint64), ("streamTailMs", C.c_float),
                 ("openTiles", C.c_uint32), ("openTileMicroTriangles", C.c_uint64), ("streamEarlyItems", C.c_uint32), ("persistentMs", C.c_float),
                 ("genericMs", C.c_float), ("genericMicroTriangles", C.c_uint64), ("exchangeBytes", C.c_uint64), ("contributionBytes", C.c_uint64),
-                ("streamPreviewMs", C.c_float), ("streamFirstCopyMs", C.c_float), ("streamLastCopyMs", C.c_float), ("streamRangeReadyMs", C.c_float * 32)]
+                ("streamPreviewMs", C.c_float), ("streamFirstCopyMs", C.c_float), ("streamLastCopyMs", C.c_float), ("streamRangeReadyMs", C.c_float * 32),
+                ("resultTransfer", C.c_uint32), ("expandThreads", C.c_uint32), ("compressedBytes", C.c_uint64), ("compressMs", C.c_float), ("expandMs", C.c_float)]
 
 
 def get_timings(lib, baker):
@@ -206,6 +207,7 @@ def main():
     ap.add_argument("--sat-off-sample", type=int, default=50000, help="c2 only: triangles of the SAT-off (no coarse pass) GPU measurement; CPU uses 1/20 of it (0 = skip)")
     ap.add_argument("--generic-pass", type=int, default=0, help="ommxBakerKnob_GenericPass (0 = library default, 1 = inside the persistent launch, 2 = deferred pass)")
     ap.add_argument("--stream-chunks", type=int, default=0, help="ommxBakerKnob_StreamChunks for the ommCpuBake measurement (0 = library default)")
+    ap.add_argument("--result-transfer", type=int, default=0, help="ommxBakerKnob_ResultTransfer for the ommCpuBake measurement (0 = library default, 1 = plain copy, 2 = streamed placement, 3 = compressed)")
     ap.add_argument("--concurrent", type=int, default=0, help="also measure K host threads baking concurrently on ONE baker through ommCpuBake (bakes/s for 1, 4, .. K threads; "
                                                               "the reference documents caller-level parallelism as a first-class strategy, docs/integration_guide.md:434)")
     args = ap.parse_args()
@@ -239,6 +241,8 @@ def main():
         prod.set_knob(baker, ot.KNOB_STREAM_CHUNKS, args.stream_chunks)
     if args.generic_pass:
         prod.set_knob(baker, ot.KNOB_GENERIC_PASS, args.generic_pass)
+    if args.result_transfer:
+        prod.set_knob(baker, ot.KNOB_RESULT_TRANSFER, args.result_transfer)
     th = prod.create_texture(baker, [tex], alpha_cutoff=0.5)
     host_desc = desc_for(th, uv, ix, lv, kw)
     # inputs resident in HBM before the timed region: torch owns the device buffers, the library gets raw pointers
@@ -428,6 +432,11 @@ def main():
             havg = lambda f: avg(f, host_tms)
             line["host_api"] = {"entry": "ommCpuBake (host arrays in/out, PCIe inclusive)", "ms_per_bake": host_ms, "bakes": host_steps, "first_call_ms": host_first_ms,
                                 "micro_triangles_per_s": micro_tris / (host_ms * 1e-3),
+                                "result_transfer": {"mode": ["auto", "plain copy", "streamed placement (DMA engine, while the classification runs)",
+                                                             "compressed (codec stream over PCIe, expanded by the baker's helper threads)"][int(host_tms[-1].resultTransfer) & 3],
+                                                    "array_data_bytes": result_info["arrayDataBytes"], "bytes_over_pcie": int(host_tms[-1].compressedBytes) or int(host_tms[-1].streamedBytes) or result_info["arrayDataBytes"],
+                                                    "codec_and_readback_ms": havg("compressMs"), "copy_and_expand_ms": havg("expandMs"), "expand_threads": int(host_tms[-1].expandThreads),
+                                                    "expand_GBps": result_info["arrayDataBytes"] / (havg("expandMs") * 1e6) if havg("expandMs") > 0 else None},
                                 "stream": {"ranges": int(host_tms[-1].streamChunks), "streamed_bytes": int(host_tms[-1].streamedBytes), "exposed_copy_ms": havg("streamTailMs"),
                                            "early_items": int(host_tms[-1].streamEarlyItems),
                                            "preview_ms": havg("streamPreviewMs"), "first_copy_issued_ms": havg("streamFirstCopyMs"), "last_copy_issued_ms": havg("streamLastCopyMs"),

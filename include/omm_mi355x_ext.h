@@ -50,6 +50,12 @@ typedef struct ommxBakeTimings {
     float    streamFirstCopyMs;    /* the first range's blocks are placed and their copy is issued */
     float    streamLastCopyMs;     /* the last range's copy is issued */
     float    streamRangeReadyMs[32]; /* range k placed (its event seen by the host thread, which then issues its copy) */
+    /* (round 5) how arrayData reached the host (ommxResultTransfer_*; ommCpuBake only) and, for the compressed form: */
+    uint32_t resultTransfer;
+    uint32_t expandThreads;        /* host threads that expanded the codec stream (the caller's included) */
+    uint64_t compressedBytes;      /* bytes of the codec stream that crossed PCIe instead of arrayDataSize */
+    float    compressMs;           /* wall clock from the end of the bake proper to the stream's size on the host (codec kernels + the small read-backs) */
+    float    expandMs;             /* wall clock of the stream's copy and its expansion into arrayData (overlapped slice by slice) */
 } ommxBakeTimings;
 
 /* ommxBakeTimings only ever grows at its END.  ommxGetLastBakeTimingsSized copies min(outBytes, the library's size) bytes and zeros the rest of `out`, so a
@@ -77,8 +83,18 @@ typedef enum ommxBakerKnob {
                                            blocks and up to two idle PINNED host blocks for arrayData (a fresh 1.3 GB host block costs more in page faults and munmap than the
                                            PCIe copy of its contents) stay with the baker until it is destroyed; 1: nothing is retained -- every block goes back to the system
                                            when the result that uses it is destroyed.  For pipelines that create many bakers, or bake rarely.  See also ommxTrimBaker. */
-    ommxBakerKnob_MAX_NUM          = 5
+    ommxBakerKnob_ResultTransfer   = 5, /* ommCpuBake: how a large arrayData reaches the caller's memory, one of ommxResultTransfer_*.  Auto (0 / default): Compressed when the
+                                           bake carries ommCpuBakeFlags_EnableInternalThreads and the process has >= 6 CPUs (affinity / cgroup quota), else Streamed */
+    ommxBakerKnob_MAX_NUM          = 6
 } ommxBakerKnob;
+typedef enum ommxResultTransfer {
+    ommxResultTransfer_Auto        = 0,
+    ommxResultTransfer_Plain       = 1, /* one device-to-host copy of the finished array after the bake (what small results always get) */
+    ommxResultTransfer_Streamed    = 2, /* rounds 3 - 4: finished blocks are placed and copied to their final offsets by the DMA engine WHILE the classification runs
+                                           (>= 64 MiB of packed states; ommxBakerKnob_StreamChunks); bound by the PCIe link */
+    ommxResultTransfer_Compressed  = 3  /* round 5: the finished array crosses PCIe as a codec stream (one nibble per 16-byte unit: the state it repeats, or raw: 6 % of the
+                                           bytes at the metric configuration) and is expanded into the caller's array by up to 16 helper threads of the baker */
+} ommxResultTransfer;
 OMM_MI355X_API ommResult ommxSetBakerKnob(ommBaker baker, ommxBakerKnob knob, uint64_t value);
 /* Gives every idle pooled block of the baker back to the system now: pinned host blocks, device result blocks, device working sets of finished bakes.  Results
  * that are still alive keep their memory.  Safe to call at any time from any thread; the next bake allocates again. */

@@ -82,6 +82,9 @@ void launch_triage(const ClassifyParams& P, const float* uv, const uint8_t* leve
 // (only != null: the listed items with (only[item] != 0) == (want != 0))
 void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
                    uint64_t* digests, hipStream_t stream, const uint8_t* only = nullptr, int want = 0);
+// ... of the active items of all levels at once (level l: activeIds[first[l] .. first[l] + count[l])): the few-long-items levels share one launch
+void launch_digest_levels(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* activeIds, const uint32_t first[kNumLevels], const uint32_t count[kNumLevels],
+                          uint32_t bits, uint64_t* digests, hipStream_t stream);
 // streamed bakes, levels >= 6: two lists in one launch of small workgroups (runs next to the persistent classification launch)
 struct DigestLists {
     // list A: ids[0 .. count) of ONE level, optionally only the items with (only[item] != 0) == (want != 0)

@@ -1338,14 +1338,22 @@ __device__ __forceinline__ void digest_items_lds_body(const uint8_t* __restrict_
 // wave 0 runs the 64 chains (item, accumulator) over x values it reads from LDS -- ~100 cycles per round --, the other three waves produce the x of
 // the next 32 stripes and fetch the packed states of the 32 after those, one barrier per 32 stripes:
 //     step k:   wave 0: chain over X[k & 1]      waves 1-3: issue loads of chunk k + 2; X[(k + 1) & 1] <- pack[(k + 1) & 1]; pack[k & 1] <- the loaded chunk
+// Several levels in ONE launch (round 5): a bake of mixed levels used to run one of these launches per level, one after the other, each as long as its longest
+// chain (configs[4]: five launches, 5.9 ms); the chains of different levels are independent, so the workgroups of all of them go into one grid, highest
+// level first, and the launch takes as long as the level-10 chain alone.
 constexpr int DL_ITEMS = 16, DL_STRIPES = 32;
-__global__ __launch_bounds__(256) void digest_items_chain(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs, const uint32_t* __restrict__ itemIds,
-                                                          uint32_t numItems, uint32_t level, uint32_t bits, uint64_t* __restrict__ digests)
+struct DigestChainLevels { uint32_t n; uint32_t level[kNumLevels], count[kNumLevels], blockStart[kNumLevels + 1]; const uint32_t* ids[kNumLevels]; };
+__global__ __launch_bounds__(256) void digest_items_chain(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs, DigestChainLevels V,
+                                                          uint32_t bits, uint64_t* __restrict__ digests)
 {
     __shared__ uint32_t s_pack[2][DL_ITEMS][64 + 1];            // packed states of DL_STRIPES stripes per item: 4 * bits bytes per stripe, <= 256 bytes
     __shared__ uint64_t s_x[2][DL_STRIPES][DL_ITEMS * 4];       // x[stripe][item * 4 + accumulator]
     __shared__ const uint8_t* s_ptr[DL_ITEMS];
-    const uint32_t tid = threadIdx.x, first = blockIdx.x * DL_ITEMS;
+    uint32_t seg = 0;
+    while (seg + 1u < V.n && blockIdx.x >= V.blockStart[seg + 1u]) ++seg;
+    const uint32_t* __restrict__ itemIds = V.ids[seg];
+    const uint32_t numItems = V.count[seg], level = V.level[seg];
+    const uint32_t tid = threadIdx.x, first = (blockIdx.x - V.blockStart[seg]) * DL_ITEMS;
     if (tid < (uint32_t)DL_ITEMS) s_ptr[tid] = first + tid < numItems ? states + stateOfs[itemIds[first + tid]] : nullptr;
     const uint32_t M = 1u << (2 * level);
     const uint32_t chunkBytes = 4u * bits * DL_STRIPES, quads = chunkBytes / 16u;   // 256 or 128 bytes per item and step
@@ -1400,6 +1408,22 @@ __global__ __launch_bounds__(256) void digest_items_chain(const uint8_t* __restr
     if (it < numItems && acc == 0) digests[itemIds[it]] = h;
 }
 
+// few, long items (every workgroup resident at once: 16 384 items fill the chip, twice that still gains): the split form above
+static bool digest_wants_chain(uint32_t numItems, uint32_t level, uint32_t bits) { return numItems != 0 && ((((1u << (2 * level)) * bits) >> 3) >= 1024u) && numItems <= 32768u; }
+// the active items of ALL levels (level l: ids first[l] .. + count[l] of activeIds): the levels the chain form suits in one launch, the others one launch each
+void launch_digest_levels(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* activeIds, const uint32_t first[kNumLevels], const uint32_t count[kNumLevels],
+                          uint32_t bits, uint64_t* digests, hipStream_t stream)
+{
+    DigestChainLevels V; memset(&V, 0, sizeof V);
+    for (int l = kNumLevels - 1; l >= 0; --l) {   // (highest level first: the longest chains start first)
+        if (!digest_wants_chain(count[l], (uint32_t)l, bits)) continue;
+        V.level[V.n] = (uint32_t)l; V.count[V.n] = count[l]; V.ids[V.n] = activeIds + first[l];
+        V.blockStart[V.n + 1u] = V.blockStart[V.n] + (count[l] + DL_ITEMS - 1u) / DL_ITEMS; V.n++;
+    }
+    if (V.n) hipLaunchKernelGGL(digest_items_chain, dim3(V.blockStart[V.n]), dim3(256), 0, stream, states, stateOfs, V, bits, digests);
+    for (int l = 0; l < kNumLevels; ++l)
+        if (count[l] && !digest_wants_chain(count[l], (uint32_t)l, bits)) launch_digest(states, stateOfs, activeIds + first[l], count[l], (uint32_t)l, bits, digests, stream);
+}
 void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
                    uint64_t* digests, hipStream_t stream, const uint8_t* only, int want)
 {
@@ -1408,9 +1432,10 @@ void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32
     DigestLists D; memset(&D, 0, sizeof D); D.ids = itemIds; D.count = numItems; D.level = level; D.only = only; D.want = want;
     // (256-byte chunks x 64 items: a full-size launch is faster with them than with 1 KB chunks -- 0.77 vs 1.12 ms for 127 k items, more workgroups per CU
     //  hide the latency)
-    // few, long items (every workgroup resident at once: 16 384 items fill the chip, twice that still gains): the split form above
-    if (bytesPerItem >= 1024u && numItems <= 32768u && only == nullptr) {
-        hipLaunchKernelGGL(digest_items_chain, dim3((numItems + DL_ITEMS - 1u) / DL_ITEMS), dim3(256), 0, stream, states, stateOfs, itemIds, numItems, level, bits, digests);
+    if (digest_wants_chain(numItems, level, bits) && only == nullptr) {
+        DigestChainLevels V; memset(&V, 0, sizeof V);
+        V.n = 1; V.level[0] = level; V.count[0] = numItems; V.ids[0] = itemIds; V.blockStart[0] = 0; V.blockStart[1] = (numItems + DL_ITEMS - 1u) / DL_ITEMS;
+        hipLaunchKernelGGL(digest_items_chain, dim3(V.blockStart[1]), dim3(256), 0, stream, states, stateOfs, V, bits, digests);
         return;
     }
     if (bytesPerItem >= 256u) { // (powers of two: a multiple of the chunk size)

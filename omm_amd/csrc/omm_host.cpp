@@ -8,6 +8,7 @@
 #include "bake_types.h"
 #include "bake_kernels.h"
 #include "host_tail.h"
+#include "host_expand.h"
 
 #include <hip/hip_runtime.h>
 #include <hsa/hsa.h>
@@ -301,6 +302,13 @@ struct Baker {
     std::shared_ptr<HostPool> hostPool = std::make_shared<HostPool>();
     std::shared_ptr<DevPool> devPool = std::make_shared<DevPool>();
     std::shared_ptr<ArenaPool> arenas = std::make_shared<ArenaPool>();   // device working sets, one per bake in flight
+    // helper threads of the compressed result (host_expand.h): started by the first bake that may use them (ommCpuBakeFlags_EnableInternalThreads)
+    std::mutex workersMu; std::unique_ptr<WorkerPool> workers;
+    WorkerPool& worker_pool(unsigned threads) {
+        std::lock_guard<std::mutex> g(workersMu);
+        if (!workers) workers.reset(new WorkerPool(threads > 1 ? threads - 1 : 0));   // (the calling thread is one of them)
+        return *workers;
+    }
     std::mutex timingsMu; ommxBakeTimings timings; bool haveTimings = false;
     std::atomic<uint64_t> knobs[ommxBakerKnob_MAX_NUM];   // ommxSetBakerKnob: 0 = default
     Baker() { for (auto& k : knobs) k.store(0); }
@@ -1049,8 +1057,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     }
     // ---- CalcDigest (bake_cpu_impl.cpp:1038-1040): active items here, uniform ones from the table in the tail ----
     if (!noDedup && !streamChunks)   // (a streamed bake computed them range by range)
-        for (int l = 0; l < kNumLevels; ++l)
-            launch_digest(dStates, dStateOfs, dActiveIds + bounds.b[l][bounds.rank], bounds.b[l][bounds.rank + 1] - bounds.b[l][bounds.rank], (uint32_t)l, (uint32_t)storeBits, dDigests, stream);
+        launch_digest_levels(dStates, dStateOfs, dActiveIds, lvlFirst, lvlCount, (uint32_t)storeBits, dDigests, stream);
     if (!HIP_OK(hipGetLastError())) return L.failure("[Failure] - kernel launch failed");
     const int e3 = et.mark();
     // ---- streamed result: everything is enqueued; follow the classification launches and send what each one placed ----
@@ -1270,6 +1277,7 @@ uint32_t max_index(const void* idx, ommIndexFormat fmt, size_t n)
     return avx2 ? max_of_u32_avx2((const uint32_t*)idx, n) : max_of((const uint32_t*)idx, n);
 }
 
+constexpr uint64_t kCompressedMinBytes = 32ull << 20;   // smaller arrays cross the link as they are (0.6 ms at 57 GB/s)
 // ommCpuBake: host arrays in, host arrays out
 ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult* out)
 {
@@ -1367,7 +1375,16 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     } arrayAlloc{ &baker, res, 0, false };
     StreamOut so; so.set = ses.set.get(); so.allocUser = &arrayAlloc; so.alloc = &ArrayAlloc::get;
     if (const uint64_t k = baker.knob(ommxBakerKnob_StreamChunks)) { so.chunksWanted = (uint32_t)k; so.forced = true; }
-    const bool canStream = ses.open_comm() && ses.open_place();
+    // How a large arrayData reaches the caller (ommxBakerKnob_ResultTransfer).  COMPRESSED (round 5): the bake finishes on the device, the array crosses PCIe as
+    // a codec stream (tail_kernels.hip: 6 % of its bytes at the metric configuration) and host threads expand it into the caller's array -- 190 - 250 GB/s with
+    // 8 - 16 threads on the GPU box (profiles/r05_host_fill_rates.txt) against the 57 GB/s of the link.  It needs the caller's permission to use threads
+    // (ommCpuBakeFlags_EnableInternalThreads, omm.h:303) and CPUs to run them on (below six, the STREAMED form -- blocks placed and copied by the DMA engine
+    // while the classification runs -- is the faster one: one thread expands 30 GB/s).
+    const uint64_t transferKnob = baker.knob(ommxBakerKnob_ResultTransfer);
+    const unsigned expandThreads = effective_cpus() < 16u ? effective_cpus() : 16u;
+    const bool wantCompressed = !so.forced && (transferKnob == ommxResultTransfer_Compressed ||
+                                               (transferKnob == ommxResultTransfer_Auto && ((uint32_t)d.bakeFlags & (uint32_t)ommCpuBakeFlags_EnableInternalThreads) != 0 && expandThreads >= 6u));
+    const bool canStream = !wantCompressed && transferKnob != ommxResultTransfer_Plain && ses.open_comm() && ses.open_place();
     so.copyStream = ses.commStream; so.placeStream = ses.placeStream; so.device = baker.bind_device();
     const ommResult br = bake_core(baker, d, din, &d, ses.arena, ses.states, stream, et, R, tm, nullptr, nullptr, canStream ? &so : nullptr);
     if (br != ommResult_SUCCESS) return br;
@@ -1375,11 +1392,29 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     // ---- copy the (rest of the) result out through the user's allocator ----
     const int d0 = et.mark();
     const uint32_t E = R.numDescs;
+    // ---- compressed result: codec stream of the finished array (device), one copy of the stream, expansion by the baker's helper threads ----
+    struct CodecOut { uint8_t* dBlock = nullptr; DevPool* pool = nullptr; uint8_t* dComp = nullptr; uint32_t* dSize = nullptr; HostCodecLayout L{}; uint64_t padded = 0, cap = 0; bool on = false;
+                      ~CodecOut() { if (dBlock) pool->release(dBlock); } } co;
+    const double c0 = now_ms();
+    if (E && wantCompressed && !so.used && R.arrayDataSize >= kCompressedMinBytes) {
+        // (the device array was taken from the result pool, whose blocks are multiples of 4096 bytes: the codec may read the padding, the host never writes it)
+        co.padded = (R.arrayDataSize + 255u) & ~255ull; co.L = host_codec_layout(co.padded);
+        co.cap = co.L.offRaw + co.padded / 2u + 16u;   // a stream that does not shrink below half takes the plain copy
+        const size_t scratchBytes = pad256(shard_codec_scratch_bytes(co.padded));
+        co.pool = baker.devPool.get(); co.dBlock = (uint8_t*)baker.devPool->acquire(256 + scratchBytes + (size_t)co.cap);
+        if (co.dBlock && co.L.blocks < 0x7FFFFFFFull) {
+            co.dSize = (uint32_t*)co.dBlock; co.dComp = co.dBlock + 256 + scratchBytes;
+            co.on = HIP_OK(run_shard_compress(R.arrayData, co.padded, co.dComp, co.cap, co.dSize, co.dBlock + 256, scratchBytes, stream));
+        }
+        (void)hipGetLastError();
+    }
+    uint32_t codecUnits = kCodecIncompressible;
     if (E) {
-        ok = ArrayAlloc::get(&arrayAlloc, R.arrayDataSize, nullptr) != nullptr;   // (a streamed bake has it already)
+        ok = ArrayAlloc::get(&arrayAlloc, R.arrayDataSize, nullptr) != nullptr;   // (a streamed bake has it already; every other path asks for the exact size)
         res->descs = (ommCpuOpacityMicromapDesc*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, 16);
         ok = ok && res->descs;
-        if (!so.used) ok = ok && HIP_OK(hipMemcpyAsync(res->arrayData, R.arrayData, (size_t)R.arrayDataSize, hipMemcpyDeviceToHost, stream));
+        if (co.on) ok = ok && HIP_OK(hipMemcpyAsync(&codecUnits, co.dSize, sizeof codecUnits, hipMemcpyDeviceToHost, stream));
+        else if (!so.used) ok = ok && HIP_OK(hipMemcpyAsync(res->arrayData, R.arrayData, (size_t)R.arrayDataSize, hipMemcpyDeviceToHost, stream));
         ok = ok && HIP_OK(hipMemcpyAsync(res->descs, R.descs, sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, hipMemcpyDeviceToHost, stream));
     }
     res->index = (int32_t*)baker.mem.allocate(sizeof(int32_t) * (size_t)(T ? T : 1), 16);
@@ -1391,6 +1426,61 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     const int d1 = et.mark();
     ok = ok && HIP_OK(hipStreamSynchronize(stream));
     if (so.chunks) { ok = so.finish() && ok; if (so.used) tm.streamTailMs = (float)(so.lastByteMs - so.classifyEndMs); }   // (the last streamed bytes arrive while the small arrays above are read back)
+    if (ok && co.on) {
+        const double c1 = now_ms();
+        if (codecUnits == kCodecIncompressible) {   // (noise-like states: the array itself crosses the link)
+            ok = HIP_OK(hipMemcpyAsync(res->arrayData, R.arrayData, (size_t)R.arrayDataSize, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipStreamSynchronize(stream));
+            tm.resultTransfer = ommxResultTransfer_Plain;
+        } else {
+            const uint64_t streamBytes = 16ull * codecUnits;
+            // the stream lands in the working set's pinned block; the expansion starts when the offsets and codes are there and follows the raw units slice by slice
+            ok = ses.set->pinned.reserve((size_t)streamBytes + 4096) && streamBytes >= co.L.offRaw && streamBytes <= co.cap;
+            uint8_t* hStream = ses.set->pinned.base;
+            constexpr uint32_t kSlices = 8;
+            hipEvent_t evs[kSlices + 1]; uint32_t nev = 0;
+            for (; ok && nev < kSlices + 1; ++nev) if (!HIP_OK(hipEventCreateWithFlags(&evs[nev], hipEventDisableTiming))) break;
+            ok = ok && nev == kSlices + 1;
+            if (ok) {
+                // piece 0: header, offsets, codes; pieces 1 .. kSlices: the raw units in order (a block's raw units lie in the piece its offset points into, or later)
+                ok = HIP_OK(hipMemcpyAsync(hStream, co.dComp, (size_t)co.L.offRaw, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipEventRecord(evs[0], stream));
+                const uint64_t rawBytes = streamBytes - co.L.offRaw;
+                uint64_t cut[kSlices + 1];
+                for (uint32_t k = 0; k <= kSlices; ++k) cut[k] = (rawBytes * k / kSlices) & ~15ull;
+                cut[kSlices] = rawBytes;
+                for (uint32_t k = 0; ok && k < kSlices; ++k) {
+                    if (cut[k + 1] > cut[k]) ok = HIP_OK(hipMemcpyAsync(hStream + co.L.offRaw + cut[k], co.dComp + co.L.offRaw + cut[k], (size_t)(cut[k + 1] - cut[k]), hipMemcpyDeviceToHost, stream));
+                    ok = ok && HIP_OK(hipEventRecord(evs[k + 1], stream));
+                }
+                ok = ok && HIP_OK(hipEventSynchronize(evs[0]));
+                if (ok) {
+                    // codec blocks [blockCut[k], blockCut[k + 1]) need raw units below cut[k + 1] only: found by bisection over the (monotone) offsets
+                    const uint32_t* ofs = (const uint32_t*)(hStream + co.L.offOfs);
+                    uint64_t blockCut[kSlices + 1]; blockCut[0] = 0;
+                    for (uint32_t k = 1; k <= kSlices; ++k) {
+                        if (k == kSlices) { blockCut[k] = co.L.blocks; break; }
+                        uint64_t lo = blockCut[k - 1], hi = co.L.blocks;   // largest b with 16 * ofs[b] <= cut[k], i.e. every raw unit of the blocks before b has arrived with piece k
+                        while (lo < hi) { const uint64_t mid = (lo + hi + 1) / 2; if (16ull * ofs[mid] <= cut[k]) lo = mid; else hi = mid - 1; }
+                        blockCut[k] = lo;
+                    }
+                    WorkerPool& pool = baker.worker_pool(expandThreads);
+                    uint8_t* dst = (uint8_t*)res->arrayData; const uint64_t dstBytes = R.arrayDataSize; const HostCodecLayout L = co.L;
+                    constexpr uint64_t kTaskBlocks = 512;   // 2 MiB of the array per task
+                    for (uint32_t k = 0; ok && k < kSlices; ++k) {
+                        ok = HIP_OK(hipEventSynchronize(evs[k + 1]));
+                        const uint64_t b0 = blockCut[k], b1 = blockCut[k + 1];
+                        if (!ok || b1 <= b0) continue;
+                        const uint32_t tasks = (uint32_t)((b1 - b0 + kTaskBlocks - 1) / kTaskBlocks);
+                        pool.run(tasks, [&](uint32_t t) { const uint64_t s0 = b0 + (uint64_t)t * kTaskBlocks, s1 = s0 + kTaskBlocks < b1 ? s0 + kTaskBlocks : b1; codec_expand_blocks(dst, dstBytes, hStream, L, s0, s1); });
+                    }
+                    tm.expandThreads = pool.workers() + 1u;
+                }
+            }
+            for (uint32_t k = 0; k < nev; ++k) (void)hipEventDestroy(evs[k]);
+            tm.resultTransfer = ommxResultTransfer_Compressed; tm.compressedBytes = streamBytes;
+        }
+        tm.compressMs = (float)(c1 - c0); tm.expandMs = (float)(now_ms() - c1);
+    } else if (so.used) tm.resultTransfer = ommxResultTransfer_Streamed;
+    else tm.resultTransfer = ommxResultTransfer_Plain;
     if (!ok) { return L.failure("[Failure] - device to host transfer of the bake result failed"); }
 
     // histograms: format {2-state, 4-state} x level ascending, non-zero entries only (:1833-1850); one global format here
@@ -2300,6 +2390,7 @@ OMM_MI355X_API ommResult ommxSetBakerKnob(ommBaker baker, ommxBakerKnob knob, ui
     if (knob == ommxBakerKnob_ShardChunkBytes && value != 0 && value < 256) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_StreamChunks && value > kMaxStreamRanges) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_GenericPass && value > 2) return ommResult_INVALID_ARGUMENT;
+    if (knob == ommxBakerKnob_ResultTransfer && value > (uint64_t)ommxResultTransfer_Compressed) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_RetainMemory) {
         if (value > 1) return ommResult_INVALID_ARGUMENT;
         Baker* bk = untag<Baker>(baker);

@@ -382,14 +382,21 @@ def test_full_size_mixed_levels_config4(product, oracle):
     t = product.create_texture(b, [tex], alpha_cutoff=0.5)
     kw = dict(addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, dyn_scale=2.0)
     d = ot.make_desc(t, uv, ix, 10, levels=lv, **kw)
-    full = product.bake(b, d, want_stats=False)
-    # ommCpuBake streams this result while it classifies (tail_kernels.hip "Streamed result"): it must not have fallen back -- at this size a family of
-    # possible duplicates once spanned two levels and pulled level-10 items behind their own placement -- and the bytes must be those of the
-    # device-resident entry, which assembles the result after the classification
     import bench, ctypes
-    tm = bench.BakeTimings()
+    # default transfer of a bake that may use threads, on a host with >= 6 CPUs: the finished array crosses PCIe as a codec stream and is expanded by the
+    # baker's helper threads (round 5) -- the bytes must be those of the device-resident entry
+    full = product.bake(b, d, want_stats=False)
     tm = bench.get_timings(product, b)
-    assert tm.streamChunks > 1 and tm.streamedBytes == full.array_data.size, (tm.streamChunks, tm.streamedBytes)
+    if bench.effective_cpus(os.cpu_count())[0] >= 6:
+        assert tm.resultTransfer == ot.TRANSFER_COMPRESSED and 0 < tm.compressedBytes < full.array_data.size // 4 and tm.expandThreads >= 6, (tm.resultTransfer, tm.compressedBytes, tm.expandThreads)
+    # the streamed transfer (rounds 3 - 4: blocks placed and copied while the classification runs, tail_kernels.hip "Streamed result"): it must not have fallen
+    # back -- at this size a family of possible duplicates once spanned two levels and pulled level-10 items behind their own placement
+    product.set_knob(b, ot.KNOB_RESULT_TRANSFER, ot.TRANSFER_STREAMED)
+    streamed = product.bake(b, d, want_stats=False)
+    tm = bench.get_timings(product, b)
+    assert tm.resultTransfer == ot.TRANSFER_STREAMED and tm.streamChunks > 1 and tm.streamedBytes == full.array_data.size, (tm.resultTransfer, tm.streamChunks, tm.streamedBytes)
+    assert streamed.same_as(full), streamed.diff(full)
+    del streamed
     dev = ot.bake_device(product, ot.Hip(), b, d, uv, ix, levels=lv)
     assert dev.same_as(full), dev.diff(full)
     del dev
@@ -1444,12 +1451,17 @@ def test_both_formats_and_both_generic_passes_at_scale(product):
     kw = dict(kw, fmt=ot.FMT_2STATE); lvl = kw.pop("level")
     b = product.create_baker(); t = product.create_texture(b, [tex], alpha_cutoff=0.5)
     d = ot.make_desc(t, uv, ix, lvl, **kw)
+    product.set_knob(b, ot.KNOB_RESULT_TRANSFER, ot.TRANSFER_STREAMED)
     host = product.bake(b, d, want_stats=False)
-    tm = bench.BakeTimings()
     tm = bench.get_timings(product, b)
     assert tm.streamChunks > 1 and tm.streamedBytes == host.array_data.size > (64 << 20), (tm.streamChunks, tm.streamedBytes, host.array_data.size)
     dev = ot.bake_device(product, hip, b, d, uv, ix)
     assert dev.same_as(host), dev.diff(host)
+    product.set_knob(b, ot.KNOB_RESULT_TRANSFER, ot.TRANSFER_COMPRESSED)   # ... and as a codec stream expanded by the helper threads (one-bit blocks)
+    comp = product.bake(b, d, want_stats=False)
+    tm = bench.get_timings(product, b)
+    assert tm.resultTransfer == ot.TRANSFER_COMPRESSED and 0 < tm.compressedBytes < host.array_data.size // 2, (tm.resultTransfer, tm.compressedBytes)
+    assert comp.same_as(host), comp.diff(host)
     product.destroy_texture(b, t); product.destroy_baker(b)
     # (b)
     tex, uv, ix, lv, kw = wl.workload("cards", 8000)
@@ -1565,4 +1577,52 @@ def test_curve_free_regions_device_against_oracle_on_adversarial_inputs(product,
     bad = []
     region_cases.run(product, seed=seed, tri_seed_base=2000 if seed == 11 else 7000 + seed, each=lambda k, r: (None if r.same_as(want[k]) else bad.append((k, r.diff(want[k])))))
     assert len(want) == 84 and not bad, bad[:3]
+
+
+
+
+@pytest.mark.gpu
+def test_result_transfer_modes_give_the_same_bytes(product, oracle):
+    """ommxBakerKnob_ResultTransfer: plain copy, streamed placement and the compressed form (codec stream + helper threads) of ommCpuBake, on results
+    from a few hundred kilobytes (always the plain copy) to well above the 32 MiB where the compressed form starts; noise-like states (a 0 / 1 random texture:
+    the stream does not shrink below half and the array crosses the link as it is); a bake without ommCpuBakeFlags_EnableInternalThreads keeps to the streamed
+    form by default; the smallest against the oracle."""
+    import bench, workloads as wl
+    rng = np.random.RandomState(3)
+    cases = [("c2", 2000, None), ("c2", 60000, None), ("noise", 600, (rng.rand(1024, 1024) > 0.5).astype(np.float32))]
+    for kind, n, tex_override in cases:
+        if kind == "noise":   # micro-triangles of a texel each on 0 / 1 noise, promotion by majority: UO / UT at random, units of 64 states rarely repeat one
+            tex = tex_override; uv, ix = ot.random_triangles(77, n, 0.5); lv = None
+            kw = dict(level=9, addr=ot.WRAP, promo=ot.PROMO_NEAREST)
+        else:
+            tex, uv, ix, lv, kw = wl.workload(kind, n)
+        kw = dict(kw); lvl = kw.pop("level")
+        b = product.create_baker(); t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+        d = ot.make_desc(t, uv, ix, lvl, **kw)
+        got = {}
+        for mode in (ot.TRANSFER_PLAIN, ot.TRANSFER_STREAMED, ot.TRANSFER_COMPRESSED, ot.TRANSFER_AUTO):
+            product.set_knob(b, ot.KNOB_RESULT_TRANSFER, mode)
+            got[mode] = (product.bake(b, d, want_stats=False), bench.get_timings(product, b))
+        ref = got[ot.TRANSFER_PLAIN][0]
+        assert got[ot.TRANSFER_PLAIN][1].resultTransfer == ot.TRANSFER_PLAIN
+        for mode, (r, tm) in got.items():
+            assert r.same_as(ref), (kind, n, mode, r.diff(ref))
+        big = ref.array_data.size >= (32 << 20)
+        tmc = got[ot.TRANSFER_COMPRESSED][1]
+        if not big:
+            assert tmc.resultTransfer == ot.TRANSFER_PLAIN
+        elif tex_override is None:
+            assert tmc.resultTransfer == ot.TRANSFER_COMPRESSED and 0 < tmc.compressedBytes < ref.array_data.size // 2 and tmc.expandThreads >= 1, (tmc.resultTransfer, tmc.compressedBytes)
+        else:
+            assert tmc.resultTransfer == ot.TRANSFER_PLAIN and tmc.compressMs > 0, (tmc.resultTransfer, tmc.compressedBytes, ref.array_data.size)   # (tried, incompressible)
+        # without the caller's permission to use threads the default is never the compressed form
+        product.set_knob(b, ot.KNOB_RESULT_TRANSFER, ot.TRANSFER_AUTO)
+        r0 = product.bake(b, ot.make_desc(t, uv, ix, lvl, **dict(kw, flags=0)), want_stats=False)
+        assert bench.get_timings(product, b).resultTransfer != ot.TRANSFER_COMPRESSED and r0.same_as(ref)
+        if n <= 2000:
+            ob = oracle.create_baker(); otx = oracle.create_texture(ob, [tex], alpha_cutoff=0.5)
+            want = oracle.bake(ob, ot.make_desc(otx, uv, ix, lvl, **kw), want_stats=False)
+            oracle.destroy_texture(ob, otx); oracle.destroy_baker(ob)
+            assert ref.same_as(want), ref.diff(want)
+        product.destroy_texture(b, t); product.destroy_baker(b)
 
