@@ -126,7 +126,7 @@ void launch_narrow_indices(const int32_t* in, uint32_t n, int bytesPerIndex, voi
 // first copy; section 2k + 1 = the tiles of EARLY items of later ranges whose family starts in range k, in the queue's second copy ([total, 2 total)),
 // ordered by range with a staging pass (early_tiles_*).
 // record = 7 x uint4 (everything a tile's workgroup needs, in ONE memory round trip):
-//   [0] x = item | degenerate << 30 | rectOk << 31, y = tile in item | level << 24 | no-single-texel-micro-triangle << 31, z = sx | sy << 16, w = ex | ey << 16 (addressed texel rectangle)
+//   [0] x = item | degenerate << 30 | rectOk << 31, y = tile in item | dead << 23 | level << 24 | no-single-texel-micro-triangle << 31, z = sx | sy << 16, w = ex | ey << 16 (addressed texel rectangle)
 //   [1] the item's uv[0..3]      [2] uv[4], uv[5], address of the tile's packed states (lo, hi)
 //   [3..6] one verdict byte per 64-group of the tile (triage_groups below; a 1024-tile uses the first 16)
 constexpr uint32_t kTileRecordWords = 7;   // uint4 per record (bake_kernels.h: kTileRecordBytes)
@@ -134,6 +134,7 @@ static_assert(kTileRecordWords * 16u == kTileRecordBytes, "tile record size");
 // verdict byte of a 64-group: 0..3 = every micro-triangle of the group has that state; kGvUnknown = test them one by one; kGvAllOpen = none of them is resolved by
 // the coarse pass; kGvEdgeFree | code = region_curve_state()'s edge-free verdict -(kRegionEdgeFreeBase + code), code = 16 above + mask of the wrong-side corners
 constexpr uint32_t kGvUnknown = 0xFFu, kGvAllOpen = 0xFEu, kGvEdgeFree = 0x80u;
+constexpr uint32_t kTileDead = 1u << 23;   // word [0].y of a record: every group of the tile was settled by triage_groups (the tile index needs 12 of the 24 low bits)
 __device__ __forceinline__ uint32_t group_verdict_byte(int gs)
 {
     return gs >= 0 ? (uint32_t)gs : (gs == kRegionUnknown ? kGvUnknown : (gs == kRegionAllOpen ? kGvAllOpen : (kGvEdgeFree | ((uint32_t)(-gs - kRegionEdgeFreeBase) & 31u))));
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
 // pass of its own: lane = (open tile, group), no barriers, no LDS; the verdict bytes land in the tile's record, which the persistent workgroup reads anyway.
 // ------------------------------------------------------------------------------------------------
 template <bool FP32, class MD, int TILE>
-__global__ __launch_bounds__(256) void triage_groups(ClassifyParams P, uint4* __restrict__ queue, const uint32_t* __restrict__ queueCtl, uint32_t numSections)
+__global__ __launch_bounds__(256) void triage_groups(ClassifyParams P, ItemArrays A, uint4* __restrict__ queue, const uint32_t* __restrict__ queueCtl, uint32_t numSections)
 {
     constexpr uint32_t GROUPS = (uint32_t)TILE / 64u, PER_BLOCK = 256u / GROUPS;   // 64 groups: a wave per tile; 16 groups: four tiles per wave
     const uint32_t g = threadIdx.x % GROUPS, slot = threadIdx.x / GROUPS;
@@ -268,6 +269,30 @@ __global__ __launch_bounds__(256) void triage_groups(ClassifyParams P, uint4* __
                 gs = (cs >= 0 || (cs <= -kRegionEdgeFreeBase && fast)) ? cs : gs;
             }
             ((uint8_t*)(rec + 3))[g] = (uint8_t)group_verdict_byte(gs);
+            // A settled group is final right here: its constant packed states go to the tile's block, its state into the item's mask / known count (the
+            // persistent workgroup packs the open groups only).  A tile whose groups are ALL settled -- 14 % of the open tiles of the metric configuration --
+            // is marked dead in its record: the persistent launch passes it without touching the window, a barrier or the states.
+            const uint32_t bits = (uint32_t)P.format, groupBytes = 8u * bits;   // 64 micro-triangles x bits
+            if (gs >= 0) {
+                uint8_t* dst = (uint8_t*)(((unsigned long long)r2.w << 32) | r2.z) + (size_t)g * groupBytes;
+                uint32_t v = 0;
+                for (uint32_t b = 0; b < 32u; b += bits) v |= (uint32_t)gs << b;
+                if (bits == 2u) *(uint4*)dst = make_uint4(v, v, v, v); else *(uint2*)dst = make_uint2(v, v);
+            }
+            // per tile (= GROUPS consecutive lanes of the wave): which states its settled groups have, how many of them are known (T / O)
+            const uint32_t lane = threadIdx.x & 63u, sh = lane & ~(GROUPS - 1u);   // (GROUPS == 64: the whole wave, sh == 0)
+            const unsigned long long tileLanes = GROUPS == 64u ? ~0ull : (((1ull << GROUPS) - 1ull) << sh);
+            uint32_t mask = 0;
+            #pragma unroll
+            for (int st = 0; st < 4; ++st) if (__ballot(gs == st) & tileLanes) mask |= 1u << st;
+            const uint32_t known = (uint32_t)__popcll(__ballot(gs == 0 || gs == 1) & tileLanes) * 64u;
+            const bool allSettled = (__ballot(gs < 0) & tileLanes) == 0ull;
+            if (g == 0u) {
+                const uint32_t item = r0.x & 0x3FFFFFFFu;
+                if (mask) atomicOr(&A.stateMask[item], mask);
+                if (P.wantKnownCount && known) atomicAdd(&A.knownCount[item], known);
+                if (allSettled) ((uint32_t*)rec)[1] = r0.y | kTileDead;
+            }
         }
     }
 }
@@ -384,7 +409,8 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     const uint32_t M = 1u << (2 * level);
     const uint32_t itemsPerTile = SLICED ? 1u : TILE / M;
     const uint32_t firstItem = SLICED ? 0u : tile * itemsPerTile;
-    const uint32_t base = SLICED ? (rec.y & 0xFFFFFFu) * TILE : 0u; // first micro-triangle of the slice
+    const uint32_t base = SLICED ? (rec.y & 0x7FFFFFu) * TILE : 0u; // first micro-triangle of the slice
+    const bool dead = SLICED && (rec.y & kTileDead) != 0u;          // (block-uniform) triage_groups settled every group of this tile: nothing is left to do
     uint32_t itemsHere = SLICED ? 1u : numItems - firstItem;
     if (itemsHere > itemsPerTile) itemsHere = itemsPerTile;
     const uint32_t count = SLICED ? (uint32_t)TILE : itemsHere * M;   // micro-triangles in this tile
@@ -401,8 +427,9 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         BirdGroup bg; bg.word = s_gdec[SLICED ? i >> 6 : 0u];
         return micro_triangle_grouped(uUv, bg, (uint32_t)s_btab[SLICED ? ((bg.word >> 24) & 3u) * 64u + (i & 63u) : 0u], level);
     };
+    if (SLICED) uItem = rec.x & 0x3FFFFFFFu;
+    if (!dead) {
     if (SLICED) {
-        uItem = rec.x & 0x3FFFFFFFu;
         uUv[0] = uniform_f32(__uint_as_float(rec1.x)); uUv[1] = uniform_f32(__uint_as_float(rec1.y)); uUv[2] = uniform_f32(__uint_as_float(rec1.z));
         uUv[3] = uniform_f32(__uint_as_float(rec1.w)); uUv[4] = uniform_f32(__uint_as_float(rec2.x)); uUv[5] = uniform_f32(__uint_as_float(rec2.y));
         uMaxAbs = uniform_f32(item_max_abs(uUv));
@@ -606,6 +633,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         }
         __syncthreads();
     }
+    }   // (!dead)
 
     // ---- phase 3: pack + per-item summary ----
     OMMX_FRESH_TID();
@@ -614,21 +642,17 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     if (SLICED) {
         uint32_t* dst = (uint32_t*)(((unsigned long long)uniform_u32(rec2.w) << 32) | uniform_u32(rec2.z));   // (from the tile record)
         uint32_t localMask = 0, localKnown = 0;   // (tiles settled as a whole never get here: triage_tiles wrote them)
-        for (uint32_t w = tid; w < (uint32_t)TILE / perWord; w += BLOCK) {
+        // the words of the OPEN groups (s_glist); the settled groups' words, their states and known counts are final since triage_groups
+        const uint32_t wpgLog = bits == 2u ? 2u : 1u, openWords = dead ? 0u : s_gcount << wpgLog;   // 4 (4-state) or 2 (2-state) words per group
+        for (uint32_t q = tid; q < openWords; q += BLOCK) {
+            const uint32_t w = ((uint32_t)s_glist[q >> wpgLog] << wpgLog) + (q & ((1u << wpgLog) - 1u));
             uint32_t v = 0;
-            const int gs = s_group[(w * perWord) >> 6];   // a word never straddles two 64-groups (perWord is 16 or 32)
-            if (gs >= 0) { // settled group: constant word (phase 1 wrote no states for it)
-                for (uint32_t k = 0; k < perWord; ++k) v |= (uint32_t)gs << (k * bits);
-                localMask |= 1u << gs;
-                localKnown += gs < 2 ? perWord : 0u;
-            } else {
-                for (uint32_t k = 0; k < perWord; ++k) {
-                    uint32_t st = s_state[w * perWord + k];
-                    if (DEFER && st == kDeferredState) continue;   // (its bits stay 0 for classify_generic's atomicOr; mask and known count come from there too)
-                    v |= st << (k * bits);
-                    localMask |= 1u << st;
-                    localKnown += st < 2u;
-                }
+            for (uint32_t k = 0; k < perWord; ++k) {
+                uint32_t st = s_state[w * perWord + k];
+                if (DEFER && st == kDeferredState) continue;   // (its bits stay 0 for classify_generic's atomicOr; mask and known count come from there too)
+                v |= st << (k * bits);
+                localMask |= 1u << st;
+                localKnown += st < 2u;
             }
             dst[w] = v;
         }
@@ -642,8 +666,8 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         if (tid == 0) s_next = nextPos;   // next tile of this workgroup (requested at the top of the loop); published with the barrier below
         __syncthreads();
         if (tid == 0) {
-            atomicOr(&A.stateMask[uItem], s_mask);
-            if (P.wantKnownCount) atomicAdd(&A.knownCount[uItem], s_known);
+            if (s_mask) atomicOr(&A.stateMask[uItem], s_mask);
+            if (P.wantKnownCount && s_known) atomicAdd(&A.knownCount[uItem], s_known);
             // leaving the section: every store of this workgroup's tiles in it is ordered before the count (the fences above, this thread's release)
             const uint32_t sec = s_sec, retired = s_retired + 1u;
             if (s_nsec != sec) {
@@ -1049,11 +1073,11 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
         const uint32_t cap = numCUs * 16u;   // workgroups (a wave per 4096-tile / four 1024-tiles per wave); the queue's fill is only known on the device
         if (plan.totalSmall) {
             const uint64_t need = (plan.totalSmall + 15u) / 16u;
-            hipLaunchKernelGGL((triage_groups<FP32, MD, 1024>), dim3((uint32_t)(need < cap ? need : cap)), dim3(256), 0, stream, P, q1024, (const uint32_t*)ctl1024, 1u);
+            hipLaunchKernelGGL((triage_groups<FP32, MD, 1024>), dim3((uint32_t)(need < cap ? need : cap)), dim3(256), 0, stream, P, A, q1024, (const uint32_t*)ctl1024, 1u);
         }
         if (plan.totalBig) {
             const uint64_t need = (plan.totalBig + 3u) / 4u;
-            hipLaunchKernelGGL((triage_groups<FP32, MD, 4096>), dim3((uint32_t)(need < cap ? need : cap)), dim3(256), 0, stream, P, queue, (const uint32_t*)queueCtl, paired ? 2u * K : K);
+            hipLaunchKernelGGL((triage_groups<FP32, MD, 4096>), dim3((uint32_t)(need < cap ? need : cap)), dim3(256), 0, stream, P, A, queue, (const uint32_t*)queueCtl, paired ? 2u * K : K);
         }
     }
     // ---- small items: one launch per level ----

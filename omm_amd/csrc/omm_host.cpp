@@ -1395,6 +1395,7 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     // ---- compressed result: codec stream of the finished array (device), one copy of the stream, expansion by the baker's helper threads ----
     struct CodecOut { uint8_t* dBlock = nullptr; DevPool* pool = nullptr; uint8_t* dComp = nullptr; uint32_t* dSize = nullptr; HostCodecLayout L{}; uint64_t padded = 0, cap = 0; bool on = false;
                       ~CodecOut() { if (dBlock) pool->release(dBlock); } } co;
+    std::vector<uint8_t> codecHead;   // header + offsets of the codec stream (1 MB per GB of arrayData)
     const double c0 = now_ms();
     if (E && wantCompressed && !so.used && R.arrayDataSize >= kCompressedMinBytes) {
         // (the device array was taken from the result pool, whose blocks are multiples of 4096 bytes: the codec may read the padding, the host never writes it)
@@ -1408,13 +1409,14 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
         }
         (void)hipGetLastError();
     }
-    uint32_t codecUnits = kCodecIncompressible;
     if (E) {
         ok = ArrayAlloc::get(&arrayAlloc, R.arrayDataSize, nullptr) != nullptr;   // (a streamed bake has it already; every other path asks for the exact size)
         res->descs = (ommCpuOpacityMicromapDesc*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, 16);
         ok = ok && res->descs;
-        if (co.on) ok = ok && HIP_OK(hipMemcpyAsync(&codecUnits, co.dSize, sizeof codecUnits, hipMemcpyDeviceToHost, stream));
-        else if (!so.used) ok = ok && HIP_OK(hipMemcpyAsync(res->arrayData, R.arrayData, (size_t)R.arrayDataSize, hipMemcpyDeviceToHost, stream));
+        if (co.on) {   // the stream's header (its length) and the per-block offsets of the raw units: the first piece of the stream, needed before the others can be cut
+            codecHead.resize((size_t)co.L.offCodes);
+            ok = ok && HIP_OK(hipMemcpyAsync(codecHead.data(), co.dComp, (size_t)co.L.offCodes, hipMemcpyDeviceToHost, stream));
+        } else if (!so.used) ok = ok && HIP_OK(hipMemcpyAsync(res->arrayData, R.arrayData, (size_t)R.arrayDataSize, hipMemcpyDeviceToHost, stream));
         ok = ok && HIP_OK(hipMemcpyAsync(res->descs, R.descs, sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, hipMemcpyDeviceToHost, stream));
     }
     res->index = (int32_t*)baker.mem.allocate(sizeof(int32_t) * (size_t)(T ? T : 1), 16);
@@ -1428,53 +1430,46 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     if (so.chunks) { ok = so.finish() && ok; if (so.used) tm.streamTailMs = (float)(so.lastByteMs - so.classifyEndMs); }   // (the last streamed bytes arrive while the small arrays above are read back)
     if (ok && co.on) {
         const double c1 = now_ms();
-        if (codecUnits == kCodecIncompressible) {   // (noise-like states: the array itself crosses the link)
+        uint64_t streamBytes = 0; memcpy(&streamBytes, codecHead.data(), 8);   // (shard_codec_finish: the length the stream has, or would have had)
+        const bool fits = streamBytes <= co.cap && streamBytes >= co.L.offRaw && ses.set->pinned.reserve((size_t)streamBytes + 4096);   // (pinned staging of the stream's size)
+        uint8_t* hStream = ses.set->pinned.base;
+        if (fits) memcpy(hStream, codecHead.data(), codecHead.size());
+        if (!fits) {   // noise-like states (the stream would not be below half of the array): the array itself crosses the link
             ok = HIP_OK(hipMemcpyAsync(res->arrayData, R.arrayData, (size_t)R.arrayDataSize, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipStreamSynchronize(stream));
             tm.resultTransfer = ommxResultTransfer_Plain;
         } else {
-            const uint64_t streamBytes = 16ull * codecUnits;
-            // the stream lands in the working set's pinned block; the expansion starts when the offsets and codes are there and follows the raw units slice by slice
-            ok = ses.set->pinned.reserve((size_t)streamBytes + 4096) && streamBytes >= co.L.offRaw && streamBytes <= co.cap;
-            uint8_t* hStream = ses.set->pinned.base;
-            constexpr uint32_t kSlices = 8;
-            hipEvent_t evs[kSlices + 1]; uint32_t nev = 0;
-            for (; ok && nev < kSlices + 1; ++nev) if (!HIP_OK(hipEventCreateWithFlags(&evs[nev], hipEventDisableTiming))) break;
-            ok = ok && nev == kSlices + 1;
-            if (ok) {
-                // piece 0: header, offsets, codes; pieces 1 .. kSlices: the raw units in order (a block's raw units lie in the piece its offset points into, or later)
-                ok = HIP_OK(hipMemcpyAsync(hStream, co.dComp, (size_t)co.L.offRaw, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipEventRecord(evs[0], stream));
-                const uint64_t rawBytes = streamBytes - co.L.offRaw;
-                uint64_t cut[kSlices + 1];
-                for (uint32_t k = 0; k <= kSlices; ++k) cut[k] = (rawBytes * k / kSlices) & ~15ull;
-                cut[kSlices] = rawBytes;
-                for (uint32_t k = 0; ok && k < kSlices; ++k) {
-                    if (cut[k + 1] > cut[k]) ok = HIP_OK(hipMemcpyAsync(hStream + co.L.offRaw + cut[k], co.dComp + co.L.offRaw + cut[k], (size_t)(cut[k + 1] - cut[k]), hipMemcpyDeviceToHost, stream));
-                    ok = ok && HIP_OK(hipEventRecord(evs[k + 1], stream));
-                }
-                ok = ok && HIP_OK(hipEventSynchronize(evs[0]));
-                if (ok) {
-                    // codec blocks [blockCut[k], blockCut[k + 1]) need raw units below cut[k + 1] only: found by bisection over the (monotone) offsets
-                    const uint32_t* ofs = (const uint32_t*)(hStream + co.L.offOfs);
-                    uint64_t blockCut[kSlices + 1]; blockCut[0] = 0;
-                    for (uint32_t k = 1; k <= kSlices; ++k) {
-                        if (k == kSlices) { blockCut[k] = co.L.blocks; break; }
-                        uint64_t lo = blockCut[k - 1], hi = co.L.blocks;   // largest b with 16 * ofs[b] <= cut[k], i.e. every raw unit of the blocks before b has arrived with piece k
-                        while (lo < hi) { const uint64_t mid = (lo + hi + 1) / 2; if (16ull * ofs[mid] <= cut[k]) lo = mid; else hi = mid - 1; }
-                        blockCut[k] = lo;
-                    }
-                    WorkerPool& pool = baker.worker_pool(expandThreads);
-                    uint8_t* dst = (uint8_t*)res->arrayData; const uint64_t dstBytes = R.arrayDataSize; const HostCodecLayout L = co.L;
-                    constexpr uint64_t kTaskBlocks = 512;   // 2 MiB of the array per task
-                    for (uint32_t k = 0; ok && k < kSlices; ++k) {
-                        ok = HIP_OK(hipEventSynchronize(evs[k + 1]));
-                        const uint64_t b0 = blockCut[k], b1 = blockCut[k + 1];
-                        if (!ok || b1 <= b0) continue;
-                        const uint32_t tasks = (uint32_t)((b1 - b0 + kTaskBlocks - 1) / kTaskBlocks);
-                        pool.run(tasks, [&](uint32_t t) { const uint64_t s0 = b0 + (uint64_t)t * kTaskBlocks, s1 = s0 + kTaskBlocks < b1 ? s0 + kTaskBlocks : b1; codec_expand_blocks(dst, dstBytes, hStream, L, s0, s1); });
-                    }
-                    tm.expandThreads = pool.workers() + 1u;
-                }
+            // The rest of the stream lands in the working set's pinned block slice by slice -- the codes of a range of codec blocks and the raw units those blocks
+            // point at (both contiguous: the offsets are a prefix sum) -- and the helper threads expand slice k while slice k + 1 is on the link.
+            constexpr uint32_t kSlices = 12;
+            const uint32_t* ofs = (const uint32_t*)(hStream + co.L.offOfs);
+            hipEvent_t evs[kSlices]; uint32_t nev = 0;
+            for (; nev < kSlices; ++nev) if (!HIP_OK(hipEventCreateWithFlags(&evs[nev], hipEventDisableTiming))) break;
+            ok = nev == kSlices;
+            uint64_t blockCut[kSlices + 1];
+            for (uint32_t k = 0; k <= kSlices; ++k) blockCut[k] = co.L.blocks * k / kSlices;
+            for (uint32_t k = 0; ok && k < kSlices; ++k) {
+                const uint64_t b0 = blockCut[k], b1 = blockCut[k + 1];
+                const uint64_t c0b = co.L.offCodes + b0 * 128u, c1b = b1 == co.L.blocks ? co.L.offRaw : co.L.offCodes + b1 * 128u;
+                const uint64_t r0b = co.L.offRaw + 16ull * ofs[b0], r1b = co.L.offRaw + 16ull * ofs[b1];
+                ok = r0b <= r1b && r1b <= streamBytes;   // (a corrupt offset table must not turn into a wild copy)
+                if (ok && c1b > c0b) ok = HIP_OK(hipMemcpyAsync(hStream + c0b, co.dComp + c0b, (size_t)(c1b - c0b), hipMemcpyDeviceToHost, stream));
+                if (ok && r1b > r0b) ok = HIP_OK(hipMemcpyAsync(hStream + r0b, co.dComp + r0b, (size_t)(r1b - r0b), hipMemcpyDeviceToHost, stream));
+                ok = ok && HIP_OK(hipEventRecord(evs[k], stream));
             }
+            if (ok) {
+                WorkerPool& pool = baker.worker_pool(expandThreads);
+                uint8_t* dst = (uint8_t*)res->arrayData; const uint64_t dstBytes = R.arrayDataSize; const HostCodecLayout L = co.L;
+                constexpr uint64_t kTaskBlocks = 512;   // 2 MiB of the array per task
+                for (uint32_t k = 0; ok && k < kSlices; ++k) {
+                    ok = HIP_OK(hipEventSynchronize(evs[k]));
+                    const uint64_t b0 = blockCut[k], b1 = blockCut[k + 1];
+                    if (!ok || b1 <= b0) continue;
+                    const uint32_t tasks = (uint32_t)((b1 - b0 + kTaskBlocks - 1) / kTaskBlocks);
+                    pool.run(tasks, [&](uint32_t t) { const uint64_t s0 = b0 + (uint64_t)t * kTaskBlocks, s1 = s0 + kTaskBlocks < b1 ? s0 + kTaskBlocks : b1; codec_expand_blocks(dst, dstBytes, hStream, L, s0, s1); });
+                }
+                tm.expandThreads = pool.workers() + 1u;
+            }
+            if (!ok) (void)hipStreamSynchronize(stream);   // (nothing may still be landing in the pinned block when the session hands it back)
             for (uint32_t k = 0; k < nev; ++k) (void)hipEventDestroy(evs[k]);
             tm.resultTransfer = ommxResultTransfer_Compressed; tm.compressedBytes = streamBytes;
         }
