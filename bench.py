@@ -208,6 +208,7 @@ def main():
     ap.add_argument("--generic-pass", type=int, default=0, help="ommxBakerKnob_GenericPass (0 = library default, 1 = inside the persistent launch, 2 = deferred pass)")
     ap.add_argument("--stream-chunks", type=int, default=0, help="ommxBakerKnob_StreamChunks for the ommCpuBake measurement (0 = library default)")
     ap.add_argument("--result-transfer", type=int, default=0, help="ommxBakerKnob_ResultTransfer for the ommCpuBake measurement (0 = library default, 1 = plain copy, 2 = streamed placement, 3 = compressed)")
+    ap.add_argument("--expand-threads", type=int, default=0, help="ommxBakerKnob_ExpandThreads (0 = library default)")
     ap.add_argument("--concurrent", type=int, default=0, help="also measure K host threads baking concurrently on ONE baker through ommCpuBake (bakes/s for 1, 4, .. K threads; "
                                                               "the reference documents caller-level parallelism as a first-class strategy, docs/integration_guide.md:434)")
     args = ap.parse_args()
@@ -243,6 +244,8 @@ def main():
         prod.set_knob(baker, ot.KNOB_GENERIC_PASS, args.generic_pass)
     if args.result_transfer:
         prod.set_knob(baker, ot.KNOB_RESULT_TRANSFER, args.result_transfer)
+    if args.expand_threads:
+        prod.set_knob(baker, ot.KNOB_EXPAND_THREADS, args.expand_threads)
     th = prod.create_texture(baker, [tex], alpha_cutoff=0.5)
     host_desc = desc_for(th, uv, ix, lv, kw)
     # inputs resident in HBM before the timed region: torch owns the device buffers, the library gets raw pointers
@@ -436,6 +439,8 @@ def main():
                                                              "compressed (codec stream over PCIe, expanded by the baker's helper threads)"][int(host_tms[-1].resultTransfer) & 3],
                                                     "array_data_bytes": result_info["arrayDataBytes"], "bytes_over_pcie": int(host_tms[-1].compressedBytes) or int(host_tms[-1].streamedBytes) or result_info["arrayDataBytes"],
                                                     "codec_and_readback_ms": havg("compressMs"), "copy_and_expand_ms": havg("expandMs"), "expand_threads": int(host_tms[-1].expandThreads),
+                                                    "copy_and_expand_ms_min_max": [float(min(t.expandMs for t in host_tms)), float(max(t.expandMs for t in host_tms))],
+                                                    "bake_ms_min_max": [float(min(t.totalMs for t in host_tms)), float(max(t.totalMs for t in host_tms))],
                                                     "expand_GBps": result_info["arrayDataBytes"] / (havg("expandMs") * 1e6) if havg("expandMs") > 0 else None},
                                 "stream": {"ranges": int(host_tms[-1].streamChunks), "streamed_bytes": int(host_tms[-1].streamedBytes), "exposed_copy_ms": havg("streamTailMs"),
                                            "early_items": int(host_tms[-1].streamEarlyItems),

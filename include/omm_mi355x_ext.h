@@ -85,7 +85,8 @@ typedef enum ommxBakerKnob {
                                            when the result that uses it is destroyed.  For pipelines that create many bakers, or bake rarely.  See also ommxTrimBaker. */
     ommxBakerKnob_ResultTransfer   = 5, /* ommCpuBake: how a large arrayData reaches the caller's memory, one of ommxResultTransfer_*.  Auto (0 / default): Compressed when the
                                            bake carries ommCpuBakeFlags_EnableInternalThreads and the process has >= 6 CPUs (affinity / cgroup quota), else Streamed */
-    ommxBakerKnob_MAX_NUM          = 6
+    ommxBakerKnob_ExpandThreads    = 6, /* threads (the caller's included, <= 64) that expand a compressed result; 0 / default: three quarters of the CPUs the process may use, at most 12 */
+    ommxBakerKnob_MAX_NUM          = 7
 } ommxBakerKnob;
 typedef enum ommxResultTransfer {
     ommxResultTransfer_Auto        = 0,
@@ -93,7 +94,7 @@ typedef enum ommxResultTransfer {
     ommxResultTransfer_Streamed    = 2, /* rounds 3 - 4: finished blocks are placed and copied to their final offsets by the DMA engine WHILE the classification runs
                                            (>= 64 MiB of packed states; ommxBakerKnob_StreamChunks); bound by the PCIe link */
     ommxResultTransfer_Compressed  = 3  /* round 5: the finished array crosses PCIe as a codec stream (one nibble per 16-byte unit: the state it repeats, or raw: 6 % of the
-                                           bytes at the metric configuration) and is expanded into the caller's array by up to 16 helper threads of the baker */
+                                           bytes at the metric configuration) and is expanded into the caller's array by helper threads of the baker (ommxBakerKnob_ExpandThreads) */
 } ommxResultTransfer;
 OMM_MI355X_API ommResult ommxSetBakerKnob(ommBaker baker, ommxBakerKnob knob, uint64_t value);
 /* Gives every idle pooled block of the baker back to the system now: pinned host blocks, device result blocks, device working sets of finished bakes.  Results

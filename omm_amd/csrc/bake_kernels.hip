@@ -316,7 +316,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                                                         const uint4* __restrict__ tileQueue, uint32_t* __restrict__ queueCtl, uint32_t numSections, GenericQueue G)
 {
     __shared__ unsigned long long s_gbase;       // DEFER: first entry of this tile's reservation in the generic queue
-    __shared__ uint8_t  s_state[TILE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_state[TILE];
     __shared__ uint16_t s_queue[TILE];
     __shared__ int      s_group[TILE / GROUP];
     __shared__ uint16_t s_glist[TILE / GROUP];   // sliced tiles: the groups that are not settled, compacted (phase 1 walks only these)
@@ -444,7 +444,11 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
             TexRect r; r.sx = (int)(rec.z & 0xFFFFu); r.sy = (int)(rec.z >> 16); r.ex = (int)(rec.w & 0xFFFFu); r.ey = (int)(rec.w >> 16); r.ok = (rec.x >> 31) != 0u;
             const int ww = r.ex - r.sx + 1, wh = r.ey - r.sy + 1;
             bool windowOk = false;
+#ifdef OMMX_EXP_NO_WINDOW
+            if (false) {
+#else
             if (r.ok && ww <= WIN && wh <= WIN) {
+#endif
                 const DevMip& m0 = P.mips[0];
                 // 64 x 4 thread grid over the window (no integer division by the run-time width): column = lane, one row per wave and pass
                 const int cx = (int)(tid & 63u);
@@ -470,6 +474,9 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 if (gs < 0) s_glist[__popcll(open & ((1ull << g) - 1ull))] = (uint16_t)g;
                 if (gs == kRegionAllOpen) s_olist[__popcll(allOpen & ((1ull << g) - 1ull))] = (uint16_t)g;
                 if (g == 0) { s_gcount = (uint32_t)__popcll(open); s_ocount = (uint32_t)__popcll(allOpen); }
+#ifdef OMMX_EXP_FIXED_ONLY   // (timing experiment, wrong results: every tile as if it had no open group -- what is left is the per-tile fixed cost)
+                if (g == 0) { s_gcount = 0; s_ocount = 0; }
+#endif
             }
             __syncthreads();
             if (windowOk) { const DevMip& m0 = P.mips[0]; W.tex = (lds_float*)s_wtex; W.sat = (lds_u32*)s_wsat; W.base = m0.texels; W.sx = r.sx; W.sy = r.sy; W.w = ww; W.h = wh; } // (SAT part is only read when coarse is on)
@@ -647,6 +654,24 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         for (uint32_t q = tid; q < openWords; q += BLOCK) {
             const uint32_t w = ((uint32_t)s_glist[q >> wpgLog] << wpgLog) + (q & ((1u << wpgLog) - 1u));
             uint32_t v = 0;
+            if (!DEFER) {
+                // 16 (4-state) or 32 (2-state) state bytes -> one word with 128-bit LDS reads and bit gathers instead of a loop over bytes; which states occur
+                // and how many are known (T / O) from the packed word itself
+                if (bits == 2u) {
+                    const uint4 x = *(const uint4*)&s_state[w * 16u];
+                    auto g4 = [](uint32_t d) { d &= 0x03030303u; return (d | (d >> 6) | (d >> 12) | (d >> 18)) & 0xFFu; };
+                    v = g4(x.x) | (g4(x.y) << 8) | (g4(x.z) << 16) | (g4(x.w) << 24);
+                    const uint32_t lo = v & 0x55555555u, hi = (v >> 1) & 0x55555555u;
+                    localMask |= ((0x55555555u & ~lo & ~hi) ? 1u : 0u) | ((lo & ~hi) ? 2u : 0u) | ((hi & ~lo) ? 4u : 0u) | ((lo & hi) ? 8u : 0u);
+                    localKnown += (uint32_t)__popc(0x55555555u & ~hi);
+                } else {
+                    const uint4 x = *(const uint4*)&s_state[w * 32u], y = *(const uint4*)&s_state[w * 32u + 16u];
+                    auto g1 = [](uint32_t d) { d &= 0x01010101u; return (d | (d >> 7) | (d >> 14) | (d >> 21)) & 0xFu; };
+                    v = g1(x.x) | (g1(x.y) << 4) | (g1(x.z) << 8) | (g1(x.w) << 12) | (g1(y.x) << 16) | (g1(y.y) << 20) | (g1(y.z) << 24) | (g1(y.w) << 28);
+                    localMask |= (v != 0xFFFFFFFFu ? 1u : 0u) | (v != 0u ? 2u : 0u);
+                    localKnown += 32u;
+                }
+            } else
             for (uint32_t k = 0; k < perWord; ++k) {
                 uint32_t st = s_state[w * perWord + k];
                 if (DEFER && st == kDeferredState) continue;   // (its bits stay 0 for classify_generic's atomicOr; mask and known count come from there too)

@@ -3,6 +3,7 @@
 #include <emmintrin.h>
 #include <sched.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace ommx {

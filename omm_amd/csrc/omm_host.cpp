@@ -303,11 +303,12 @@ struct Baker {
     std::shared_ptr<DevPool> devPool = std::make_shared<DevPool>();
     std::shared_ptr<ArenaPool> arenas = std::make_shared<ArenaPool>();   // device working sets, one per bake in flight
     // helper threads of the compressed result (host_expand.h): started by the first bake that may use them (ommCpuBakeFlags_EnableInternalThreads)
-    std::mutex workersMu; std::unique_ptr<WorkerPool> workers;
-    WorkerPool& worker_pool(unsigned threads) {
+    std::mutex workersMu; std::shared_ptr<WorkerPool> workers; unsigned workersWanted = 0;
+    std::shared_ptr<WorkerPool> worker_pool(unsigned threads) {
         std::lock_guard<std::mutex> g(workersMu);
-        if (!workers) workers.reset(new WorkerPool(threads > 1 ? threads - 1 : 0));   // (the calling thread is one of them)
-        return *workers;
+        const unsigned want = threads > 1 ? threads - 1 : 0;   // (the calling thread is one of them)
+        if (!workers || workersWanted != want) { workers = std::make_shared<WorkerPool>(want); workersWanted = want; }   // (a bake in flight keeps the pool it took)
+        return workers;
     }
     std::mutex timingsMu; ommxBakeTimings timings; bool haveTimings = false;
     std::atomic<uint64_t> knobs[ommxBakerKnob_MAX_NUM];   // ommxSetBakerKnob: 0 = default
@@ -1381,9 +1382,13 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     // (ommCpuBakeFlags_EnableInternalThreads, omm.h:303) and CPUs to run them on (below six, the STREAMED form -- blocks placed and copied by the DMA engine
     // while the classification runs -- is the faster one: one thread expands 30 GB/s).
     const uint64_t transferKnob = baker.knob(ommxBakerKnob_ResultTransfer);
-    const unsigned expandThreads = effective_cpus() < 16u ? effective_cpus() : 16u;
+    // threads: three quarters of the CPUs the process may use, at most 12 -- the probe's rate is flat from 12 threads on, and a process that runs as many
+    // busy threads as its cgroup quota allows is throttled for the rest of the scheduler period as soon as anything else (the HIP runtime's threads, the
+    // caller's) runs beside them: measured 6 - 19 ms per expansion with 16 threads on 16 CPUs of quota (ommxBakerKnob_ExpandThreads overrides)
+    unsigned expandThreads = effective_cpus() * 3u / 4u; expandThreads = expandThreads > 12u ? 12u : (expandThreads < 1u ? 1u : expandThreads);
+    if (const uint64_t k = baker.knob(ommxBakerKnob_ExpandThreads)) expandThreads = (unsigned)k;
     const bool wantCompressed = !so.forced && (transferKnob == ommxResultTransfer_Compressed ||
-                                               (transferKnob == ommxResultTransfer_Auto && ((uint32_t)d.bakeFlags & (uint32_t)ommCpuBakeFlags_EnableInternalThreads) != 0 && expandThreads >= 6u));
+                                               (transferKnob == ommxResultTransfer_Auto && ((uint32_t)d.bakeFlags & (uint32_t)ommCpuBakeFlags_EnableInternalThreads) != 0 && effective_cpus() >= 6u));
     const bool canStream = !wantCompressed && transferKnob != ommxResultTransfer_Plain && ses.open_comm() && ses.open_place();
     so.copyStream = ses.commStream; so.placeStream = ses.placeStream; so.device = baker.bind_device();
     const ommResult br = bake_core(baker, d, din, &d, ses.arena, ses.states, stream, et, R, tm, nullptr, nullptr, canStream ? &so : nullptr);
@@ -1457,7 +1462,7 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
                 ok = ok && HIP_OK(hipEventRecord(evs[k], stream));
             }
             if (ok) {
-                WorkerPool& pool = baker.worker_pool(expandThreads);
+                const std::shared_ptr<WorkerPool> poolRef = baker.worker_pool(expandThreads); WorkerPool& pool = *poolRef;
                 uint8_t* dst = (uint8_t*)res->arrayData; const uint64_t dstBytes = R.arrayDataSize; const HostCodecLayout L = co.L;
                 constexpr uint64_t kTaskBlocks = 512;   // 2 MiB of the array per task
                 for (uint32_t k = 0; ok && k < kSlices; ++k) {
@@ -2386,6 +2391,7 @@ OMM_MI355X_API ommResult ommxSetBakerKnob(ommBaker baker, ommxBakerKnob knob, ui
     if (knob == ommxBakerKnob_StreamChunks && value > kMaxStreamRanges) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_GenericPass && value > 2) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_ResultTransfer && value > (uint64_t)ommxResultTransfer_Compressed) return ommResult_INVALID_ARGUMENT;
+    if (knob == ommxBakerKnob_ExpandThreads && value > 64) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_RetainMemory) {
         if (value > 1) return ommResult_INVALID_ARGUMENT;
         Baker* bk = untag<Baker>(baker);
