@@ -242,17 +242,37 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
 // a barrier, and the test's registers (RcShape, RcTex, the cell loop) were live across the whole kernel -- 160 bytes of scratch per lane.  Here it is a dense
 // pass of its own: lane = (open tile, group), no barriers, no LDS; the verdict bytes land in the tile's record, which the persistent workgroup reads anyway.
 // ------------------------------------------------------------------------------------------------
+// Chunks (round 5).  The groups that stay open are a quarter of a tile's 64 on average, so a workgroup of the persistent launch would spend its fixed per-tile
+// work (record, texel window, five barriers, tables) on ~20 groups.  triage_groups therefore goes over the queue in windows of kChunkWindow adjacent records
+// (tiles of one work item are adjacent: triage_tiles appends them wave by wave) and joins records of the same item whose open groups fit into 64 slots:
+// the first becomes the chunk's HEAD -- bits 12..18 of its word [0].y say which of the following records belong to it, its rectangle becomes the union --
+// the others are marked kTileDead like the tiles without any open group: whoever pops them has nothing to do.
+constexpr uint32_t kChunkWindow = 8, kChunkMaskShift = 12, kChunkMaskBits = 0x7Fu;
 template <bool FP32, class MD, int TILE>
 __global__ __launch_bounds__(256) void triage_groups(ClassifyParams P, ItemArrays A, uint4* __restrict__ queue, const uint32_t* __restrict__ queueCtl, uint32_t numSections)
 {
     constexpr uint32_t GROUPS = (uint32_t)TILE / 64u, PER_BLOCK = 256u / GROUPS;   // 64 groups: a wave per tile; 16 groups: four tiles per wave
+    constexpr uint32_t SPAN = GROUPS == 64u ? kChunkWindow : 1u;                   // records a wave (4096-tiles) / a 16-lane slot (1024-tiles: one tile per item, nothing to join) takes in a row
     const uint32_t g = threadIdx.x % GROUPS, slot = threadIdx.x / GROUPS;
     const bool coarse = P.useCoarse != 0;
     const bool fastFine = P.filterLinear != 0 && P.mipCount == 1 && !P.noFine && P.altKernel == 0;
     const bool curveOn = (OMMX_RC_LEVELS & 4) && region_curve_applies(P);
+    const uint32_t bits = (uint32_t)P.format, groupBytes = 8u * bits;   // 64 micro-triangles x bits
     for (uint32_t sec = 0; sec < numSections; ++sec) {
         const uint32_t base = queueCtl[kSecBases + sec], tail = queueCtl[kSecTails + sec];
-        for (uint32_t r = blockIdx.x * PER_BLOCK + slot; r < tail; r += gridDim.x * PER_BLOCK) {
+        for (uint32_t w0 = (blockIdx.x * PER_BLOCK + slot) * SPAN; w0 < tail; w0 += gridDim.x * PER_BLOCK * SPAN) {
+            // the chunk being built (wave-uniform; 4096-tiles only): head record, its item, open groups so far, follower mask, union rectangle
+            uint32_t hRec = 0xFFFFFFFFu, hItem = 0, hOpen = 0, hMask = 0, hY = 0, hSx = 0, hSy = 0, hEx = 0, hEy = 0; bool hOk = false;
+            auto flush = [&]() {
+                if (hRec != 0xFFFFFFFFu && hMask != 0u && g == 0u) {
+                    uint32_t* hw = (uint32_t*)(queue + (size_t)kTileRecordWords * (base + hRec));
+                    hw[0] = (hw[0] & 0x7FFFFFFFu) | (hOk ? 0x80000000u : 0u); hw[1] = hY | (hMask << kChunkMaskShift); hw[2] = hSx | (hSy << 16); hw[3] = hEx | (hEy << 16);
+                }
+                hRec = 0xFFFFFFFFu;
+            };
+            for (uint32_t j = 0; j < SPAN; ++j) {
+            const uint32_t r = w0 + j;
+            if (r >= tail) break;   // (uniform over the lanes that share the records)
             uint4* rec = queue + (size_t)kTileRecordWords * (base + r);
             const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
             float uv[6] = { __uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x), __uint_as_float(r2.y) };
@@ -272,7 +292,6 @@ __global__ __launch_bounds__(256) void triage_groups(ClassifyParams P, ItemArray
             // A settled group is final right here: its constant packed states go to the tile's block, its state into the item's mask / known count (the
             // persistent workgroup packs the open groups only).  A tile whose groups are ALL settled -- 14 % of the open tiles of the metric configuration --
             // is marked dead in its record: the persistent launch passes it without touching the window, a barrier or the states.
-            const uint32_t bits = (uint32_t)P.format, groupBytes = 8u * bits;   // 64 micro-triangles x bits
             if (gs >= 0) {
                 uint8_t* dst = (uint8_t*)(((unsigned long long)r2.w << 32) | r2.z) + (size_t)g * groupBytes;
                 uint32_t v = 0;
@@ -286,13 +305,29 @@ __global__ __launch_bounds__(256) void triage_groups(ClassifyParams P, ItemArray
             #pragma unroll
             for (int st = 0; st < 4; ++st) if (__ballot(gs == st) & tileLanes) mask |= 1u << st;
             const uint32_t known = (uint32_t)__popcll(__ballot(gs == 0 || gs == 1) & tileLanes) * 64u;
-            const bool allSettled = (__ballot(gs < 0) & tileLanes) == 0ull;
+            const uint32_t open = (uint32_t)__popcll(__ballot(gs < 0) & tileLanes);
+            const uint32_t item = r0.x & 0x3FFFFFFFu;
+            // join: this record follows the chunk's head when it is of the same item and its open groups still fit
+            bool follower = false;
+            if (GROUPS == 64u && open != 0u) {
+                const uint32_t ry = uniform_u32(r0.y), rx = uniform_u32(r0.x), rz = uniform_u32(r0.z), rw = uniform_u32(r0.w), ritem = rx & 0x3FFFFFFFu;
+                if (hRec != 0xFFFFFFFFu && ritem == hItem && hOpen + open <= 64u) {
+                    follower = true;
+                    hMask |= 1u << (r - hRec - 1u); hOpen += open; hOk = hOk && (rx >> 31) != 0u;
+                    const uint32_t sx = rz & 0xFFFFu, sy = rz >> 16, ex = rw & 0xFFFFu, ey = rw >> 16;
+                    hSx = sx < hSx ? sx : hSx; hSy = sy < hSy ? sy : hSy; hEx = ex > hEx ? ex : hEx; hEy = ey > hEy ? ey : hEy;
+                } else {
+                    flush();
+                    hRec = r; hItem = ritem; hOpen = open; hMask = 0; hY = ry; hOk = (rx >> 31) != 0u; hSx = rz & 0xFFFFu; hSy = rz >> 16; hEx = rw & 0xFFFFu; hEy = rw >> 16;
+                }
+            }
             if (g == 0u) {
-                const uint32_t item = r0.x & 0x3FFFFFFFu;
                 if (mask) atomicOr(&A.stateMask[item], mask);
                 if (P.wantKnownCount && known) atomicAdd(&A.knownCount[item], known);
-                if (allSettled) ((uint32_t*)rec)[1] = r0.y | kTileDead;
+                if (open == 0u || follower) ((uint32_t*)rec)[1] = r0.y | kTileDead;
             }
+            }
+            flush();
         }
     }
 }
@@ -319,8 +354,11 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     __shared__ __attribute__((aligned(16))) uint8_t s_state[TILE];
     __shared__ uint16_t s_queue[TILE];
     __shared__ int      s_group[TILE / GROUP];
-    __shared__ uint16_t s_glist[TILE / GROUP];   // sliced tiles: the groups that are not settled, compacted (phase 1 walks only these)
-    __shared__ uint16_t s_olist[TILE / GROUP];   // ... and those of them that are all-open (taken as whole waves by the single-texel pass)
+    // sliced tiles: the 64-group SLOTS 0 .. s_gcount-1 of the workgroup hold the OPEN groups of the chunk's tiles (triage_groups settled the others), slot s =
+    // group s_gid[s] of the work item's level-(N - 3) enumeration; s_group[s] = its verdict (< 0), s_gdec[s] its bird-curve decode
+    __shared__ uint32_t s_gid[SLICED ? TILE / GROUP : 1];
+    __shared__ uint32_t s_mopen[8];              // open groups of each member record of the chunk
+    __shared__ uint16_t s_olist[TILE / GROUP];   // the slots that are all-open (taken as whole waves by the single-texel pass)
     __shared__ uint32_t s_gcount, s_ocount;
     __shared__ uint32_t s_qcount, s_ecount;      // queue fill counts (front / back of s_queue)
     __shared__ uint32_t s_mask, s_known;
@@ -336,7 +374,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
 #define OMMX_FRESH_TID() ((void)0)
 #endif
     // DEFER: hand `n` queued micro-triangles (s_queue[0 .. n)) to the generic queue; false = no room, the caller walks them itself.  Block-uniform.
-    auto defer_generic = [&](uint32_t n, uint32_t itemWord, uint32_t level, uint32_t base) -> bool {
+    auto defer_generic = [&](uint32_t n, uint32_t itemWord, uint32_t level) -> bool {
         if (!DEFER || !SLICED || n == 0u) return false;
         OMMX_FRESH_TID();
         if (tid == 0) {
@@ -353,7 +391,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         }
         for (uint32_t q = tid; q < n; q += BLOCK) {
             const uint32_t i = s_queue[q];
-            G.entries[gb + q] = make_uint2(itemWord & 0x7FFFFFFFu, (level << 24) | (base + i));
+            G.entries[gb + q] = make_uint2(itemWord & 0x7FFFFFFFu, (level << 24) | (s_gid[i >> 6] * 64u + (i & 63u)));
             s_state[i] = (uint8_t)kDeferredState;
         }
         return true;
@@ -409,8 +447,9 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     const uint32_t M = 1u << (2 * level);
     const uint32_t itemsPerTile = SLICED ? 1u : TILE / M;
     const uint32_t firstItem = SLICED ? 0u : tile * itemsPerTile;
-    const uint32_t base = SLICED ? (rec.y & 0x7FFFFFu) * TILE : 0u; // first micro-triangle of the slice
-    const bool dead = SLICED && (rec.y & kTileDead) != 0u;          // (block-uniform) triage_groups settled every group of this tile: nothing is left to do
+    const uint32_t headTile = SLICED ? (rec.y & 0xFFFu) : 0u;        // tile (in its item) of the chunk's head record
+    const uint32_t followers = SLICED ? (rec.y >> kChunkMaskShift) & kChunkMaskBits : 0u;   // which of the next records belong to the chunk (triage_groups)
+    const bool dead = SLICED && (rec.y & kTileDead) != 0u;          // (block-uniform) nothing to do here: no open group, or a follower of an earlier head
     uint32_t itemsHere = SLICED ? 1u : numItems - firstItem;
     if (itemsHere > itemsPerTile) itemsHere = itemsPerTile;
     const uint32_t count = SLICED ? (uint32_t)TILE : itemsHere * M;   // micro-triangles in this tile
@@ -419,7 +458,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     // block-uniform item data of a sliced tile
     uint32_t uItem = 0; float uUv[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }; float uMaxAbs = 0.f; bool uDegenerate = false, uFast = false;
     TexWindow W = no_window();
-    if (tid == 0) { s_qcount = 0; s_mask = 0; s_known = 0; s_pending = 0; s_fine = 0; }
+    if (tid == 0) { s_qcount = 0; s_mask = 0; s_known = 0; s_pending = 0; s_fine = 0; s_ocount = 0; }
     // the single-texel fast pass (fine_single_texel) covers Linear filtering of one mip on non-degenerate items; everything else is generic
     const bool fastFine = SLICED && P.filterLinear != 0 && P.mipCount == 1 && !P.noFine && P.altKernel == 0;
     // micro-triangle i (0 .. TILE) of a sliced tile through the split bird decode: group word + table entry instead of the full decode
@@ -463,20 +502,49 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 }
                 windowOk = true;
             }
-            // ---- phase 0c: the verdicts of the tile's 64-groups (triage_groups wrote them into the record: summed-area table, then the curve-free-region
-            //      test), their bird-curve decode words and the compacted lists of the groups that are not settled / wholly open ----
-            if (tid < (uint32_t)(TILE / GROUP)) {   // (4096-tile: 64 groups = all of wave 0; 1024-tile: 16 of its lanes)
-                const uint32_t g = tid;
-                const int gs = group_verdict((uint32_t)((const uint8_t*)(tileQueue + (size_t)kTileRecordWords * qpos + 3))[g]);
-                s_group[g] = gs;
-                s_gdec[g] = bird_group((base >> 6) + g, level - 3).word;
-                const unsigned long long open = __ballot(gs < 0), allOpen = __ballot(gs == kRegionAllOpen);
-                if (gs < 0) s_glist[__popcll(open & ((1ull << g) - 1ull))] = (uint16_t)g;
-                if (gs == kRegionAllOpen) s_olist[__popcll(allOpen & ((1ull << g) - 1ull))] = (uint16_t)g;
-                if (g == 0) { s_gcount = (uint32_t)__popcll(open); s_ocount = (uint32_t)__popcll(allOpen); }
-#ifdef OMMX_EXP_FIXED_ONLY   // (timing experiment, wrong results: every tile as if it had no open group -- what is left is the per-tile fixed cost)
-                if (g == 0) { s_gcount = 0; s_ocount = 0; }
-#endif
+            // ---- phase 0c: the slot tables.  Wave w takes the chunk's member records w and w + 4 (member 0 = the head, then the records its follower mask
+            //      names): lane = group of the member's tile, verdict byte from the record, the open ones counted (s_mopen); after a barrier every wave
+            //      knows where its members' slots start ----
+            constexpr uint32_t GPT = (uint32_t)TILE / GROUP;   // groups per tile
+            const uint32_t lane = tid & 63u, wv = tid >> 6;
+            int mgs[2] = { 0, 0 }; uint32_t mtile[2] = { 0u, 0u }; unsigned long long mopen[2] = { 0ull, 0ull };
+            #pragma unroll
+            for (uint32_t h = 0; h < 2u; ++h) {
+                const uint32_t mi = wv + 4u * h;   // member index
+                // record of member mi: the head itself, or head + 1 + (position of the mi-th set bit of the follower mask)
+                uint32_t fm = followers, ofs = 0; bool have = mi == 0u;
+                for (uint32_t k = 1; k <= mi && fm; ++k) { const uint32_t bit = (uint32_t)__ffs((int)fm) - 1u; fm &= fm - 1u; if (k == mi) { ofs = bit + 1u; have = true; } }
+                if (have) {
+                    const uint4* mrec = tileQueue + (size_t)kTileRecordWords * (qpos + ofs);
+                    mtile[h] = uniform_u32(((const uint32_t*)mrec)[1]) & 0xFFFu;
+                    if (lane < GPT) mgs[h] = group_verdict((uint32_t)((const uint8_t*)(mrec + 3))[lane]);
+                    mopen[h] = __ballot(lane < GPT && mgs[h] < 0);
+                }
+                if (lane == 0u) s_mopen[mi] = (uint32_t)__popcll(mopen[h]);
+            }
+            __syncthreads();
+            {
+                uint32_t total = 0, start[2] = { 0u, 0u };
+                #pragma unroll
+                for (uint32_t mi = 0; mi < 8u; ++mi) { if (mi == wv) start[0] = total; if (mi == wv + 4u) start[1] = total; total += s_mopen[mi]; }
+                #pragma unroll
+                for (uint32_t h = 0; h < 2u; ++h) {
+                    const bool mine = lane < GPT && ((mopen[h] >> lane) & 1ull) != 0ull;
+                    const uint32_t sl = start[h] + (uint32_t)__popcll(mopen[h] & ((1ull << lane) - 1ull));
+                    if (mine) {
+                        const uint32_t gid = mtile[h] * GPT + lane;
+                        s_group[sl] = mgs[h]; s_gid[sl] = gid; s_gdec[sl] = bird_group(gid, level - 3).word;
+                    }
+                    // the all-open slots, compacted in any order (the single-texel pass takes them as whole waves)
+                    const unsigned long long ao = __ballot(mine && mgs[h] == kRegionAllOpen);
+                    if (ao) {
+                        uint32_t ob = 0;
+                        if (lane == 0u) ob = atomicAdd(&s_ocount, (uint32_t)__popcll(ao));
+                        ob = __shfl(ob, 0);
+                        if (mine && mgs[h] == kRegionAllOpen) s_olist[ob + (uint32_t)__popcll(ao & ((1ull << lane) - 1ull))] = (uint16_t)sl;
+                    }
+                }
+                if (tid == 0) s_gcount = total;
             }
             __syncthreads();
             if (windowOk) { const DevMip& m0 = P.mips[0]; W.tex = (lds_float*)s_wtex; W.sat = (lds_u32*)s_wsat; W.base = m0.texels; W.sx = r.sx; W.sy = r.sy; W.w = ww; W.h = wh; } // (SAT part is only read when coarse is on)
@@ -543,12 +611,9 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 if (unresolved) s_queue[wbase + __popcll(vote & ((1ull << lane) - 1ull))] = (uint16_t)i;
             }
         };
-        if (SLICED) { // walk the compacted list of open groups: settled groups cost nothing here (phase 3 packs them from s_group)
+        if (SLICED) { // every slot holds an open group
             const uint32_t gcount = s_gcount;
-            for (uint32_t k = tid >> 6; k < gcount; k += BLOCK / 64) {
-                const uint32_t g = s_glist[k];
-                phase1_group(g * 64u + (tid & 63u), s_group[g]);
-            }
+            for (uint32_t g = tid >> 6; g < gcount; g += BLOCK / 64) phase1_group(g * 64u + (tid & 63u), s_group[g]);
         } else {
             for (uint32_t i = tid; i < ((count + 63u) & ~63u); i += BLOCK) {
                 const int gs = s_group[i >> 6];      // wave-uniform: a wave is exactly one group
@@ -589,7 +654,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 if (tid == 0) { s_qcount = 0; s_ecount = 0; }
                 __syncthreads();
                 for (uint32_t k = tid >> 6; k < gcount; k += BLOCK / 64) {
-                    const uint32_t i = s_glist[k] * 64u + (tid & 63u);
+                    const uint32_t i = k * 64u + (tid & 63u);
                     const uint32_t code = s_state[i];
                     const unsigned long long vg = __ballot(code == 0xFFu), ve = __ballot(code >= (uint32_t)kNeedsEdges && code != 0xFFu);
                     if (vg | ve) {
@@ -616,7 +681,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
             // ---- phase 2c: the generic pass for whatever did not fit the single-texel pattern ----
             OMMX_FRESH_TID();
             if (tid == 0 && s_fine) atomicAdd(A.fineCount + (size_t)((blockIdx.x + 7u * blockIdx.y) & (kFineSlots - 1)) * kFineStride, (unsigned long long)s_fine);
-            if (!defer_generic(qn2, rec.x, level, base))
+            if (!defer_generic(qn2, rec.x, level))
             for (uint32_t q0 = 0; q0 < qn2; q0 += BLOCK) {
                 const uint32_t q = q0 + tid;
                 if (q < qn2) {
@@ -624,12 +689,12 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                     s_state[i] = (uint8_t)fine_state<FP32, MD>(P, tile_micro_triangle(i), uDegenerate, W);
                 }
             }
-        } else if (!defer_generic(qn, rec.x, level, base))
+        } else if (!defer_generic(qn, rec.x, level))
         for (uint32_t q0 = 0; q0 < qn; q0 += BLOCK) { // q0 is block-uniform (scalar loop counter): one VGPR less across the level-line pass
             const uint32_t q = q0 + tid;
             if (q < qn) {
                 const uint32_t i = s_queue[q];
-                const uint32_t u = SLICED ? base + i : (i & (M - 1u));
+                const uint32_t u = SLICED ? s_gid[i >> 6] * 64u + (i & 63u) : (i & (M - 1u));
                 if (SLICED) {
                     s_state[i] = (uint8_t)fine_state<FP32, MD>(P, micro_triangle(uUv, u, level), uDegenerate, W);
                 } else {
@@ -649,10 +714,10 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     if (SLICED) {
         uint32_t* dst = (uint32_t*)(((unsigned long long)uniform_u32(rec2.w) << 32) | uniform_u32(rec2.z));   // (from the tile record)
         uint32_t localMask = 0, localKnown = 0;   // (tiles settled as a whole never get here: triage_tiles wrote them)
-        // the words of the OPEN groups (s_glist); the settled groups' words, their states and known counts are final since triage_groups
+        // the words of the slots (all open groups); the settled groups' words, their states and known counts are final since triage_groups
         const uint32_t wpgLog = bits == 2u ? 2u : 1u, openWords = dead ? 0u : s_gcount << wpgLog;   // 4 (4-state) or 2 (2-state) words per group
         for (uint32_t q = tid; q < openWords; q += BLOCK) {
-            const uint32_t w = ((uint32_t)s_glist[q >> wpgLog] << wpgLog) + (q & ((1u << wpgLog) - 1u));
+            const uint32_t w = q;   // word q of the slots' states; it belongs to slot q >> wpgLog, i.e. to group s_gid[..] of the item
             uint32_t v = 0;
             if (!DEFER) {
                 // 16 (4-state) or 32 (2-state) state bytes -> one word with 128-bit LDS reads and bit gathers instead of a loop over bytes; which states occur
@@ -679,7 +744,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 localMask |= 1u << st;
                 localKnown += st < 2u;
             }
-            dst[w] = v;
+            dst[(int)((s_gid[q >> wpgLog] - headTile * ((uint32_t)TILE / GROUP)) << wpgLog) + (int)(q & ((1u << wpgLog) - 1u))] = v;   // (a follower's tile may lie in front of the head's: the offset is signed)
         }
         if (localMask) atomicOr(&s_mask, localMask);
         if (P.wantKnownCount && localKnown) atomicAdd(&s_known, localKnown);

@@ -133,13 +133,24 @@ struct ArenaPool {
         return std::unique_ptr<ArenaSet>(new ArenaSet());
     }
     std::atomic<bool> retain{ true };
-    void release(std::unique_ptr<ArenaSet> a) { std::lock_guard<std::mutex> g(mu); if (retain.load() && idle.size() < 2) idle.push_back(std::move(a)); }   // (else freed here)
+    // Idle sets kept: two whatever their size, and up to sixteen as long as the idle ones together stay below 1 GiB -- K caller threads that bake small
+    // meshes on one baker (docs/integration_guide.md:434) would otherwise free and re-create K - 2 working sets (arenas: hipMalloc / hipFree, both
+    // device-synchronising; three streams) on every round.
+    static size_t bytes_of(const ArenaSet& a) { return a.tables.cap + a.states.cap + a.xchg.cap + a.pinned.cap; }
+    void release(std::unique_ptr<ArenaSet> a) {
+        std::unique_ptr<ArenaSet> drop;   // (freed outside the lock)
+        {
+            std::lock_guard<std::mutex> g(mu);
+            size_t held = bytes_of(*a); for (const auto& i : idle) held += bytes_of(*i);
+            if (retain.load() && (idle.size() < 2 || (idle.size() < 16 && held <= ((size_t)1 << 30)))) idle.push_back(std::move(a)); else drop = std::move(a);
+        }
+    }
     void trim() { std::vector<std::unique_ptr<ArenaSet>> drop; { std::lock_guard<std::mutex> g(mu); drop.swap(idle); } }   // (freed outside the lock)
 };
 
 // ---- device blocks of bake results, reused across bakes (hipMalloc / hipFree of a 1.3 GB block are synchronous and cost ~1 ms) ----
 struct DevPool {
-    struct Blk { void* p; size_t cap; bool used; };
+    struct Blk { void* p; size_t cap; bool used; bool exempt; };
     std::mutex mu; std::vector<Blk> blks; std::atomic<bool> retain{ true };
     ~DevPool() { for (auto& b : blks) (void)hipFree(b.p); }
     void* acquire(size_t bytes) {
@@ -156,19 +167,26 @@ struct DevPool {
             if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         }
         std::lock_guard<std::mutex> g(mu);
-        blks.push_back({ p, cap, true });
+        blks.push_back({ p, cap, true, false });
         return p;
     }
     void release(void* p) {
         if (!p) return;
         { std::lock_guard<std::mutex> g(mu); for (auto& b : blks) if (b.p == p) b.used = false; }
-        trim(retain.load() ? 6 : 0);                  // at most two idle result sets (arrayData, descs, index)
+        trim(retain.load() ? 6 : 0, retain.load() ? (size_t)256 << 20 : 0);
     }
-    void trim(size_t keepIdle) {
-        std::lock_guard<std::mutex> g(mu);
-        size_t idle = 0; for (auto& b : blks) idle += !b.used;
-        for (size_t i = 0; i < blks.size() && idle > keepIdle; )
-            if (!blks[i].used) { (void)hipFree(blks[i].p); blks.erase(blks.begin() + (long)i); idle--; } else ++i;
+    // at most keepIdle idle blocks (two result sets: arrayData, descs, index) -- not counting up to 64 SMALL idle blocks of at most smallBytes together:
+    // concurrent small bakes on one baker hand dozens of kilobyte-sized blocks back and forth, and hipFree synchronises the device
+    void trim(size_t keepIdle, size_t smallBytes = 0) {
+        std::vector<void*> drop;   // (hipFree outside the lock)
+        {
+            std::lock_guard<std::mutex> g(mu);
+            size_t small = 0, smallCount = 0, idle = 0;
+            for (auto& b : blks) if (!b.used) { if (b.cap <= ((size_t)4 << 20) && small + b.cap <= smallBytes && smallCount < 64) { small += b.cap; smallCount++; b.exempt = true; } else { b.exempt = false; idle++; } }
+            for (size_t i = 0; i < blks.size() && idle > keepIdle; )
+                if (!blks[i].used && !blks[i].exempt) { drop.push_back(blks[i].p); blks.erase(blks.begin() + (long)i); idle--; } else ++i;
+        }
+        for (void* p : drop) (void)hipFree(p);
     }
 };
 
