@@ -52,7 +52,7 @@ class BakeTimings(C.Structure):
                 ("openTiles", C.c_uint32), ("openTileMicroTriangles", C.c_uint64), ("streamEarlyItems", C.c_uint32), ("persistentMs", C.c_float),
                 ("genericMs", C.c_float), ("genericMicroTriangles", C.c_uint64), ("exchangeBytes", C.c_uint64), ("contributionBytes", C.c_uint64),
                 ("streamPreviewMs", C.c_float), ("streamFirstCopyMs", C.c_float), ("streamLastCopyMs", C.c_float), ("streamRangeReadyMs", C.c_float * 32),
-                ("resultTransfer", C.c_uint32), ("expandThreads", C.c_uint32), ("compressedBytes", C.c_uint64), ("compressMs", C.c_float), ("expandMs", C.c_float)]
+                ("resultTransfer", C.c_uint32), ("expandThreads", C.c_uint32), ("compressedBytes", C.c_uint64), ("compressMs", C.c_float), ("expandMs", C.c_float), ("devices", C.c_uint32)]
 
 
 def get_timings(lib, baker):
@@ -208,6 +208,7 @@ def main():
     ap.add_argument("--generic-pass", type=int, default=0, help="ommxBakerKnob_GenericPass (0 = library default, 1 = inside the persistent launch, 2 = deferred pass)")
     ap.add_argument("--stream-chunks", type=int, default=0, help="ommxBakerKnob_StreamChunks for the ommCpuBake measurement (0 = library default)")
     ap.add_argument("--result-transfer", type=int, default=0, help="ommxBakerKnob_ResultTransfer for the ommCpuBake measurement (0 = library default, 1 = plain copy, 2 = streamed placement, 3 = compressed)")
+    ap.add_argument("--devices", type=int, default=0, help="ommxBakerKnob_Devices for the ommCpuBake measurement: the bake spread over N devices of THIS process (on a one-GPU box the ranks share the device)")
     ap.add_argument("--expand-threads", type=int, default=0, help="ommxBakerKnob_ExpandThreads (0 = library default)")
     ap.add_argument("--concurrent", type=int, default=0, help="also measure K host threads baking concurrently on ONE baker through ommCpuBake (bakes/s for 1, 4, .. K threads; "
                                                               "the reference documents caller-level parallelism as a first-class strategy, docs/integration_guide.md:434)")
@@ -358,6 +359,8 @@ def main():
 
     # ---- the SDK entry point proper: host arrays in, host arrays out (metric 2) ----
     host_ms, host_first_ms, host_tms = None, None, []
+    if args.devices:
+        prod.set_knob(baker, ot.KNOB_DEVICES, args.devices)
     if rank == 0 and host_steps > 0:
         t1 = time.perf_counter()
         r, out = prod.bake_raw(baker, host_desc)
@@ -375,6 +378,8 @@ def main():
             host_tms.append(get_timings(prod, baker))
             prod.fn("ommCpuDestroyBakeResult")(out)
         host_ms = (time.perf_counter() - t1) / host_steps * 1e3
+    if args.devices:
+        prod.set_knob(baker, ot.KNOB_DEVICES, 0)
 
     comm_info = None
     if comm is not None:   # what the communicator itself says about its size: a SCALE line proves that the collectives really ran over N ranks
@@ -441,7 +446,8 @@ def main():
                                                     "codec_and_readback_ms": havg("compressMs"), "copy_and_expand_ms": havg("expandMs"), "expand_threads": int(host_tms[-1].expandThreads),
                                                     "copy_and_expand_ms_min_max": [float(min(t.expandMs for t in host_tms)), float(max(t.expandMs for t in host_tms))],
                                                     "bake_ms_min_max": [float(min(t.totalMs for t in host_tms)), float(max(t.totalMs for t in host_tms))],
-                                                    "expand_GBps": result_info["arrayDataBytes"] / (havg("expandMs") * 1e6) if havg("expandMs") > 0 else None},
+                                                    "expand_GBps": result_info["arrayDataBytes"] / (havg("expandMs") * 1e6) if havg("expandMs") > 0 else None,
+                                                    "devices": int(host_tms[-1].devices) or 1},
                                 "stream": {"ranges": int(host_tms[-1].streamChunks), "streamed_bytes": int(host_tms[-1].streamedBytes), "exposed_copy_ms": havg("streamTailMs"),
                                            "early_items": int(host_tms[-1].streamEarlyItems),
                                            "preview_ms": havg("streamPreviewMs"), "first_copy_issued_ms": havg("streamFirstCopyMs"), "last_copy_issued_ms": havg("streamLastCopyMs"),

@@ -56,6 +56,7 @@ typedef struct ommxBakeTimings {
     uint64_t compressedBytes;      /* bytes of the codec stream that crossed PCIe instead of arrayDataSize */
     float    compressMs;           /* wall clock from the end of the bake proper to the stream's size on the host (codec kernels + the small read-backs) */
     float    expandMs;             /* wall clock of the stream's copy and its expansion into arrayData (overlapped slice by slice) */
+    uint32_t devices;              /* devices a multi-device ommCpuBake ran on (ommxBakerKnob_Devices); 0 / 1: one */
 } ommxBakeTimings;
 
 /* ommxBakeTimings only ever grows at its END.  ommxGetLastBakeTimingsSized copies min(outBytes, the library's size) bytes and zeros the rest of `out`, so a
@@ -86,7 +87,11 @@ typedef enum ommxBakerKnob {
     ommxBakerKnob_ResultTransfer   = 5, /* ommCpuBake: how a large arrayData reaches the caller's memory, one of ommxResultTransfer_*.  Auto (0 / default): Compressed when the
                                            bake carries ommCpuBakeFlags_EnableInternalThreads and the process has >= 6 CPUs (affinity / cgroup quota), else Streamed */
     ommxBakerKnob_ExpandThreads    = 6, /* threads (the caller's included, <= 64) that expand a compressed result; 0 / default: three quarters of the CPUs the process may use, at most 12 */
-    ommxBakerKnob_MAX_NUM          = 7
+    ommxBakerKnob_Devices          = 7, /* ommCpuBake over N >= 2 devices of this process (at most 16): one host thread per device, rank r on HIP device (baker's + r) mod the
+                                           device count; the texture is copied to the other devices by the first bake that needs it; every device classifies its share of
+                                           the work items and sends its own blocks to the host as a codec stream over its own PCIe link.  Not for bakes with near-duplicate
+                                           merging / maxArrayDataSize or per-triangle formats (those keep to one device).  0 / 1: one device */
+    ommxBakerKnob_MAX_NUM          = 8
 } ommxBakerKnob;
 typedef enum ommxResultTransfer {
     ommxResultTransfer_Auto        = 0,

@@ -133,4 +133,34 @@ void codec_expand_blocks(uint8_t* dst, uint64_t dstBytes, const uint8_t* stream,
     if (((uintptr_t)dst & 15u) == 0) expand<true>(dst, dstBytes, stream, L, b0, b1); else expand<false>(dst, dstBytes, stream, L, b0, b1);
 }
 
+void codec_scatter_omms(const HostScatter& S, uint32_t j0, uint32_t j1)
+{
+    for (uint32_t j = j0; j < j1; ++j) {
+        const uint32_t item = S.order[j], n = S.sizes[j];
+        uint8_t* dst = S.arrayData + S.dstOfs[j];
+        if (!S.active[item]) {   // uniform item: constant pattern (as the device scatter computes it)
+            uint32_t st = 0; for (uint32_t m = S.stateMask[item]; m > 1u; m >>= 1) ++st;
+            uint32_t usedBits = (1u << (2u * S.level[item])) * (uint32_t)S.bits; if (usedBits > 8u) usedBits = 8u;
+            uint32_t pat = 0;
+            for (uint32_t b = 0; b < usedBits; b += (uint32_t)S.bits) pat |= st << b;
+            memset(dst, (int)(pat & 0xFFu), n);
+            continue;
+        }
+        const uint32_t r = S.owner[item];
+        if (r >= S.world) continue;   // (cannot happen: every active item has an owner; checked by the caller's layout)
+        const uint64_t c0 = S.cofs[j], c1 = c0 + n;
+        if (S.raw[r]) { memcpy(dst, S.stream[r] + c0, n); continue; }
+        if (((c0 | (uint64_t)n) & 4095u) == 0u) {   // whole codec blocks (every block of level >= 7 in 4-state): straight into the result
+            codec_expand_blocks((uint8_t*)((uintptr_t)dst - (uintptr_t)c0), c1, S.stream[r], S.L, c0 / 4096u, c1 / 4096u);
+            continue;
+        }
+        for (uint64_t B = c0 / 4096u; B * 4096u < c1; ++B) {   // small or unaligned blocks: one codec block at a time through a scratch page
+            alignas(64) uint8_t tmp[4096];
+            codec_expand_blocks((uint8_t*)((uintptr_t)tmp - (uintptr_t)(B * 4096u)), (B + 1u) * 4096u, S.stream[r], S.L, B, B + 1u);
+            const uint64_t lo = B * 4096u > c0 ? B * 4096u : c0, hi = (B + 1u) * 4096u < c1 ? (B + 1u) * 4096u : c1;
+            memcpy(dst + (lo - c0), tmp + (lo - B * 4096u), (size_t)(hi - lo));
+        }
+    }
+}
+
 } // namespace ommx

@@ -45,4 +45,15 @@ HostCodecLayout host_codec_layout(uint64_t paddedBytes);
 // written (the device pads the array to a multiple of 256 bytes).  Write-only on dst (non-temporal stores when dst is 16-byte aligned).
 void codec_expand_blocks(uint8_t* dst, uint64_t dstBytes, const uint8_t* stream, const HostCodecLayout& L, uint64_t b0, uint64_t b1);
 
+// Multi-device ommCpuBake: every device hands its own surviving blocks to the host as ONE codec stream of its contribution (the blocks it owns, back to
+// back in the order of the result; all contributions padded to the same size, hence one layout); the host writes every block of the result from its owner's
+// stream -- the host form of tail_kernels.hip: shard_scatter_streams.  OMMs [j0, j1) of the result.
+struct HostScatter {
+    uint32_t world; const uint8_t* stream[16]; bool raw[16];   // raw[r]: rank r's contribution did not shrink and arrived as it is
+    HostCodecLayout L;
+    const uint8_t *active, *owner, *level; const uint32_t *stateMask, *order, *dstOfs, *sizes; const uint64_t* cofs; int bits;
+    uint8_t* arrayData;
+};
+void codec_scatter_omms(const HostScatter& S, uint32_t j0, uint32_t j1);
+
 } // namespace ommx

@@ -320,6 +320,8 @@ struct Baker {
     std::shared_ptr<HostPool> hostPool = std::make_shared<HostPool>();
     std::shared_ptr<DevPool> devPool = std::make_shared<DevPool>();
     std::shared_ptr<ArenaPool> arenas = std::make_shared<ArenaPool>();   // device working sets, one per bake in flight
+    // multi-device ommCpuBake (ommxBakerKnob_Devices): one shadow baker per further device (own pools and working sets; allocator, logger and knobs of this one)
+    std::mutex peersMu; std::vector<std::unique_ptr<Baker>> peers;
     // helper threads of the compressed result (host_expand.h): started by the first bake that may use them (ommCpuBakeFlags_EnableInternalThreads)
     std::mutex workersMu; std::shared_ptr<WorkerPool> workers; unsigned workersWanted = 0;
     std::shared_ptr<WorkerPool> worker_pool(unsigned threads) {
@@ -349,6 +351,9 @@ struct Texture {
     Allocator mem; const Logger* log = nullptr;
     ommCpuTextureFormat format = ommCpuTextureFormat_MAX_NUM; ommCpuTextureFlags flags = ommCpuTextureFlags_None; float alphaCutoff = -1.f;
     std::vector<TexMip> mips;
+    int device = -1;   // the HIP device the texels live on (the baker's)
+    // multi-device ommCpuBake (ommxBakerKnob_Devices): copies of the texels and summed-area tables on the other devices, made by the first bake that needs them
+    std::mutex replicaMu; std::vector<std::unique_ptr<Texture>> replicas;
     ~Texture() { for (auto& m : mips) { if (m.texels) (void)hipFree(m.texels); if (m.sat) (void)hipFree(m.sat); } }
 };
 
@@ -593,6 +598,7 @@ struct ShardCtx {
     uint32_t* dMeta = nullptr; uint8_t* dOwner = nullptr; uint64_t *dCofs = nullptr, *dTotals = nullptr; uint8_t *dContrib = nullptr, *dGathered = nullptr;
     uint8_t *dComp = nullptr, *dGatherComp = nullptr, *dCodecScratch = nullptr; uint32_t* dCompSize = nullptr; uint64_t compCap = 0; size_t codecScratchBytes = 0;   // block exchange codec (RCCL path): own stream, all ranks' streams, own size word, count / scan scratch
     uint64_t totals[kMaxRanks]; uint64_t strideBytes = 0;
+    const float* dTriArea = nullptr;   // per-triangle UV areas in the session's arena (ommDebugGetStats2's side channel)
 };
 
 // opt-in lossy reducers (near-duplicate merge, maxArrayDataSize): classification on the device, serial tail on the host
@@ -1115,7 +1121,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     if (sh) { // sharded bake: hand the per-item metadata of this rank's share to the caller and stop here (ommxShardedBegin)
         const uint32_t numActive = hc.activeStart[kNumLevels];
         sh->bounds = bounds; sh->ti = ti; sh->to = to; sh->hc = hc; sh->dStates = dStates; sh->dActive = dActive; sh->dLevel = dLevel; sh->dScratch = dScratch;
-        sh->dStateOfs = dStateOfs; sh->dMask = dMask; sh->dActiveIds = dActiveIds; sh->dIndex = dIndex; sh->dArrayHist = dArrayHist; sh->dIndexHist = dIndexHist;
+        sh->dStateOfs = dStateOfs; sh->dMask = dMask; sh->dActiveIds = dActiveIds; sh->dIndex = dIndex; sh->dArrayHist = dArrayHist; sh->dIndexHist = dIndexHist; sh->dTriArea = dTriArea;
         sh->scratchBytes = scratchBytes; sh->flags = flags; sh->T = T; sh->bits = bits;
         launch_shard_pack_meta(bounds, dActiveIds, numActive, dMask, dKnown, dDigests, sh->dMeta, stream);
         if (!sh->asyncBegin && !HIP_OK(hipStreamSynchronize(stream))) return L.failure("[Failure] - sharded classification failed");   // (the one-call RCCL path stays on the stream)
@@ -1296,6 +1302,7 @@ uint32_t max_index(const void* idx, ommIndexFormat fmt, size_t n)
     return avx2 ? max_of_u32_avx2((const uint32_t*)idx, n) : max_of((const uint32_t*)idx, n);
 }
 
+ommResult bake_impl_multi(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult* out, uint32_t devices);   // (below, next to the sharded bake it is made of)
 constexpr uint64_t kCompressedMinBytes = 32ull << 20;   // smaller arrays cross the link as they are (0.6 ms at 57 GB/s)
 // ommCpuBake: host arrays in, host arrays out
 ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult* out)
@@ -1305,6 +1312,10 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     const ommResult fr = scope_fences(baker, d, true);
     if (fr != ommResult_SUCCESS) return fr;
     const uint32_t T = d.indexCount / 3u;
+    // several devices behind the one call (ommxBakerKnob_Devices): the work items are shared out, every device hands its own blocks to the host
+    // (not where blocks cannot travel in their packed form -- the lossy reducers, bit 9 with the 2-state format -- and not with per-triangle formats: one device)
+    if (const uint64_t nd = baker.knob(ommxBakerKnob_Devices))
+        if (nd >= 2 && !wants_host_tail(d) && !d.formats && !(((uint32_t)d.bakeFlags & (1u << 9)) != 0 && d.format == ommFormat_OC1_2_State)) return bake_impl_multi(baker, d, out, (uint32_t)nd);
     const DeviceScope onBakersDevice(baker.bind_device());
     BakeSession ses(baker);
     if (!ses.open()) return L.failure("[Failure] - no usable HIP device (the MI355X baker has no CPU fallback)");
@@ -1582,7 +1593,7 @@ ommResult create_texture_impl(Baker* b, const ommCpuTextureDesc* desc, ommCpuTex
     if (desc->mipCount > (uint32_t)kMaxMips) return L.invalid("[Invalid Arg] - more than 17 mips");
     Texture* t = b->mem.make<Texture>();
     if (!t) return ommResult_FAILURE;
-    t->mem = b->mem; t->log = &b->log; t->format = desc->format; t->flags = desc->flags; t->alphaCutoff = desc->alphaCutoff;
+    t->mem = b->mem; t->log = &b->log; t->format = desc->format; t->flags = desc->flags; t->alphaCutoff = desc->alphaCutoff; t->device = b->bind_device();
     const bool linear = ((uint32_t)desc->flags & (uint32_t)ommCpuTextureFlags_DisableZOrder) != 0;
     const size_t px = desc->format == ommCpuTextureFormat_FP32 ? 4 : 1;
     const bool enableSAT = desc->alphaCutoff >= 0; // texture_impl.cpp:91
@@ -2086,7 +2097,7 @@ ommResult sharded_tail(ShardedBake* sb)
 
 // phase 3: result buffers, descriptors, index buffer; `scatter` places the gathered blocks (one call or one per chunk)
 template <class ScatterFn>
-ommResult sharded_finish(ShardedBake* sb, ScatterFn&& scatter, ommxDeviceBakeResult* outResult)
+ommResult sharded_finish(ShardedBake* sb, ScatterFn&& scatter, ommxDeviceBakeResult* outResult, bool wantArray = true)
 {
     ShardCtx& c = sb->ctx; Baker* b = sb->baker; const Logger& L = b->log; hipStream_t stream = sb->ses.stream;
     const uint32_t E = c.counts.numOmms, T = c.T;
@@ -2098,8 +2109,8 @@ ommResult sharded_finish(ShardedBake* sb, ScatterFn&& scatter, ommxDeviceBakeRes
     R.bits = c.bits; R.numDescs = E; R.arrayDataSize = E ? c.counts.arrayDataSize : 0; R.numTris = T;
     bool ok = true;
     if (E) {
-        R.arrayData = (uint8_t*)R.dev_alloc((size_t)c.counts.arrayDataSize); R.descs = (ommCpuOpacityMicromapDesc*)R.dev_alloc(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E);
-        ok = R.arrayData != nullptr && R.descs != nullptr;
+        R.arrayData = wantArray ? (uint8_t*)R.dev_alloc((size_t)c.counts.arrayDataSize) : nullptr; R.descs = (ommCpuOpacityMicromapDesc*)R.dev_alloc(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E);
+        ok = (R.arrayData != nullptr || !wantArray) && R.descs != nullptr;
         ok = scatter(ok ? R.arrayData : nullptr) && ok;   // (called either way: the RCCL form agrees on the allocation across ranks before its all-gathers)
         if (ok) launch_write_descs(c.to.order, c.to.dstOfs, c.dLevel, c.bits, E, R.descs, stream);
     }
@@ -2130,6 +2141,240 @@ ommResult sharded_finish(ShardedBake* sb, ScatterFn&& scatter, ommxDeviceBakeRes
     sb->tm.totalMs = (float)(now_ms() - sb->t0);
     { std::lock_guard<std::mutex> g(b->timingsMu); b->timings = sb->tm; b->haveTimings = true; }
     *outResult = (ommxDeviceBakeResult)res;
+    return ommResult_SUCCESS;
+}
+
+// ================================================================================================
+// ommCpuBake over several devices of one process (ommxBakerKnob_Devices = N; SURVEY.md section 8e behind the SDK's entry point, omm.h:574).
+//
+// One host thread per device ("rank"; rank 0 = the caller's thread on the baker's device, rank r on device (primary + r) mod the device count -- with fewer
+// devices than ranks several ranks share one, which is how the path is tested on a one-GPU box).  Every rank uploads the triangle data over its own PCIe
+// link and runs the sharded bake's phases on its device: set-up and triage replicated, classification and digests of ITS share of the active work items
+// (sharded_begin), the 16 bytes of metadata per active item summed across the ranks THROUGH HOST MEMORY (no device-to-device traffic at all), the
+// deterministic tail replicated (sharded_tail).  Then every rank turns the blocks it owns into ONE codec stream and sends it over its own link; the host
+// writes every block of the result from its owner's stream (codec_scatter_omms, the helper threads).  Descriptors, index buffer and histograms come from rank 0.
+// No all-gather of the array: the 1.27 GB of the metric configuration cross the links as N streams of ~82 / N MB.
+// ================================================================================================
+struct RankTeam {
+    uint32_t n = 1; std::mutex mu; std::condition_variable cv; uint32_t arrived = 0; uint64_t generation = 0; bool allOk = true, result = true;
+    // every rank arrives with its status; all leave with the conjunction
+    bool barrier(bool ok) {
+        std::unique_lock<std::mutex> lk(mu);
+        allOk = allOk && ok;
+        if (++arrived == n) { result = allOk; allOk = true; arrived = 0; ++generation; cv.notify_all(); return result; }
+        const uint64_t g = generation;
+        cv.wait(lk, [&] { return generation != g; });
+        return result;
+    }
+};
+// the texture of `d` on device `dev` (the original when that is where it lives)
+Texture* texture_on_device(Texture* t, int dev)
+{
+    if (t->device < 0 || t->device == dev) return t;
+    std::lock_guard<std::mutex> g(t->replicaMu);
+    for (auto& r : t->replicas) if (r->device == dev) return r.get();
+    const DeviceScope onDev(dev);
+    std::unique_ptr<Texture> r(new (std::nothrow) Texture());
+    if (!r) return nullptr;
+    r->mem = t->mem; r->log = t->log; r->format = t->format; r->flags = t->flags; r->alphaCutoff = t->alphaCutoff; r->device = dev;
+    const size_t px = t->format == ommCpuTextureFormat_FP32 ? 4 : 1;
+    for (const TexMip& m : t->mips) {
+        TexMip c = m; c.texels = nullptr; c.sat = nullptr;
+        const size_t n = (size_t)m.w * (size_t)m.h;
+        bool ok = HIP_OK(hipMalloc((void**)&c.texels, n * px)) && HIP_OK(hipMemcpy(c.texels, m.texels, n * px, hipMemcpyDefault));
+        if (ok && m.sat) ok = HIP_OK(hipMalloc((void**)&c.sat, n * 4)) && HIP_OK(hipMemcpy(c.sat, m.sat, n * 4, hipMemcpyDefault));
+        r->mips.push_back(c);   // (freed by ~Texture, also when the copy failed half way)
+        if (!ok) { (void)hipGetLastError(); return nullptr; }
+    }
+    t->replicas.push_back(std::move(r));
+    return t->replicas.back().get();
+}
+Baker* peer_baker(Baker& b, uint32_t rank, int dev)
+{
+    if (rank == 0) return &b;
+    std::lock_guard<std::mutex> g(b.peersMu);
+    while (b.peers.size() < rank) {
+        std::unique_ptr<Baker> p(new (std::nothrow) Baker());
+        if (!p) return nullptr;
+        p->mem = b.mem; p->log = b.log; p->type = b.type;
+        b.peers.push_back(std::move(p));
+    }
+    Baker* p = b.peers[rank - 1].get();
+    p->device.store(dev);
+    for (int k = 0; k < (int)ommxBakerKnob_MAX_NUM; ++k) p->knobs[k].store(k == (int)ommxBakerKnob_Devices ? 0 : b.knobs[k].load());
+    p->arenas->retain.store(b.arenas->retain.load()); p->devPool->retain.store(b.devPool->retain.load()); p->hostPool->retain.store(b.hostPool->retain.load());
+    return p;
+}
+
+ommResult bake_impl_multi(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult* out, uint32_t N)
+{
+    const Logger& L = baker.log;
+    const double t0 = now_ms();
+    const uint32_t T = d.indexCount / 3u;
+    const int primary = baker.bind_device();
+    int deviceCount = 0;
+    if (primary < 0 || !HIP_OK(hipGetDeviceCount(&deviceCount)) || deviceCount < 1) return L.failure("[Failure] - no usable HIP device (the MI355X baker has no CPU fallback)");
+    if (N > (uint32_t)kMaxRanks) N = kMaxRanks;
+    Texture* tex0 = untag<Texture>(d.texture);
+    // ---- per rank: device, baker, texture (made before the threads start: replicas and shadow bakers are created once and kept) ----
+    struct Rank {
+        int dev = 0; Baker* baker = nullptr; Texture* tex = nullptr; ShardedBake* sb = nullptr; uint8_t* dRaw = nullptr; uint8_t* dCodec = nullptr;
+        std::vector<uint32_t> meta; const uint8_t* hStream = nullptr; bool raw = false; ommResult status = ommResult_SUCCESS;
+    };
+    std::vector<Rank> ranks(N);
+    for (uint32_t r = 0; r < N; ++r) {
+        ranks[r].dev = (primary + (int)r) % deviceCount;
+        ranks[r].baker = peer_baker(baker, r, ranks[r].dev);
+        ranks[r].tex = texture_on_device(tex0, ranks[r].dev);
+        if (!ranks[r].baker || !ranks[r].tex) return L.failure("[Failure] - multi-device bake: could not set up a device (texture copy / memory)");
+    }
+    const size_t idxSize = d.indexFormat == ommIndexFormat_UINT_8 ? 1 : (d.indexFormat == ommIndexFormat_UINT_16 ? 2 : 4);
+    const uint32_t maxIndex = max_index(d.indexBuffer, d.indexFormat, 3ull * T);
+    const uint32_t stride = d.texCoordStrideInBytes ? d.texCoordStrideInBytes : (d.texCoordFormat == ommTexCoordFormat_UV32_FLOAT ? 8u : 4u);
+    const size_t elem = d.texCoordFormat == ommTexCoordFormat_UV32_FLOAT ? 8 : 4;
+    const size_t uvBytes = T ? (size_t)stride * maxIndex + elem : 0, idxBytes = idxSize * 3ull * T, lvlBytes = d.subdivisionLevels ? T : 0;
+
+    RankTeam team; team.n = N;
+    std::vector<uint32_t> metaSum; size_t metaWords = 0;
+    HostCodecLayout layout{}; uint64_t strideBytes = 0;
+    // phase A (all ranks): upload, share of the classification, metadata through the host, tail, own contribution as a codec stream on the host
+    auto body = [&](uint32_t r) {
+        Rank& R = ranks[r];
+        const DeviceScope onDev(R.dev);
+        Baker& sub = *R.baker;
+        bool ok = true;
+        R.dRaw = (uint8_t*)sub.devPool->acquire(pad256(uvBytes) + pad256(idxBytes) + pad256(lvlBytes) + 256);
+        ok = R.dRaw != nullptr;
+        if (ok && uvBytes) ok = HIP_OK(hipMemcpy(R.dRaw, d.texCoords, uvBytes, hipMemcpyHostToDevice));
+        if (ok && idxBytes) ok = HIP_OK(hipMemcpy(R.dRaw + pad256(uvBytes), d.indexBuffer, idxBytes, hipMemcpyHostToDevice));
+        if (ok && lvlBytes) ok = HIP_OK(hipMemcpy(R.dRaw + pad256(uvBytes) + pad256(idxBytes), d.subdivisionLevels, lvlBytes, hipMemcpyHostToDevice));
+        ommCpuBakeInputDesc dd = d;
+        dd.texture = (ommCpuTexture)((uintptr_t)R.tex | kTexture);
+        dd.texCoords = R.dRaw; dd.indexBuffer = R.dRaw + pad256(uvBytes); dd.subdivisionLevels = lvlBytes ? R.dRaw + pad256(uvBytes) + pad256(idxBytes) : nullptr;
+        if (ok) { R.status = sharded_begin(&sub, &dd, r, N, false, &R.sb); ok = R.status == ommResult_SUCCESS; if (!ok) R.sb = nullptr; }
+        else R.status = ommResult_FAILURE;
+        if (!team.barrier(ok)) return;
+        // ---- metadata of the active items (mask, known count, digest: 4 words each; zero outside a rank's share): summed across the ranks in host memory ----
+        ShardCtx& c = R.sb->ctx; hipStream_t stream = R.sb->ses.stream;
+        const size_t words = 4ull * c.hc.activeStart[kNumLevels];
+        R.meta.resize(words ? words : 1);
+        if (words) ok = HIP_OK(hipMemcpy(R.meta.data(), c.dMeta, words * 4, hipMemcpyDeviceToHost));
+        if (r == 0) { metaWords = words; metaSum.assign(words ? words : 1, 0u); }
+        if (!team.barrier(ok)) return;
+        ok = words == metaWords;   // (every rank ran the same set-up: anything else is an internal error)
+        for (size_t k = metaWords * r / N; ok && k < metaWords * (r + 1) / N; ++k) { uint32_t a = 0; for (uint32_t q = 0; q < N; ++q) a += ranks[q].meta[k]; metaSum[k] = a; }
+        if (!team.barrier(ok)) return;
+        if (words) ok = HIP_OK(hipMemcpy(c.dMeta, metaSum.data(), words * 4, hipMemcpyHostToDevice));
+        // ---- replicated tail, layout, this rank's blocks packed into its contribution ----
+        if (ok) { R.status = sharded_tail(R.sb); ok = R.status == ommResult_SUCCESS; }
+        // ---- the contribution as a codec stream, over this device's own link ----
+        const uint64_t padded = c.strideBytes;
+        const HostCodecLayout Lc = host_codec_layout(padded);
+        const uint64_t cap = Lc.offRaw + padded / 2u + 16u;
+        const size_t scratchBytes = pad256(shard_codec_scratch_bytes(padded));
+        if (ok) { R.dCodec = (uint8_t*)sub.devPool->acquire(256 + scratchBytes + (size_t)cap); ok = R.dCodec != nullptr && Lc.blocks < 0x7FFFFFFFull; }
+        uint64_t streamBytes = 0;
+        if (ok) {
+            uint8_t* dComp = R.dCodec + 256 + scratchBytes;
+            ok = HIP_OK(run_shard_compress(c.dContrib, padded, dComp, cap, (uint32_t*)R.dCodec, R.dCodec + 256, scratchBytes, stream))
+              && HIP_OK(hipMemcpyAsync(&streamBytes, dComp, 8, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipStreamSynchronize(stream));
+            R.raw = ok && (streamBytes > cap || streamBytes < Lc.offRaw);
+            const uint64_t take = R.raw ? c.totals[r] : streamBytes;
+            ok = ok && R.sb->ses.set->pinned.reserve((size_t)take + 4096);
+            if (ok && take) ok = HIP_OK(hipMemcpyAsync(R.sb->ses.set->pinned.base, R.raw ? c.dContrib : dComp, (size_t)take, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipStreamSynchronize(stream));
+            R.hStream = R.sb->ses.set->pinned.base;
+        }
+        if (r == 0) { layout = Lc; strideBytes = padded; }
+        (void)team.barrier(ok);
+    };
+    // rank 0 is the calling thread; a rank whose thread cannot be started is run by the caller AFTER the others would deadlock the barriers: refuse instead
+    std::vector<std::thread> threads;
+    bool spawned = true;
+    try { threads.reserve(N); for (uint32_t r = 1; r < N; ++r) threads.emplace_back(body, r); } catch (...) { spawned = false; }
+    if (!spawned) {
+        // (threads that did start wait in the first barrier for ranks that never come: let them through with a failure)
+        for (size_t k = threads.size() + 1; k < N; ++k) (void)team.barrier(false);
+        (void)team.barrier(false);
+        for (auto& t : threads) t.join();
+        for (Rank& R : ranks) { const DeviceScope onDev(R.dev); if (R.sb) R.baker->mem.destroy(R.sb); if (R.dRaw) R.baker->devPool->release(R.dRaw); if (R.dCodec) R.baker->devPool->release(R.dCodec); }
+        return L.failure("[Failure] - multi-device bake: could not start a thread per device");
+    }
+    body(0);
+    for (auto& t : threads) t.join();
+    struct Cleanup { std::vector<Rank>& ranks; ~Cleanup() { for (Rank& R : ranks) { const DeviceScope onDev(R.dev); if (R.sb) R.baker->mem.destroy(R.sb); if (R.dRaw) R.baker->devPool->release(R.dRaw); if (R.dCodec) R.baker->devPool->release(R.dCodec); } } } cleanup{ ranks };
+    for (const Rank& R : ranks) if (R.status != ommResult_SUCCESS) return R.status;
+    for (const Rank& R : ranks) if (!R.sb || !R.hStream) return L.failure("[Failure] - multi-device bake: a device failed");
+    const double tA = now_ms();
+
+    // ---- rank 0: layout tables to the host, descriptors / index buffer / histograms, then the blocks from their owners' streams ----
+    const DeviceScope onPrimary(primary);
+    ShardedBake* sb0 = ranks[0].sb; ShardCtx& c0 = sb0->ctx; hipStream_t stream0 = sb0->ses.stream;
+    const uint32_t E = c0.counts.numOmms, U = c0.ti.numItems;
+    std::vector<uint32_t> hOrder(E ? E : 1), hDstOfs(E ? E : 1), hSizes(E ? E : 1), hMask(U ? U : 1); std::vector<uint64_t> hCofs(E ? E : 1);
+    std::vector<uint8_t> hActive(U ? U : 1), hOwner(U ? U : 1), hLevel(U ? U : 1);
+    bool ok = true;
+    if (E) ok = HIP_OK(hipMemcpyAsync(hOrder.data(), c0.to.order, (size_t)E * 4, hipMemcpyDeviceToHost, stream0)) && HIP_OK(hipMemcpyAsync(hDstOfs.data(), c0.to.dstOfs, (size_t)E * 4, hipMemcpyDeviceToHost, stream0))
+              && HIP_OK(hipMemcpyAsync(hSizes.data(), c0.to.sizes, (size_t)E * 4, hipMemcpyDeviceToHost, stream0)) && HIP_OK(hipMemcpyAsync(hCofs.data(), c0.dCofs, (size_t)E * 8, hipMemcpyDeviceToHost, stream0));
+    if (ok && U) ok = HIP_OK(hipMemcpyAsync(hActive.data(), c0.dActive, U, hipMemcpyDeviceToHost, stream0)) && HIP_OK(hipMemcpyAsync(hOwner.data(), c0.dOwner, U, hipMemcpyDeviceToHost, stream0))
+                   && HIP_OK(hipMemcpyAsync(hLevel.data(), c0.dLevel, U, hipMemcpyDeviceToHost, stream0)) && HIP_OK(hipMemcpyAsync(hMask.data(), c0.dMask, (size_t)U * 4, hipMemcpyDeviceToHost, stream0));
+    ommxDeviceBakeResult dres = nullptr;
+    if (ok) { const ommResult fr = sharded_finish(sb0, [](uint8_t*) { return true; }, &dres, false); if (fr != ommResult_SUCCESS) return fr; }   // (synchronises the stream: the copies above are complete)
+    if (!ok) return L.failure("[Failure] - device to host transfer of the bake result failed");
+    DeviceBakeResult* dr = (DeviceBakeResult*)dres;
+    struct DresGuard { Baker& b; DeviceBakeResult* p; ~DresGuard() { b.mem.destroy(p); } } dresGuard{ baker, dr };
+    DeviceResult& DR = dr->R;
+
+    BakeResult* res = baker.mem.make<BakeResult>();
+    if (!res) return ommResult_FAILURE;
+    res->mem = baker.mem;
+    struct ResGuard { Baker& b; BakeResult*& r; ~ResGuard() { if (r) b.mem.destroy(r); } } resGuard{ baker, res };
+    if (E) {
+        if (baker.mem.alloc == default_alloc && (size_t)DR.arrayDataSize >= HostPool::kMinBytes) { res->arrayData = baker.hostPool->acquire((size_t)DR.arrayDataSize); if (res->arrayData) res->pool = baker.hostPool; }
+        if (!res->arrayData) res->arrayData = baker.mem.allocate((size_t)DR.arrayDataSize, 64);
+        res->descs = (ommCpuOpacityMicromapDesc*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, 16);
+    }
+    res->index = (int32_t*)baker.mem.allocate(sizeof(int32_t) * (size_t)(T ? T : 1), 16);
+    res->triArea = (float*)baker.mem.allocate(sizeof(float) * (size_t)(T ? T : 1), 16);
+    res->arrayHist = (ommCpuOpacityMicromapUsageCount*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapUsageCount) * 2 * kNumLevels, 16);
+    res->indexHist = (ommCpuOpacityMicromapUsageCount*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapUsageCount) * 2 * kNumLevels, 16);
+    if ((E && (!res->arrayData || !res->descs)) || !res->index || !res->triArea || !res->arrayHist || !res->indexHist) return L.failure("[Failure] - the memory allocator returned null for the bake result");
+    const size_t outIdx = DR.indexFormat == ommIndexFormat_UINT_8 ? 1 : (DR.indexFormat == ommIndexFormat_UINT_16 ? 2 : 4);
+    if (E) ok = HIP_OK(hipMemcpyAsync(res->descs, DR.descs, sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, hipMemcpyDeviceToHost, stream0));
+    if (ok && T) ok = HIP_OK(hipMemcpyAsync(res->index, DR.index, outIdx * T, hipMemcpyDeviceToHost, stream0)) && HIP_OK(hipMemcpyAsync(res->triArea, c0.dTriArea, sizeof(float) * (size_t)T, hipMemcpyDeviceToHost, stream0));
+    // the blocks: OMM ranges of ~2 MiB each to the helper threads, while the small arrays above are on their way
+    uint32_t threadsUsed = 1;
+    if (ok && E) {
+        HostScatter S; memset(&S, 0, sizeof S);
+        S.world = N; S.L = layout; S.bits = c0.bits;
+        for (uint32_t r = 0; r < N; ++r) { S.stream[r] = ranks[r].hStream; S.raw[r] = ranks[r].raw; }
+        S.active = hActive.data(); S.owner = hOwner.data(); S.level = hLevel.data(); S.stateMask = hMask.data(); S.order = hOrder.data(); S.dstOfs = hDstOfs.data();
+        S.sizes = hSizes.data(); S.cofs = hCofs.data(); S.arrayData = (uint8_t*)res->arrayData;
+        std::vector<uint32_t> cut; cut.push_back(0);
+        uint64_t acc = 0; for (uint32_t j = 0; j < E; ++j) { acc += hSizes[j]; if (acc >= ((uint64_t)2 << 20)) { cut.push_back(j + 1); acc = 0; } }
+        if (cut.back() != E) cut.push_back(E);
+        unsigned nth = effective_cpus() * 3u / 4u; nth = nth > 12u ? 12u : (nth < 1u ? 1u : nth);
+        if (const uint64_t k = baker.knob(ommxBakerKnob_ExpandThreads)) nth = (unsigned)k;
+        const std::shared_ptr<WorkerPool> pool = baker.worker_pool(nth);
+        pool->run((uint32_t)cut.size() - 1u, [&](uint32_t t) { codec_scatter_omms(S, cut[t], cut[t + 1]); });
+        threadsUsed = pool->workers() + 1u;
+    }
+    ok = ok && HIP_OK(hipStreamSynchronize(stream0));
+    if (!ok) { (void)hipStreamSynchronize(stream0); return L.failure("[Failure] - device to host transfer of the bake result failed"); }
+    memcpy(res->arrayHist, dr->arrayHist, sizeof(ommCpuOpacityMicromapUsageCount) * 2 * kNumLevels);
+    memcpy(res->indexHist, dr->indexHist, sizeof(ommCpuOpacityMicromapUsageCount) * 2 * kNumLevels);
+    res->desc.arrayData = E ? res->arrayData : nullptr; res->desc.arrayDataSize = E ? (uint32_t)DR.arrayDataSize : 0;
+    res->desc.descArray = E ? res->descs : nullptr; res->desc.descArrayCount = E;
+    res->desc.descArrayHistogram = res->arrayHist; res->desc.descArrayHistogramCount = dr->desc.descArrayHistogramCount;
+    res->desc.indexBuffer = res->index; res->desc.indexCount = T; res->desc.indexFormat = DR.indexFormat;
+    res->desc.indexHistogram = res->indexHist; res->desc.indexHistogramCount = dr->desc.indexHistogramCount;
+    {
+        std::lock_guard<std::mutex> g(baker.timingsMu);   // (sharded_finish stored rank 0's phase clocks)
+        uint64_t wire = 0; for (uint32_t r = 0; r < N; ++r) wire += ranks[r].raw ? c0.totals[r] : (ranks[r].hStream ? *(const uint64_t*)ranks[r].hStream : 0);
+        baker.timings.devices = N; baker.timings.resultTransfer = ommxResultTransfer_Compressed; baker.timings.compressedBytes = wire; baker.timings.expandThreads = threadsUsed;
+        baker.timings.expandMs = (float)(now_ms() - tA); baker.timings.totalMs = (float)(now_ms() - t0); baker.timings.contributionBytes = strideBytes;
+    }
+    *out = (ommCpuBakeResult)res;
+    res = nullptr;
     return ommResult_SUCCESS;
 }
 } // namespace
@@ -2410,6 +2655,7 @@ OMM_MI355X_API ommResult ommxSetBakerKnob(ommBaker baker, ommxBakerKnob knob, ui
     if (knob == ommxBakerKnob_GenericPass && value > 2) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_ResultTransfer && value > (uint64_t)ommxResultTransfer_Compressed) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_ExpandThreads && value > 64) return ommResult_INVALID_ARGUMENT;
+    if (knob == ommxBakerKnob_Devices && value > (uint64_t)kMaxRanks) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_RetainMemory) {
         if (value > 1) return ommResult_INVALID_ARGUMENT;
         Baker* bk = untag<Baker>(baker);

@@ -49,6 +49,66 @@ int main()
             ++cases;
         }
     }
-    printf("ok %d effective_cpus %u\n", cases, effective_cpus());
+    // ---- codec_scatter_omms: blocks of a result from the codec streams of their owners' contributions (multi-device ommCpuBake) ----
+    int scatterCases = 0;
+    for (uint32_t world : { 1u, 2u, 3u, 8u }) for (int bits = 1; bits <= 2; ++bits) for (int rep = 0; rep < 3; ++rep) {
+        // OMMs in descending level order (sizes 4^level * bits / 8, at least 1 byte), like the result's; items: some uniform (no stored states)
+        std::vector<uint32_t> order, dstOfs, sizes, stateMask; std::vector<uint64_t> cofs; std::vector<uint8_t> active, owner, level;
+        std::vector<uint64_t> fill(world, 0);
+        uint64_t total = 0;
+        for (int lv = 8; lv >= 0; --lv) {
+            const uint32_t count = lv >= 7 ? 3 + rnd() % 6 : 5 + rnd() % 40;
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t item = (uint32_t)active.size(), bytes = ((1u << (2 * lv)) * (uint32_t)bits) >> 3 ? ((1u << (2 * lv)) * (uint32_t)bits) >> 3 : 1u;
+                const bool uni = rnd() % 7 == 0;
+                active.push_back(uni ? 0 : 1); level.push_back((uint8_t)lv); stateMask.push_back(1u << (rnd() % (bits == 2 ? 4 : 2)));
+                const uint32_t r = (uint32_t)(rnd() % world); owner.push_back(uni ? 0xFF : (uint8_t)r);
+                order.push_back(item); dstOfs.push_back((uint32_t)total); sizes.push_back(bytes); cofs.push_back(uni ? 0 : fill[r]);
+                if (!uni) fill[r] += bytes;
+                total += bytes;
+            }
+        }
+        uint64_t stride = 0; for (uint32_t r = 0; r < world; ++r) stride = fill[r] > stride ? fill[r] : stride;
+        stride = (stride + 255) & ~255ull; if (!stride) stride = 256;
+        // expected result + the contributions
+        std::vector<uint8_t> want(total, 0); std::vector<std::vector<uint8_t>> contrib(world, std::vector<uint8_t>(stride, 0));
+        static const uint8_t pat[4] = { 0x00, 0x55, 0xAA, 0xFF };
+        for (size_t j = 0; j < order.size(); ++j) {
+            uint8_t* d = &want[dstOfs[j]];
+            if (!active[j]) { uint32_t st = 0; for (uint32_t m = stateMask[j]; m > 1; m >>= 1) ++st; uint32_t used = (1u << (2 * level[j])) * bits; if (used > 8) used = 8; uint32_t p = 0; for (uint32_t b = 0; b < used; b += bits) p |= st << b; memset(d, (int)p, sizes[j]); continue; }
+            for (uint32_t o = 0; o < sizes[j]; ) { uint32_t len = 16 * (1 + rnd() % 64); if (o + len > sizes[j]) len = sizes[j] - o; if (rnd() % 5 == 0) for (uint32_t k = 0; k < len; ++k) d[o + k] = (uint8_t)rnd(); else memset(d + o, pat[rnd() % 4], len); o += len; }
+            memcpy(&contrib[owner[j]][cofs[j]], d, sizes[j]);
+        }
+        const HostCodecLayout L = host_codec_layout(stride);
+        std::vector<std::vector<uint8_t>> streams(world);
+        HostScatter S; memset(&S, 0, sizeof S);
+        S.world = world; S.L = L; S.bits = bits;
+        for (uint32_t r = 0; r < world; ++r) {
+            S.raw[r] = rep == 2 && r == 0;   // (one rank's contribution travels uncompressed)
+            if (S.raw[r]) { S.stream[r] = contrib[r].data(); continue; }
+            streams[r].assign(L.offRaw + 16 * L.units + 64, 0xEE);
+            uint32_t* ofs = (uint32_t*)(streams[r].data() + L.offOfs); uint32_t nraw = 0;
+            for (uint64_t u = 0; u < L.units; ++u) {
+                if (u % 256 == 0) ofs[u / 256] = nraw;
+                uint32_t w[4]; memcpy(w, &contrib[r][u * 16], 16);
+                const bool same = w[0] == w[1] && w[0] == w[2] && w[0] == w[3];
+                const uint32_t code = !same ? 4u : (w[0] == 0u ? 0u : (w[0] == 0x55555555u ? 1u : (w[0] == 0xAAAAAAAAu ? 2u : (w[0] == 0xFFFFFFFFu ? 3u : 4u))));
+                uint8_t& c = streams[r][L.offCodes + u / 2];
+                c = (uint8_t)((u & 1) ? ((c & 0x0F) | (code << 4)) : code);
+                if (code == 4u) { memcpy(&streams[r][L.offRaw + 16ull * nraw], w, 16); ++nraw; }
+            }
+            ofs[L.blocks] = nraw; S.stream[r] = streams[r].data();
+        }
+        std::vector<uint8_t> got(total + 64, 0xCD);
+        S.active = active.data(); S.owner = owner.data(); S.level = level.data(); S.stateMask = stateMask.data(); S.order = order.data(); S.dstOfs = dstOfs.data();
+        S.sizes = sizes.data(); S.cofs = cofs.data(); S.arrayData = got.data();
+        WorkerPool pool(3);
+        const uint32_t E = (uint32_t)order.size(), tasks = (E + 15) / 16;
+        pool.run(tasks, [&](uint32_t t) { codec_scatter_omms(S, t * 16, t * 16 + 16 < E ? t * 16 + 16 : E); });
+        if (memcmp(got.data(), want.data(), total) != 0) { printf("SCATTER MISMATCH world=%u bits=%d rep=%d\n", world, bits, rep); return 1; }
+        for (int k = 0; k < 64; ++k) if (got[total + k] != 0xCD) { printf("SCATTER OVERRUN world=%u\n", world); return 1; }
+        ++scatterCases;
+    }
+    printf("ok %d scatter %d effective_cpus %u\n", cases, scatterCases, effective_cpus());
     return 0;
 }

@@ -1626,3 +1626,42 @@ def test_result_transfer_modes_give_the_same_bytes(product, oracle):
             assert ref.same_as(want), ref.diff(want)
         product.destroy_texture(b, t); product.destroy_baker(b)
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [2, 3, 8])
+def test_multi_device_ommCpuBake_equals_one_device(product, oracle, devices):
+    """ommxBakerKnob_Devices: ommCpuBake spread over N devices of the process (one host thread per device; on a one-GPU box the ranks share the device, which
+    exercises everything but the peer copies of the texture): replicated set-up, every rank's share of the classification, the item metadata summed through
+    host memory, the replicated tail, every rank's own blocks as a codec stream, the host writing each block from its owner's stream.  Same bytes as the
+    one-device bake -- mixed levels incl. blocks below a codec block (levels 3 - 5), 2-state and 4-state, uniform items with special indices disabled,
+    a noise texture (raw contributions), dynamic levels -- and the smallest against the oracle."""
+    import bench, workloads as wl
+    rng = np.random.RandomState(5)
+    cases = []
+    tex, uv, ix, lv, kw = wl.workload("c2", 3000); cases.append(("c2", tex, uv, ix, lv, dict(kw)))
+    tex, uv, ix, lv, kw = wl.workload("c4", 6000); cases.append(("c4", tex, uv, ix, lv, dict(kw)))
+    tex, uv, ix, lv, kw = wl.workload("cards", 300); cases.append(("cards", tex, uv, ix, lv, dict(kw)))
+    tex, uv, ix, lv, kw = wl.workload("c1", 5000); cases.append(("c1-2state-nospecial", tex, uv, ix, lv, dict(kw, fmt=ot.FMT_2STATE, flags=ot.FLAG_THREADS | ot.FLAG_NO_SPECIAL)))
+    uvn, ixn = ot.random_triangles(78, 120, 0.4)
+    cases.append(("noise", (rng.rand(512, 512) > 0.5).astype(np.float32), uvn, ixn, (3 + (np.arange(120) % 6)).astype(np.uint8), dict(level=8, addr=ot.WRAP, promo=ot.PROMO_NEAREST)))
+    for name, tex, uv, ix, lv, kw in cases:
+        lvl = kw.pop("level")
+        b = product.create_baker(); t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+        d = ot.make_desc(t, uv, ix, lvl, levels=lv, **kw)
+        one = product.bake(b, d)
+        product.set_knob(b, ot.KNOB_DEVICES, devices)
+        many = product.bake(b, d)
+        tm = bench.get_timings(product, b)
+        assert tm.devices == devices, (name, tm.devices)
+        assert many.same_as(one), (name, devices, many.diff(one))
+        again = product.bake(b, d)   # (shadow bakers, texture copies and pools are reused)
+        assert again.same_as(one), (name, devices, "second bake", again.diff(one))
+        product.set_knob(b, ot.KNOB_DEVICES, 0)
+        assert product.bake(b, d).same_as(one)
+        if name == "c2":
+            ob = oracle.create_baker(); otx = oracle.create_texture(ob, [tex], alpha_cutoff=0.5)
+            want = oracle.bake(ob, ot.make_desc(otx, uv, ix, lvl, levels=lv, **kw))
+            oracle.destroy_texture(ob, otx); oracle.destroy_baker(ob)
+            assert many.same_as(want), many.diff(want)
+        product.destroy_texture(b, t); product.destroy_baker(b)
+
