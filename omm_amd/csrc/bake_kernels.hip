@@ -249,10 +249,12 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
 // the others are marked kTileDead like the tiles without any open group: whoever pops them has nothing to do.
 constexpr uint32_t kChunkWindow = 8, kChunkMaskShift = 12, kChunkMaskBits = 0x7Fu;
 template <bool FP32, class MD, int TILE>
-__global__ __launch_bounds__(256) void triage_groups(ClassifyParams P, ItemArrays A, uint4* __restrict__ queue, const uint32_t* __restrict__ queueCtl, uint32_t numSections)
+__global__ __launch_bounds__(256) void triage_groups(ClassifyParams P, ItemArrays A, uint4* __restrict__ queue, const uint32_t* __restrict__ queueCtl, uint32_t numSections, uint32_t window)
 {
     constexpr uint32_t GROUPS = (uint32_t)TILE / 64u, PER_BLOCK = 256u / GROUPS;   // 64 groups: a wave per tile; 16 groups: four tiles per wave
-    constexpr uint32_t SPAN = GROUPS == 64u ? kChunkWindow : 1u;                   // records a wave (4096-tiles) / a 16-lane slot (1024-tiles: one tile per item, nothing to join) takes in a row
+    // records a wave takes in a row: kChunkWindow for 4096-tiles -- 1 when every item is ONE tile (level 6 only; 1024-tiles always): nothing to join there, and a wave
+    // that walks 8 records one after the other is 8 x the latency of a small bake's triage (configs[1]: 60 -> 15 us)
+    const uint32_t SPAN = GROUPS == 64u ? window : 1u;
     const uint32_t g = threadIdx.x % GROUPS, slot = threadIdx.x / GROUPS;
     const bool coarse = P.useCoarse != 0;
     const bool fastFine = P.filterLinear != 0 && P.mipCount == 1 && !P.noFine && P.altKernel == 0;
@@ -1163,11 +1165,12 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
         const uint32_t cap = numCUs * 16u;   // workgroups (a wave per 4096-tile / four 1024-tiles per wave); the queue's fill is only known on the device
         if (plan.totalSmall) {
             const uint64_t need = (plan.totalSmall + 15u) / 16u;
-            hipLaunchKernelGGL((triage_groups<FP32, MD, 1024>), dim3((uint32_t)(need < cap ? need : cap)), dim3(256), 0, stream, P, A, q1024, (const uint32_t*)ctl1024, 1u);
+            hipLaunchKernelGGL((triage_groups<FP32, MD, 1024>), dim3((uint32_t)(need < cap ? need : cap)), dim3(256), 0, stream, P, A, q1024, (const uint32_t*)ctl1024, 1u, 1u);
         }
         if (plan.totalBig) {
-            const uint64_t need = (plan.totalBig + 3u) / 4u;
-            hipLaunchKernelGGL((triage_groups<FP32, MD, 4096>), dim3((uint32_t)(need < cap ? need : cap)), dim3(256), 0, stream, P, A, queue, (const uint32_t*)queueCtl, paired ? 2u * K : K);
+            const uint32_t window = plan.big.level[0] == 6u ? 1u : kChunkWindow;   // (levels highest first: 6 on top = one tile per item everywhere)
+            const uint64_t need = (plan.totalBig + 4u * window - 1u) / (4u * window);
+            hipLaunchKernelGGL((triage_groups<FP32, MD, 4096>), dim3((uint32_t)(need < cap ? need : cap)), dim3(256), 0, stream, P, A, queue, (const uint32_t*)queueCtl, paired ? 2u * K : K, window);
         }
     }
     // ---- small items: one launch per level ----
