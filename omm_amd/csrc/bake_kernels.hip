@@ -246,10 +246,13 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
 // work (record, texel window, five barriers, tables) on ~20 groups.  triage_groups therefore goes over the queue in windows of kChunkWindow adjacent records
 // (tiles of one work item are adjacent: triage_tiles appends them wave by wave) and joins records of the same item whose open groups fit into 64 slots:
 // the first becomes the chunk's HEAD -- bits 12..18 of its word [0].y say which of the following records belong to it, its rectangle becomes the union --
-// the others are marked kTileDead like the tiles without any open group: whoever pops them has nothing to do.
+// the others are marked kTileDead like the tiles without any open group (whoever pops them has nothing to do) and carry their first slot in those bits.
 constexpr uint32_t kChunkWindow = 8, kChunkMaskShift = 12, kChunkMaskBits = 0x7Fu;
+#ifndef OMMX_TRIAGE_WAVES
+#define OMMX_TRIAGE_WAVES 5   // (96 VGPRs, no scratch; 4 / 5 waves: 0.85 -> 0.75 ms at c2; 6 waves spill 60 bytes)
+#endif
 template <bool FP32, class MD, int TILE>
-__global__ __launch_bounds__(256) void triage_groups(ClassifyParams P, ItemArrays A, uint4* __restrict__ queue, const uint32_t* __restrict__ queueCtl, uint32_t numSections, uint32_t window)
+__global__ __launch_bounds__(256, OMMX_TRIAGE_WAVES) void triage_groups(ClassifyParams P, ItemArrays A, uint4* __restrict__ queue, const uint32_t* __restrict__ queueCtl, uint32_t numSections, uint32_t window)
 {
     constexpr uint32_t GROUPS = (uint32_t)TILE / 64u, PER_BLOCK = 256u / GROUPS;   // 64 groups: a wave per tile; 16 groups: four tiles per wave
     // records a wave takes in a row: kChunkWindow for 4096-tiles -- 1 when every item is ONE tile (level 6 only; 1024-tiles always): nothing to join there, and a wave
@@ -310,11 +313,11 @@ __global__ __launch_bounds__(256) void triage_groups(ClassifyParams P, ItemArray
             const uint32_t open = (uint32_t)__popcll(__ballot(gs < 0) & tileLanes);
             const uint32_t item = r0.x & 0x3FFFFFFFu;
             // join: this record follows the chunk's head when it is of the same item and its open groups still fit
-            bool follower = false;
+            bool follower = false; uint32_t followerStart = 0;
             if (GROUPS == 64u && open != 0u) {
                 const uint32_t ry = uniform_u32(r0.y), rx = uniform_u32(r0.x), rz = uniform_u32(r0.z), rw = uniform_u32(r0.w), ritem = rx & 0x3FFFFFFFu;
                 if (hRec != 0xFFFFFFFFu && ritem == hItem && hOpen + open <= 64u) {
-                    follower = true;
+                    follower = true; followerStart = hOpen;   // (its open groups take the slots behind those of the members before it)
                     hMask |= 1u << (r - hRec - 1u); hOpen += open; hOk = hOk && (rx >> 31) != 0u;
                     const uint32_t sx = rz & 0xFFFFu, sy = rz >> 16, ex = rw & 0xFFFFu, ey = rw >> 16;
                     hSx = sx < hSx ? sx : hSx; hSy = sy < hSy ? sy : hSy; hEx = ex > hEx ? ex : hEx; hEy = ey > hEy ? ey : hEy;
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(256) void triage_groups(ClassifyParams P, ItemArray
             if (g == 0u) {
                 if (mask) atomicOr(&A.stateMask[item], mask);
                 if (P.wantKnownCount && known) atomicAdd(&A.knownCount[item], known);
-                if (open == 0u || follower) ((uint32_t*)rec)[1] = r0.y | kTileDead;
+                if (open == 0u || follower) ((uint32_t*)rec)[1] = r0.y | kTileDead | (followerStart << kChunkMaskShift);   // (bits 12..18 of a follower: its first slot)
             }
             }
             flush();
@@ -359,7 +362,6 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     // sliced tiles: the 64-group SLOTS 0 .. s_gcount-1 of the workgroup hold the OPEN groups of the chunk's tiles (triage_groups settled the others), slot s =
     // group s_gid[s] of the work item's level-(N - 3) enumeration; s_group[s] = its verdict (< 0), s_gdec[s] its bird-curve decode
     __shared__ uint32_t s_gid[SLICED ? TILE / GROUP : 1];
-    __shared__ uint32_t s_mopen[8];              // open groups of each member record of the chunk
     __shared__ uint16_t s_olist[TILE / GROUP];   // the slots that are all-open (taken as whole waves by the single-texel pass)
     __shared__ uint32_t s_gcount, s_ocount;
     __shared__ uint32_t s_qcount, s_ecount;      // queue fill counts (front / back of s_queue)
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     };
     if (SLICED) {
         s_btab[tid] = (uint8_t)bird_table_entry(tid >> 6, tid & 63u);   // (BLOCK == 256 entries)
-        if (tid == 0) { uint32_t sec = 0; s_next = next_record(sec); s_sec = sec; s_nsec = sec; s_retired = 0; }
+        if (tid == 0) { uint32_t sec = 0; s_next = next_record(sec); s_sec = sec; s_nsec = sec; s_retired = 0; s_ocount = 0; }
         __syncthreads();
         qpos = uniform_u32(s_next);
     }
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     // block-uniform item data of a sliced tile
     uint32_t uItem = 0; float uUv[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }; float uMaxAbs = 0.f; bool uDegenerate = false, uFast = false;
     TexWindow W = no_window();
-    if (tid == 0) { s_qcount = 0; s_mask = 0; s_known = 0; s_pending = 0; s_fine = 0; s_ocount = 0; }
+    if (tid == 0) { s_qcount = 0; s_mask = 0; s_known = 0; s_pending = 0; s_fine = 0; }   // (s_ocount: see the end of the tile -- phase 0 adds to it before its first barrier)
     // the single-texel fast pass (fine_single_texel) covers Linear filtering of one mip on non-degenerate items; everything else is generic
     const bool fastFine = SLICED && P.filterLinear != 0 && P.mipCount == 1 && !P.noFine && P.altKernel == 0;
     // micro-triangle i (0 .. TILE) of a sliced tile through the split bird decode: group word + table entry instead of the full decode
@@ -505,48 +507,37 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 windowOk = true;
             }
             // ---- phase 0c: the slot tables.  Wave w takes the chunk's member records w and w + 4 (member 0 = the head, then the records its follower mask
-            //      names): lane = group of the member's tile, verdict byte from the record, the open ones counted (s_mopen); after a barrier every wave
-            //      knows where its members' slots start ----
+            //      names): lane = group of the member's tile, verdict byte from the record; the member's open groups take consecutive slots from the start
+            //      that triage_groups left in the follower's record ----
             constexpr uint32_t GPT = (uint32_t)TILE / GROUP;   // groups per tile
             const uint32_t lane = tid & 63u, wv = tid >> 6;
-            int mgs[2] = { 0, 0 }; uint32_t mtile[2] = { 0u, 0u }; unsigned long long mopen[2] = { 0ull, 0ull };
             #pragma unroll
             for (uint32_t h = 0; h < 2u; ++h) {
                 const uint32_t mi = wv + 4u * h;   // member index
                 // record of member mi: the head itself, or head + 1 + (position of the mi-th set bit of the follower mask)
                 uint32_t fm = followers, ofs = 0; bool have = mi == 0u;
                 for (uint32_t k = 1; k <= mi && fm; ++k) { const uint32_t bit = (uint32_t)__ffs((int)fm) - 1u; fm &= fm - 1u; if (k == mi) { ofs = bit + 1u; have = true; } }
-                if (have) {
-                    const uint4* mrec = tileQueue + (size_t)kTileRecordWords * (qpos + ofs);
-                    mtile[h] = uniform_u32(((const uint32_t*)mrec)[1]) & 0xFFFu;
-                    if (lane < GPT) mgs[h] = group_verdict((uint32_t)((const uint8_t*)(mrec + 3))[lane]);
-                    mopen[h] = __ballot(lane < GPT && mgs[h] < 0);
+                if (!have) continue;   // (wave-uniform)
+                const uint4* mrec = tileQueue + (size_t)kTileRecordWords * (qpos + ofs);
+                const uint32_t my = uniform_u32(((const uint32_t*)mrec)[1]);
+                const uint32_t mtile = my & 0xFFFu, start = mi == 0u ? 0u : (my >> kChunkMaskShift) & kChunkMaskBits;
+                const int gs = lane < GPT ? group_verdict((uint32_t)((const uint8_t*)(mrec + 3))[lane]) : 0;
+                const unsigned long long open = __ballot(lane < GPT && gs < 0);
+                const bool mine = ((open >> lane) & 1ull) != 0ull;
+                const uint32_t sl = start + (uint32_t)__popcll(open & ((1ull << lane) - 1ull));
+                if (mine) {
+                    const uint32_t gid = mtile * GPT + lane;
+                    s_group[sl] = gs; s_gid[sl] = gid; s_gdec[sl] = bird_group(gid, level - 3).word;
                 }
-                if (lane == 0u) s_mopen[mi] = (uint32_t)__popcll(mopen[h]);
-            }
-            __syncthreads();
-            {
-                uint32_t total = 0, start[2] = { 0u, 0u };
-                #pragma unroll
-                for (uint32_t mi = 0; mi < 8u; ++mi) { if (mi == wv) start[0] = total; if (mi == wv + 4u) start[1] = total; total += s_mopen[mi]; }
-                #pragma unroll
-                for (uint32_t h = 0; h < 2u; ++h) {
-                    const bool mine = lane < GPT && ((mopen[h] >> lane) & 1ull) != 0ull;
-                    const uint32_t sl = start[h] + (uint32_t)__popcll(mopen[h] & ((1ull << lane) - 1ull));
-                    if (mine) {
-                        const uint32_t gid = mtile[h] * GPT + lane;
-                        s_group[sl] = mgs[h]; s_gid[sl] = gid; s_gdec[sl] = bird_group(gid, level - 3).word;
-                    }
-                    // the all-open slots, compacted in any order (the single-texel pass takes them as whole waves)
-                    const unsigned long long ao = __ballot(mine && mgs[h] == kRegionAllOpen);
-                    if (ao) {
-                        uint32_t ob = 0;
-                        if (lane == 0u) ob = atomicAdd(&s_ocount, (uint32_t)__popcll(ao));
-                        ob = __shfl(ob, 0);
-                        if (mine && mgs[h] == kRegionAllOpen) s_olist[ob + (uint32_t)__popcll(ao & ((1ull << lane) - 1ull))] = (uint16_t)sl;
-                    }
+                // the all-open slots, compacted in any order (the single-texel pass takes them as whole waves)
+                const unsigned long long ao = __ballot(mine && gs == kRegionAllOpen);
+                if (ao) {
+                    uint32_t ob = 0;
+                    if (lane == 0u) ob = atomicAdd(&s_ocount, (uint32_t)__popcll(ao));
+                    ob = __shfl(ob, 0);
+                    if (mine && gs == kRegionAllOpen) s_olist[ob + (uint32_t)__popcll(ao & ((1ull << lane) - 1ull))] = (uint16_t)sl;
                 }
-                if (tid == 0) s_gcount = total;
+                if (fm == 0u && lane == 0u) s_gcount = start + (uint32_t)__popcll(open);   // (the last member: no follower behind it)
             }
             __syncthreads();
             if (windowOk) { const DevMip& m0 = P.mips[0]; W.tex = (lds_float*)s_wtex; W.sat = (lds_u32*)s_wsat; W.base = m0.texels; W.sx = r.sx; W.sy = r.sy; W.w = ww; W.h = wh; } // (SAT part is only read when coarse is on)
@@ -755,7 +746,8 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
         // workgroup-scope release in front of it needs no wait), then ONE device-scope release by thread 0 writes the L2 back -- a write-back per wave
         // measured 0.8 ms more on the metric configuration
         if (s_nsec != s_sec) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
-        if (tid == 0) s_next = nextPos;   // next tile of this workgroup (requested at the top of the loop); published with the barrier below
+        if (tid == 0) { s_next = nextPos; s_ocount = 0; }   // next tile of this workgroup (requested at the top of the loop); published with the barrier below
+                                                          // (s_ocount was last read in phase 2a; the next tile's phase 0 adds to it in front of its first barrier)
         __syncthreads();
         if (tid == 0) {
             if (s_mask) atomicOr(&A.stateMask[uItem], s_mask);
