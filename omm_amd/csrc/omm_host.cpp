@@ -615,6 +615,7 @@ struct StreamOut {
     // in
     uint32_t chunksWanted = 0;        // 0 = decide from the size of the bake
     bool forced = false;              // (knob set: stream whatever the size)
+    bool compressedAvailable = false; // the caller can send the finished array as a codec stream instead (helper threads): stream only when that is the faster of the two
     ArenaSet* set = nullptr; hipStream_t copyStream = nullptr, placeStream = nullptr;
     void* allocUser = nullptr; uint8_t* (*alloc)(void* user, uint64_t upperBoundBytes, bool* pinned) = nullptr;   // the host arrayData, before the first block leaves
     int device = 0;
@@ -981,6 +982,17 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             // cards, where streaming the 0.28 GB result made the bake 10 ms SLOWER).
             const double classifyMs = 2.5e-10 * microAll + 4e-9 * (double)hc.workload, copyMs = (double)hc.stateBytes / 57e6;
             if (copyMs <= 0.25 * classifyMs) k = 0;
+            // ... and, when the compressed transfer is available too (round 5: the codec stream over the link, expanded by the helper threads AFTER the bake), only
+            // when streaming wins.  Both are priced from the same two quantities, with this round's rates (1.35e-10 ms per micro-triangle: 8.8 ms for 6.5e10, 88 for
+            // 6.0e11) and 65 % of the packed states as the result (what is left after promotion and dedup at the metric configuration):
+            //     streamed    6 + max(1.15 classification + 2.7 (preview), result / 57 GB/s)       c2: 28.3 (29.4 measured)   configs[4]: 110 (was 118 at 95 ms)
+            //     compressed  3.3 + classification + result / 150 GB/s + codec (0.63 ms per GB)       c2: 18.4 (17 - 20)         configs[4]: 117 (124)
+            // -- a long classification hides the whole copy, a short one is better off with every workgroup on the chip and the expansion behind it.
+            if (k && so->compressedAvailable) {
+                const double cMs = 1.35e-10 * microAll + 4e-9 * (double)hc.workload, resultBytes = 0.65 * (double)hc.stateBytes;
+                const double streamedMs = 6.0 + std::max(1.15 * cMs + 2.7, resultBytes / 57e6), compressedMs = 3.3 + cMs + resultBytes / 150e6 + resultBytes * 0.63e-9;
+                if (compressedMs <= streamedMs) k = 0;
+            }
         }
         if (k > kMaxStreamRanges) k = kMaxStreamRanges;
         if (k && so->set->pinned.reserve(4096) && (hostArray = so->alloc(so->allocUser, hc.stateBytes, &hostPinned)) != nullptr) { streamChunks = k; hCursor = (unsigned long long*)so->set->pinned.base; }
@@ -1418,7 +1430,10 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     if (const uint64_t k = baker.knob(ommxBakerKnob_ExpandThreads)) expandThreads = (unsigned)k;
     const bool wantCompressed = !so.forced && (transferKnob == ommxResultTransfer_Compressed ||
                                                (transferKnob == ommxResultTransfer_Auto && ((uint32_t)d.bakeFlags & (uint32_t)ommCpuBakeFlags_EnableInternalThreads) != 0 && effective_cpus() >= 6u));
-    const bool canStream = !wantCompressed && transferKnob != ommxResultTransfer_Plain && ses.open_comm() && ses.open_place();
+    // (automatic choice with threads: both transfers are on offer, bake_core prices them once it knows the size of the bake -- a classification of 100 ms hides the
+    //  whole copy of a streamed result, configs[4]; a short one is better off with the compressed transfer behind it, the metric configuration)
+    so.compressedAvailable = wantCompressed && transferKnob == ommxResultTransfer_Auto;
+    const bool canStream = (!wantCompressed || so.compressedAvailable) && transferKnob != ommxResultTransfer_Plain && ses.open_comm() && ses.open_place();
     so.copyStream = ses.commStream; so.placeStream = ses.placeStream; so.device = baker.bind_device();
     const ommResult br = bake_core(baker, d, din, &d, ses.arena, ses.states, stream, et, R, tm, nullptr, nullptr, canStream ? &so : nullptr);
     if (br != ommResult_SUCCESS) return br;

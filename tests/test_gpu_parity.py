@@ -387,8 +387,14 @@ def test_full_size_mixed_levels_config4(product, oracle):
     # baker's helper threads (round 5) -- the bytes must be those of the device-resident entry
     full = product.bake(b, d, want_stats=False)
     tm = bench.get_timings(product, b)
-    if bench.effective_cpus(os.cpu_count())[0] >= 6:
-        assert tm.resultTransfer == ot.TRANSFER_COMPRESSED and 0 < tm.compressedBytes < full.array_data.size // 4 and tm.expandThreads >= 4, (tm.resultTransfer, tm.compressedBytes, tm.expandThreads)
+    assert tm.resultTransfer in (ot.TRANSFER_COMPRESSED, ot.TRANSFER_STREAMED), tm.resultTransfer   # (the automatic choice: a classification this long hides a streamed copy)
+    # the compressed transfer: the finished array crosses PCIe as a codec stream and is expanded by the baker's helper threads (round 5)
+    product.set_knob(b, ot.KNOB_RESULT_TRANSFER, ot.TRANSFER_COMPRESSED)
+    comp = product.bake(b, d, want_stats=False)
+    tm = bench.get_timings(product, b)
+    assert tm.resultTransfer == ot.TRANSFER_COMPRESSED and 0 < tm.compressedBytes < full.array_data.size // 4 and tm.expandThreads >= 1, (tm.resultTransfer, tm.compressedBytes, tm.expandThreads)
+    assert comp.same_as(full), comp.diff(full)
+    del comp
     # the streamed transfer (rounds 3 - 4: blocks placed and copied while the classification runs, tail_kernels.hip "Streamed result"): it must not have fallen
     # back -- at this size a family of possible duplicates once spanned two levels and pulled level-10 items behind their own placement
     product.set_knob(b, ot.KNOB_RESULT_TRANSFER, ot.TRANSFER_STREAMED)
