@@ -1508,14 +1508,26 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
             if (ok) {
                 const std::shared_ptr<WorkerPool> poolRef = baker.worker_pool(expandThreads); WorkerPool& pool = *poolRef;
                 uint8_t* dst = (uint8_t*)res->arrayData; const uint64_t dstBytes = R.arrayDataSize; const HostCodecLayout L = co.L;
-                constexpr uint64_t kTaskBlocks = 512;   // 2 MiB of the array per task
-                for (uint32_t k = 0; ok && k < kSlices; ++k) {
-                    ok = HIP_OK(hipEventSynchronize(evs[k]));
-                    const uint64_t b0 = blockCut[k], b1 = blockCut[k + 1];
-                    if (!ok || b1 <= b0) continue;
-                    const uint32_t tasks = (uint32_t)((b1 - b0 + kTaskBlocks - 1) / kTaskBlocks);
-                    pool.run(tasks, [&](uint32_t t) { const uint64_t s0 = b0 + (uint64_t)t * kTaskBlocks, s1 = s0 + kTaskBlocks < b1 ? s0 + kTaskBlocks : b1; codec_expand_blocks(dst, dstBytes, hStream, L, s0, s1); });
-                }
+                // ONE run over all tasks (2 MiB of the array each, in slice order): a task whose slice is not on the host yet polls the slices' events in order --
+                // whichever thread gets there first moves the `arrived` mark -- so the threads never meet at a barrier between slices (12 runs, one per slice,
+                // cost ~0.5 ms of joins and idle tails)
+                constexpr uint64_t kTaskBlocks = 512;
+                const uint64_t numTasks = (co.L.blocks + kTaskBlocks - 1) / kTaskBlocks;
+                std::atomic<uint32_t> arrived{ 0 }; std::atomic<bool> failed{ false };
+                ok = HIP_OK(hipEventSynchronize(evs[0]));
+                if (ok) arrived.store(1);
+                if (ok) pool.run((uint32_t)numTasks, [&](uint32_t t) {
+                    const uint64_t s0 = (uint64_t)t * kTaskBlocks, s1 = s0 + kTaskBlocks < L.blocks ? s0 + kTaskBlocks : L.blocks;
+                    uint32_t need = 0; while (need + 1u < kSlices && blockCut[need + 1u] < s1) ++need;   // the last slice this task reads from
+                    for (uint32_t a; (a = arrived.load(std::memory_order_acquire)) <= need && !failed.load(std::memory_order_relaxed); ) {
+                        const hipError_t q = hipEventQuery(evs[a]);
+                        if (q == hipSuccess) { uint32_t expect = a; arrived.compare_exchange_strong(expect, a + 1u, std::memory_order_acq_rel); }
+                        else if (q != hipErrorNotReady) { (void)hipGetLastError(); failed.store(true); }
+                        else { (void)hipGetLastError(); std::this_thread::yield(); }
+                    }
+                    if (!failed.load(std::memory_order_relaxed)) codec_expand_blocks(dst, dstBytes, hStream, L, s0, s1);
+                });
+                ok = ok && !failed.load();
                 tm.expandThreads = pool.workers() + 1u;
             }
             if (!ok) (void)hipStreamSynchronize(stream);   // (nothing may still be landing in the pinned block when the session hands it back)
