@@ -1,6 +1,7 @@
 // host_expand.cpp -- see host_expand.h
 #include "host_expand.h"
 #include <emmintrin.h>
+#include <immintrin.h>
 #include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -84,6 +85,20 @@ HostCodecLayout host_codec_layout(uint64_t paddedBytes)
 
 namespace {
 const uint32_t kPattern[4] = { 0u, 0x55555555u, 0xAAAAAAAAu, 0xFFFFFFFFu };
+// a 4 KiB block of one repeated state (96 % of the blocks of a bake): non-temporal stores as wide as the CPU has them (the destination is 16-byte aligned;
+// 4 KiB blocks of an aligned array are then 32- / 64-byte aligned iff the array is, which is checked per call)
+__attribute__((target("avx2"))) void fill4k_avx2(uint8_t* d, uint32_t pattern)
+{
+    const __m256i v = _mm256_set1_epi32((int)pattern);
+    for (int k = 0; k < 128; ++k) _mm256_stream_si256((__m256i*)(d + 32 * k), v);
+}
+void fill4k_sse2(uint8_t* d, uint32_t pattern)
+{
+    const __m128i v = _mm_set1_epi32((int)pattern);
+    for (int k = 0; k < 256; ++k) _mm_stream_si128((__m128i*)(d + 16 * k), v);
+}
+typedef void (*Fill4k)(uint8_t*, uint32_t);
+const Fill4k g_fill4k = __builtin_cpu_supports("avx2") ? fill4k_avx2 : fill4k_sse2;
 template <bool NT> inline void put16(uint8_t* d, __m128i v) { if (NT) _mm_stream_si128((__m128i*)d, v); else _mm_storeu_si128((__m128i*)d, v); }
 template <bool NT>
 void expand(uint8_t* dst, uint64_t dstBytes, const uint8_t* stream, const HostCodecLayout& L, uint64_t b0, uint64_t b1)
@@ -101,6 +116,7 @@ void expand(uint8_t* dst, uint64_t dstBytes, const uint8_t* stream, const HostCo
             bool same = (w0 & 0xCCCCCCCCCCCCCCCCull) == 0 && ((w0 >> 4) & 0x0F0F0F0F0F0F0F0Full) == (w0 & 0x0F0F0F0F0F0F0F0Full) && w0 == (w0 & 0xFF) * 0x0101010101010101ull;
             for (int k = 1; same && k < 16; ++k) { uint64_t w; memcpy(&w, codes + 8 * k, 8); same = w == w0; }
             if (same) {
+                if (NT && ((uintptr_t)d & 31u) == 0u) { g_fill4k(d, kPattern[w0 & 3u]); continue; }
                 const __m128i v = _mm_set1_epi32((int)kPattern[w0 & 3u]);
                 for (int k = 0; k < 256; ++k) put16<NT>(d + 16 * k, v);
                 continue;

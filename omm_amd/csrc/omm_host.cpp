@@ -2183,16 +2183,19 @@ ommResult sharded_finish(ShardedBake* sb, ScatterFn&& scatter, ommxDeviceBakeRes
 // No all-gather of the array: the 1.27 GB of the metric configuration cross the links as N streams of ~82 / N MB.
 // ================================================================================================
 struct RankTeam {
-    uint32_t n = 1; std::mutex mu; std::condition_variable cv; uint32_t arrived = 0; uint64_t generation = 0; bool allOk = true, result = true;
-    // every rank arrives with its status; all leave with the conjunction
+    uint32_t n = 1; std::mutex mu; std::condition_variable cv; uint32_t arrived = 0; uint64_t generation = 0; bool allOk = true, result = true, aborted = false;
+    // every rank arrives with its status; all leave with the conjunction.  A rank that cannot go on at all (an exception) calls abort(): every rank that waits
+    // or arrives later leaves with false at once, so nobody waits for a rank that is gone.
     bool barrier(bool ok) {
         std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return false;
         allOk = allOk && ok;
         if (++arrived == n) { result = allOk; allOk = true; arrived = 0; ++generation; cv.notify_all(); return result; }
         const uint64_t g = generation;
-        cv.wait(lk, [&] { return generation != g; });
-        return result;
+        cv.wait(lk, [&] { return generation != g || aborted; });
+        return aborted ? false : result;
     }
+    void abort() { std::lock_guard<std::mutex> g(mu); aborted = true; cv.notify_all(); }
 };
 // the texture of `d` on device `dev` (the original when that is where it lives)
 Texture* texture_on_device(Texture* t, int dev)
@@ -2317,16 +2320,16 @@ ommResult bake_impl_multi(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBake
     // rank 0 is the calling thread; a rank whose thread cannot be started is run by the caller AFTER the others would deadlock the barriers: refuse instead
     std::vector<std::thread> threads;
     bool spawned = true;
-    try { threads.reserve(N); for (uint32_t r = 1; r < N; ++r) threads.emplace_back(body, r); } catch (...) { spawned = false; }
+    // (nothing may leave a rank's thread: an exception -- std::bad_alloc of a host vector -- fails the rank and releases the others from their barriers)
+    auto guardedBody = [&](uint32_t r) { try { body(r); } catch (...) { ranks[r].status = ommResult_FAILURE; team.abort(); } };
+    try { threads.reserve(N); for (uint32_t r = 1; r < N; ++r) threads.emplace_back(guardedBody, r); } catch (...) { spawned = false; }
     if (!spawned) {
-        // (threads that did start wait in the first barrier for ranks that never come: let them through with a failure)
-        for (size_t k = threads.size() + 1; k < N; ++k) (void)team.barrier(false);
-        (void)team.barrier(false);
+        team.abort();   // (threads that did start wait in the first barrier for ranks that never come)
         for (auto& t : threads) t.join();
         for (Rank& R : ranks) { const DeviceScope onDev(R.dev); if (R.sb) R.baker->mem.destroy(R.sb); if (R.dRaw) R.baker->devPool->release(R.dRaw); if (R.dCodec) R.baker->devPool->release(R.dCodec); }
         return L.failure("[Failure] - multi-device bake: could not start a thread per device");
     }
-    body(0);
+    guardedBody(0);
     for (auto& t : threads) t.join();
     struct Cleanup { std::vector<Rank>& ranks; ~Cleanup() { for (Rank& R : ranks) { const DeviceScope onDev(R.dev); if (R.sb) R.baker->mem.destroy(R.sb); if (R.dRaw) R.baker->devPool->release(R.dRaw); if (R.dCodec) R.baker->devPool->release(R.dCodec); } } } cleanup{ ranks };
     for (const Rank& R : ranks) if (R.status != ommResult_SUCCESS) return R.status;
