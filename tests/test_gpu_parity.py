@@ -1671,3 +1671,30 @@ def test_multi_device_ommCpuBake_equals_one_device(product, oracle, devices):
             assert many.same_as(want), many.diff(want)
         product.destroy_texture(b, t); product.destroy_baker(b)
 
+
+@pytest.mark.gpu
+def test_compressed_transfer_from_concurrent_callers(product):
+    """Several caller threads bake large results on ONE baker at the same time (docs/integration_guide.md:434): each call has its own working set and pinned
+    staging, the baker's helper threads expand one result at a time; and a multi-device bake next to them.  Same bytes as a bake on its own."""
+    import threading, bench, workloads as wl
+    tex, uv, ix, lv, kw = wl.workload("c2", 60000)
+    kw = dict(kw); lvl = kw.pop("level")
+    b = product.create_baker(); t = product.create_texture(b, [tex], alpha_cutoff=0.5)
+    d = ot.make_desc(t, uv, ix, lvl, **kw)
+    product.set_knob(b, ot.KNOB_RESULT_TRANSFER, ot.TRANSFER_COMPRESSED)
+    ref = product.bake(b, d, want_stats=False)
+    assert bench.get_timings(product, b).resultTransfer == ot.TRANSFER_COMPRESSED
+    out, errs = {}, []
+    def work(k):
+        try:
+            for rep in range(3):
+                out[(k, rep)] = product.bake(b, d, want_stats=False)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for th in ths: th.start()
+    for th in ths: th.join()
+    assert not errs, errs
+    assert len(out) == 12 and all(r.same_as(ref) for r in out.values())
+    product.destroy_texture(b, t); product.destroy_baker(b)
+
