@@ -12,6 +12,8 @@ Prints ONE JSON line (rank 0):
   = bake_wall_time_ms   arrays out, PCIe inclusive (SURVEY.md section 8d defines both metrics on it); K timed steps after W warm-up steps; details: host_api
   device_resident       the SAME bake through ommxBakeDevice (UV / index inputs and result arrays resident in HBM), same steps and warm-up.
                         (N > 1 GPUs: the sharded device-resident entry is the headline; value_same_entry_as_n_gt_1 = the same entry at every N.)
+  host_api              details of the ommCpuBake steps: how arrayData reached the host (result_transfer: plain / streamed / compressed, --result-transfer;
+                        bytes over PCIe, codec and expansion times, helper threads), --devices N = the same call spread over N devices of this process
   roofline              what limits the dominant kernel (classify_tiles): VALU issue slots; roofline_hbm = the HBM view on the units the
                         launch really processes; cpu_baseline = the oracle (port of the reference CPU baker) on the host cores, same run
 """
