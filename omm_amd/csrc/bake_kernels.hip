@@ -980,9 +980,19 @@ __device__ __forceinline__ void generic_walks(const ClassifyParams& P, const Ite
                     hb = gw - gx; hc = gy - gx; hd = gx + gz - gy - gw; ha = gx - P.cutoff;
                     const bool flat = near_zero(hb, 1e-6f) & near_zero(hc, 1e-6f) & near_zero(hd, 1e-6f);
                     const bool seen = !countsMatter & (o0 == o1) & (o1 == o2) & (o2 == o3) & (o0 ? above != 0 : below != 0);
+                    // a cell that is not flat needs its three edge tests -- unless the level curve provably stays out of it (cell_excluded, classify_device.h: audited
+                    // by the oracle next to every edge test): most cells of a long walk are such cells, all four texels on a side the walk has seen, in the smooth
+                    // flank of an alpha edge.  They are passed like the flat ones, so the edge tests below run for the cells that need them.
+                    bool edgesNeeded = !flat;
+#ifndef OMMX_NO_CELL_EXCLUSION
+                    if (edgesNeeded) {
+                        const V2 q0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy), q1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy), q2 = mk2(m.fw * t.p2.x - pfx, m.fh * t.p2.y - pfy);
+                        edgesNeeded = !cell_excluded(q0, q1, q2, ha, hb, hc, hd);
+                    }
+#endif
                     corners = !seen;
-                    cell = !seen | !flat;
-                    obits = (o0 ? 1u : 0u) | (o1 ? 2u : 0u) | (o2 ? 4u : 0u) | (o3 ? 8u : 0u) | (flat ? 16u : 0u);
+                    cell = !seen | edgesNeeded;
+                    obits = (o0 ? 1u : 0u) | (o1 ? 2u : 0u) | (o2 ? 4u : 0u) | (o3 ? 8u : 0u) | (flat ? 16u : 0u) | (edgesNeeded ? 32u : 0u);
                     step();
                 }
             }
@@ -990,7 +1000,7 @@ __device__ __forceinline__ void generic_walks(const ClassifyParams& P, const Ite
         }
         // ---- the cells that need work: bake_kernels_cpu.h:241-399 ----
         if (cell) {
-            const bool o0 = (obits & 1u) != 0u, o1 = (obits & 2u) != 0u, o2 = (obits & 4u) != 0u, o3 = (obits & 8u) != 0u, flat = (obits & 16u) != 0u;
+            const bool o0 = (obits & 1u) != 0u, o1 = (obits & 2u) != 0u, o2 = (obits & 4u) != 0u, o3 = (obits & 8u) != 0u, flat = (obits & 16u) != 0u, edgesNeeded = (obits & 32u) != 0u;
             bool both = false;
             if (corners) {
                 const float ipx = pfx * m.rw, ipy = pfy * m.rh;
@@ -1001,7 +1011,7 @@ __device__ __forceinline__ void generic_walks(const ClassifyParams& P, const Ite
                 both = isO & isT;
                 if (flat & !both) vote(o0, above, below);
             }
-            if (!flat & !both & (countsMatter | !(above != 0 && below != 0))) {
+            if (edgesNeeded & !both & (countsMatter | !(above != 0 && below != 0))) {
                 const V2 q0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy), q1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy), q2 = mk2(m.fw * t.p2.x - pfx, m.fh * t.p2.y - pfy);
                 const bool x0 = edge_crosses_level_curve(q0, q1, ha, hb, hc, hd), x1 = edge_crosses_level_curve(q1, q2, ha, hb, hc, hd), x2 = edge_crosses_level_curve(q2, q0, ha, hb, hc, hd);
                 if (x0 | x1 | x2) { above += 1; below += 1; }

@@ -491,6 +491,51 @@ __device__ __forceinline__ bool curve_excluded(V2 r0, V2 r1, V2 r2, float ha, fl
     return ok & (F > 0.f) & (F * c0lb > 1.01f * E * C1b * C1b);
 }
 
+// ---- cell exclusion: curve_excluded()'s question for micro-triangles LARGER than the texel (the deferred generic pass: classify_generic) ----
+// r0..r2 are the vertices in the texel's frame (the texel is [0,1]^2), up to tens of texels away.  An edge test succeeds only if its computed root
+// (x^, y^) passes in_unit_square -- an exact test on the computed values -- so the region that matters is the unit cell itself, where the extremes of the
+// bilinear f sit in the four corners: f00 = ha, f10 = ha + hb, f01 = ha + hc, f11 = ha + hb + hc + hd.  The approximate-zero bounds R of the three
+// branches (above) hold with the coordinate bound 2.5 replaced by Rc = the largest |coordinate| of the three vertices: it enters only through the
+// intercept |m| <= Rc (1 + K) of an edge's carrier line and, with it, the bounds C1, C2 on the line's coefficients.  Slopes are bounded per edge
+// (one v_rcp_f32 each, widened by 2e-6) instead of over the triangle: asset triangles have axis-aligned edges, for which a common bound is useless --
+//     |kd| < 1e-6       the reference's vertical branch (same float, same decision): R = 5.2 e S;
+//     dy == 0           k = +-0 exactly, so c0 = +-0 and the reference takes its linear branch: R_linear with K = 0;
+//     1e-6 <= |kd| < 1e-4   steep, the bounds explode: not excluded.
+// If min |f| over the corners, less the evaluation error of the corners (66 e S), exceeds every edge's bound, the level curve cannot be found inside this
+// texel by any of the three edge tests, and they are skipped.  The kernel evaluates the bounds with e = 4.8e-7, EIGHT times the rounding unit they were
+// derived for: the bounds are tiny against a typical |f| (the audit's exclusion rate barely moves between 8x and 1x), so the margin is free.  Audited
+// like curve_excluded: the audit build of the oracle evaluates this predicate next to the three edge tests for every visit of the level-line kernel,
+// at 8x (shipped), at 1x (the derivation) and at 0.25x (a probe below it, which does find exclusions next to a crossing: the derivation is not slack
+// by a large factor, the shipped form is) -- tests/test_edge_prefilter_audit.py.
+__device__ __forceinline__ bool cell_excluded(V2 r0, V2 r1, V2 r2, float ha, float hb, float hc, float hd)
+{
+    const float E = 4.8e-7f;
+    const float f10 = ha + hb, f01 = ha + hc, f11 = f10 + (hc + hd);
+    const float fmn = __builtin_fminf(__builtin_fminf(ha, f10), __builtin_fminf(f01, f11)), fmx = __builtin_fmaxf(__builtin_fmaxf(ha, f10), __builtin_fmaxf(f01, f11));
+    const float aa = __builtin_fabsf(ha), ab = __builtin_fabsf(hb), ac = __builtin_fabsf(hc), ad = __builtin_fabsf(hd);
+    const float S = aa + ab + ac + ad;
+    const float F = __builtin_fmaxf(fmn, -fmx) - 66.f * E * S;
+    const float Rc = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(r0.x), __builtin_fabsf(r0.y)), __builtin_fmaxf(__builtin_fabsf(r1.x), __builtin_fabsf(r1.y))),
+                                     __builtin_fmaxf(__builtin_fabsf(r2.x), __builtin_fabsf(r2.y)));
+    bool ok = (Rc <= 64.f) & (F > 0.f);
+    const V2 ea[3] = { r0, r1, r2 }, eb[3] = { r1, r2, r0 };
+    #pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const float dx = __builtin_fabsf(eb[e].x - ea[e].x), dy = __builtin_fabsf(eb[e].y - ea[e].y);
+        const bool vertical = dx < 1e-6f;
+        const float Kub = (dy * __builtin_amdgcn_rcpf(dx)) * 1.000002f, Klb = (dy * __builtin_amdgcn_rcpf(dx)) * 0.999998f;
+        const float Mb = Rc * (1.f + Kub) * 1.000001f;
+        const float C1b = (ac * Kub + ad * Mb + ab) * 1.000001f;
+        const float C2b = (aa + ac * Mb) * 1.000001f;
+        const float rest = 1.0001e-6f + E * (9.1f * C2b + 8.1f * C1b + 6.1f * ad * Kub + 2.02f * (ac + ad) * (Kub + 1.f)) + 1e-30f;
+        const float c0lb = __builtin_fmaxf(ad * Klb * 0.999999f, 0.999999e-6f);
+        const float Fe = F - rest;
+        const bool sloped = (dx >= 1e-4f) & (Fe > 0.f) & ((dy == 0.f) | (Fe * c0lb > 1.01f * E * C1b * C1b));
+        ok = ok & (vertical ? (F > 5.2f * E * S + 1e-30f) : sloped);
+    }
+    return ok;
+}
+
 // bake_kernels_cpu.h:241-399 : one texel of the bilinear footprint grid.  Adds to (above, below).
 template <bool FP32, bool DEGENERATE, class MD>
 __device__ __forceinline__ void level_line_texel(const ClassifyParams& P, const DevMip& m, const MicroTri& tIn, int px, int py,

@@ -87,3 +87,50 @@ def test_curve_exclusion_on_adversarial_patches(audit):
     calls3, excluded3, bad3, crossings3 = (audit.dll.orc_audit_curve_counter(i) for i in range(4))
     assert calls3 > 200000 and excluded3 > 1000 and crossings3 > 1000, (calls3, excluded3, crossings3)
     assert bad3 == 0
+
+
+def _cell_counts(audit):
+    audit.dll.orc_audit_cell_counter.restype = C.c_longlong
+    audit.dll.orc_audit_cell_counter.argtypes = [C.c_int]
+    return [audit.dll.orc_audit_cell_counter(i) for i in range(8)]
+
+
+def test_cell_exclusion_on_asset_sized_triangles(audit):
+    """cell_excluded() (classify_device.h): micro-triangles LARGER than a texel -- the generic texel-loop path of asset-sized
+    triangles.  Every visit of the level-line kernel evaluates the predicate next to the three edge tests: it must never hold where one of them finds
+    the curve.  Axis-aligned quads (vertical and exactly horizontal edges), random triangles, smooth / noisy / adversarial alpha, UNORM8 and FP32,
+    micro-triangles of 1 .. 60 texels.  The kernel ships the bounds with 8x the rounding unit they are derived for; the derivation itself (1x) and a probe
+    below it (0.25x) are evaluated alongside."""
+    import workloads as wl
+    audit.dll.orc_audit_cell_reset()
+    rng = np.random.RandomState(11)
+    yy, xx = np.mgrid[0:256, 0:256].astype(np.float32)
+    texs = [
+        ot.foliage_texture(77, 512, 512, feature=48),
+        (ot.value_noise(5, 300, 200, octaves=5, base_cell=24)).astype(np.float32),
+        (0.5 + 1e-6 * (xx - 128) + 3e-7 * (yy - 128) + 1e-8 * (xx - 128) * (yy - 128)).astype(np.float32),        # nearly flat, twist ~1e-8
+        (0.5 + 1e-3 * np.sin(xx * 0.7) * np.cos(yy * 0.9) + 2e-6 * rng.rand(256, 256)).astype(np.float32),         # alpha hugging the cutoff
+        (rng.rand(256, 256) > 0.5).astype(np.float32),                                                                # 0 / 1 noise: steep patches, |hd| up to 2
+        (0.5 + 0.25 * np.sin(xx * 0.05) + 1e-5 * xx * yy / 256).astype(np.float32),
+    ]
+    b = audit.create_baker()
+    for ti, tx in enumerate(texs):
+        t = audit.create_texture(b, [tx], alpha_cutoff=-1.0)
+        size = tx.shape[0]
+        # quads of 20 .. 400 texels at levels 3 .. 6 (micro-triangles of 1 .. 50 texels), and random (not axis-aligned) triangles
+        uv, ix, lv = wl.card_quads(30 + ti, 12, size, lo_texels=20.0, hi_texels=min(400.0, size * 0.8))
+        for level in (3, 5):
+            audit.bake(b, ot.make_desc(t, uv, ix, level, addr=ot.CLAMP, promo=ot.PROMO_NEAREST, flags=ot.FLAG_THREADS | ot.FLAG_NO_DEDUP), want_stats=False)
+        uv2, ix2 = ot.random_triangles(400 + ti, 40, 0.15)
+        for level, addr in ((3, ot.WRAP), (5, ot.MIRROR)):
+            audit.bake(b, ot.make_desc(t, uv2, ix2, level, addr=addr, promo=ot.PROMO_NEAREST, flags=ot.FLAG_THREADS | ot.FLAG_NO_DEDUP), want_stats=False)
+        # nearly vertical / nearly horizontal edges: the quads sheared by a few 1e-7 .. 1e-3
+        uvs = uv.copy(); uvs[:, 0] += (uvs[:, 1] * np.float32(1e-4)).astype(np.float32)
+        audit.bake(b, ot.make_desc(t, uvs, ix, 4, addr=ot.CLAMP, promo=ot.PROMO_NEAREST, flags=ot.FLAG_THREADS | ot.FLAG_NO_DEDUP), want_stats=False)
+        audit.destroy_texture(b, t)
+    audit.destroy_baker(b)
+    calls, excluded, bad, crossings, derived, derived_bad, probe, probe_bad = _cell_counts(audit)
+    assert calls > 1000000 and excluded > calls // 10 and crossings > 10000, (calls, excluded, crossings)
+    assert bad == 0, (calls, excluded, bad)                 # the shipped predicate (8x)
+    assert derived_bad == 0, (derived, derived_bad)         # the bounds as derived (1x)
+    assert probe >= derived >= excluded                     # (0.25x: below the derivation; it may -- and does -- exclude next to a crossing: probe_bad is not asserted)
