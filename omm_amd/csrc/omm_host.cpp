@@ -2291,9 +2291,9 @@ ommResult bake_impl_multi(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBake
         if (words) ok = HIP_OK(hipMemcpy(R.meta.data(), c.dMeta, words * 4, hipMemcpyDeviceToHost));
         if (r == 0) { metaWords = words; metaSum.assign(words ? words : 1, 0u); }
         if (!team.barrier(ok)) return;
-        ok = words == metaWords;   // (every rank ran the same set-up: anything else is an internal error)
-        for (size_t k = metaWords * r / N; ok && k < metaWords * (r + 1) / N; ++k) { uint32_t a = 0; for (uint32_t q = 0; q < N; ++q) a += ranks[q].meta[k]; metaSum[k] = a; }
-        if (!team.barrier(ok)) return;
+        if (!team.barrier(words == metaWords)) return;   // (every rank ran the same set-up: anything else is an internal error -- and nobody may read a shorter copy)
+        for (size_t k = metaWords * r / N; k < metaWords * (r + 1) / N; ++k) { uint32_t a = 0; for (uint32_t q = 0; q < N; ++q) a += ranks[q].meta[k]; metaSum[k] = a; }
+        if (!team.barrier(true)) return;
         if (words) ok = HIP_OK(hipMemcpy(c.dMeta, metaSum.data(), words * 4, hipMemcpyHostToDevice));
         // ---- replicated tail, layout, this rank's blocks packed into its contribution ----
         if (ok) { R.status = sharded_tail(R.sb); ok = R.status == ommResult_SUCCESS; }
