@@ -2,8 +2,12 @@
 #include "host_expand.h"
 #include <emmintrin.h>
 #include <immintrin.h>
+#include <pthread.h>
 #include <sched.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -74,6 +78,36 @@ void WorkerPool::run(uint32_t tasks, const std::function<void(uint32_t)>& fn)
     std::unique_lock<std::mutex> lk(mu_);
     done_.wait(lk, [&] { return active_ == 0; });
     fn_ = nullptr;
+}
+
+int WorkerPool::bind_near(const void* memory)
+{
+    std::lock_guard<std::mutex> one(runMu_);
+    // the node of the page (move_pages with a null target list only reports): raw syscall, no libnuma in the image
+    void* page = (void*)((uintptr_t)memory & ~(uintptr_t)4095); int node = -1;
+#ifdef SYS_move_pages
+    if (syscall(SYS_move_pages, 0, 1ul, &page, (const int*)nullptr, &node, 0) != 0) node = -1;
+#endif
+    if (node < 0 || node == boundNode_) return node;
+    char path[96]; snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) return -1;
+    char list[4096] = { 0 };
+    const bool got = fgets(list, sizeof list, f) != nullptr; fclose(f);
+    if (!got) return -1;
+    cpu_set_t allowed, want; CPU_ZERO(&allowed); CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return -1;
+    for (char* p = list; *p; ) {   // "0-63,128-191"
+        char* end = nullptr; const long a = strtol(p, &end, 10); if (end == p) break;
+        long b = a; p = end;
+        if (*p == '-') { b = strtol(p + 1, &end, 10); p = end; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (CPU_ISSET((int)c, &allowed)) CPU_SET((int)c, &want);
+        if (*p == ',') ++p; else break;
+    }
+    if (CPU_COUNT(&want) == 0) return -1;
+    for (auto& t : threads_) (void)pthread_setaffinity_np(t.native_handle(), sizeof want, &want);
+    boundNode_ = node;
+    return node;
 }
 
 HostCodecLayout host_codec_layout(uint64_t paddedBytes)

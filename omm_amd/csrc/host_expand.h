@@ -26,6 +26,9 @@ public:
     WorkerPool(const WorkerPool&) = delete; WorkerPool& operator=(const WorkerPool&) = delete;
     unsigned workers() const { return (unsigned)threads_.size(); }
     void run(uint32_t tasks, const std::function<void(uint32_t)>& fn);
+    // Moves the workers onto the CPUs of the NUMA node that holds `memory` (the array they are about to fill); the calling thread's affinity is not touched.
+    // Best effort: returns the node, or -1 when it could not be found / nothing was changed.
+    int bind_near(const void* memory);
 private:
     void loop();
     std::vector<std::thread> threads_;
@@ -34,6 +37,7 @@ private:
     const std::function<void(uint32_t)>* fn_ = nullptr;
     uint32_t tasks_ = 0; uint64_t generation_ = 0; unsigned active_ = 0; bool stop_ = false;
     std::atomic<uint32_t> next_{ 0 };
+    int boundNode_ = -2;
 };
 
 // Layout of a codec stream (the same arithmetic as tail_kernels.hip: codec_layout): header 16 B | first raw unit of every 256-unit block (uint32, blocks + 1) |
