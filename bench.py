@@ -157,7 +157,7 @@ def cpu_baseline(tex, uv, ix, lv, kw, sample, sat=True, grow=True, sweep=True):
     The main run uses as many threads as this process has CPUs (affinity mask and cgroup quota: `effective_cpus`, printed next to the hardware threads) on a
     sample that grows until it is >= 8 s of wall time, with the oracle's own phase clocks (set-up, ResampleCoarse, ResampleFine, serial tail:
     oracle_ommxGetLastBakeTimings); a quarter of the sample is baked again at twice that many threads and at all hardware threads (oversubscribed when
-    the quota is the limit).  `value` is the best of the rates, `cores` the thread count of that run."""
+    the quota is the limit): they are reported in threads_sweep; `value` is the rate of the main run, `cores` its thread count."""
     hw, eff, host = host_info()
     orc = ot.Lib("oracle")
     orc.dll.oracle_ommxSetThreads(eff)
@@ -187,10 +187,11 @@ def cpu_baseline(tex, uv, ix, lv, kw, sample, sat=True, grow=True, sweep=True):
     orc.destroy_texture(b, t)
     orc.destroy_baker(b)
     best = max(threads, key=lambda k: threads[k]["micro_triangles_per_s"])
-    out = {"unit": "micro-triangles/s", "value": threads[best]["micro_triangles_per_s"], "cores": int(best), "kind": "port", "host": host,
+    main = str(ph["threads"])   # `value` / `cores`: the run with one thread per usable CPU (the sweep's other entries are oversubscribed; best_threads names the fastest)
+    out = {"unit": "micro-triangles/s", "value": threads[main]["micro_triangles_per_s"], "cores": int(main), "kind": "port", "host": host,
            "host_threads": hw, "effective_cpus": eff, "threads_sweep": threads, "best_threads": int(best),
            "sample_triangles": n, "seconds": dt, "phases_at_effective_cpus_s": {k: ph[k] for k in ("setup_s", "coarse_s", "fine_s", "tail_s")},
-           "note": "same loop structure as the reference (static-schedule OpenMP over work items, serial set-up and tail); `cores` = the thread count of the best run; "
+           "note": "same loop structure as the reference (static-schedule OpenMP over work items, serial set-up and tail); `value` / `cores` = the run with one thread per usable CPU; "
                    "`effective_cpus` = what the affinity mask / cgroup quota let this process use at once (thread counts above it are oversubscribed: they say "
                    "nothing about how the loops scale on more cores); the phases are the oracle's own wall clocks of the run at effective_cpus threads"}
     return out, res, (suv, six, slv), dt, ph
