@@ -26,8 +26,8 @@ public:
     WorkerPool(const WorkerPool&) = delete; WorkerPool& operator=(const WorkerPool&) = delete;
     unsigned workers() const { return (unsigned)threads_.size(); }
     void run(uint32_t tasks, const std::function<void(uint32_t)>& fn);
-    // Moves the workers onto the CPUs of the NUMA node that holds `memory` (the array they are about to fill); the calling thread's affinity is not touched.
-    // Best effort: returns the node, or -1 when it could not be found / nothing was changed.
+    // Moves the workers onto the NUMA node that holds `memory` (the array they are about to fill), each onto its own slice of the node's cores; the calling
+    // thread's affinity is not touched.  Best effort: returns the node, or -1 when it could not be found / nothing was changed.
     int bind_near(const void* memory);
 private:
     void loop();

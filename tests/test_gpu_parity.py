@@ -975,7 +975,9 @@ def test_bench_contract_small():
     assert d["device_resident"]["entry"] == "ommxBakeDevice" and 0 < d["device_resident"]["ms_per_bake"] and d["device_resident"]["micro_triangles_per_s"] > 0
     fpo = d["fine_pass_only"]                       # the same numerator on both sides: the sample's micro-triangles that enter ResampleFine, counted by the oracle
     assert fpo["cpu_micro_triangles_per_s"] > 0 and fpo["gpu_micro_triangles_per_s"] > 0
-    assert d["cpu_baseline"]["best_threads"] == d["cpu_baseline"]["cores"] and str(d["cpu_baseline"]["best_threads"]) in d["cpu_baseline"]["threads_sweep"]
+    cb = d["cpu_baseline"]   # value / cores: the run with one thread per usable CPU; the oversubscribed runs are in the sweep
+    assert cb["cores"] == cb["effective_cpus"] >= 1 and str(cb["cores"]) in cb["threads_sweep"] and str(cb["best_threads"]) in cb["threads_sweep"]
+    assert cb["value"] == cb["threads_sweep"][str(cb["cores"])]["micro_triangles_per_s"] > 0
     assert d["roofline"]["bound"] == "hbm"          # (the issue-slot roofline needs the PMC summary of the full-size workload)
     for cfgname in ("c1", "c4", "cards"):
         o2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", cfgname, "--tris", "1500", "--steps", "1", "--warmup", "1", "--cpu-sample", "200",
