@@ -200,7 +200,7 @@ def cpu_baseline(tex, uv, ix, lv, kw, sample, sat=True, grow=True, sweep=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--tris", type=int, default=0, help="override the configuration's triangle count")
