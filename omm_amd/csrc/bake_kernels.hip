@@ -1022,6 +1022,273 @@ __device__ __forceinline__ void generic_walks(const ClassifyParams& P, const Ite
     if (lane == 0u && classified) atomicAdd(G.count + 2, (unsigned long long)classified);
 }
 
+
+// ---- the dense form of the walks (round 5) ----
+// The walks above keep one lane per micro-triangle for everything, so a wave's instructions are issued for a third of its lanes: the skip to the next covered
+// texel runs for the one lane at the start of a wide row, the corner votes for the dozen lanes whose cell is not on a seen side, the edge tests for the cells
+// that need them.  Here a lane OWNS a micro-triangle (its record lies in the wave's LDS: edge functions, box, vertices, cursor, vote counters) and WORKS on
+// whatever visit is next: every round the active owners offer OMMX_GENERIC_QUOTA texels of their boxes each, the wave tests them 64 at a time (texel_under's
+// three edge functions), the covered ones go into a ring of visits; whenever the ring holds 64, the wave fetches 64 cells and does their votes; cells that need
+// their edge tests go into a second ring and are done 64 at a time as well.  The votes of a micro-triangle are sums (bake_kernels_cpu.h:241-399 adds to two
+// counters per texel; GetStateFromCoverage reads the sums), so the order in which its texels are visited does not matter, and when only (any above, any below)
+// counts -- every promotion but Nearest -- the visits of a micro-triangle that is already mixed are dropped wherever they are: the serial loop's early exit.
+// An owner finishes when its box is exhausted (or it is mixed) AND none of its visits is in a ring (a counter per owner), so a record is never reused under a
+// visit.  No workgroup barrier: the structures are per wave, a wave's LDS operations execute in order.
+#ifndef OMMX_GENERIC_DENSE
+#define OMMX_GENERIC_DENSE 1
+#endif
+#ifndef OMMX_GENERIC_QUOTA_LOG2
+#define OMMX_GENERIC_QUOTA_LOG2 2   // texels an owner offers per round: 2 / 4 / 8 = 19.3 / 18.2 / 19.5 ms on the cards workload
+#endif
+#ifndef OMMX_GENERIC_DENSE_REFILL
+#define OMMX_GENERIC_DENSE_REFILL 24   // idle owners that trigger a refill: 16 / 24 / 32 = 18.46 / 18.2 / 18.2 ms
+#endif
+constexpr uint32_t GD_REC = 20u;      // dwords per owner record: 0-8 three edges (nx, ny, c); 9 above, 10 below, 11 visits in flight; 12-17 p0, p1, p2; 18 minx, 19 miny (the rest of the box and the cursor stay in the owner's registers)
+constexpr uint32_t GD_RING = 128u;    // entries per ring (a ring holds < 64 before 64 are pushed)
+constexpr uint32_t GD_WAVE_DWORDS = 64u * GD_REC + 2u * GD_RING + 16u;   // records, two rings of one word per visit (owner | dx << 6 | dy << 19, relative to the box), the slot map
+constexpr int GD_MAX_EXTENT = 8192;   // boxes wider or higher than this (13 bits per offset) are offered a piece of a row at a time, each piece after the visits of the one before
+#define OMMX_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+template <bool FP32, int KIND, class MD>
+__device__ __forceinline__ void generic_dense(const ClassifyParams& P, const ItemArrays& A, const GenericQueue& G, uint32_t n, uint32_t* __restrict__ L)
+{
+    constexpr uint32_t Q = 1u << OMMX_GENERIC_QUOTA_LOG2, MASK = GD_RING - 1u;
+    const DevMip& m = P.mips[0];
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below_me = (1ull << lane) - 1ull;
+    const bool countsMatter = P.promotion == 0;
+    const float off = KIND == 0 ? -0.5f : 0.f;
+    uint32_t* const rec = L;
+    uint32_t* const cRing = L + 64u * GD_REC; uint32_t* const eRing = cRing + GD_RING;
+    uint8_t* const slotMap = (uint8_t*)(eRing + GD_RING);
+    uint32_t* const mine = rec + lane * GD_REC;
+    unsigned long long* const cursorWord = G.count + 1;
+    uint32_t chunkNext = 0, chunkEnd = 0;
+    bool drained = false;
+    uint32_t classified = 0;
+    uint32_t cHead = 0, cCount = 0, eHead = 0, eCount = 0;   // (wave-uniform) the two rings
+#ifdef OMMX_GD_STATS
+    uint32_t st[12] = { 0 };
+#define GD_STAT(i, v) st[i] += (v)
+#else
+#define GD_STAT(i, v) do { } while (0)
+#endif
+    // the owner's side of this lane
+    bool have = false, result = false;
+    uint32_t item = 0, levelWord = 0, fAbove = 0, fBelow = 0;
+    int direct = -1, cx = 0, cy = 0, minx = 0, xend = 1, yend = 0;
+    int vminx = 0, vminy = 0, vxend = 1, vyend = 0;   // the part of the box on offer (see `big`)
+    bool big = false;
+
+    // ---- 64 visits (or what is left): the cell of a covered texel and its votes; cells that need their edge tests move on to the second ring ----
+    auto cell_stage = [&](uint32_t cnt) {
+        const bool on = lane < cnt;
+        const uint32_t idx = (cHead + lane) & MASK;
+        const uint32_t word = on ? cRing[idx] : 0u, slot = word & 63u;
+        cHead = (cHead + cnt) & MASK; cCount -= cnt;
+        uint32_t* const r = rec + slot * GD_REC;
+        const uint4 v1 = *(const uint4*)(r + 16);   // p2, minx, miny
+        const int x = (int)v1.z + (int)((word >> 6) & 8191u), y = (int)v1.w + (int)(word >> 19);
+        const uint2 ab = on ? make_uint2(r[9], r[10]) : make_uint2(0u, 0u);
+        const uint32_t above = ab.x, below = ab.y;
+        const bool live = on && (countsMatter || !(above != 0 && below != 0));
+        GD_STAT(4, 1u); GD_STAT(5, (uint32_t)__popcll(__ballot(live)));
+        uint32_t da = 0, db = 0;
+        bool toEdge = false;
+        float ha = 0.f, hb = 0.f, hc = 0.f, hd = 0.f;
+        if (live) {
+            if (KIND == 1) nearest_texel<FP32, MD>(P, m, x, y, da, db, no_window());
+            else {
+                const uint4 v0 = *(const uint4*)(r + 12);
+                MicroTri t; t.p0 = mk2(__uint_as_float(v0.x), __uint_as_float(v0.y)); t.p1 = mk2(__uint_as_float(v0.z), __uint_as_float(v0.w)); t.p2 = mk2(__uint_as_float(v1.x), __uint_as_float(v1.y));
+                finish_tri(t);
+                const float pfx = (float)x + 0.5f, pfy = (float)y + 0.5f;
+                float gx, gy, gz, gw;   // 00, 01, 11, 10
+                fetch_cell<FP32, MD, true>(P, m, MD::pow2(P), x, y, no_window(), gx, gy, gz, gw);
+                const bool o0 = P.cutoff < gx, o1 = P.cutoff < gy, o2 = P.cutoff < gz, o3 = P.cutoff < gw;
+                hb = gw - gx; hc = gy - gx; hd = gx + gz - gy - gw; ha = gx - P.cutoff;
+                const bool flat = near_zero(hb, 1e-6f) & near_zero(hc, 1e-6f) & near_zero(hd, 1e-6f);
+                const bool seen = !countsMatter & (o0 == o1) & (o1 == o2) & (o2 == o3) & (o0 ? above != 0 : below != 0);
+                bool edgesNeeded = !flat;
+#ifndef OMMX_NO_CELL_EXCLUSION
+                if (edgesNeeded) {
+                    const V2 q0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy), q1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy), q2 = mk2(m.fw * t.p2.x - pfx, m.fh * t.p2.y - pfy);
+                    edgesNeeded = !cell_excluded(q0, q1, q2, ha, hb, hc, hd);
+                }
+#endif
+                bool both = false;
+                if (!seen) {
+                    const float ipx = pfx * m.rw, ipy = pfy * m.rh;
+                    const bool in0 = point_in_triangle_flat(t, ipx, ipy), in1 = point_in_triangle_flat(t, ipx, ipy + m.rh);
+                    const bool in2 = point_in_triangle_flat(t, ipx + m.rw, ipy + m.rh), in3 = point_in_triangle_flat(t, ipx + m.rw, ipy);
+                    const bool isO = (in0 & o0) | (in1 & o1) | (in2 & o2) | (in3 & o3), isT = (in0 & !o0) | (in1 & !o1) | (in2 & !o2) | (in3 & !o3);
+                    da += isO ? 1u : 0u; db += isT ? 1u : 0u;
+                    both = isO & isT;
+                    if (flat & !both) vote(o0, da, db);
+                }
+                toEdge = edgesNeeded & !both & (countsMatter | !((above + da) != 0 && (below + db) != 0));
+            }
+        }
+        if (da) atomicAdd(r + 9, da);
+        if (db) atomicAdd(r + 10, db);
+        const unsigned long long em = __ballot(toEdge);
+        if (toEdge) {
+            const uint32_t e = (eHead + eCount + (uint32_t)__popcll(em & below_me)) & MASK;
+            eRing[e] = word;   // (the cell is fetched again there: 16 bytes of ring per entry cost a wave per SIMD)
+        }
+        eCount += (uint32_t)__popcll(em); GD_STAT(6, (uint32_t)__popcll(em));
+        if (on && !toEdge) atomicSub(r + 11, 1u);
+        OMMX_WAVE_SYNC();
+    };
+    // ---- 64 cells' edge tests (bake_kernels_cpu.h:241-399: an edge of the micro-triangle that crosses the level curve inside the cell votes for both sides) ----
+    auto edge_stage = [&](uint32_t cnt) {
+        const bool on = lane < cnt;
+        const uint32_t idx = (eHead + lane) & MASK;
+        const uint32_t word = on ? eRing[idx] : 0u, slot = word & 63u;
+        eHead = (eHead + cnt) & MASK; eCount -= cnt;
+        uint32_t* const r = rec + slot * GD_REC;
+        const uint2 ab = on ? make_uint2(r[9], r[10]) : make_uint2(0u, 0u);
+        GD_STAT(7, 1u); GD_STAT(8, (uint32_t)__popcll(__ballot(on && (countsMatter || !(ab.x != 0 && ab.y != 0)))));
+        if (on && (countsMatter || !(ab.x != 0 && ab.y != 0))) {
+            const uint4 v0 = *(const uint4*)(r + 12), v1 = *(const uint4*)(r + 16);
+            const int x = (int)v1.z + (int)((word >> 6) & 8191u), y = (int)v1.w + (int)(word >> 19);
+            const float pfx = (float)x + 0.5f, pfy = (float)y + 0.5f;
+            float gx, gy, gz, gw;   // 00, 01, 11, 10
+            fetch_cell<FP32, MD, true>(P, m, MD::pow2(P), x, y, no_window(), gx, gy, gz, gw);
+            const float hb = gw - gx, hc = gy - gx, hd = gx + gz - gy - gw, ha = gx - P.cutoff;
+            const V2 q0 = mk2(m.fw * __uint_as_float(v0.x) - pfx, m.fh * __uint_as_float(v0.y) - pfy), q1 = mk2(m.fw * __uint_as_float(v0.z) - pfx, m.fh * __uint_as_float(v0.w) - pfy),
+                     q2 = mk2(m.fw * __uint_as_float(v1.x) - pfx, m.fh * __uint_as_float(v1.y) - pfy);
+            const bool x0 = edge_crosses_level_curve(q0, q1, ha, hb, hc, hd), x1 = edge_crosses_level_curve(q1, q2, ha, hb, hc, hd), x2 = edge_crosses_level_curve(q2, q0, ha, hb, hc, hd);
+            if (x0 | x1 | x2) { atomicAdd(r + 9, 1u); atomicAdd(r + 10, 1u); }
+        }
+        if (on) atomicSub(r + 11, 1u);
+        OMMX_WAVE_SYNC();
+    };
+
+    for (;;) {
+        // ---- owners: finished? ----
+        bool exhausted = false, mixed = false, waiting = false;
+        if (have) {
+            const uint4 w = *(const uint4*)(mine + 8);
+            const uint2 ab = make_uint2(w.y, w.z);
+            const uint32_t pending = w.w;
+            mixed = !countsMatter && ab.x != 0 && ab.y != 0;
+            exhausted = cy >= yend;
+            if (pending == 0u && (exhausted | mixed)) { have = false; result = true; fAbove = ab.x; fBelow = ab.y; }
+            waiting = big && pending != 0u;
+        }
+        const unsigned long long busy = __ballot(have);
+        const uint32_t idle = 64u - (uint32_t)__popcll(busy);
+        if ((!drained && idle >= (uint32_t)OMMX_GENERIC_DENSE_REFILL) || busy == 0ull) {
+            // ---- commit what is finished, hand out the next entries ----
+            classified += generic_commit(P, A, result, item, levelWord & 0xFFFFFFu, direct >= 0 ? direct : state_from_coverage(P, fAbove, fBelow));
+            result = false;
+            if (drained) break;   // (busy == 0)
+            if (chunkNext == chunkEnd) {
+                unsigned long long start = 0;
+                if (lane == 0u) start = atomicAdd(cursorWord, (unsigned long long)OMMX_GENERIC_CHUNK);
+                start = (unsigned long long)__shfl((long long)start, 0);
+                if (start >= (unsigned long long)n) drained = true;
+                else { chunkNext = (uint32_t)start; chunkEnd = start + OMMX_GENERIC_CHUNK < (unsigned long long)n ? (uint32_t)start + OMMX_GENERIC_CHUNK : n; }
+            }
+            if (!drained) {
+                const uint32_t avail = chunkEnd - chunkNext, take = idle < avail ? idle : avail;
+                const uint32_t rank = (uint32_t)__popcll(~busy & below_me);
+                bool get = !have && rank < take;
+                uint2 ent = get ? G.entries[chunkNext + rank] : make_uint2(0u, 0u);
+                chunkNext += take;
+                if (ent.x == 0xFFFFFFFFu) get = false;   // (null entry: the inside part of a reservation that did not fit)
+                const bool degenerate = get && ((ent.x >> 30) & 1u) != 0u;
+                if (get) { item = ent.x & 0x3FFFFFFFu; levelWord = ent.y; direct = -1; }
+                if (__ballot(degenerate) != 0ull) {   // (rare: degenerate items take the serial form)
+                    if (degenerate) { direct = fine_state<FP32, MD>(P, micro_triangle(A.uv + 6ull * item, levelWord & 0xFFFFFFu, levelWord >> 24), true, no_window()); result = true; get = false; }
+                }
+                GD_STAT(9, 1u); GD_STAT(10, (uint32_t)__popcll(__ballot(get)));
+                if (get) {
+                    const MicroTri t = micro_triangle(A.uv + 6ull * item, levelWord & 0xFFFFFFu, levelWord >> 24);
+                    uint32_t a0 = 0, b0 = 0;
+                    if (KIND == 0) vote(P.cutoff < bilinear<FP32, MD, true>(P, m, t.p0, no_window()), a0, b0);
+                    const RasterBox B = raster_box(m, t, off);
+                    minx = B.minx; xend = B.xend; yend = B.yend; cx = B.minx; cy = B.miny;
+                    // (the part of the box the workers see: all of it, unless its offsets do not fit the rings' 13 bits -- a micro-triangle more than 8192 texels across)
+                    big = (long long)B.xend - (long long)B.minx > (long long)GD_MAX_EXTENT || (long long)B.yend - (long long)B.miny > (long long)GD_MAX_EXTENT;
+                    vminx = B.minx; vminy = B.miny; vxend = B.xend; vyend = B.yend;
+                    *(uint4*)(mine + 0) = make_uint4(__float_as_uint(B.e0.nx), __float_as_uint(B.e0.ny), __float_as_uint(B.e0.c), __float_as_uint(B.e1.nx));
+                    *(uint4*)(mine + 4) = make_uint4(__float_as_uint(B.e1.ny), __float_as_uint(B.e1.c), __float_as_uint(B.e2.nx), __float_as_uint(B.e2.ny));
+                    *(uint4*)(mine + 8) = make_uint4(__float_as_uint(B.e2.c), a0, b0, 0u);
+                    *(uint4*)(mine + 12) = make_uint4(__float_as_uint(t.p0.x), __float_as_uint(t.p0.y), __float_as_uint(t.p1.x), __float_as_uint(t.p1.y));
+                    *(uint4*)(mine + 16) = make_uint4(__float_as_uint(t.p2.x), __float_as_uint(t.p2.y), (uint32_t)vminx, (uint32_t)vminy);
+                    have = true;
+                }
+            }
+            OMMX_WAVE_SYNC();
+            continue;
+        }
+        // ---- every active owner offers the next Q texels of its box; 64 of them are tested per pass, the covered ones become visits ----
+        const bool active = have && !exhausted && !mixed && !waiting;
+        const unsigned long long emask = __ballot(active);
+        const uint32_t nAct = (uint32_t)__popcll(emask);
+        if (nAct == 0u) {   // nothing to enumerate: what the waiting owners wait for is in the rings
+            GD_STAT(11, 1u);
+            while (cCount) { cell_stage(cCount < 64u ? cCount : 64u); if (eCount >= 64u) edge_stage(64u); }
+            while (eCount) edge_stage(eCount < 64u ? eCount : 64u);
+            continue;
+        }
+        if (active) slotMap[(uint32_t)__popcll(emask & below_me)] = (uint8_t)lane;
+        if (active && big) {   // (rare) the next piece: the rest of the cursor's row, at most Q texels; the ring words of its visits count from the cursor
+            vminx = cx; vminy = cy; vxend = (long long)xend - (long long)cx > (long long)Q ? cx + (int)Q : xend; vyend = cy + 1;
+            *(uint2*)(mine + 18) = make_uint2((uint32_t)vminx, (uint32_t)vminy);
+        }
+        OMMX_WAVE_SYNC();
+        const uint32_t passes = (nAct * Q + 63u) >> 6;
+        GD_STAT(0, 1u); GD_STAT(1, passes);
+        for (uint32_t p = 0; p < passes; ++p) {
+            const uint32_t rk = p * (64u >> OMMX_GENERIC_QUOTA_LOG2) + (lane >> OMMX_GENERIC_QUOTA_LOG2);
+            const bool valid = rk < nAct;
+            const uint32_t slot = valid ? (uint32_t)slotMap[rk] : 0u;
+            uint32_t* const r = rec + slot * GD_REC;
+            bool covered = false;
+            int x = 0, y = 0;
+            // (box and cursor come from the owner's registers)
+            const int bminx = __shfl(vminx, (int)slot), bminy = __shfl(vminy, (int)slot), bxend = __shfl(vxend, (int)slot), byend = __shfl(vyend, (int)slot);
+            x = __shfl(cx, (int)slot); y = __shfl(cy, (int)slot);
+            if (valid) {
+                const uint4 w0 = *(const uint4*)(r + 0), w1 = *(const uint4*)(r + 4); const uint32_t w2x = r[8];
+                const uint32_t d = lane & (Q - 1u);
+                #pragma unroll
+                for (uint32_t s = 0; s + 1u < Q; ++s) if (s < d) { if (++x == bxend) { x = bminx; ++y; } }
+                if (y < byend) {
+                    EdgeEq e0, e1, e2;
+                    e0.nx = __uint_as_float(w0.x); e0.ny = __uint_as_float(w0.y); e0.c = __uint_as_float(w0.z); e0.bias = 0.f;
+                    e1.nx = __uint_as_float(w0.w); e1.ny = __uint_as_float(w1.x); e1.c = __uint_as_float(w1.y); e1.bias = 0.f;
+                    e2.nx = __uint_as_float(w1.z); e2.ny = __uint_as_float(w1.w); e2.c = __uint_as_float(w2x); e2.bias = 0.f;
+                    const float sx = (float)x, sy = (float)y;
+                    covered = (eval_cons(e0, sx, sy) < 0.f) & (eval_cons(e1, sx, sy) < 0.f) & (eval_cons(e2, sx, sy) < 0.f);
+                }
+            }
+            const unsigned long long cm = __ballot(covered);
+            GD_STAT(2, (uint32_t)__popcll(__ballot(valid && y < byend))); GD_STAT(3, (uint32_t)__popcll(cm));
+            if (covered) {
+                const uint32_t c = (cHead + cCount + (uint32_t)__popcll(cm & below_me)) & MASK;
+                cRing[c] = slot | ((uint32_t)(x - bminx) << 6) | ((uint32_t)(y - bminy) << 19);
+                atomicAdd(r + 11, 1u);
+            }
+            cCount += (uint32_t)__popcll(cm);
+            OMMX_WAVE_SYNC();
+            if (cCount >= 64u) { cell_stage(64u); if (eCount >= 64u) edge_stage(64u); }
+        }
+        if (active) {
+            const uint32_t steps = big ? (uint32_t)(vxend - vminx) : Q;
+            #pragma unroll
+            for (uint32_t s = 0; s < Q; ++s) if (s < steps && cy < yend) { if (++cx == xend) { cx = minx; ++cy; } }
+        }
+        OMMX_WAVE_SYNC();
+    }
+    if (lane == 0u && classified) atomicAdd(G.count + 2, (unsigned long long)classified);
+#ifdef OMMX_GD_STATS
+    if (lane == 0u) for (int i = 0; i < 12; ++i) atomicAdd(G.count + 8 + i, (unsigned long long)st[i]);
+#endif
+}
+
 #ifndef OMMX_GENERIC_WAVES
 #define OMMX_GENERIC_WAVES 6
 #endif
@@ -1031,7 +1298,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OMMX_GENERI
     const uint32_t n = *G.count < (unsigned long long)G.capacity ? (uint32_t)*G.count : G.capacity;
     const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * 256u + threadIdx.x) >> 6, waves = (gridDim.x * 256u) >> 6;
     if (P.mipCount == 1 && !(P.filterLinear && P.altKernel)) {
+#if OMMX_GENERIC_DENSE
+        __shared__ __attribute__((aligned(16))) uint32_t s_dense[4][GD_WAVE_DWORDS];
+        if (P.filterLinear) generic_dense<FP32, 0, MD>(P, A, G, n, s_dense[threadIdx.x >> 6]); else generic_dense<FP32, 1, MD>(P, A, G, n, s_dense[threadIdx.x >> 6]);
+#else
         if (P.filterLinear) generic_walks<FP32, 0, MD>(P, A, G, n); else generic_walks<FP32, 1, MD>(P, A, G, n);
+#endif
         return;
     }
     uint32_t classified = 0;
@@ -1210,7 +1482,7 @@ static void launch_classify_md(const ClassifyParams& P, const ItemArrays& A, con
     // ---- deferred generic pass: the micro-triangles of several texels that the persistent launches queued instead of walking ----
     if (deferred) {
         if (chunks.markGeneric) chunks.markGeneric(chunks.user);
-        hipLaunchKernelGGL((classify_generic<FP32, MD>), dim3(numCUs * 8u), dim3(256), 0, stream, P, A, chunks.generic);
+        hipLaunchKernelGGL((classify_generic<FP32, MD>), dim3(numCUs * (OMMX_GENERIC_DENSE ? (uint32_t)OMMX_GENERIC_WAVES : 8u)), dim3(256), 0, stream, P, A, chunks.generic);
     }
     for (uint32_t k = 0; k < K; ++k) {
         if (chunks.after) {   // the work items of this range, as segments of the per-level active lists, in the order of the final result

@@ -1195,7 +1195,11 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     uint32_t queueTails[2] = { 0u, 0u };   // open tiles of the two tile sizes (statistics)
     uint32_t hostCtl[kClassifyCtlWords]; memset(hostCtl, 0, sizeof hostCtl);
     if (hc.activeStart[kNumLevels]) ok = ok && HIP_OK(hipMemcpyAsync(hostCtl, dQueueCtl, sizeof hostCtl, hipMemcpyDeviceToHost, stream));
-    unsigned long long genericWords[3] = { 0, 0, 0 };   // reservations (incl. null padding), the pass's cursor, micro-triangles it classified
+#ifdef OMMX_GD_STATS
+    unsigned long long genericWords[20] = { 0 };
+#else
+    unsigned long long genericWords[3] = { 0, 0, 0 };
+#endif   // reservations (incl. null padding), the pass's cursor, micro-triangles it classified
     if (dGeneric) ok = ok && HIP_OK(hipMemcpyAsync(genericWords, dGeneric, sizeof genericWords, hipMemcpyDeviceToHost, stream));
     const int e5 = et.mark();
     ok = ok && HIP_OK(hipStreamSynchronize(stream));
@@ -1209,6 +1213,9 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     tm.streamPreviewMs = pv0 >= 0 ? et.ms(pv0, pv1) : 0.f;
     tm.tailMs = et.ms(e3, e4); tm.gatherMs = et.ms(e4, e5); tm.persistentMs = mk.mark >= 0 ? et.ms(mk.mark, mk.markGeneric >= 0 ? mk.markGeneric : e2) : 0.f;
     tm.genericMs = mk.markGeneric >= 0 ? et.ms(mk.markGeneric, e2) : 0.f; tm.genericMicroTriangles = genericWords[2];
+#ifdef OMMX_GD_STATS
+    if (dGeneric) { fprintf(stderr, "GDSTATS entries %llu:", genericWords[2]); for (int i = 0; i < 12; ++i) fprintf(stderr, " %llu", genericWords[8 + i]); fprintf(stderr, "\n"); }
+#endif
     for (int k = 0; k < kFineSlots; ++k) fineCount += fineSlots[(size_t)k * kFineStride];
     queueTails[1] = hostCtl[kCtl1024 + kSecTails]; for (uint32_t k = 0; k < kMaxClassifyChunks; ++k) queueTails[0] += hostCtl[kSecTails + k];   // (1024-tile queue; sections of the 4096-tile queue)
     tm.openTiles = queueTails[0] + queueTails[1]; tm.openTileMicroTriangles = (uint64_t)queueTails[0] * 4096u + (uint64_t)queueTails[1] * 1024u;

@@ -1551,6 +1551,23 @@ def test_texel_walk_shapes(product, oracle):
     both(product, oracle, [const], uv, ix, 6, addr=ot.MIRROR_ONCE, promo=ot.PROMO_FORCE_OPAQUE, sat=False, knobs=knobs)
 
 
+def test_texel_walks_of_boxes_wider_than_the_visit_rings_offsets(product, oracle):
+    """The deferred pass keeps a visit as (owner, x offset, y offset) in one word, 13 bits per offset; a micro-triangle whose raster box is wider or higher than
+    8192 texels is offered to the wave a piece of a row at a time instead (bake_kernels.hip: generic_dense, `big`).  Level-5 triangles 300 texture periods long
+    and two texels thin, along x and along y (micro-triangle boxes of ~9600 x 2 texels), next to ordinary ones; counts decide under the Nearest promotion,
+    so every covered texel must vote exactly once."""
+    knobs = [(ot.KNOB_GENERIC_PASS, 2)]
+    tex8 = ot.foliage_texture(9, 1024, 1024, feature=32)
+    tri = np.array([[[0.1, 0.5], [300.1, 0.501], [150.0, 0.5025]],
+                    [[0.5, 0.2], [0.502, 300.2], [0.5005, 150.0]],
+                    [[0.2, 0.2], [0.45, 0.22], [0.3, 0.4]],
+                    [[3.1, 0.7], [303.1, 0.7], [150.0, 0.7021]]], np.float32)
+    uv = np.ascontiguousarray(tri.reshape(-1, 2)); ix = np.arange(12, dtype=np.uint32)
+    for promo in (ot.PROMO_NEAREST, ot.PROMO_FORCE_OPAQUE):
+        both(product, oracle, [tex8], uv, ix, 5, addr=ot.WRAP, promo=promo, knobs=knobs)
+    both(product, oracle, [tex8], uv, ix, 5, filt=ot.NEAREST, addr=ot.MIRROR, promo=ot.PROMO_NEAREST, sat=False, knobs=knobs)
+
+
 def test_near_duplicate_merge_and_budget_at_scale(product, oracle):
     """The serial reducers (near-duplicate LSH merge, maxArrayDataSize budget) work on the device's 2-bit packed states, uniform work items as
     (state, level): a level-8 bake of 20 000 triangles needs 40 MB on the host for them, not the 2.6 GB of one byte x 2 per micro-triangle of every
