@@ -1049,6 +1049,24 @@ def test_fuzz_all_knobs(product, oracle, seed):
     both(product, oracle, mips, uv, ix, level, sat=sat, cutoff=cutoff, **kw)
 
 
+@pytest.mark.parametrize("seed", list(range(400, 496)))
+def test_fuzz_deferred_texel_walks(product, oracle, seed):
+    """The deferred generic pass (bake_kernels.hip: classify_generic / generic_dense -- owners, visit rings, votes summed in LDS) against the oracle over the fuzz
+    generator's textures, address modes, filters, promotions, formats, flags and per-triangle levels, with triangles of 4 .. 300 texels at levels 5 .. 8:
+    micro-triangles from a fraction of a texel to a dozen texels across, i.e. walks of every length in one wave."""
+    mips, _, _, _, cutoff, sat, kw = _fuzz_case(seed)
+    h = lambda k: int(ot.hash_u32(np.array([seed * 977 + k], dtype=np.int64))[0])
+    level = 5 + h(1) % 4
+    texels = [4.0, 20.0, 80.0, 300.0][h(2) % 4]
+    n = [120, 120, 60, 24][h(2) % 4]
+    uv, ix = ot.random_triangles(seed + 3, n, texels / max(mips[0].shape))
+    uv = (uv + np.float32([0.0, 0.0, -3.0, 17.0][h(3) % 4])).astype(np.float32)
+    kw = dict(kw); kw.pop("levels", None); kw["dyn_scale"] = 0.0
+    if h(4) % 2:
+        kw["levels"] = (5 + ot.hash_u32(np.arange(n) + seed) % (level - 4)).astype(np.uint8)
+    both(product, oracle, mips, uv, ix, level, sat=sat, cutoff=cutoff, knobs=[(ot.KNOB_GENERIC_PASS, 2)], **kw)
+
+
 def test_concurrent_bakes_on_one_baker(product):
     """ommCpuBake is re-entrant (the reference bakes are independent objects, bake.cpp:103-116): four host threads share one baker
     and one texture; a call that finds the baker's device arena busy works in a private one."""
