@@ -101,7 +101,8 @@ void launch_sat_build(const void* texels, int fp32, uint32_t* sat, uint32_t* scr
 // storeBits: packing of `states` (== bits, except a 2-state bake without fine pass, whose states are kept in 2 bits: the gather then packs them to 1 bit by
 // the reference's rule, byte[i >> 3] |= state << (i & 7) truncated to the byte, bake_cpu_impl.cpp:1811)
 void launch_gather_omms(const uint8_t* states, const uint64_t* stateOfs, const uint8_t* active, const uint32_t* stateMask, const uint8_t* level, int bits, int storeBits,
-                        const uint32_t* order, const uint32_t* dstOfs, const uint32_t* sizes, uint32_t numOmms, uint8_t* arrayData, hipStream_t stream);
+                        const uint32_t* order, const uint32_t* dstOfs, const uint32_t* sizes, uint32_t numOmms, uint8_t* arrayData, hipStream_t stream,
+                        uint8_t* unitCodes = nullptr, uint32_t* blockRawCounts = nullptr);
 void launch_write_indices(const int32_t* triToItem, const uint32_t* rep, const int32_t* itemValue, uint32_t numTris, int32_t unresolved,
                           int32_t* out, hipStream_t stream);
 
@@ -147,6 +148,17 @@ void launch_shard_gather(const uint8_t* states, const uint64_t* stateOfs, const 
 // block exchange codec (tail_kernels.hip): a rank's contribution (a multiple of 256 bytes) as a stream of unit codes + raw units
 constexpr uint32_t kCodecIncompressible = 0xFFFFFFFEu;
 size_t shard_codec_scratch_bytes(uint64_t contributionBytes);
+// The same stream from codes and per-block raw counts that the gather has produced next to the array (launch_gather_omms with unitCodes / blockRawCounts: one
+// byte per 16-byte unit, one zeroed word per 256-unit block + 1): the array is read once more for its raw units only, not twice in full.
+hipError_t run_shard_compress_coded(const uint8_t* contrib, uint64_t contributionBytes, const uint8_t* unitCodes, uint32_t* blockRawCounts, uint8_t* comp, uint64_t capBytes,
+                                    uint32_t* sizeWord, void* scratch, size_t scratchBytes, hipStream_t stream);
+// the code of one 16-byte unit of arrayData: 0..3 = sixteen bytes of 0x00 / 0x55 / 0xAA / 0xFF, 4 = raw
+__host__ __device__ inline uint32_t codec_unit_code(uint32_t x, uint32_t y, uint32_t z, uint32_t w)
+{
+    const bool same = x == y && x == z && x == w;
+    return !same ? 4u : (x == 0u ? 0u : (x == 0x55555555u ? 1u : (x == 0xAAAAAAAAu ? 2u : (x == 0xFFFFFFFFu ? 3u : 4u))));
+}
+constexpr uint32_t kCodecBlockUnits = 256;
 hipError_t run_shard_compress(const uint8_t* contrib, uint64_t contributionBytes, uint8_t* comp, uint64_t capBytes, uint32_t* sizeWord, void* scratch, size_t scratchBytes, hipStream_t stream);
 void launch_shard_scatter_streams(const uint8_t* streams, uint64_t streamPitch, uint64_t contributionBytes, const uint8_t* active, const uint8_t* owner,
                                   const uint32_t* stateMask, const uint8_t* level, int bits, const uint32_t* order, const uint64_t* cofs, const uint32_t* dstOfs,
@@ -216,7 +228,7 @@ struct TailOutputs {            // device buffers owned by the caller
     uint32_t* arrayHist;        // [13]
     uint32_t* indexHist;        // [13]
 };
-struct TailCounts { uint32_t numOmms; uint64_t arrayDataSize; };
+struct TailCounts { uint32_t numOmms; uint64_t arrayDataSize; uint32_t smallOmms; };   // smallOmms: emitted OMMs of less than 16 bytes (levels 0 - 2; 0 - 3 in 2-state)
 
 // compaction of the active (non-uniform) items into per-level lists + their packed-state slots; synchronises the stream once
 // (item count and level boundaries are read from / written to the device-resident counters block; no synchronisation)

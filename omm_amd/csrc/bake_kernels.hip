@@ -1930,12 +1930,46 @@ __global__ __launch_bounds__(256) void tail_gather_omms(const uint8_t* __restric
                                                         const uint8_t* __restrict__ active, const uint32_t* __restrict__ stateMask,
                                                         const uint8_t* __restrict__ level, int bits, int storeBits,
                                                         const uint32_t* __restrict__ order, const uint32_t* __restrict__ dstOfs,
-                                                        const uint32_t* __restrict__ sizes, uint32_t numOmms, uint8_t* __restrict__ arrayData)
+                                                        const uint32_t* __restrict__ sizes, uint32_t numOmms, uint8_t* __restrict__ arrayData,
+                                                        uint8_t* __restrict__ unitCodes, uint32_t* __restrict__ blockRawCounts)
 {
     for (uint32_t j = blockIdx.x; j < numOmms; j += gridDim.x) {
         const uint32_t item = order[j];
         uint8_t* dst = arrayData + dstOfs[j];
         const uint32_t n = sizes[j];
+        if (unitCodes) {
+            // The compressed result transfer (omm_host.cpp): the exchange codec's code of every 16-byte unit and the number of raw units per 256-unit block are
+            // produced HERE, where the unit is in a register anyway, instead of by a pass of their own over the finished array.  The caller guarantees: every OMM is
+            // a multiple of 16 bytes (no level below 3; 4 in 2-state) and storeBits == bits.
+            const bool uniform = !active[item];
+            uint32_t pat = 0;
+            if (uniform) {
+                const uint32_t st = (uint32_t)(31 - __clz((int)stateMask[item]));
+                for (uint32_t b = 0; b < 8u; b += (uint32_t)bits) pat |= st << b;
+                pat *= 0x01010101u;
+            }
+            const uint4* s4 = (const uint4*)(states + (uniform ? 0ull : stateOfs[item])); uint4* d4 = (uint4*)dst;
+            const uint32_t units = n / 16u, u0 = dstOfs[j] / 16u;
+            for (uint32_t k0 = 0; k0 < units; k0 += blockDim.x) {
+                const uint32_t k = k0 + threadIdx.x;
+                const bool live = k < units;
+                uint4 v = make_uint4(pat, pat, pat, pat);
+                if (live && !uniform) v = s4[k];
+                const uint32_t code = codec_unit_code(v.x, v.y, v.z, v.w);
+                if (live) { d4[k] = v; unitCodes[u0 + k] = (uint8_t)code; }
+                // raw units per codec block: the units of a wave are consecutive, so they lie in at most two blocks
+                const uint32_t blk = (u0 + k) / kCodecBlockUnits;
+                unsigned long long todo = __ballot(live && code == 4u);
+                while (todo) {
+                    const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+                    const uint32_t b0 = (uint32_t)__shfl((int)blk, (int)leader);
+                    const unsigned long long same = __ballot(live && code == 4u && blk == b0) & todo;
+                    if ((threadIdx.x & 63u) == leader) atomicAdd(&blockRawCounts[b0], (uint32_t)__popcll(same));
+                    todo &= ~same;
+                }
+            }
+            continue;
+        }
         if (!active[item]) {
             const uint32_t st = (uint32_t)(31 - __clz((int)stateMask[item]));
             uint32_t usedBits = (1u << (2u * level[item])) * (uint32_t)bits; if (usedBits > 8u) usedBits = 8u;
@@ -1964,11 +1998,14 @@ __global__ __launch_bounds__(256) void tail_gather_omms(const uint8_t* __restric
 }
 
 void launch_gather_omms(const uint8_t* states, const uint64_t* stateOfs, const uint8_t* active, const uint32_t* stateMask, const uint8_t* level, int bits, int storeBits,
-                        const uint32_t* order, const uint32_t* dstOfs, const uint32_t* sizes, uint32_t numOmms, uint8_t* arrayData, hipStream_t stream)
+                        const uint32_t* order, const uint32_t* dstOfs, const uint32_t* sizes, uint32_t numOmms, uint8_t* arrayData, hipStream_t stream,
+                        uint8_t* unitCodes, uint32_t* blockRawCounts)
 {
     if (numOmms == 0) return;
     const uint32_t grid = numOmms < 65536u * 4u ? numOmms : 65536u * 4u;
-    hipLaunchKernelGGL(tail_gather_omms, dim3(grid), dim3(256), 0, stream, states, stateOfs, active, stateMask, level, bits, storeBits, order, dstOfs, sizes, numOmms, arrayData);
+    if (storeBits != bits || !blockRawCounts) unitCodes = nullptr;
+    hipLaunchKernelGGL(tail_gather_omms, dim3(grid), dim3(256), 0, stream, states, stateOfs, active, stateMask, level, bits, storeBits, order, dstOfs, sizes, numOmms, arrayData,
+                       unitCodes, blockRawCounts);
 }
 
 // index buffer: triangle -> unique work item -> dedup representative -> special index or descriptor slot

@@ -32,6 +32,7 @@
 #include <unistd.h>
 #include <unordered_map>
 #include <vector>
+#include <functional>
 #include <xmmintrin.h>
 #include <emmintrin.h>
 
@@ -571,6 +572,9 @@ struct DeviceResult {
     uint32_t hist[2 * kNumLevels]; int bits = 2;
     const float* triAreaScratch = nullptr; // per-triangle UV areas in the bake's arena: valid until the session ends (ommCpuBake copies them out)
     std::shared_ptr<DevPool> pool;   // the baker's (results may outlive their baker)
+    // ommCpuBake's compressed transfer: asked right before the gather, when the array's size is known and every OMM is a multiple of 16 bytes; may hand out a byte per
+    // 16-byte unit and a zeroed word per 256-unit block (+ 1) for the gather to fill with the exchange codec's codes and raw counts (launch_gather_omms)
+    std::function<bool(uint64_t arrayDataSize, uint8_t** unitCodes, uint32_t** blockRawCounts)> gatherCodes;
     DeviceResult() { memset(hist, 0, sizeof hist); }
     DeviceResult(const DeviceResult&) = delete;
     DeviceResult& operator=(const DeviceResult&) = delete;
@@ -1175,7 +1179,11 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         if (!streamed) R.arrayData = (uint8_t*)R.dev_alloc((size_t)counts.arrayDataSize);
         ok = R.descs != nullptr && (streamed || R.arrayData != nullptr);
         if (ok) {
-            if (!streamed) launch_gather_omms(dStates, dStateOfs, dActive, dMask, dLevel, bits, storeBits, dOrder, dDstOfs, dSizes, E, R.arrayData, stream);
+            if (!streamed) {
+                uint8_t* unitCodes = nullptr; uint32_t* blockRawCounts = nullptr;
+                if (R.gatherCodes && storeBits == bits && counts.smallOmms == 0 && !R.gatherCodes(counts.arrayDataSize, &unitCodes, &blockRawCounts)) { unitCodes = nullptr; blockRawCounts = nullptr; }
+                launch_gather_omms(dStates, dStateOfs, dActive, dMask, dLevel, bits, storeBits, dOrder, dDstOfs, dSizes, E, R.arrayData, stream, unitCodes, blockRawCounts);
+            }
             launch_write_descs(dOrder, dDstOfs, dLevel, bits, E, R.descs, stream);
         }
     }
@@ -1442,27 +1450,47 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
     so.compressedAvailable = wantCompressed && transferKnob == ommxResultTransfer_Auto;
     const bool canStream = (!wantCompressed || so.compressedAvailable) && transferKnob != ommxResultTransfer_Plain && ses.open_comm() && ses.open_place();
     so.copyStream = ses.commStream; so.placeStream = ses.placeStream; so.device = baker.bind_device();
+    struct CodecOut { uint8_t* dBlock = nullptr; DevPool* pool = nullptr; uint8_t* dComp = nullptr; uint32_t* dSize = nullptr; HostCodecLayout L{}; uint64_t padded = 0, cap = 0; bool on = false;
+                      uint8_t* unitCodes = nullptr; uint32_t* blockRawCounts = nullptr; size_t scratchBytes = 0;   // (set when the gather produces the codes)
+                      ~CodecOut() { if (dBlock) pool->release(dBlock); } } co;
+    // one device block for the codec: size word (256 B) | scan scratch | [unit codes | block counts] | the stream
+    auto codec_block = [&](uint64_t arrayDataSize, bool withCodes) -> bool {
+        co.padded = (arrayDataSize + 255u) & ~255ull; co.L = host_codec_layout(co.padded);
+        co.cap = co.L.offRaw + co.padded / 2u + 16u;   // a stream that does not shrink below half takes the plain copy
+        co.scratchBytes = pad256(shard_codec_scratch_bytes(co.padded));
+        const size_t codeBytes = withCodes ? pad256((size_t)(co.padded / 16u)) : 0, countBytes = withCodes ? pad256(((size_t)co.L.blocks + 1) * 4) : 0;
+        co.pool = baker.devPool.get(); co.dBlock = (uint8_t*)baker.devPool->acquire(256 + co.scratchBytes + codeBytes + countBytes + (size_t)co.cap);
+        if (!co.dBlock || co.L.blocks >= 0x7FFFFFFFull) return false;
+        co.dSize = (uint32_t*)co.dBlock; co.dComp = co.dBlock + 256 + co.scratchBytes + codeBytes + countBytes;
+        if (withCodes) { co.unitCodes = co.dBlock + 256 + co.scratchBytes; co.blockRawCounts = (uint32_t*)(co.unitCodes + codeBytes); }
+        return true;
+    };
+    if (wantCompressed) R.gatherCodes = [&](uint64_t arrayDataSize, uint8_t** unitCodes, uint32_t** blockRawCounts) -> bool {
+        if (arrayDataSize < kCompressedMinBytes || (arrayDataSize & 15u) != 0 || !codec_block(arrayDataSize, true)) return false;
+        // (the units of the padding behind the array count as zeros; the counts start at zero)
+        const uint64_t units = arrayDataSize / 16u, paddedUnits = co.padded / 16u;
+        bool okm = HIP_OK(hipMemsetAsync(co.blockRawCounts, 0, ((size_t)co.L.blocks + 1) * 4, stream));
+        if (okm && paddedUnits > units) okm = HIP_OK(hipMemsetAsync(co.unitCodes + units, 0, (size_t)(paddedUnits - units), stream));
+        if (!okm) { co.unitCodes = nullptr; co.blockRawCounts = nullptr; return false; }
+        *unitCodes = co.unitCodes; *blockRawCounts = co.blockRawCounts;
+        return true;
+    };
     const ommResult br = bake_core(baker, d, din, &d, ses.arena, ses.states, stream, et, R, tm, nullptr, nullptr, canStream ? &so : nullptr);
+    R.gatherCodes = nullptr;
     if (br != ommResult_SUCCESS) return br;
 
     // ---- copy the (rest of the) result out through the user's allocator ----
     const int d0 = et.mark();
     const uint32_t E = R.numDescs;
     // ---- compressed result: codec stream of the finished array (device), one copy of the stream, expansion by the baker's helper threads ----
-    struct CodecOut { uint8_t* dBlock = nullptr; DevPool* pool = nullptr; uint8_t* dComp = nullptr; uint32_t* dSize = nullptr; HostCodecLayout L{}; uint64_t padded = 0, cap = 0; bool on = false;
-                      ~CodecOut() { if (dBlock) pool->release(dBlock); } } co;
     std::vector<uint8_t> codecHead;   // header + offsets of the codec stream (1 MB per GB of arrayData)
     const double c0 = now_ms();
     if (E && wantCompressed && !so.used && R.arrayDataSize >= kCompressedMinBytes) {
         // (the device array was taken from the result pool, whose blocks are multiples of 4096 bytes: the codec may read the padding, the host never writes it)
-        co.padded = (R.arrayDataSize + 255u) & ~255ull; co.L = host_codec_layout(co.padded);
-        co.cap = co.L.offRaw + co.padded / 2u + 16u;   // a stream that does not shrink below half takes the plain copy
-        const size_t scratchBytes = pad256(shard_codec_scratch_bytes(co.padded));
-        co.pool = baker.devPool.get(); co.dBlock = (uint8_t*)baker.devPool->acquire(256 + scratchBytes + (size_t)co.cap);
-        if (co.dBlock && co.L.blocks < 0x7FFFFFFFull) {
-            co.dSize = (uint32_t*)co.dBlock; co.dComp = co.dBlock + 256 + scratchBytes;
-            co.on = HIP_OK(run_shard_compress(R.arrayData, co.padded, co.dComp, co.cap, co.dSize, co.dBlock + 256, scratchBytes, stream));
-        }
+        if (co.unitCodes)   // the gather has left the codes of the units and the raw counts of the blocks: the array is read for its raw units only
+            co.on = HIP_OK(run_shard_compress_coded(R.arrayData, co.padded, co.unitCodes, co.blockRawCounts, co.dComp, co.cap, co.dSize, co.dBlock + 256, co.scratchBytes, stream));
+        else if (!co.dBlock && codec_block(R.arrayDataSize, false))
+            co.on = HIP_OK(run_shard_compress(R.arrayData, co.padded, co.dComp, co.cap, co.dSize, co.dBlock + 256, co.scratchBytes, stream));
         (void)hipGetLastError();
     }
     if (E) {

@@ -161,13 +161,19 @@ __global__ __launch_bounds__(256) void tail_order_sizes(const uint32_t* __restri
 __global__ __launch_bounds__(256) void tail_item_values(const uint32_t* __restrict__ order, const uint32_t* __restrict__ numEmitted,
                                                         const uint64_t* __restrict__ ofs64, uint32_t* __restrict__ dstOfs,
                                                         const int32_t* __restrict__ special, uint32_t numItems, int32_t* __restrict__ itemValue,
-                                                        const uint64_t* __restrict__ sizes64, const uint32_t* __restrict__ errorFlag, uint64_t* __restrict__ summary)
+                                                        const uint64_t* __restrict__ sizes64, const uint32_t* __restrict__ errorFlag, uint64_t* __restrict__ summary,
+                                                        const uint32_t* __restrict__ arrayHist, int bits)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t E = *numEmitted;
     // what the host needs to continue, in one place for ONE read-back: OMM count, consistency flag, arrayData size
     // (= ofs[n-1] + sizes[n-1]: entries past numEmitted are zero-sized)
-    if (i == 0) { summary[0] = (uint64_t)E | ((uint64_t)*errorFlag << 32); summary[1] = ofs64[numItems - 1u] + sizes64[numItems - 1u]; }
+    if (i == 0) {
+        summary[0] = (uint64_t)E | ((uint64_t)*errorFlag << 32); summary[1] = ofs64[numItems - 1u] + sizes64[numItems - 1u];
+        uint32_t small = 0;   // emitted OMMs of less than 16 bytes (tail_order_sizes has filled the histogram)
+        for (int l = 0; l < (bits == 2 ? 3 : 4); ++l) small += arrayHist[l];
+        summary[2] = small;
+    }
     if (i < numItems && special[i] != 0) itemValue[i] = special[i];
     if (i < E) { itemValue[order[i]] = (int32_t)i; dstOfs[i] = (uint32_t)ofs64[i]; }
 }
@@ -443,8 +449,7 @@ __host__ __device__ inline CodecLayout codec_layout(uint64_t contributionBytes)
 }
 __device__ __forceinline__ uint32_t codec_code(const uint4& v)
 {
-    const bool same = v.x == v.y && v.x == v.z && v.x == v.w;
-    return !same ? 4u : (v.x == 0u ? 0u : (v.x == 0x55555555u ? 1u : (v.x == 0xAAAAAAAAu ? 2u : (v.x == 0xFFFFFFFFu ? 3u : 4u))));
+    return codec_unit_code(v.x, v.y, v.z, v.w);
 }
 // raw units in front of this thread inside its 256-unit block, and the block's total (all threads call; s: 4 words of LDS)
 __device__ __forceinline__ uint32_t codec_rank(bool raw, uint32_t* s, uint32_t& total)
@@ -479,6 +484,21 @@ __global__ __launch_bounds__(256) void shard_codec_write(const uint4* __restrict
     const uint32_t other = (uint32_t)__shfl_xor((int)code, 1);
     if (live && (threadIdx.x & 1u) == 0u) comp[c.offCodes + u / 2u] = (uint8_t)(code | (other << 4));   // (units is even: contributions are multiples of 256 bytes)
     if (live && code == 4u) ((uint4*)(comp + c.offRaw))[ofs[blockIdx.x] + rank] = v;
+}
+// the same stream from the gather's unit codes: only the raw units are read from the array
+__global__ __launch_bounds__(256) void shard_codec_write_coded(const uint4* __restrict__ contrib, const uint8_t* __restrict__ unitCodes, CodecLayout c, uint8_t* __restrict__ comp, uint64_t capBytes)
+{
+    __shared__ uint32_t s[4];
+    const uint32_t* ofs = (const uint32_t*)(comp + c.offOfs);
+    if (c.offRaw + 16ull * ofs[c.blocks] > capBytes) return;
+    const uint64_t u = (uint64_t)blockIdx.x * kCodecBlock + threadIdx.x;
+    const bool live = u < c.units;
+    const uint32_t code = live ? (uint32_t)unitCodes[u] : 0u;
+    uint32_t total;
+    const uint32_t rank = codec_rank(live && code == 4u, s, total);
+    const uint32_t other = (uint32_t)__shfl_xor((int)code, 1);
+    if (live && (threadIdx.x & 1u) == 0u) comp[c.offCodes + u / 2u] = (uint8_t)(code | (other << 4));
+    if (live && code == 4u) ((uint4*)(comp + c.offRaw))[ofs[blockIdx.x] + rank] = contrib[u];
 }
 __global__ void shard_codec_finish(CodecLayout c, uint8_t* __restrict__ comp, uint64_t capBytes, uint32_t* __restrict__ sizeWord)
 {
@@ -594,6 +614,18 @@ hipError_t run_shard_compress(const uint8_t* contrib, uint64_t contributionBytes
     hipLaunchKernelGGL(shard_codec_count, dim3((uint32_t)c.blocks), dim3(256), 0, stream, (const uint4*)contrib, c, counts);
     TAIL_CHECK(rocprim::exclusive_scan(tmp, tb, counts, (uint32_t*)(comp + c.offOfs), (uint32_t)0, (size_t)(c.blocks + 1), rocprim::plus<uint32_t>(), stream));
     hipLaunchKernelGGL(shard_codec_write, dim3((uint32_t)c.blocks), dim3(256), 0, stream, (const uint4*)contrib, c, comp, capBytes);
+    hipLaunchKernelGGL(shard_codec_finish, dim3(1), dim3(1), 0, stream, c, comp, capBytes, sizeWord);
+    return hipGetLastError();
+}
+hipError_t run_shard_compress_coded(const uint8_t* contrib, uint64_t contributionBytes, const uint8_t* unitCodes, uint32_t* blockRawCounts, uint8_t* comp, uint64_t capBytes,
+                                    uint32_t* sizeWord, void* scratch, size_t scratchBytes, hipStream_t stream)
+{
+    const CodecLayout c = codec_layout(contributionBytes);
+    if (scratchBytes < shard_codec_scratch_bytes(contributionBytes) || capBytes < c.offRaw + 16u || c.blocks >= 0x7FFFFFFFull) return hipErrorInvalidValue;
+    void* tmp = (uint8_t*)scratch + ((size_t)(c.blocks + 1) * 4 + 255) / 256 * 256;
+    size_t tb = scratchBytes - ((size_t)(c.blocks + 1) * 4 + 255) / 256 * 256;
+    TAIL_CHECK(rocprim::exclusive_scan(tmp, tb, blockRawCounts, (uint32_t*)(comp + c.offOfs), (uint32_t)0, (size_t)(c.blocks + 1), rocprim::plus<uint32_t>(), stream));
+    hipLaunchKernelGGL(shard_codec_write_coded, dim3((uint32_t)c.blocks), dim3(256), 0, stream, (const uint4*)contrib, unitCodes, c, comp, capBytes);
     hipLaunchKernelGGL(shard_codec_finish, dim3(1), dim3(1), 0, stream, c, comp, capBytes, sizeWord);
     return hipGetLastError();
 }
@@ -1034,7 +1066,7 @@ size_t tail_scratch_bytes(uint32_t numItems, uint32_t numTris)
 hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch, size_t scratchBytes, TailCounts* counts, hipStream_t stream)
 {
     const uint32_t n = in.numItems;
-    counts->numOmms = 0; counts->arrayDataSize = 0;
+    counts->numOmms = 0; counts->arrayDataSize = 0; counts->smallOmms = 0;
     if (out.indexHist == out.arrayHist + 64 && in.errorFlag == out.arrayHist + 128)   // (the bake takes the three from its arena back to back: one fill)
         TAIL_CHECK(hipMemsetAsync(out.arrayHist, 0, sizeof(uint32_t) * 129, stream));
     else {
@@ -1071,12 +1103,12 @@ hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch,
         tb = s.tmpBytes;
         TAIL_CHECK(rocprim::exclusive_scan(s.tmp, tb, s.sizes64, s.ofs64, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), stream));
         hipLaunchKernelGGL(tail_item_values, grid, block, 0, stream, out.order, s.numEmitted, s.ofs64, out.dstOfs, out.special, n, out.itemValue,
-                           s.sizes64, in.errorFlag, s.total);
-        uint64_t summary[2] = { 0, 0 };
+                           s.sizes64, in.errorFlag, s.total, out.arrayHist, in.format);
+        uint64_t summary[3] = { 0, 0, 0 };
         TAIL_CHECK(hipMemcpyAsync(summary, s.total, sizeof summary, hipMemcpyDeviceToHost, stream));
         TAIL_CHECK(hipStreamSynchronize(stream));
         const uint32_t E = (uint32_t)summary[0], err = (uint32_t)(summary[0] >> 32);
-        counts->numOmms = E; counts->arrayDataSize = summary[1];
+        counts->numOmms = E; counts->arrayDataSize = summary[1]; counts->smallOmms = (uint32_t)summary[2];
         if (err) return hipErrorAssert;
     }
     if (in.numTris != 0)

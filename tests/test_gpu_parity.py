@@ -1632,9 +1632,20 @@ def test_result_transfer_modes_give_the_same_bytes(product, oracle):
     form by default; the smallest against the oracle."""
     import bench, workloads as wl
     rng = np.random.RandomState(3)
-    cases = [("c2", 2000, None), ("c2", 60000, None), ("noise", 600, (rng.rand(1024, 1024) > 0.5).astype(np.float32))]
+    # (the compressed form has the gather produce the codec's unit codes when every OMM is a multiple of 16 bytes in the bake's own packing: the "small" case mixes
+    #  levels 0 - 2 into a large bake, "uniform" emits the uniform work items instead of special indices (pattern fills), "2state" packs 2-bit states into 1 bit)
+    cases = [("c2", 2000, None), ("c2", 60000, None), ("noise", 600, (rng.rand(1024, 1024) > 0.5).astype(np.float32)),
+             ("small", 110000, None), ("uniform", 60000, None), ("2state", 120000, None)]
     for kind, n, tex_override in cases:
-        if kind == "noise":   # micro-triangles of a texel each on 0 / 1 noise, promotion by majority: UO / UT at random, units of 64 states rarely repeat one
+        if kind in ("small", "uniform", "2state"):
+            tex, uv, ix, lv, kw = wl.workload("c2", n); kw = dict(kw)
+            if kind == "small":
+                lv = np.full(n, kw["level"], np.uint8); lv[::7] = 0; lv[1::7] = 1; lv[2::7] = 2; lv[3::7] = 3; kw["levels"] = lv
+            elif kind == "uniform":
+                kw["flags"] = kw.get("flags", ot.FLAG_THREADS) | ot.FLAG_NO_SPECIAL
+            else:
+                kw["fmt"] = ot.FMT_2STATE
+        elif kind == "noise":   # micro-triangles of a texel each on 0 / 1 noise, promotion by majority: UO / UT at random, units of 64 states rarely repeat one
             tex = tex_override; uv, ix = ot.random_triangles(77, n, 0.5); lv = None
             kw = dict(level=9, addr=ot.WRAP, promo=ot.PROMO_NEAREST)
         else:
@@ -1660,7 +1671,7 @@ def test_result_transfer_modes_give_the_same_bytes(product, oracle):
             assert tmc.resultTransfer == ot.TRANSFER_PLAIN and tmc.compressMs > 0, (tmc.resultTransfer, tmc.compressedBytes, ref.array_data.size)   # (tried, incompressible)
         # without the caller's permission to use threads the default is never the compressed form
         product.set_knob(b, ot.KNOB_RESULT_TRANSFER, ot.TRANSFER_AUTO)
-        r0 = product.bake(b, ot.make_desc(t, uv, ix, lvl, **dict(kw, flags=0)), want_stats=False)
+        r0 = product.bake(b, ot.make_desc(t, uv, ix, lvl, **dict(kw, flags=kw.get("flags", ot.FLAG_THREADS) & ~ot.FLAG_THREADS)), want_stats=False)
         assert bench.get_timings(product, b).resultTransfer != ot.TRANSFER_COMPRESSED and r0.same_as(ref)
         if n <= 2000:
             ob = oracle.create_baker(); otx = oracle.create_texture(ob, [tex], alpha_cutoff=0.5)
