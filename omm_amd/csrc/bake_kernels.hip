@@ -1040,6 +1040,9 @@ __device__ __forceinline__ void generic_walks(const ClassifyParams& P, const Ite
 #ifndef OMMX_GENERIC_QUOTA_LOG2
 #define OMMX_GENERIC_QUOTA_LOG2 2   // texels an owner offers per round: 2 / 4 / 8 = 19.3 / 18.2 / 19.5 ms on the cards workload
 #endif
+#ifndef OMMX_GENERIC_DENSE_CHUNK
+#define OMMX_GENERIC_DENSE_CHUNK 256u   // queue entries a wave takes from the cursor at a time: 1024 / 256 / 128 = 18.2 / 16.9 / 17.0 ms (the last chunk of a wave is the launch's tail)
+#endif
 #ifndef OMMX_GENERIC_DENSE_REFILL
 #define OMMX_GENERIC_DENSE_REFILL 24   // idle owners that trigger a refill: 16 / 24 / 32 = 18.46 / 18.2 / 18.2 ms
 #endif
@@ -1185,10 +1188,10 @@ __device__ __forceinline__ void generic_dense(const ClassifyParams& P, const Ite
             if (drained) break;   // (busy == 0)
             if (chunkNext == chunkEnd) {
                 unsigned long long start = 0;
-                if (lane == 0u) start = atomicAdd(cursorWord, (unsigned long long)OMMX_GENERIC_CHUNK);
+                if (lane == 0u) start = atomicAdd(cursorWord, (unsigned long long)OMMX_GENERIC_DENSE_CHUNK);
                 start = (unsigned long long)__shfl((long long)start, 0);
                 if (start >= (unsigned long long)n) drained = true;
-                else { chunkNext = (uint32_t)start; chunkEnd = start + OMMX_GENERIC_CHUNK < (unsigned long long)n ? (uint32_t)start + OMMX_GENERIC_CHUNK : n; }
+                else { chunkNext = (uint32_t)start; chunkEnd = start + OMMX_GENERIC_DENSE_CHUNK < (unsigned long long)n ? (uint32_t)start + OMMX_GENERIC_DENSE_CHUNK : n; }
             }
             if (!drained) {
                 const uint32_t avail = chunkEnd - chunkNext, take = idle < avail ? idle : avail;
@@ -1640,33 +1643,38 @@ __global__ __launch_bounds__(256) void digest_items(const uint8_t* __restrict__ 
 //  like every kernel of the placement stream they stay small, 25 VGPRs with rolled loops)
 template <int DG_CHUNK, int DG_ITEMS, bool MIXED>
 __device__ __forceinline__ void digest_items_lds_body(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs, const DigestLists& D, uint32_t blocksA, uint32_t bits,
-                                                      uint64_t* __restrict__ digests);
+                                                      uint64_t* __restrict__ digests, uint32_t blk);
 template <int DG_CHUNK, int DG_ITEMS, bool MIXED>
 __global__ __launch_bounds__(256) void digest_items_lds(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs, DigestLists D, uint32_t blocksA, uint32_t bits,
                                                         uint64_t* __restrict__ digests)
 {
-    digest_items_lds_body<DG_CHUNK, DG_ITEMS, MIXED>(states, stateOfs, D, blocksA, bits, digests);
+    digest_items_lds_body<DG_CHUNK, DG_ITEMS, MIXED>(states, stateOfs, D, blocksA, bits, digests, blockIdx.x);
 }
 template <int DG_CHUNK, int DG_ITEMS, bool MIXED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void digest_items_lds_guest(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs, DigestLists D,
                                                                                                    uint32_t blocksA, uint32_t bits, uint64_t* __restrict__ digests)
 {
-    digest_items_lds_body<DG_CHUNK, DG_ITEMS, MIXED>(states, stateOfs, D, blocksA, bits, digests);
+    digest_items_lds_body<DG_CHUNK, DG_ITEMS, MIXED>(states, stateOfs, D, blocksA, bits, digests, blockIdx.x);
 }
 template <int DG_CHUNK, int DG_ITEMS, bool MIXED>
 __device__ __forceinline__ void digest_items_lds_body(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs, const DigestLists& D, uint32_t blocksA, uint32_t bits,
-                                                      uint64_t* __restrict__ digests)
+                                                      uint64_t* __restrict__ digests, uint32_t blk)
 {
     constexpr int DG_STRIDE = DG_CHUNK / 4 + 1;
     __shared__ uint32_t s_buf[DG_ITEMS * DG_STRIDE];
     __shared__ const uint8_t* s_ptr[DG_ITEMS];
     __shared__ uint32_t s_bytes[MIXED ? DG_ITEMS : 1], s_maxBytes;
+    // XXH64's round multiplies the 8 input bytes by P2 first.  The 8 bytes are the states of 8 micro-triangles, unpacked from two bytes of packed 2-bit states:
+    // x = A + (B << 32) with A, B = the spread of one packed byte each, so x * P2 = A * P2 + ((B * P2) << 32) mod 2^64 -- two reads of a 256-entry table of
+    // spread(b) * P2 instead of the unpack and four quarter-rate 32-bit multiplies (digest of configs[2]'s 127 k level-8 items: 0.76 -> see DESIGN 5).
+    __shared__ uint64_t s_tab[256];
     const uint32_t tid = threadIdx.x;
-    const bool listB = MIXED && blockIdx.x >= blocksA;
-    const uint32_t* itemIds = D.ids; uint32_t numItems = D.count, first = blockIdx.x * DG_ITEMS;
+    if (bits == 2) s_tab[tid & 255u] = (uint64_t)spread4x2(tid & 255u) * XP2;
+    const bool listB = MIXED && blk >= blocksA;
+    const uint32_t* itemIds = D.ids; uint32_t numItems = D.count, first = blk * DG_ITEMS;
     const uint8_t* only = D.only;
     if (listB) {
-        numItems = *D.liveCount < D.capacityB ? *D.liveCount : D.capacityB; itemIds = D.listB + *D.liveStart; first = (blockIdx.x - blocksA) * DG_ITEMS; only = nullptr;
+        numItems = *D.liveCount < D.capacityB ? *D.liveCount : D.capacityB; itemIds = D.listB + *D.liveStart; first = (blk - blocksA) * DG_ITEMS; only = nullptr;
     }
     if (first >= numItems) return;
     if (DG_ITEMS < 64) __builtin_amdgcn_s_setprio(3);   // (a latency-bound guest next to the classification: its few instructions should not queue behind 6 waves per SIMD)
@@ -1690,7 +1698,32 @@ __device__ __forceinline__ void digest_items_lds_body(const uint8_t* __restrict_
     uint64_t v = acc == 0 ? seed + XP1 + XP2 : (acc == 1 ? seed + XP2 : (acc == 2 ? seed : seed - XP1));
     __syncthreads();
     const uint32_t bytesPerItem = MIXED ? s_maxBytes : myBytes;
+    // The full-size form fetches chunk k + 1 into registers while chunk k is hashed: with one workgroup per CU (the few thousand level-10 items of a mixed bake) the
+    // latency of the fetch was half of every step.  The guest forms (32 VGPRs) fetch and store in one go.
+    constexpr bool PREFETCH = DG_ITEMS == 64 && !MIXED;
+    constexpr uint32_t LOADS = DG_ITEMS * (DG_CHUNK / 16) / 256;   // 16-byte pieces per thread and chunk
+    uint4 pre[PREFETCH ? LOADS : 1];
+    auto fetch = [&](uint32_t chunk) {
+        #pragma unroll
+        for (uint32_t j = 0; j < LOADS; ++j) {
+            const uint32_t k = tid + j * 256u, row = k / (DG_CHUNK / 16), part = k % (DG_CHUNK / 16);
+            const uint8_t* src = s_ptr[row];
+            pre[PREFETCH ? j : 0] = src ? *(const uint4*)(src + chunk + part * 16u) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    if (PREFETCH && bytesPerItem) fetch(0);
     for (uint32_t chunk = 0; chunk < bytesPerItem; chunk += DG_CHUNK) {
+        if (PREFETCH) {
+            #pragma unroll
+            for (uint32_t j = 0; j < LOADS; ++j) {
+                const uint32_t k = tid + j * 256u, row = k / (DG_CHUNK / 16), part = k % (DG_CHUNK / 16);
+                uint32_t* dst = s_buf + row * DG_STRIDE + part * 4u;
+                const uint4 w = pre[PREFETCH ? j : 0];
+                dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+            }
+            __syncthreads();
+            if (chunk + DG_CHUNK < bytesPerItem) fetch(chunk + DG_CHUNK);
+        } else {
         #pragma unroll DG_ITEMS < 64 ? 1 : 4   // (the guest forms keep their register count down: see digest_items_lds_guest)
         for (uint32_t k = tid; k < DG_ITEMS * (DG_CHUNK / 16); k += 256) {
             const uint32_t row = k / (DG_CHUNK / 16), part = k % (DG_CHUNK / 16);
@@ -1701,11 +1734,16 @@ __device__ __forceinline__ void digest_items_lds_body(const uint8_t* __restrict_
             dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
         }
         __syncthreads();
+        }
         if (!hasher || (MIXED && chunk >= myBytes)) { /* a load-only thread, or this item's stream has ended */ }
         else if (bits == 2) {
             const uint16_t* q = (const uint16_t*)(s_buf + il * DG_STRIDE) + acc;
             #pragma unroll DG_ITEMS < 64 ? 2 : 4
-            for (uint32_t st = 0; st < stripesPerChunk; ++st) v = xxh_round(v, expand8((uint32_t)q[4 * st], 2));
+            for (uint32_t st = 0; st < stripesPerChunk; ++st) {
+                const uint32_t piece = (uint32_t)q[4 * st];
+                const uint64_t xp = s_tab[piece & 0xffu] + ((uint64_t)(uint32_t)s_tab[piece >> 8] << 32);
+                v = rotl64(v + xp, 31) * XP1;
+            }
         } else {
             const uint8_t* q = (const uint8_t*)(s_buf + il * DG_STRIDE) + acc;
             #pragma unroll DG_ITEMS < 64 ? 2 : 4
@@ -1734,6 +1772,17 @@ __device__ __forceinline__ void digest_items_lds_body(const uint8_t* __restrict_
 // level first, and the launch takes as long as the level-10 chain alone.
 constexpr int DL_ITEMS = 16, DL_STRIPES = 32;
 struct DigestChainLevels { uint32_t n; uint32_t level[kNumLevels], count[kNumLevels], blockStart[kNumLevels + 1]; const uint32_t* ids[kNumLevels]; };
+// MANY items of several levels in one launch of the form above (a workgroup holds 64 items of one level; highest level first, so the longest streams start first):
+// the levels of a mixed bake used to take one launch each, one after the other, each as long as its longest item.
+__global__ __launch_bounds__(256) void digest_items_lds_levels(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs, DigestChainLevels V, uint32_t bits,
+                                                               uint64_t* __restrict__ digests)
+{
+    uint32_t seg = 0;
+    while (seg + 1u < V.n && blockIdx.x >= V.blockStart[seg + 1u]) ++seg;
+    DigestLists D; memset(&D, 0, sizeof D);
+    D.ids = V.ids[seg]; D.count = V.count[seg]; D.level = V.level[seg];
+    digest_items_lds_body<256, 64, false>(states, stateOfs, D, 0u, bits, digests, blockIdx.x - V.blockStart[seg]);
+}
 __global__ __launch_bounds__(256) void digest_items_chain(const uint8_t* __restrict__ states, const uint64_t* __restrict__ stateOfs, DigestChainLevels V,
                                                           uint32_t bits, uint64_t* __restrict__ digests)
 {
@@ -1800,8 +1849,14 @@ __global__ __launch_bounds__(256) void digest_items_chain(const uint8_t* __restr
 }
 
 // few, long items (every workgroup resident at once: 16 384 items fill the chip, twice that still gains): the split form above
-static bool digest_wants_chain(uint32_t numItems, uint32_t level, uint32_t bits) { return numItems != 0 && ((((1u << (2 * level)) * bits) >> 3) >= 1024u) && numItems <= 32768u; }
-// the active items of ALL levels (level l: ids first[l] .. + count[l] of activeIds): the levels the chain form suits in one launch, the others one launch each
+// FEW long items (a workgroup-step of the split form takes ~12 us whatever the number of workgroups up to 3 per CU; with the table-driven round of the plain form a lane
+// alone needs ~110 cycles per stripe, so the split form pays only while the plain form would leave most of the chip idle)
+#ifndef OMMX_DIGEST_CHAIN_MAX_ITEMS
+#define OMMX_DIGEST_CHAIN_MAX_ITEMS 2048u
+#endif
+static bool digest_wants_chain(uint32_t numItems, uint32_t level, uint32_t bits) { return numItems != 0 && ((((1u << (2 * level)) * bits) >> 3) >= 1024u) && numItems <= OMMX_DIGEST_CHAIN_MAX_ITEMS; }
+static bool digest_wants_lds(uint32_t numItems, uint32_t level, uint32_t bits) { return numItems != 0 && ((((1u << (2 * level)) * bits) >> 3) >= 256u) && !digest_wants_chain(numItems, level, bits); }
+// the active items of ALL levels (level l: ids first[l] .. + count[l] of activeIds): the levels a form suits in one launch of it, the small levels one launch each
 void launch_digest_levels(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* activeIds, const uint32_t first[kNumLevels], const uint32_t count[kNumLevels],
                           uint32_t bits, uint64_t* digests, hipStream_t stream)
 {
@@ -1812,8 +1867,15 @@ void launch_digest_levels(const uint8_t* states, const uint64_t* stateOfs, const
         V.blockStart[V.n + 1u] = V.blockStart[V.n] + (count[l] + DL_ITEMS - 1u) / DL_ITEMS; V.n++;
     }
     if (V.n) hipLaunchKernelGGL(digest_items_chain, dim3(V.blockStart[V.n]), dim3(256), 0, stream, states, stateOfs, V, bits, digests);
+    memset(&V, 0, sizeof V);
+    for (int l = kNumLevels - 1; l >= 0; --l) {
+        if (!digest_wants_lds(count[l], (uint32_t)l, bits)) continue;
+        V.level[V.n] = (uint32_t)l; V.count[V.n] = count[l]; V.ids[V.n] = activeIds + first[l];
+        V.blockStart[V.n + 1u] = V.blockStart[V.n] + (count[l] + 63u) / 64u; V.n++;
+    }
+    if (V.n) hipLaunchKernelGGL(digest_items_lds_levels, dim3(V.blockStart[V.n]), dim3(256), 0, stream, states, stateOfs, V, bits, digests);
     for (int l = 0; l < kNumLevels; ++l)
-        if (count[l] && !digest_wants_chain(count[l], (uint32_t)l, bits)) launch_digest(states, stateOfs, activeIds + first[l], count[l], (uint32_t)l, bits, digests, stream);
+        if (count[l] && !digest_wants_chain(count[l], (uint32_t)l, bits) && !digest_wants_lds(count[l], (uint32_t)l, bits)) launch_digest(states, stateOfs, activeIds + first[l], count[l], (uint32_t)l, bits, digests, stream);
 }
 void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
                    uint64_t* digests, hipStream_t stream, const uint8_t* only, int want)
