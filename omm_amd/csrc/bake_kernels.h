@@ -77,7 +77,7 @@ hipError_t launch_classify(const ClassifyParams& P, const ItemArrays& A, const u
                            void* queue, uint32_t* queueCtl, uint32_t numCUs, hipStream_t stream, const ClassifyChunks* chunks = nullptr);
 // level-0 hierarchical query per work item (summed-area table, then the curve-free-region test): uniform items get stateMask = 1 << state and active = 0
 void launch_triage(const ClassifyParams& P, const float* uv, const uint8_t* level, const uint8_t* degenerate, const SetupCounters* counters, uint32_t maxItems,
-                   uint32_t* stateMask, uint8_t* active, hipStream_t stream);
+                   uint32_t* stateMask, uint8_t* active, void* prepScratch /* run_prep's scratch block: its first prep_state_words() words are zeroed */, hipStream_t stream);
 // XXH64(seed 42) of the 3-state byte stream of each listed item -> digests[item]
 // (only != null: the listed items with (only[item] != 0) == (want != 0))
 void launch_digest(const uint8_t* states, const uint64_t* stateOfs, const uint32_t* itemIds, uint32_t numItems, uint32_t level, uint32_t bits,
@@ -102,7 +102,8 @@ void launch_sat_build(const void* texels, int fp32, uint32_t* sat, uint32_t* scr
 // the reference's rule, byte[i >> 3] |= state << (i & 7) truncated to the byte, bake_cpu_impl.cpp:1811)
 void launch_gather_omms(const uint8_t* states, const uint64_t* stateOfs, const uint8_t* active, const uint32_t* stateMask, const uint8_t* level, int bits, int storeBits,
                         const uint32_t* order, const uint32_t* dstOfs, const uint32_t* sizes, uint32_t numOmms, uint8_t* arrayData, hipStream_t stream,
-                        uint8_t* unitCodes = nullptr, uint32_t* blockRawCounts = nullptr);
+                        uint8_t* unitCodes = nullptr, uint32_t* blockRawCounts = nullptr,
+                        void* descs = nullptr /* ommCpuOpacityMicromapDesc[numOmms]: written by the gather when given */);
 void launch_write_indices(const int32_t* triToItem, const uint32_t* rep, const int32_t* itemValue, uint32_t numTris, int32_t unresolved,
                           int32_t* out, hipStream_t stream);
 
@@ -126,11 +127,13 @@ struct SetupCounters {                                         // one device-res
     uint64_t stateBytes;                                       // filled by run_prep
 };
 size_t setup_scratch_bytes(uint32_t numTris);
-hipError_t run_setup_fetch(const SetupParams& S, void* scratch, size_t scratchBytes, SetupCounters* counters, hipStream_t stream);
+// (also zeroes two word ranges of the caller -- the bake's per-item known counts and its statistic counters -- and fills the UV-dedup table run_setup_items uses)
+hipError_t run_setup_fetch(const SetupParams& S, void* scratch, size_t scratchBytes, SetupCounters* counters, uint32_t* zero, uint32_t zeroWords, uint32_t* zero2, uint32_t zero2Words,
+                           float* triArea /* per triangle UV area, or null */, hipStream_t stream);
 hipError_t copy_pending_to_host(void* scratch, size_t scratchBytes, uint32_t numTris, uint32_t numPending, uint32_t* pendingTris, float* pendingUv, void* tmp, hipStream_t stream);
 hipError_t run_setup_fix_pending(const SetupParams& S, void* scratch, size_t scratchBytes, const uint32_t* pendingTris, const uint8_t* levels, uint32_t numPending, void* tmp, hipStream_t stream);
 hipError_t run_setup_items(const SetupParams& S, void* scratch, size_t scratchBytes, SetupCounters* counters, float* itemUv, uint8_t* itemLevel,
-                           uint8_t* itemDegenerate, int32_t* triToItem, uint32_t* itemIds, float* triArea /* per triangle UV area, or null */, hipStream_t stream);
+                           uint8_t* itemDegenerate, int32_t* triToItem, uint32_t* itemIds, hipStream_t stream);
 
 // ---- multi-GPU sharding helpers (tail_kernels.hip) ----
 constexpr int kMaxRanks = 16;
@@ -227,11 +230,15 @@ struct TailOutputs {            // device buffers owned by the caller
     int32_t*  indexBuffer;      // per triangle
     uint32_t* arrayHist;        // [13]
     uint32_t* indexHist;        // [13]
+    void*     narrowIndex;      // per triangle, narrowBytes (1 / 2 / 4) each: the index buffer in the result's format, or null
+    int       narrowBytes;
 };
 struct TailCounts { uint32_t numOmms; uint64_t arrayDataSize; uint32_t smallOmms; };   // smallOmms: emitted OMMs of less than 16 bytes (levels 0 - 2; 0 - 3 in 2-state)
 
 // compaction of the active (non-uniform) items into per-level lists + their packed-state slots; synchronises the stream once
 // (item count and level boundaries are read from / written to the device-resident counters block; no synchronisation)
+// words at the start of the scratch block that launch_triage zeroes for run_prep (ticket + count / byte states of its tiles of 1024 items)
+inline uint32_t prep_state_words(uint32_t maxItems) { return 64u + 4u * ((maxItems + 1023u) / 1024u + 1u); }
 hipError_t run_prep(const uint32_t* itemIds, const uint8_t* active, const uint8_t* level, int bits, uint32_t maxItems, SetupCounters* counters,
                     uint32_t* activeIds, uint64_t* stateOfs, void* scratch, size_t scratchBytes, hipStream_t stream);
 void launch_narrow_indices(const int32_t* in, uint32_t n, int bytesPerIndex, void* out, hipStream_t stream);

@@ -72,9 +72,11 @@ __device__ __forceinline__ TexWindow no_window()
 }
 
 __global__ __launch_bounds__(256) void triage_items(ClassifyParams P, const float* __restrict__ uv, const uint8_t* __restrict__ level, const uint8_t* __restrict__ degenerate,
-                                                    const SetupCounters* __restrict__ counters, uint32_t* __restrict__ stateMask, uint8_t* __restrict__ active)
+                                                    const SetupCounters* __restrict__ counters, uint32_t* __restrict__ stateMask, uint8_t* __restrict__ active,
+                                                    uint32_t* __restrict__ zero, uint32_t zeroWords)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t w = i; w < zeroWords; w += gridDim.x * blockDim.x) zero[w] = 0u;   // (run_prep's tile states: the launch behind this one)
     if (i >= counters->numItems) return;
     int st = -1;
     const float* t = uv + 6ull * i;
@@ -91,10 +93,11 @@ __global__ __launch_bounds__(256) void triage_items(ClassifyParams P, const floa
 }
 
 void launch_triage(const ClassifyParams& P, const float* uv, const uint8_t* level, const uint8_t* degenerate, const SetupCounters* counters, uint32_t maxItems,
-                   uint32_t* stateMask, uint8_t* active, hipStream_t stream)
+                   uint32_t* stateMask, uint8_t* active, void* prepScratch, hipStream_t stream)
 {
     if (maxItems == 0) return;
-    hipLaunchKernelGGL(triage_items, dim3((maxItems + 255u) / 256u), dim3(256), 0, stream, P, uv, level, degenerate, counters, stateMask, active);
+    hipLaunchKernelGGL(triage_items, dim3((maxItems + 255u) / 256u), dim3(256), 0, stream, P, uv, level, degenerate, counters, stateMask, active,
+                       (uint32_t*)prepScratch, prep_state_words(maxItems));
 }
 
 // index narrowing (bake_cpu_impl.cpp:1872-1902) for results that stay on the device
@@ -1993,10 +1996,12 @@ __global__ __launch_bounds__(256) void tail_gather_omms(const uint8_t* __restric
                                                         const uint8_t* __restrict__ level, int bits, int storeBits,
                                                         const uint32_t* __restrict__ order, const uint32_t* __restrict__ dstOfs,
                                                         const uint32_t* __restrict__ sizes, uint32_t numOmms, uint8_t* __restrict__ arrayData,
-                                                        uint8_t* __restrict__ unitCodes, uint32_t* __restrict__ blockRawCounts)
+                                                        uint8_t* __restrict__ unitCodes, uint32_t* __restrict__ blockRawCounts, uint2* __restrict__ descs)
 {
     for (uint32_t j = blockIdx.x; j < numOmms; j += gridDim.x) {
         const uint32_t item = order[j];
+        // ommCpuOpacityMicromapDesc { u32 offset; u16 subdivisionLevel; u16 format; } (was a launch of its own: tail_descs)
+        if (descs && threadIdx.x == 0) descs[j] = make_uint2(dstOfs[j], (uint32_t)level[item] | ((uint32_t)bits << 16));
         uint8_t* dst = arrayData + dstOfs[j];
         const uint32_t n = sizes[j];
         if (unitCodes) {
@@ -2061,13 +2066,13 @@ __global__ __launch_bounds__(256) void tail_gather_omms(const uint8_t* __restric
 
 void launch_gather_omms(const uint8_t* states, const uint64_t* stateOfs, const uint8_t* active, const uint32_t* stateMask, const uint8_t* level, int bits, int storeBits,
                         const uint32_t* order, const uint32_t* dstOfs, const uint32_t* sizes, uint32_t numOmms, uint8_t* arrayData, hipStream_t stream,
-                        uint8_t* unitCodes, uint32_t* blockRawCounts)
+                        uint8_t* unitCodes, uint32_t* blockRawCounts, void* descs)
 {
     if (numOmms == 0) return;
     const uint32_t grid = numOmms < 65536u * 4u ? numOmms : 65536u * 4u;
     if (storeBits != bits || !blockRawCounts) unitCodes = nullptr;
     hipLaunchKernelGGL(tail_gather_omms, dim3(grid), dim3(256), 0, stream, states, stateOfs, active, stateMask, level, bits, storeBits, order, dstOfs, sizes, numOmms, arrayData,
-                       unitCodes, blockRawCounts);
+                       unitCodes, blockRawCounts, (uint2*)descs);
 }
 
 // index buffer: triangle -> unique work item -> dedup representative -> special index or descriptor slot

@@ -400,6 +400,11 @@ struct UniformDigests {
     }
 };
 const UniformDigests& uniform_digests() { static const UniformDigests t; return t; }
+// what a bake's first transfer carries: the zeroed counters block (its 256-byte arena slot) and, in the slot behind it, the digest table -- one copy instead
+// of a copy and a fill (two fill launches: 200 bytes are not a multiple of 16)
+struct BakeHead { uint8_t counters[256]; uint64_t uniform[kNumLevels * 4]; BakeHead() { memset(counters, 0, sizeof counters); memcpy(uniform, uniform_digests().v, sizeof uniform); } };
+static_assert(sizeof(SetupCounters) <= 256, "the counters block must fit its arena slot");
+const BakeHead& bake_head() { static const BakeHead h; return h; }
 
 // ---- x86 conversion semantics used by the reference's host-side arithmetic ----
 inline int f2i(float f) { return _mm_cvtt_ss2si(_mm_set_ss(f)); }
@@ -827,9 +832,9 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     const bool checkWorkload = ((flags & (1u << 5)) != 0) || d.maxWorkloadSize != 0xFFFFFFFFFFFFFFFFull;
     S.keyMask = ~0ull;
     if (const uint64_t kb = baker.knob(ommxBakerKnob_SetupKeyBits)) S.keyMask = (1ull << kb) - 1ull;   // (tests: forced key collisions)
-    bool ok = HIP_OK(hipMemcpyAsync(dUniformDigest, uniform_digests().v, sizeof(uint64_t) * kNumLevels * 4, hipMemcpyHostToDevice, stream));
-    ok = ok && HIP_OK(hipMemsetAsync(dKnown, 0, (size_t)maxItems * 4, stream));
-    ok = ok && HIP_OK(run_setup_fetch(S, dScratch, scratchBytes, dCounters, stream));
+    bool ok = (const uint8_t*)dUniformDigest == (const uint8_t*)dCounters + 256   // (adjacent arena slots: see BakeHead)
+           && HIP_OK(hipMemcpyAsync(dCounters, &bake_head(), sizeof(BakeHead), hipMemcpyHostToDevice, stream));
+    ok = ok && HIP_OK(run_setup_fetch(S, dScratch, scratchBytes, dCounters, dKnown, maxItems, (uint32_t*)dFine, 2u * kFineSlots * kFineStride, dTriArea, stream));
     if (!ok) return L.failure("[Failure] - no usable HIP device (the MI355X baker has no CPU fallback)");
     SetupCounters hc; memset(&hc, 0, sizeof hc);
     if (d.dynamicSubdivisionScale > 0.f && T) { // degenerate triangles under dynamic subdivision need glibc's log2f: host (bake_cpu_impl.cpp:511-528)
@@ -861,7 +866,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             if (!HIP_OK(run_setup_fix_pending(S, dScratch, scratchBytes, pend.data(), plv.data(), hc.numPending, tmp.p, stream))) return L.failure("[Failure] - device work-item setup failed");
         }
     }
-    if (!HIP_OK(run_setup_items(S, dScratch, scratchBytes, dCounters, dUv, dLevel, dDegen, dTriToItem, dItemIds, dTriArea, stream)))
+    if (!HIP_OK(run_setup_items(S, dScratch, scratchBytes, dCounters, dUv, dLevel, dDegen, dTriToItem, dItemIds, stream)))
         return L.failure("[Failure] - device work-item setup failed");
     const int e1 = et.mark();
 
@@ -887,7 +892,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     P.altKernel = (flags & (1u << 8)) ? ((flags & (1u << 7)) ? 2 : 1) : 0;   // DisableLevelLineIntersection (+ EnableAABBTesting), bake_cpu_impl.cpp:44-45,915-966
 
     // ---- level-0 hierarchical query per item + compaction of the items that need per-micro-triangle work; ONE sync ----
-    launch_triage(P, dUv, dLevel, dDegen, dCounters, maxItems, dMask, dActive, stream);
+    launch_triage(P, dUv, dLevel, dDegen, dCounters, maxItems, dMask, dActive, dScratch, stream);
     if (!HIP_OK(run_prep(dItemIds, dActive, dLevel, storeBits, maxItems, dCounters, dActiveIds, dStateOfs, dScratch, scratchBytes, stream)) ||
         !HIP_OK(hipMemcpyAsync(&hc, dCounters, sizeof hc, hipMemcpyDeviceToHost, stream)) || !HIP_OK(hipStreamSynchronize(stream)))
         return L.failure("[Failure] - device work-list compaction failed");
@@ -937,7 +942,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             ok = ok && HIP_OK(hipMemcpyAsync(dItemIds, itemIds.data(), (size_t)U * 4, hipMemcpyHostToDevice, stream));
         }
         if (T) ok = ok && HIP_OK(hipMemcpyAsync(dTriToItem, triToItem.data(), (size_t)T * 4, hipMemcpyHostToDevice, stream));
-        launch_triage(P, dUv, dLevel, dDegen, dCounters, maxItems, dMask, dActive, stream);
+        launch_triage(P, dUv, dLevel, dDegen, dCounters, maxItems, dMask, dActive, dScratch, stream);
         ok = ok && HIP_OK(run_prep(dItemIds, dActive, dLevel, storeBits, maxItems, dCounters, dActiveIds, dStateOfs, dScratch, scratchBytes, stream));
         ok = ok && HIP_OK(hipMemcpyAsync(&hc, dCounters, sizeof hc, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipStreamSynchronize(stream));
         if (!ok) return L.failure("[Failure] - serial work-item setup failed");
@@ -1024,7 +1029,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
 
     // ---- ResampleCoarse + ResampleFine (bake_cpu_impl.cpp:715-1029) on the active items ----
     ItemArrays A; A.uv = dUv; A.degenerate = dDegen; A.stateOfs = dStateOfs; A.states = dStates; A.stateMask = dMask; A.knownCount = dKnown; A.fineCount = dFine;
-    if (!HIP_OK(hipMemsetAsync(dFine, 0, sizeof(unsigned long long) * kFineSlots * kFineStride, stream))) return L.failure("[Failure] - device memset failed");
+    // (dFine was zeroed by the first set-up launch, with the known counts)
     if (sh && sh->mergeStates && !HIP_OK(hipMemsetAsync(dStates, 0, stateBytes, stream))) return L.failure("[Failure] - device memset failed");
     if (sh && sh->world > 1) { // even out the per-rank cost: interleave every level's active list (tail_kernels.hip: shard_interleave)
         // the permuted copy goes through the (idle) setup / tail scratch block: no allocation, no synchronisation, stream ordered
@@ -1146,6 +1151,14 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         for (int l = 0; l < kNumLevels; ++l) tm.microTriangles += (uint64_t)hc.levelCount[l] << (2 * l);
         return ommResult_SUCCESS;
     }
+    // the index format depends on the triangle count alone: the tail's index kernel writes the narrowed buffer next to the int32 one (bake_cpu_impl.cpp:1872-1902)
+    const bool allow8 = (flags & (1u << 6)) != 0, force32 = (flags & (1u << 2)) != 0;
+    int idxBytes = 4; R.indexFormat = ommIndexFormat_UINT_32;
+    if (allow8 && T <= 127 && !force32) { idxBytes = 1; R.indexFormat = ommIndexFormat_UINT_8; }
+    else if (T <= 32767 && !force32) { idxBytes = 2; R.indexFormat = ommIndexFormat_UINT_16; }
+    R.index = R.dev_alloc((size_t)(T ? T : 1) * 4); // the reference narrows in place inside an int32 vector (:1882-1900)
+    if (!R.index) return L.failure("[Failure] - could not allocate the device result");
+    to.narrowIndex = R.index; to.narrowBytes = idxBytes;
     TailCounts counts;
     if (!HIP_OK(run_tail(ti, to, dScratch, scratchBytes, &counts, stream))) return L.failure("[Failure] - device tail failed");
     if (counts.arrayDataSize > 0xFFFFFFFFull) return ommResult_FAILURE; // bake_cpu_impl.cpp:1774-1775
@@ -1182,18 +1195,10 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
             if (!streamed) {
                 uint8_t* unitCodes = nullptr; uint32_t* blockRawCounts = nullptr;
                 if (R.gatherCodes && storeBits == bits && counts.smallOmms == 0 && !R.gatherCodes(counts.arrayDataSize, &unitCodes, &blockRawCounts)) { unitCodes = nullptr; blockRawCounts = nullptr; }
-                launch_gather_omms(dStates, dStateOfs, dActive, dMask, dLevel, bits, storeBits, dOrder, dDstOfs, dSizes, E, R.arrayData, stream, unitCodes, blockRawCounts);
-            }
-            launch_write_descs(dOrder, dDstOfs, dLevel, bits, E, R.descs, stream);
+                launch_gather_omms(dStates, dStateOfs, dActive, dMask, dLevel, bits, storeBits, dOrder, dDstOfs, dSizes, E, R.arrayData, stream, unitCodes, blockRawCounts, R.descs);
+            } else launch_write_descs(dOrder, dDstOfs, dLevel, bits, E, R.descs, stream);   // (the gather writes the descriptors of its OMMs itself)
         }
     }
-    const bool allow8 = (flags & (1u << 6)) != 0, force32 = (flags & (1u << 2)) != 0;
-    int idxBytes = 4; R.indexFormat = ommIndexFormat_UINT_32;
-    if (allow8 && T <= 127 && !force32) { idxBytes = 1; R.indexFormat = ommIndexFormat_UINT_8; }
-    else if (T <= 32767 && !force32) { idxBytes = 2; R.indexFormat = ommIndexFormat_UINT_16; }
-    R.index = R.dev_alloc((size_t)(T ? T : 1) * 4); // the reference narrows in place inside an int32 vector (:1882-1900)
-    ok = ok && R.index != nullptr;
-    if (ok) launch_narrow_indices(dIndex, T, idxBytes, R.index, stream);
     // the two histograms, the consistency word and the striped statistic counters were taken from the arena back to back: ONE read-back
     unsigned long long fineCount = 0;
     std::vector<unsigned long long> fineSlots((size_t)kFineSlots * kFineStride, 0ull);

@@ -12,8 +12,9 @@
 // (bake_cpu_impl.cpp:511-528) -- is not evaluated here: such triangles are reported in `pending` for the host.
 #include <hip/hip_runtime.h>
 #include <string.h>
-#include <rocprim/rocprim.hpp>
+
 #include "hash_build.h"
+#include "scan_lookback.h"
 #include <stdint.h>
 #include "bake_types.h"
 #include "bake_kernels.h"
@@ -49,9 +50,17 @@ __device__ __forceinline__ uint32_t cvt_u32_x86(float f)
 
 __global__ __launch_bounds__(256) void setup_fetch(SetupParams S, float* __restrict__ triUv, uint8_t* __restrict__ triLevel,
                                                    uint8_t* __restrict__ triFlags, uint64_t* __restrict__ hashKeys,
-                                                   SetupCounters* __restrict__ counters, uint32_t* __restrict__ pendingList)
+                                                   SetupCounters* __restrict__ counters, uint32_t* __restrict__ pendingList,
+                                                   uint32_t* __restrict__ ones, uint32_t onesWords, uint32_t* __restrict__ zero, uint32_t zeroWords,
+                                                   uint32_t* __restrict__ zero2, uint32_t zero2Words, uint32_t* __restrict__ zero3, uint32_t zero3Words,
+                                                   float* __restrict__ triArea)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    // fills that later launches need (each was a fill launch or two of its own): the UV-dedup hash table to all ones, the caller's words to zero
+    for (uint32_t w = t; w < onesWords; w += gridDim.x * blockDim.x) ones[w] = 0xFFFFFFFFu;
+    for (uint32_t w = t; w < zeroWords; w += gridDim.x * blockDim.x) zero[w] = 0u;
+    for (uint32_t w = t; w < zero2Words; w += gridDim.x * blockDim.x) zero2[w] = 0u;
+    for (uint32_t w = t; w < zero3Words; w += gridDim.x * blockDim.x) zero3[w] = 0u;   // (setup_dedup_lookup's scan states)
     if (t >= S.numTris) return;
     // ---- FetchUVTriangle (util/geometry.h:191-239) ----
     uint32_t idx[3];
@@ -118,6 +127,17 @@ __global__ __launch_bounds__(256) void setup_fetch(SetupParams S, float* __restr
         h &= 0x7FFFFFFFFFFFFFFFULL & S.keyMask; // keep clear of the invalid-triangle key range
     }
     hashKeys[t] = h;
+    // UV-space area of the input triangle (bake_cpu_impl.cpp:1904-1915, GetArea2D util/geometry.h:141-149): the side channel of ommDebugGetStats2's
+    // knownAreaMetric.  Triangles that own no work item (NaN / Inf coordinates) keep area 0 like the reference's value-initialised vector.
+    if (triArea) {
+        float a = 0.f;
+        if (!invalid) {
+            const float v0x = p[4] - p[0], v0y = p[5] - p[1], v1x = p[2] - p[0], v1y = p[3] - p[1];
+            const float nx = v0y * 0.f - v1y * 0.f, ny = 0.f * v1x - 0.f * v0x, nz = v0x * v1y - v1x * v0y;   // glm::cross(float3(v0, 0), float3(v1, 0))
+            a = 0.5f * __builtin_sqrtf(nx * nx + ny * ny + nz * nz);
+        }
+        triArea[t] = a;
+    }
 }
 
 // after the host has filled in the levels of the pending triangles: recompute their hash keys
@@ -146,24 +166,44 @@ __global__ __launch_bounds__(256) void setup_dedup_insert(const uint64_t* __rest
 
 // first occurrence, item flag, and the collision check: a triangle whose key equals the first occurrence's must have the same (UV, level)
 // tuple, else the 64-bit hash collided and the host redoes the dedup exactly
-__global__ __launch_bounds__(256) void setup_dedup_lookup(const uint64_t* __restrict__ hashKeys, const uint8_t* __restrict__ triFlags, uint32_t n, HashTable table,
+// ... and (round 5) the item numbers: the exclusive scan of the item flags in the same launch -- single pass with decoupled look-back (a tile publishes its
+// count with flag 1, collects the counts of the tiles before it until one with an inclusive prefix, flag 2; tiles handed out by ticket; state word =
+// flag << 62 | count; `scanState`: ticket word, then the states from word 64 on -- zeroed by setup_fetch).  It was a rocPRIM scan of two launches.
+__global__ __launch_bounds__(1024) void setup_dedup_lookup(const uint64_t* __restrict__ hashKeys, const uint8_t* __restrict__ triFlags, uint32_t n, HashTable table,
                                                           int disableDedup, const float* __restrict__ triUv, const uint8_t* __restrict__ triLevel,
-                                                          uint32_t* __restrict__ firstTri, uint32_t* __restrict__ isItem, SetupCounters* __restrict__ counters)
+                                                          uint32_t* __restrict__ firstTri, uint32_t* __restrict__ isItem, uint32_t* __restrict__ itemOfTri,
+                                                          uint32_t* __restrict__ scanState, SetupCounters* __restrict__ counters)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const bool invalid = (triFlags[t] & 1u) != 0;
-    uint32_t f = t;
-    if (!invalid && !disableDedup) {
-        f = hash_get(table, hashKeys[t], t);
-        if (f != t) {
-            bool same = triLevel[t] == triLevel[f];
-            for (int q = 0; q < 6; ++q) { const float x = triUv[6ull * t + q], y = triUv[6ull * f + q]; same &= (x == y); }
-            if (!same) atomicOr(&counters->collision, 1u);
+    __shared__ uint32_t s_tile, s_wave[16], s_excl;
+    if (threadIdx.x == 0) s_tile = atomicAdd(scanState, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile, t = tile * 1024u + threadIdx.x;
+    if (tile * 1024u >= n) return;   // (uniform per workgroup)
+    uint32_t item = 0;
+    if (t < n) {
+        const bool invalid = (triFlags[t] & 1u) != 0;
+        uint32_t f = t;
+        if (!invalid && !disableDedup) {
+            f = hash_get(table, hashKeys[t], t);
+            if (f != t) {
+                bool same = triLevel[t] == triLevel[f];
+                for (int q = 0; q < 6; ++q) { const float x = triUv[6ull * t + q], y = triUv[6ull * f + q]; same &= (x == y); }
+                if (!same) atomicOr(&counters->collision, 1u);
+            }
         }
+        firstTri[t] = f;
+        item = (f == t && !invalid) ? 1u : 0u;
+        isItem[t] = item;
     }
-    firstTri[t] = f;
-    isItem[t] = (f == t && !invalid) ? 1u : 0u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(item != 0u);
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t waveBase = 0, total = 0;
+    for (uint32_t w = 0; w < 16u; ++w) { const uint32_t c = s_wave[w]; if (w < wave) waveBase += c; total += c; }
+    if (wave == 0) { const unsigned long long excl = lookback_exclusive((unsigned long long*)(scanState + 64), tile, total); if (lane == 0) s_excl = (uint32_t)excl; }
+    __syncthreads();
+    if (t < n) itemOfTri[t] = s_excl + waveBase + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
 }
 
 __global__ __launch_bounds__(256) void setup_emit_items(SetupParams S, const float* __restrict__ triUv, const uint8_t* __restrict__ triLevel,
@@ -295,28 +335,12 @@ __global__ __launch_bounds__(256) void setup_split_scatter(const uint8_t* __rest
     }
 }
 
-// UV-space area of every input triangle (bake_cpu_impl.cpp:1904-1915, GetArea2D util/geometry.h:141-149): the side channel of
-// ommDebugGetStats2's knownAreaMetric.  Triangles that own no work item (NaN / Inf coordinates) keep area 0 like the reference's
-// value-initialised vector.
-__global__ __launch_bounds__(256) void setup_tri_areas(const float* __restrict__ triUv, const uint8_t* __restrict__ triFlags, uint32_t n, float* __restrict__ area)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    float a = 0.f;
-    if (!(triFlags[t] & 1u)) {
-        const float* p = triUv + 6ull * t;
-        const float v0x = p[4] - p[0], v0y = p[5] - p[1], v1x = p[2] - p[0], v1y = p[3] - p[1];
-        const float nx = v0y * 0.f - v1y * 0.f, ny = 0.f * v1x - 0.f * v0x, nz = v0x * v1y - v1x * v0y;   // glm::cross(float3(v0, 0), float3(v1, 0))
-        a = 0.5f * __builtin_sqrtf(nx * nx + ny * ny + nz * nz);
-    }
-    area[t] = a;
-}
+static uint32_t setup_scan_words(uint32_t numTris) { return 64u + 2u * ((numTris + 1023u) / 1024u + 1u); }
 
 size_t setup_scratch_bytes(uint32_t numTris)
 {
     const size_t n = numTris ? numTris : 1;
-    size_t m = 0;
-    (void)rocprim::exclusive_scan(nullptr, m, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>());
+    const size_t m = (size_t)setup_scan_words((uint32_t)n) * 4;   // setup_dedup_lookup's scan states
     const size_t p256 = 256;
     auto pad = [&](size_t v) { return (v + p256 - 1) / p256 * p256; };
     //           triUv        keys         firstTri,isItem,itemOfTri  level,flags   pending      chunk counts  hash table
@@ -346,13 +370,21 @@ static SetupScratch carve_setup(void* base, size_t bytes, uint32_t numTris)
     return s;
 }
 
-hipError_t run_setup_fetch(const SetupParams& S, void* scratch, size_t scratchBytes, SetupCounters* counters, hipStream_t stream)
+hipError_t run_setup_fetch(const SetupParams& S, void* scratch, size_t scratchBytes, SetupCounters* counters, uint32_t* zero, uint32_t zeroWords, uint32_t* zero2, uint32_t zero2Words,
+                           float* triArea, hipStream_t stream)
 {
-    SETUP_CHECK(hipMemsetAsync(counters, 0, sizeof(SetupCounters), stream));
-    if (S.numTris == 0) return hipSuccess;
+    // (`counters` arrives zeroed: the bake's first transfer carries the block)
+    if (S.numTris == 0) {
+        if (zeroWords) SETUP_CHECK(hipMemsetAsync(zero, 0, (size_t)zeroWords * 4, stream));
+        if (zero2Words) SETUP_CHECK(hipMemsetAsync(zero2, 0, (size_t)zero2Words * 4, stream));
+        return hipSuccess;
+    }
     if (scratchBytes < setup_scratch_bytes(S.numTris)) return hipErrorInvalidValue;
     SetupScratch s = carve_setup(scratch, scratchBytes, S.numTris);
-    hipLaunchKernelGGL(setup_fetch, dim3((S.numTris + 255u) / 256u), dim3(256), 0, stream, S, s.triUv, s.triLevel, s.triFlags, s.keysA, counters, s.pending);
+    const uint32_t onesWords = S.disableDedup ? 0u : (uint32_t)(hash_table_bytes(hash_table_slots(S.numTris)) / 4);
+    hipLaunchKernelGGL(setup_fetch, dim3((S.numTris + 255u) / 256u), dim3(256), 0, stream, S, s.triUv, s.triLevel, s.triFlags, s.keysA, counters, s.pending,
+                       (uint32_t*)s.hash, onesWords, zero, zeroWords, zero2, zero2Words,
+                       (uint32_t*)s.tmp, setup_scan_words(S.numTris), triArea);
     return hipGetLastError();
 }
 
@@ -408,23 +440,19 @@ hipError_t copy_pending_to_host(void* scratch, size_t scratchBytes, uint32_t num
 }
 
 hipError_t run_setup_items(const SetupParams& S, void* scratch, size_t scratchBytes, SetupCounters* counters, float* itemUv, uint8_t* itemLevel,
-                           uint8_t* itemDegenerate, int32_t* triToItem, uint32_t* itemIds, float* triArea, hipStream_t stream)
+                           uint8_t* itemDegenerate, int32_t* triToItem, uint32_t* itemIds, hipStream_t stream)
 {
     const uint32_t n = S.numTris;
     if (n == 0) return hipSuccess;
     SetupScratch s = carve_setup(scratch, scratchBytes, n);
     const dim3 grid((n + 255u) / 256u), block(256);
-    if (triArea) hipLaunchKernelGGL(setup_tri_areas, grid, block, 0, stream, s.triUv, s.triFlags, n, triArea);
     const uint32_t slots = hash_table_slots(n);
     const HashTable table = hash_table_at(s.hash, slots);
     if (!S.disableDedup) {
-        SETUP_CHECK(hipMemsetAsync(s.hash, 0xFF, hash_table_bytes(slots), stream));
-        hipLaunchKernelGGL(setup_dedup_insert, grid, block, 0, stream, s.keysA, s.triFlags, n, table);
+        hipLaunchKernelGGL(setup_dedup_insert, /* (the table was filled by setup_fetch) */ grid, block, 0, stream, s.keysA, s.triFlags, n, table);
     }
-    hipLaunchKernelGGL(setup_dedup_lookup, grid, block, 0, stream, s.keysA, s.triFlags, n, table, S.disableDedup ? 1 : 0, s.triUv, s.triLevel, s.firstTri, s.isItem, counters);
-    size_t tb;
-    tb = s.tmpBytes;
-    SETUP_CHECK(rocprim::exclusive_scan(s.tmp, tb, s.isItem, s.itemOfTri, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    hipLaunchKernelGGL(setup_dedup_lookup, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s.keysA, s.triFlags, n, table, S.disableDedup ? 1 : 0, s.triUv, s.triLevel, s.firstTri, s.isItem, s.itemOfTri,
+                       (uint32_t*)s.tmp, counters);
     hipLaunchKernelGGL(setup_emit_items, grid, block, 0, stream, S, s.triUv, s.triLevel, s.triFlags, s.firstTri, s.isItem, s.itemOfTri, itemUv, itemLevel,
                        itemDegenerate, triToItem, counters);
     const uint32_t numChunks = (n + kSplitChunk - 1u) / kSplitChunk;   // (n bounds the item count, which only the device knows here)

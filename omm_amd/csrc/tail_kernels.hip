@@ -11,6 +11,7 @@
 #include <string.h>
 #include <rocprim/rocprim.hpp>
 #include "hash_build.h"
+#include "scan_lookback.h"
 #include <stdint.h>
 #include "bake_types.h"
 #include "bake_kernels.h"
@@ -28,15 +29,43 @@ __device__ __forceinline__ uint32_t spread16(uint32_t x)
     return x;
 }
 
-// promote (bake_cpu_impl.cpp:1432-1472) + digest of uniform items from the table
-__global__ __launch_bounds__(256) void tail_summarize(TailInputs in, int32_t* __restrict__ special)
+// ---- round 5: the tail as six launches --------------------------------------------------------------------------------------------------------
+// A small bake (configs[1]: 100 000 work items, 6 299 OMMs) spends its time in launch overhead: ~5 us per launch whatever the kernel does, and the
+// tail was 30 launches (4 fills, iota, reduce, a 12-launch merge sort of ALL items, a scan, ...).  Now:
+//   tail_summarize   promote + the fills every later step needs (hash table and key list to all ones, histograms / counters / tile states to zero)
+//   dedup_insert     hash build; the LAST workgroup to finish enters the uniform bins (was dedup_insert_bins)
+//   tail_emit        look-up + spatial key + compaction of the EMITTED items only into 64-bit keys (key30 << idxBits | item): unique keys, so the
+//                    order of the compaction (atomics) does not matter and the sort needs no payload
+//   tail_rank_place  (<= kRankMax keys) descriptor slot AND array offset of an OMM by counting: slot = number of greater keys, offset = sum of
+//                    their sizes (the level is in the key); 16 lanes share one key's pass over the list -- no sort, no scan
+//   or rocPRIM sort of the keys + tail_place (single-pass scan with decoupled look-back over dynamic tile tickets)
+//   tail_indices
+// The summary the host reads back (OMM count, error flag, arrayData size, OMMs of less than 16 bytes) is written by the last workgroup of the
+// placing kernel.
+
+struct TailWork {            // scratch words of one tail run (zeroed by tail_summarize); the host reads the block back in ONE copy
+    uint32_t numEmitted, err, ticket, pad_;
+    unsigned long long arrayBytes, smallOmms;   // arrayData size; emitted OMMs of less than 16 bytes
+};
+constexpr uint32_t kRankMax = 16384u;   // keys up to which counting beats sort + scan (quadratic in the number of emitted OMMs)
+constexpr uint32_t kRankChunk = 4096u;  // keys staged in LDS at a time
+constexpr uint32_t kPlaceTile = 1024u;
+
+__device__ __forceinline__ uint32_t omm_bytes(uint32_t lvl, uint32_t bits) { const uint32_t n = ((1u << (2u * lvl)) * bits) >> 3; return n < 1u ? 1u : n; }
+
+// promote (bake_cpu_impl.cpp:1432-1472) + digest of uniform items from the table + the fills of the whole tail
+__global__ __launch_bounds__(256) void tail_summarize(TailInputs in, int32_t* __restrict__ special, uint32_t* __restrict__ ones, uint32_t onesWords,
+                                                      uint32_t* __restrict__ zeroA, uint32_t zeroAWords, uint32_t* __restrict__ zeroB, uint32_t zeroBWords)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (uint32_t w = i; w < onesWords; w += stride) ones[w] = 0xFFFFFFFFu;
+    for (uint32_t w = i; w < zeroAWords; w += stride) zeroA[w] = 0u;
+    for (uint32_t w = i; w < zeroBWords; w += stride) zeroB[w] = 0u;
     if (i >= in.numItems) return;
     const uint32_t mask = in.stateMask[i];
     const uint32_t level = in.level[i];
     const bool classified = mask != 0u && mask <= 15u;
-    if (!classified) atomicOr(in.errorFlag, 1u); // every work item must have been classified (the bake then fails; nothing below may fault on the way)
+    // (an unclassified item -- the bake then fails -- is flagged by tail_emit: the error word is among the words this kernel zeroes)
     bool allEqual = classified && (mask & (mask - 1u)) == 0u;
     int common = 31 - __clz((int)mask);
     if (allEqual && in.uniformDigest) {
@@ -50,18 +79,12 @@ __global__ __launch_bounds__(256) void tail_summarize(TailInputs in, int32_t* __
     special[i] = (allEqual && !in.disableSpecial) ? (-(int32_t)common - 1) : 0;
 }
 
-__global__ __launch_bounds__(256) void tail_iota(uint32_t* __restrict__ v, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] = i;
-}
-
 // ---- exact-duplicate detection as a hash build (DeduplicateExact, bake_cpu_impl.cpp:1031-1066: equality of the XXH64 digest only, the
 //      FIRST work item with a digest keeps its block): rep[i] = smallest item index with digest[i] (hash_build.h) ----
 // Uniform work items (87 % of the bench workload) carry one of 13 x 4 table digests (tail_summarize): their first occurrence per (level, state)
 // is a min-reduction -- LDS bins per workgroup, then at most one gated global atomic per bin and workgroup -- not 870 000 operations on three
-// table slots.  The bins enter the table afterwards (dedup_insert_bins), so a non-uniform item whose digest happens to equal a table digest
-// still merges with it, as digest-only equality demands.
+// table slots.  The bins enter the table afterwards (the last workgroup to finish does it), so a non-uniform item whose digest happens to equal a
+// table digest still merges with it, as digest-only equality demands.
 constexpr uint32_t kUniformBins = kNumLevels * 4u;
 __global__ __launch_bounds__(256) void dedup_insert(const uint64_t* __restrict__ digests, const uint32_t* __restrict__ stateMask, const uint8_t* __restrict__ level,
                                                     int haveUniformTable, uint32_t n, HashTable table, uint32_t* __restrict__ firstUniform)
@@ -88,16 +111,12 @@ __global__ __launch_bounds__(256) void dedup_insert(const uint64_t* __restrict__
     }
 }
 
+// (a launch of its own: letting the last workgroup of dedup_insert do it needs a device-wide fence per workgroup -- an L2 write-back on this chip --,
+//  measured 9 -> 35 us for the insert at configs[1])
 __global__ __launch_bounds__(64) void dedup_insert_bins(const uint64_t* __restrict__ uniformDigest, const uint32_t* __restrict__ firstUniform, HashTable table)
 {
     const uint32_t t = threadIdx.x;
     if (t < kUniformBins && firstUniform[t] != 0xFFFFFFFFu) hash_put_min(table, uniformDigest[t], firstUniform[t]);
-}
-
-__global__ __launch_bounds__(256) void dedup_lookup(const uint64_t* __restrict__ digests, uint32_t n, HashTable table, uint32_t* __restrict__ rep)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) rep[i] = hash_get(table, digests[i], i);
 }
 
 // 30-bit spatial key of a work item: level << 26 | 26 Morton bits of its centroid on the reference's 8192^2 grid (bake_cpu_impl.cpp:1722-1748; the
@@ -112,75 +131,145 @@ __device__ __forceinline__ uint32_t spatial_key30(const float* __restrict__ p, u
     return (level << 26) | (spread16((uint32_t)mx) | (spread16((uint32_t)my) << 1));   // (mx, my < 8192: 26 Morton bits)
 }
 
-// spatial sort key (bake_cpu_impl.cpp:1722-1748); non-emitted items sort to the far end
-__global__ __launch_bounds__(256) void tail_sort_keys(TailInputs in, const int32_t* __restrict__ special, const uint32_t* __restrict__ rep,
-                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ emittedFlag)
+// look-up of the first occurrence, special indices into itemValue, and the emitted items (first of their digest, not special) as sort keys:
+// spatial key (bake_cpu_impl.cpp:1722-1748) << idxBits | item -- the reference sorts pairs (key, item) descending: the same order, read back to front
+__global__ __launch_bounds__(256) void tail_emit(TailInputs in, const int32_t* __restrict__ special, HashTable table, uint32_t idxBits, uint32_t bound,
+                                                 uint32_t* __restrict__ rep, int32_t* __restrict__ itemValue, unsigned long long* __restrict__ keys,
+                                                 TailWork* __restrict__ work)
 {
+    __shared__ uint32_t s_waveBase[4], s_blockBase;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= in.numItems) return;
-    const bool emitted = rep[i] == i && special[i] == 0;
-    // the reference's 64-bit key is level << 60 | 26 Morton bits: the same order in 30 bits (level << 26 | Morton), so the sort moves half the
-    // bytes and a radix sort needs 4 digit passes instead of 8
-    uint32_t key = ~0u;
-    if (emitted) key = spatial_key30(in.uv + 6ull * i, (uint32_t)in.level[i]);
-    keys[i] = key;
-    emittedFlag[i] = emitted ? 1u : 0u;
+    bool emitted = false; unsigned long long key = 0ull;
+    if (i < in.numItems) {
+        const uint32_t mask = in.stateMask[i];
+        if (!(mask != 0u && mask <= 15u)) { atomicOr(in.errorFlag, 1u); atomicOr(&work->err, 1u); }   // (tail_summarize cannot flag it: it zeroes the words)
+        const uint32_t r = in.disableDedup ? i : hash_get(table, in.digests[i], i);
+        rep[i] = r;
+        const int32_t sp = special[i];
+        if (sp != 0) itemValue[i] = sp;
+        emitted = r == i && sp == 0;
+        if (emitted) key = ((unsigned long long)spatial_key30(in.uv + 6ull * i, (uint32_t)in.level[i]) << idxBits) | i;
+    }
+    const unsigned long long b = __ballot(emitted);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) s_waveBase[wave] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int w = 0; w < 4; ++w) { const uint32_t c = s_waveBase[w]; s_waveBase[w] = run; run += c; }
+        s_blockBase = run ? atomicAdd(&work->numEmitted, run) : 0u;
+    }
+    __syncthreads();
+    if (emitted) {
+        const uint32_t pos = s_blockBase + s_waveBase[wave] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (pos < bound) keys[pos] = key; else atomicOr(&work->err, 1u);   // (the bound is exact arithmetic on the active count: not reachable)
+    }
 }
 
-// descriptor order = emitted items of the ascending sort, back to front; sizes for the offset scan
-__global__ __launch_bounds__(256) void tail_order_sizes(const uint32_t* __restrict__ sortedItems, const uint32_t* __restrict__ numEmitted,
-                                                        const uint8_t* __restrict__ level, int bits, uint32_t* __restrict__ order,
-                                                        uint64_t* __restrict__ sizes64, uint32_t* __restrict__ sizes, uint32_t* __restrict__ arrayHist)
+// Descriptor slot and array offset by counting (<= kRankMax keys): an OMM's slot in the descending order is the number of greater keys; the level leads
+// the key, so its offset is the bytes of all OMMs of higher levels (level histogram) plus the greater keys of its own level times that level's size.
+// The list goes through LDS a chunk at a time (every workgroup stages all of it: 50 KB at configs[1]); 32 lanes share one key's pass over a chunk.
+__global__ __launch_bounds__(1024) void tail_rank_place(const unsigned long long* __restrict__ keys, uint32_t idxBits, uint32_t bound, int bits, TailWork* __restrict__ work,
+                                                        uint32_t* __restrict__ order, uint32_t* __restrict__ dstOfs, uint32_t* __restrict__ sizes,
+                                                        int32_t* __restrict__ itemValue, uint32_t* __restrict__ arrayHist)
 {
-    // histogram through LDS: a bake usually has ONE level, and ~1e5 global atomics on one address cost 0.9 ms
+    __shared__ unsigned long long s_keys[kRankChunk];
     __shared__ uint32_t h[kNumLevels];
     if (threadIdx.x < kNumLevels) h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t E = *numEmitted;
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < E) {
-        const uint32_t item = sortedItems[E - 1u - j];
-        order[j] = item;
-        const uint32_t lvl = level[item];
-        uint32_t n = ((1u << (2u * lvl)) * (uint32_t)bits) >> 3; if (n < 1u) n = 1u;
-        sizes[j] = n; sizes64[j] = n;
-        // one LDS atomic per (wave, level): lanes of the same level elect a leader
-        unsigned long long todo = __ballot(1);
-        while (todo) {
-            const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
-            const uint32_t l0 = (uint32_t)__shfl((int)lvl, (int)leader);
-            const unsigned long long same = __ballot(lvl == l0) & todo;
-            if ((threadIdx.x & 63u) == leader) atomicAdd(&h[l0], (uint32_t)__popcll(same));
-            todo &= ~same;
+    uint32_t E = __atomic_load_n(&work->numEmitted, __ATOMIC_RELAXED); if (E > bound) E = bound;
+    const uint32_t e = blockIdx.x * 32u + (threadIdx.x >> 5), sub = threadIdx.x & 31u, lvlShift = idxBits + 26u;
+    const unsigned long long mine = e < E ? keys[e] : 0ull;
+    uint32_t cnt = 0;
+    for (uint32_t c0 = 0; c0 < E; c0 += kRankChunk) {
+        __syncthreads();
+        const uint32_t m = E - c0 < kRankChunk ? E - c0 : kRankChunk;
+        for (uint32_t k = threadIdx.x; k < kRankChunk; k += 1024u) {
+            const bool live = k < m;
+            const unsigned long long kk = live ? keys[c0 + k] : 0ull;
+            if (live) s_keys[k] = kk;
+            const uint32_t lvl = live ? (uint32_t)(kk >> lvlShift) : 0xFFu;
+            unsigned long long todo = __ballot(live);   // one LDS atomic per (wave, level)
+            while (todo) {
+                const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+                const uint32_t l0 = (uint32_t)__shfl((int)lvl, (int)leader);
+                const unsigned long long same = __ballot(lvl == l0) & todo;
+                if ((threadIdx.x & 63u) == leader && l0 < (uint32_t)kNumLevels) atomicAdd(&h[l0], (uint32_t)__popcll(same));
+                todo &= ~same;
+            }
+        }
+        __syncthreads();
+        if (e < E) {
+            #pragma unroll 8
+            for (uint32_t k = sub; k < m; k += 32u) cnt += s_keys[k] > mine ? 1u : 0u;
         }
     }
     __syncthreads();
-    if (threadIdx.x < kNumLevels && h[threadIdx.x]) atomicAdd(&arrayHist[threadIdx.x], h[threadIdx.x]);
+    for (int d = 16; d >= 1; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d);
+    if (blockIdx.x == 0) {   // (every workgroup has the whole histogram; one publishes it)
+        if (threadIdx.x < kNumLevels && h[threadIdx.x]) arrayHist[threadIdx.x] = h[threadIdx.x];
+        if (threadIdx.x == 0) { uint32_t small = 0; for (int l = 0; l < (bits == 2 ? 3 : 4); ++l) small += h[l]; work->smallOmms = small; }
+    }
+    if (e < E && sub == 0) {
+        const uint32_t item = (uint32_t)(mine & ((1ull << idxBits) - 1ull)), lvl = (uint32_t)(mine >> lvlShift), sz = omm_bytes(lvl, (uint32_t)bits);
+        uint32_t above = 0; unsigned long long ofs = 0;
+        for (uint32_t l = lvl + 1u; l < (uint32_t)kNumLevels; ++l) { above += h[l]; ofs += (unsigned long long)h[l] * omm_bytes(l, (uint32_t)bits); }
+        ofs += (unsigned long long)(cnt - above) * sz;
+        order[cnt] = item; dstOfs[cnt] = (uint32_t)ofs; sizes[cnt] = sz; itemValue[item] = (int32_t)cnt;
+        if (cnt == E - 1u) work->arrayBytes = ofs + sz;
+    }
 }
 
-__global__ __launch_bounds__(256) void tail_item_values(const uint32_t* __restrict__ order, const uint32_t* __restrict__ numEmitted,
-                                                        const uint64_t* __restrict__ ofs64, uint32_t* __restrict__ dstOfs,
-                                                        const int32_t* __restrict__ special, uint32_t numItems, int32_t* __restrict__ itemValue,
-                                                        const uint64_t* __restrict__ sizes64, const uint32_t* __restrict__ errorFlag, uint64_t* __restrict__ summary,
-                                                        const uint32_t* __restrict__ arrayHist, int bits)
+// The same from the SORTED keys (ascending; descriptor j = key E - 1 - j): sizes, their exclusive scan in one pass -- a tile's total is published
+// (flag 1), its exclusive prefix collected by looking back over the tiles before it until one with an inclusive prefix (flag 2) is met; tiles are
+// handed out by a ticket, so a tile's predecessors are always running or done.  State word: flag << 62 | bytes.
+__global__ __launch_bounds__(kPlaceTile) void tail_place(const unsigned long long* __restrict__ sorted, uint32_t idxBits, uint32_t bound, int bits, TailWork* __restrict__ work,
+                                                         unsigned long long* __restrict__ tileState, uint32_t* __restrict__ order, uint32_t* __restrict__ dstOfs,
+                                                         uint32_t* __restrict__ sizes, int32_t* __restrict__ itemValue, uint32_t* __restrict__ arrayHist)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t E = *numEmitted;
-    // what the host needs to continue, in one place for ONE read-back: OMM count, consistency flag, arrayData size
-    // (= ofs[n-1] + sizes[n-1]: entries past numEmitted are zero-sized)
-    if (i == 0) {
-        summary[0] = (uint64_t)E | ((uint64_t)*errorFlag << 32); summary[1] = ofs64[numItems - 1u] + sizes64[numItems - 1u];
-        uint32_t small = 0;   // emitted OMMs of less than 16 bytes (tail_order_sizes has filled the histogram)
-        for (int l = 0; l < (bits == 2 ? 3 : 4); ++l) small += arrayHist[l];
-        summary[2] = small;
+    __shared__ uint32_t h[kNumLevels];
+    __shared__ unsigned long long s_wave[kPlaceTile / 64u], s_excl;
+    __shared__ uint32_t s_tile;
+    if (threadIdx.x < kNumLevels) h[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_tile = atomicAdd(&work->ticket, 1u);
+    __syncthreads();
+    uint32_t E = __atomic_load_n(&work->numEmitted, __ATOMIC_RELAXED); if (E > bound) E = bound;
+    const uint32_t tile = s_tile, j = tile * kPlaceTile + threadIdx.x;
+    if (tile * kPlaceTile < E) {   // (uniform per workgroup)
+        unsigned long long key = 0; uint32_t sz = 0, lvl = 0, item = 0;
+        if (j < E) {
+            key = sorted[E - 1u - j];
+            item = (uint32_t)(key & ((1ull << idxBits) - 1ull)); lvl = (uint32_t)(key >> (idxBits + 26u)); sz = omm_bytes(lvl, (uint32_t)bits);
+            atomicAdd(&h[lvl], 1u);
+        }
+        // inclusive scan of sz within the wave, wave totals through LDS
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        unsigned long long inc = sz;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, d), hi = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), d);
+            if (lane >= (uint32_t)d) inc += ((unsigned long long)hi << 32) | lo;
+        }
+        if (lane == 63u) s_wave[wave] = inc;
+        __syncthreads();
+        unsigned long long waveBase = 0, total = 0;
+        for (uint32_t w = 0; w < kPlaceTile / 64u; ++w) { const unsigned long long c = s_wave[w]; if (w < wave) waveBase += c; total += c; }
+        if (wave == 0) { const unsigned long long excl = lookback_exclusive(tileState, tile, total); if (lane == 0) s_excl = excl; }
+        __syncthreads();
+        if (j < E) {
+            const unsigned long long ofs = s_excl + waveBase + inc - sz;
+            order[j] = item; dstOfs[j] = (uint32_t)ofs; sizes[j] = sz; itemValue[item] = (int32_t)j;
+            if (j == E - 1u) work->arrayBytes = ofs + sz;
+        }
     }
-    if (i < numItems && special[i] != 0) itemValue[i] = special[i];
-    if (i < E) { itemValue[order[i]] = (int32_t)i; dstOfs[i] = (uint32_t)ofs64[i]; }
+    __syncthreads();
+    if (threadIdx.x < kNumLevels && h[threadIdx.x]) {
+        atomicAdd(&arrayHist[threadIdx.x], h[threadIdx.x]);
+        if (threadIdx.x < (bits == 2 ? 3u : 4u)) atomicAdd(&work->smallOmms, (unsigned long long)h[threadIdx.x]);
+    }
 }
 
 // index buffer + index histogram (bake_cpu_impl.cpp:1697-1702,1856-1870)
 __global__ __launch_bounds__(256) void tail_indices(TailInputs in, const uint32_t* __restrict__ rep, const int32_t* __restrict__ itemValue,
-                                                    int32_t* __restrict__ out, uint32_t* __restrict__ indexHist)
+                                                    int32_t* __restrict__ out, uint32_t* __restrict__ indexHist, void* __restrict__ narrow, int narrowBytes)
 {
     __shared__ uint32_t h[kNumLevels];
     if (threadIdx.x < kNumLevels) h[threadIdx.x] = 0;
@@ -195,6 +284,8 @@ __global__ __launch_bounds__(256) void tail_indices(TailInputs in, const uint32_
             if (v >= 0) atomicAdd(&h[in.level[r]], 1u);
         }
         out[t] = v;
+        // index narrowing (bake_cpu_impl.cpp:1872-1902; was a launch of its own)
+        if (narrow) { if (narrowBytes == 1) ((int8_t*)narrow)[t] = (int8_t)v; else if (narrowBytes == 2) ((int16_t*)narrow)[t] = (int16_t)v; else ((int32_t*)narrow)[t] = v; }
     }
     __syncthreads();
     if (threadIdx.x < kNumLevels && h[threadIdx.x]) atomicAdd(&indexHist[threadIdx.x], h[threadIdx.x]);
@@ -217,36 +308,66 @@ void launch_write_descs(const uint32_t* order, const uint32_t* dstOfs, const uin
 
 // ---- active-item compaction (after triage): per-level lists of the items that need per-micro-triangle work, and their
 //      slots in the packed-state buffer ----
-__global__ __launch_bounds__(256) void prep_flags(const uint32_t* __restrict__ itemIds, const uint8_t* __restrict__ active, const uint8_t* __restrict__ level,
-                                                  int bits, const SetupCounters* __restrict__ counters, uint32_t maxItems,
-                                                  uint32_t* __restrict__ flags, uint64_t* __restrict__ sizes)
+// One launch (round 5; it was flags + two rocPRIM scans + scatter = 6): a single-pass scan of (active flag, slot bytes) with decoupled look-back, like
+// tail_place -- a tile publishes its totals (flag 1), collects its exclusive prefix from the tiles before it until one with an inclusive prefix (flag 2),
+// tiles handed out by ticket.  The state words (prep_state_words(): ticket, then count and byte states per tile) sit at the start of the scratch block
+// and are zeroed by triage_items, the launch in front of this one.
+constexpr uint32_t kPrepTile = 1024u;   // (items per tile = threads per workgroup: a look-back per 1024 items)
+__global__ __launch_bounds__(kPrepTile) void prep_compact(const uint32_t* __restrict__ itemIds, const uint8_t* __restrict__ active, const uint8_t* __restrict__ level,
+                                                          int bits, SetupCounters* __restrict__ counters, uint32_t* __restrict__ stateWords,
+                                                          uint32_t* __restrict__ activeIds, uint64_t* __restrict__ stateOfs)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= maxItems) return;
-    uint32_t f = 0; uint64_t bytes = 0;
-    if (p < counters->numItems) {
-        const uint32_t item = itemIds[p];
+    __shared__ uint32_t s_cnt[kPrepTile / 64u], s_tile, s_exclCnt, s_start[kNumLevels + 1];
+    __shared__ unsigned long long s_bytes[kPrepTile / 64u], s_exclBytes;
+    if (threadIdx.x == 0) s_tile = atomicAdd(stateWords, 1u);
+    if (threadIdx.x <= (uint32_t)kNumLevels) s_start[threadIdx.x] = counters->levelStart[threadIdx.x];
+    __syncthreads();
+    const uint32_t n = counters->numItems, tile = s_tile, p = tile * kPrepTile + threadIdx.x;
+    if (n == 0u) {   // (no work items: the boundaries the host reads back are all zero)
+        if (tile == 0u && threadIdx.x <= (uint32_t)kNumLevels) counters->activeStart[threadIdx.x] = 0u;
+        if (tile == 0u && threadIdx.x == 0) counters->stateBytes = 0ull;
+        return;
+    }
+    if (tile * kPrepTile >= n) return;   // (uniform per workgroup; nobody looks back at a tile past the end)
+    unsigned long long* cntState = (unsigned long long*)(stateWords + 64);
+    unsigned long long* bytState = cntState + (gridDim.x + 1u);
+    uint32_t item = 0, f = 0; unsigned long long bytes = 0;
+    if (p < n) {
+        item = itemIds[p];
         f = active[item] ? 1u : 0u;
-        bytes = (((uint64_t)1 << (2u * level[item])) * (uint64_t)bits) >> 3; if (bytes < 16) bytes = 16; // 16-byte slots keep vector copies aligned
+        if (f) { bytes = (((unsigned long long)1 << (2u * level[item])) * (unsigned long long)bits) >> 3; if (bytes < 16) bytes = 16; }   // 16-byte slots keep vector copies aligned
     }
-    flags[p] = f; sizes[p] = f ? bytes : 0ull;
-}
-
-__global__ __launch_bounds__(256) void prep_scatter(const uint32_t* __restrict__ itemIds, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos,
-                                                    const uint64_t* __restrict__ ofs, const uint64_t* __restrict__ sizes, uint32_t maxItems,
-                                                    SetupCounters* __restrict__ counters, uint32_t* __restrict__ activeIds, uint64_t* __restrict__ stateOfs)
-{
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= maxItems) return;
-    const uint32_t n = counters->numItems;
-    if (p == 0) { // level boundaries of the compacted list + total bytes
-        const uint32_t total = n ? pos[n - 1] + flags[n - 1] : 0u;
-        for (int l = 0; l <= kNumLevels; ++l) { const uint32_t s = counters->levelStart[l]; counters->activeStart[l] = s < n ? pos[s] : total; }
-        counters->stateBytes = n ? ofs[n - 1] + sizes[n - 1] : 0ull;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(f != 0u);
+    const uint32_t before = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    unsigned long long inc = bytes;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, d), hi = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), d);
+        if (lane >= (uint32_t)d) inc += ((unsigned long long)hi << 32) | lo;
     }
-    if (p >= n || !flags[p]) return;
-    const uint32_t item = itemIds[p];
-    activeIds[pos[p]] = item; stateOfs[item] = ofs[p];
+    if (lane == 63u) { s_cnt[wave] = (uint32_t)__popcll(bal); s_bytes[wave] = inc; }
+    __syncthreads();
+    uint32_t waveCnt = 0, totalCnt = 0; unsigned long long waveBytes = 0, totalBytes = 0;
+    for (uint32_t w = 0; w < kPrepTile / 64u; ++w) {
+        const uint32_t c = s_cnt[w]; const unsigned long long bb = s_bytes[w];
+        if (w < wave) { waveCnt += c; waveBytes += bb; }
+        totalCnt += c; totalBytes += bb;
+    }
+    if (wave == 0) {
+        const unsigned long long exC = lookback_exclusive(cntState, tile, totalCnt), exB = lookback_exclusive(bytState, tile, totalBytes);
+        if (lane == 0) { s_exclCnt = (uint32_t)exC; s_exclBytes = exB; }
+    }
+    __syncthreads();
+    if (p >= n) return;
+    const uint32_t pos = s_exclCnt + waveCnt + before;
+    const unsigned long long ofs = s_exclBytes + waveBytes + inc - bytes;
+    if (f) { activeIds[pos] = item; stateOfs[item] = ofs; }
+    // level boundaries of the compacted list + total bytes (levelStart[l] == n: the level and all above it are empty)
+    for (int l = 0; l <= kNumLevels; ++l) if (s_start[l] == p) counters->activeStart[l] = pos;
+    if (p == n - 1u) {
+        for (int l = 0; l <= kNumLevels; ++l) if (s_start[l] >= n) counters->activeStart[l] = pos + f;
+        counters->stateBytes = ofs + bytes;
+    }
 }
 
 hipError_t run_prep(const uint32_t* itemIds, const uint8_t* active, const uint8_t* level, int bits, uint32_t maxItems, SetupCounters* counters,
@@ -254,19 +375,8 @@ hipError_t run_prep(const uint32_t* itemIds, const uint8_t* active, const uint8_
 {
     const uint32_t n = maxItems;
     if (n == 0) return hipSuccess;
-    if (scratchBytes < tail_scratch_bytes(n, 0)) return hipErrorInvalidValue;
-    uint8_t* p = (uint8_t*)scratch;
-    const size_t n64 = (((size_t)n + 1) * 8 + 255) / 256 * 256, n32 = (((size_t)n + 1) * 4 + 255) / 256 * 256;
-    uint64_t* sizes = (uint64_t*)p; p += n64; uint64_t* ofs = (uint64_t*)p; p += n64;
-    uint32_t* flags = (uint32_t*)p; p += n32; uint32_t* pos = (uint32_t*)p; p += n32;
-    void* tmp = p; size_t tmpBytes = scratchBytes - (size_t)(p - (uint8_t*)scratch);
-    const dim3 grid((n + 255u) / 256u), block(256);
-    hipLaunchKernelGGL(prep_flags, grid, block, 0, stream, itemIds, active, level, bits, counters, n, flags, sizes);
-    size_t tb = tmpBytes;
-    TAIL_CHECK(rocprim::exclusive_scan(tmp, tb, flags, pos, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>(), stream));
-    tb = tmpBytes;
-    TAIL_CHECK(rocprim::exclusive_scan(tmp, tb, sizes, ofs, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), stream));
-    hipLaunchKernelGGL(prep_scatter, grid, block, 0, stream, itemIds, flags, pos, ofs, sizes, n, counters, activeIds, stateOfs);
+    if (scratchBytes < (size_t)prep_state_words(n) * 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(prep_compact, dim3((n + kPrepTile - 1u) / kPrepTile), dim3(kPrepTile), 0, stream, itemIds, active, level, bits, counters, (uint32_t*)scratch, activeIds, stateOfs);
     return hipGetLastError();
 }
 
@@ -1022,11 +1132,10 @@ void launch_stream_verify(const uint32_t* order, const uint32_t* dstOfs, uint32_
 
 // ---- scratch layout ----
 struct Scratch {
-    uint32_t *keysA, *keysB;   // spatial sort keys (level << 26 | Morton)
-    uint64_t *sizes64, *ofs64;
-    uint32_t *valsA, *valsB, *emitted, *numEmitted;
-    uint64_t* total;
-    void* hashBase;   // digest table (hash_build.h) + kUniformBins words
+    unsigned long long *keysA, *keysB;   // sort keys of the emitted items (spatial key << idxBits | item), unsorted / sorted
+    void* hashBase;                      // digest table (hash_build.h) + kUniformBins words; directly in front of keysA: one fill sets both to all ones
+    TailWork* work;                      // counters + read-back words, directly in front of tileState: one fill zeroes both
+    unsigned long long* tileState;       // tail_place's look-back states
     void* tmp; size_t tmpBytes;
 };
 
@@ -1034,24 +1143,22 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static size_t prim_temp_bytes(uint32_t n)
 {
-    size_t a = 0, c = 0, d = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n);
-    (void)rocprim::exclusive_scan(nullptr, c, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>());
-    (void)rocprim::reduce(nullptr, d, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>());
-    size_t m = a; if (c > m) m = c; if (d > m) m = d;
-    return align_up(m, 256) + 256;
+    size_t a = 0;
+    (void)rocprim::radix_sort_keys(nullptr, a, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)n, 0u, 62u);
+    return align_up(a, 256) + 256;
 }
+static uint32_t place_tiles(uint32_t n) { return (n + kPlaceTile - 1u) / kPlaceTile; }
+static size_t tail_hash_bytes(uint32_t n) { return align_up(hash_table_bytes(hash_table_slots(n), kUniformBins), 256); }
 
-static Scratch carve(void* base, uint32_t n)
+// (the block is laid out for numItems keys and distinct digests; a run uses the front of each part)
+static Scratch carve(void* base, uint32_t n, uint32_t hashSlots)
 {
     Scratch s; uint8_t* p = (uint8_t*)base;
-    const size_t n64 = align_up((size_t)n * 8, 256), n32 = align_up((size_t)n * 4, 256);
-    s.sizes64 = (uint64_t*)p; p += n64; s.ofs64 = (uint64_t*)p; p += n64;
-    s.keysA = (uint32_t*)p; p += n32; s.keysB = (uint32_t*)p; p += n32;
-    s.valsA = (uint32_t*)p; p += n32; s.valsB = (uint32_t*)p; p += n32;
-    s.emitted = (uint32_t*)p; p += n32;
-    s.numEmitted = (uint32_t*)p; p += 256; s.total = (uint64_t*)p; p += 256;
-    s.hashBase = p; p += align_up(hash_table_bytes(hash_table_slots(n), kUniformBins), 256);
+    const size_t n64 = align_up((size_t)n * 8, 256);
+    const size_t hb = align_up(hash_table_bytes(hashSlots, kUniformBins), 256);
+    s.hashBase = p; p += hb; s.keysA = (unsigned long long*)p; p = (uint8_t*)base + tail_hash_bytes(n) + n64;
+    s.keysB = (unsigned long long*)p; p += n64;
+    s.work = (TailWork*)p; p += 256; s.tileState = (unsigned long long*)p; p += align_up((size_t)place_tiles(n) * 8, 256);
     s.tmp = p; s.tmpBytes = prim_temp_bytes(n);
     return s;
 }
@@ -1060,59 +1167,70 @@ size_t tail_scratch_bytes(uint32_t numItems, uint32_t numTris)
 {
     (void)numTris;
     const uint32_t n = numItems ? numItems : 1;
-    return 2 * align_up((size_t)n * 8, 256) + 5 * align_up((size_t)n * 4, 256) + 512 + align_up(hash_table_bytes(hash_table_slots(n), kUniformBins), 256) + prim_temp_bytes(n);
+    const size_t tail = 2 * align_up((size_t)n * 8, 256) + tail_hash_bytes(n) + 256 + align_up((size_t)place_tiles(n) * 8, 256) + prim_temp_bytes(n);
+    const size_t prep = (size_t)prep_state_words(n) * 4;   // (run_prep's tile states live in the same block)
+    return tail > prep ? tail : prep;
 }
 
 hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch, size_t scratchBytes, TailCounts* counts, hipStream_t stream)
 {
     const uint32_t n = in.numItems;
     counts->numOmms = 0; counts->arrayDataSize = 0; counts->smallOmms = 0;
-    if (out.indexHist == out.arrayHist + 64 && in.errorFlag == out.arrayHist + 128)   // (the bake takes the three from its arena back to back: one fill)
-        TAIL_CHECK(hipMemsetAsync(out.arrayHist, 0, sizeof(uint32_t) * 129, stream));
-    else {
+    // (the bake takes the two histograms and the error word from its arena back to back: tail_summarize zeroes them with everything else)
+    const bool adjacent = out.indexHist == out.arrayHist + 64 && in.errorFlag == out.arrayHist + 128;
+    if (!adjacent || n == 0) {
         TAIL_CHECK(hipMemsetAsync(out.arrayHist, 0, sizeof(uint32_t) * kNumLevels, stream));
         TAIL_CHECK(hipMemsetAsync(out.indexHist, 0, sizeof(uint32_t) * kNumLevels, stream));
         TAIL_CHECK(hipMemsetAsync(in.errorFlag, 0, sizeof(uint32_t), stream));
     }
+    TailWork* workDev = nullptr; uint32_t workBound = 0;
     if (n != 0) {
         if (scratchBytes < tail_scratch_bytes(n, in.numTris)) return hipErrorInvalidValue;
-        Scratch s = carve(scratch, n);
+        // emitted items are first occurrences that are not special: with special indices only non-uniform items (all of them on the active lists), with
+        // dedup at most one more per uniform (level, state) -- maxDistinctDigests covers both; with neither, every item
+        const bool every = (in.disableDedup && in.disableSpecial) || in.maxDistinctDigests == 0u;
+        const uint32_t bound = every || in.maxDistinctDigests > n ? n : in.maxDistinctDigests;
+        const uint32_t distinct = in.maxDistinctDigests && in.maxDistinctDigests < n ? in.maxDistinctDigests : n;
+        const uint32_t slots = in.disableDedup ? 0u : hash_table_slots(distinct);
+        uint32_t idxBits = 1; while (idxBits < 32u && (1ull << idxBits) < (unsigned long long)n) ++idxBits;
+        Scratch s = carve(scratch, n, slots ? slots : 1024u);
+        const HashTable table = hash_table_at(s.hashBase, slots ? slots : 1024u);
+        uint32_t* firstUniform = table.vals + (slots ? slots : 1024u) + 1u;   // keys, values and the uniform bins are adjacent
+        const bool rank = bound <= kRankMax;
         const dim3 grid((n + 255u) / 256u), block(256);
-        hipLaunchKernelGGL(tail_summarize, grid, block, 0, stream, in, out.special);
-        if (in.disableDedup) {
-            hipLaunchKernelGGL(tail_iota, grid, block, 0, stream, out.rep, n);
-        } else {
-            // (the scratch block is sized for numItems distinct digests; the table only needs twice the number that can occur)
-            const uint32_t distinct = in.maxDistinctDigests && in.maxDistinctDigests < n ? in.maxDistinctDigests : n;
-            const uint32_t slots = hash_table_slots(distinct);
-            const HashTable table = hash_table_at(s.hashBase, slots);
-            uint32_t* firstUniform = table.vals + slots + 1u;   // keys, values and the uniform bins are adjacent: one fill sets them all to all ones
-            TAIL_CHECK(hipMemsetAsync(s.hashBase, 0xFF, hash_table_bytes(slots, kUniformBins), stream));
+        // fills: table (when there is one) + key list to all ones, in one piece; work words + tile states to zero; histograms + error word to zero
+        uint32_t* ones = slots ? (uint32_t*)s.hashBase : (uint32_t*)s.keysA;
+        const uint32_t onesWords = (uint32_t)(((uint8_t*)(s.keysA + bound) - (uint8_t*)ones) / 4);
+        const uint32_t zeroBWords = 64u + (rank ? 0u : 2u * place_tiles(bound));
+        hipLaunchKernelGGL(tail_summarize, grid, block, 0, stream, in, out.special, ones, onesWords, adjacent ? out.arrayHist : (uint32_t*)nullptr, adjacent ? 129u : 0u,
+                           (uint32_t*)s.work, zeroBWords);
+        if (!in.disableDedup)
+        {
             hipLaunchKernelGGL(dedup_insert, grid, block, 0, stream, in.digests, in.stateMask, in.level, in.uniformDigest ? 1 : 0, n, table, firstUniform);
             if (in.uniformDigest) hipLaunchKernelGGL(dedup_insert_bins, dim3(1), dim3(64), 0, stream, in.uniformDigest, firstUniform, table);
-            hipLaunchKernelGGL(dedup_lookup, grid, block, 0, stream, in.digests, n, table, out.rep);
         }
-        hipLaunchKernelGGL(tail_sort_keys, grid, block, 0, stream, in, out.special, out.rep, s.keysA, s.emitted);
-        hipLaunchKernelGGL(tail_iota, grid, block, 0, stream, s.valsA, n);
-        size_t tb = s.tmpBytes;
-        TAIL_CHECK(rocprim::reduce(s.tmp, tb, s.emitted, s.numEmitted, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>(), stream));
-        tb = s.tmpBytes;
-        TAIL_CHECK(rocprim::radix_sort_pairs(s.tmp, tb, s.keysA, s.keysB, s.valsA, s.valsB, (size_t)n, (unsigned)0, (unsigned)32, stream));
-        TAIL_CHECK(hipMemsetAsync(s.sizes64, 0, (size_t)n * 8, stream));
-        hipLaunchKernelGGL(tail_order_sizes, grid, block, 0, stream, s.valsB, s.numEmitted, in.level, in.format, out.order, s.sizes64, out.sizes, out.arrayHist);
-        tb = s.tmpBytes;
-        TAIL_CHECK(rocprim::exclusive_scan(s.tmp, tb, s.sizes64, s.ofs64, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), stream));
-        hipLaunchKernelGGL(tail_item_values, grid, block, 0, stream, out.order, s.numEmitted, s.ofs64, out.dstOfs, out.special, n, out.itemValue,
-                           s.sizes64, in.errorFlag, s.total, out.arrayHist, in.format);
-        uint64_t summary[3] = { 0, 0, 0 };
-        TAIL_CHECK(hipMemcpyAsync(summary, s.total, sizeof summary, hipMemcpyDeviceToHost, stream));
-        TAIL_CHECK(hipStreamSynchronize(stream));
-        const uint32_t E = (uint32_t)summary[0], err = (uint32_t)(summary[0] >> 32);
-        counts->numOmms = E; counts->arrayDataSize = summary[1]; counts->smallOmms = (uint32_t)summary[2];
-        if (err) return hipErrorAssert;
+        hipLaunchKernelGGL(tail_emit, grid, block, 0, stream, in, out.special, table, idxBits, bound, out.rep, out.itemValue, s.keysA, s.work);
+        if (rank)
+            hipLaunchKernelGGL(tail_rank_place, dim3((bound + 31u) / 32u), dim3(1024), 0, stream, (const unsigned long long*)s.keysA, idxBits, bound, in.format, s.work,
+                               out.order, out.dstOfs, out.sizes, out.itemValue, out.arrayHist);
+        else {
+            size_t tb = s.tmpBytes;
+            TAIL_CHECK(rocprim::radix_sort_keys(s.tmp, tb, s.keysA, s.keysB, (size_t)bound, 0u, idxBits + 30u, stream));
+            hipLaunchKernelGGL(tail_place, dim3(place_tiles(bound)), dim3(kPlaceTile), 0, stream, (const unsigned long long*)s.keysB, idxBits, bound, in.format, s.work, s.tileState,
+                               out.order, out.dstOfs, out.sizes, out.itemValue, out.arrayHist);
+        }
+        workDev = s.work; workBound = bound;
     }
+    // (the index buffer does not wait for the read-back: it runs while the host synchronises)
     if (in.numTris != 0)
-        hipLaunchKernelGGL(tail_indices, dim3((in.numTris + 255u) / 256u), dim3(256), 0, stream, in, out.rep, out.itemValue, out.indexBuffer, out.indexHist);
+        hipLaunchKernelGGL(tail_indices, dim3((in.numTris + 255u) / 256u), dim3(256), 0, stream, in, out.rep, out.itemValue, out.indexBuffer, out.indexHist, out.narrowIndex, out.narrowBytes);
+    if (workDev) {
+        TailWork w; memset(&w, 0, sizeof w);
+        TAIL_CHECK(hipMemcpyAsync(&w, workDev, sizeof w, hipMemcpyDeviceToHost, stream));
+        TAIL_CHECK(hipStreamSynchronize(stream));
+        counts->numOmms = w.numEmitted < workBound ? w.numEmitted : workBound; counts->arrayDataSize = w.arrayBytes; counts->smallOmms = (uint32_t)w.smallOmms;
+        if (w.err) return hipErrorAssert;
+    }
     return hipGetLastError();
 }
 
