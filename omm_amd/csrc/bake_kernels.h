@@ -245,7 +245,8 @@ void launch_narrow_indices(const int32_t* in, uint32_t n, int bytesPerIndex, voi
 // scratch handling: call with scratch == nullptr to get the size
 size_t tail_scratch_bytes(uint32_t numItems, uint32_t numTris);
 // runs the device tail up to (and including) offsets; returns counts (synchronises the stream once)
-hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch, size_t scratchBytes, TailCounts* counts, hipStream_t stream);
+// (hostWork: 64 bytes of pinned host memory for the read-back, or null)
+hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch, size_t scratchBytes, TailCounts* counts, hipStream_t stream, void* hostWork = nullptr);
 void launch_write_descs(const uint32_t* order, const uint32_t* dstOfs, const uint8_t* level, int format, uint32_t numOmms, void* descArray, hipStream_t stream);
 
 } // namespace ommx

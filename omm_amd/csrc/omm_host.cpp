@@ -90,9 +90,30 @@ template <class F> ommResult guarded(const Logger* log, F&& body) noexcept
 }
 
 // ---- device arena: one grow-only HBM block per baker, reused across bakes ----
+constexpr size_t kHostBlockBytes = 64u << 10;
+// 64 KiB blocks of pinned host memory, the destination of a bake's small read-backs (counters, tail summary, histograms), which otherwise go through the
+// runtime's staging buffer -- a wait and a host copy per read-back.  Process-wide free list: pinning costs a system call and a page-table update, and
+// applications (and the test suite) create and destroy bakers by the hundred; blocks are never unpinned (a handful per concurrent bake).
+struct HostBlockPool {
+    std::mutex mu; std::vector<uint8_t*> idle;
+    uint8_t* acquire() {
+        { std::lock_guard<std::mutex> g(mu); if (!idle.empty()) { uint8_t* p = idle.back(); idle.pop_back(); return p; } }
+        uint8_t* p = nullptr;
+        if (hipHostMalloc((void**)&p, kHostBlockBytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return p;
+    }
+    void release(uint8_t* p) { if (p) { std::lock_guard<std::mutex> g(mu); idle.push_back(p); } }
+    static HostBlockPool& get() { static HostBlockPool* pool = new HostBlockPool(); return *pool; }   // (never destroyed: no HIP calls at process exit)
+};
 struct DeviceArena {
     uint8_t* base = nullptr; size_t cap = 0, used = 0;
-    ~DeviceArena() { if (base) (void)hipFree(base); }
+    uint8_t* hostBlock = nullptr; bool hostBlockTried = false;
+    ~DeviceArena() { if (base) (void)hipFree(base); HostBlockPool::get().release(hostBlock); }
+    // (null when pinning fails: the caller reads into pageable memory)
+    uint8_t* host_block() {
+        if (!hostBlockTried) { hostBlockTried = true; hostBlock = HostBlockPool::get().acquire(); }
+        return hostBlock;
+    }
     bool reserve(size_t bytes) {
         if (bytes <= cap) { used = 0; return true; }
         if (base) { (void)hipFree(base); base = nullptr; cap = 0; }
@@ -893,9 +914,12 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
 
     // ---- level-0 hierarchical query per item + compaction of the items that need per-micro-triangle work; ONE sync ----
     launch_triage(P, dUv, dLevel, dDegen, dCounters, maxItems, dMask, dActive, dScratch, stream);
+    uint8_t* const hostBlock = arena->host_block();   // layout: [0, 256) counters, [256, 512) tail summary, [1 KiB, ..) the final read-backs
+    SetupCounters* const hcDst = hostBlock ? (SetupCounters*)hostBlock : &hc;
     if (!HIP_OK(run_prep(dItemIds, dActive, dLevel, storeBits, maxItems, dCounters, dActiveIds, dStateOfs, dScratch, scratchBytes, stream)) ||
-        !HIP_OK(hipMemcpyAsync(&hc, dCounters, sizeof hc, hipMemcpyDeviceToHost, stream)) || !HIP_OK(hipStreamSynchronize(stream)))
+        !HIP_OK(hipMemcpyAsync(hcDst, dCounters, sizeof hc, hipMemcpyDeviceToHost, stream)) || !HIP_OK(hipStreamSynchronize(stream)))
         return L.failure("[Failure] - device work-list compaction failed");
+    if (hostBlock) memcpy(&hc, hcDst, sizeof hc);
 
     uint32_t U = hc.numItems;
     if (hc.collision) { // two different (UV, level) tuples shared a 64-bit hash: redo the setup serially with exact keys
@@ -944,8 +968,9 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
         if (T) ok = ok && HIP_OK(hipMemcpyAsync(dTriToItem, triToItem.data(), (size_t)T * 4, hipMemcpyHostToDevice, stream));
         launch_triage(P, dUv, dLevel, dDegen, dCounters, maxItems, dMask, dActive, dScratch, stream);
         ok = ok && HIP_OK(run_prep(dItemIds, dActive, dLevel, storeBits, maxItems, dCounters, dActiveIds, dStateOfs, dScratch, scratchBytes, stream));
-        ok = ok && HIP_OK(hipMemcpyAsync(&hc, dCounters, sizeof hc, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipStreamSynchronize(stream));
+        ok = ok && HIP_OK(hipMemcpyAsync(hcDst, dCounters, sizeof hc, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipStreamSynchronize(stream));
         if (!ok) return L.failure("[Failure] - serial work-item setup failed");
+        if (hostBlock) memcpy(&hc, hcDst, sizeof hc);
     }
     if ((flags & (1u << 5)) && hc.numDisabled != 0) { // bake_cpu_impl.cpp:652-657
         char buf[256];
@@ -1160,7 +1185,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     if (!R.index) return L.failure("[Failure] - could not allocate the device result");
     to.narrowIndex = R.index; to.narrowBytes = idxBytes;
     TailCounts counts;
-    if (!HIP_OK(run_tail(ti, to, dScratch, scratchBytes, &counts, stream))) return L.failure("[Failure] - device tail failed");
+    if (!HIP_OK(run_tail(ti, to, dScratch, scratchBytes, &counts, stream, hostBlock ? hostBlock + 256 : nullptr))) return L.failure("[Failure] - device tail failed");
     if (counts.arrayDataSize > 0xFFFFFFFFull) return ommResult_FAILURE; // bake_cpu_impl.cpp:1774-1775
     const int e4 = et.mark();
 
@@ -1203,24 +1228,31 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     unsigned long long fineCount = 0;
     std::vector<unsigned long long> fineSlots((size_t)kFineSlots * kFineStride, 0ull);
     const size_t spanBytes = (size_t)((const uint8_t*)(dFine + fineSlots.size()) - (const uint8_t*)dArrayHist);
-    std::vector<uint8_t> span(spanBytes);
-    ok = ok && HIP_OK(hipMemcpyAsync(span.data(), dArrayHist, spanBytes, hipMemcpyDeviceToHost, stream));
-    uint32_t queueTails[2] = { 0u, 0u };   // open tiles of the two tile sizes (statistics)
-    uint32_t hostCtl[kClassifyCtlWords]; memset(hostCtl, 0, sizeof hostCtl);
-    if (hc.activeStart[kNumLevels]) ok = ok && HIP_OK(hipMemcpyAsync(hostCtl, dQueueCtl, sizeof hostCtl, hipMemcpyDeviceToHost, stream));
+    // (into the arena's pinned block when there is one: three copies queued, ONE wait -- into pageable memory each copy is a wait of its own)
+    uint32_t hostCtlLocal[kClassifyCtlWords];
 #ifdef OMMX_GD_STATS
-    unsigned long long genericWords[20] = { 0 };
+    unsigned long long genericLocal[20] = { 0 };
 #else
-    unsigned long long genericWords[3] = { 0, 0, 0 };
+    unsigned long long genericLocal[3] = { 0, 0, 0 };
 #endif   // reservations (incl. null padding), the pass's cursor, micro-triangles it classified
-    if (dGeneric) ok = ok && HIP_OK(hipMemcpyAsync(genericWords, dGeneric, sizeof genericWords, hipMemcpyDeviceToHost, stream));
+    const size_t spanAt = 1024, ctlAt = spanAt + pad256(spanBytes), genAt = ctlAt + sizeof hostCtlLocal;
+    const bool pinnedBack = hostBlock && genAt + sizeof genericLocal <= kHostBlockBytes;
+    std::vector<uint8_t> spanLocal(pinnedBack ? 0 : spanBytes);
+    uint8_t* const span = pinnedBack ? hostBlock + spanAt : spanLocal.data();
+    uint32_t* const hostCtl = pinnedBack ? (uint32_t*)(hostBlock + ctlAt) : hostCtlLocal;
+    unsigned long long* const genericWords = pinnedBack ? (unsigned long long*)(hostBlock + genAt) : genericLocal;
+    memset(hostCtl, 0, sizeof hostCtlLocal); memset(genericWords, 0, sizeof genericLocal);
+    ok = ok && HIP_OK(hipMemcpyAsync(span, dArrayHist, spanBytes, hipMemcpyDeviceToHost, stream));
+    uint32_t queueTails[2] = { 0u, 0u };   // open tiles of the two tile sizes (statistics)
+    if (hc.activeStart[kNumLevels]) ok = ok && HIP_OK(hipMemcpyAsync(hostCtl, dQueueCtl, sizeof hostCtlLocal, hipMemcpyDeviceToHost, stream));
+    if (dGeneric) ok = ok && HIP_OK(hipMemcpyAsync(genericWords, dGeneric, sizeof genericLocal, hipMemcpyDeviceToHost, stream));
     const int e5 = et.mark();
     ok = ok && HIP_OK(hipStreamSynchronize(stream));
     // (a streamed result may still be on its way to the host: the caller queues its small read-backs first and then waits, StreamOut::finish)
     if (!ok) return L.failure("[Failure] - could not materialise the bake result on the device");
-    memcpy(R.hist, span.data(), sizeof(uint32_t) * kNumLevels);
-    memcpy(R.hist + kNumLevels, span.data() + ((const uint8_t*)dIndexHist - (const uint8_t*)dArrayHist), sizeof(uint32_t) * kNumLevels);
-    memcpy(fineSlots.data(), span.data() + ((const uint8_t*)dFine - (const uint8_t*)dArrayHist), sizeof(unsigned long long) * fineSlots.size());
+    memcpy(R.hist, span, sizeof(uint32_t) * kNumLevels);
+    memcpy(R.hist + kNumLevels, span + ((const uint8_t*)dIndexHist - (const uint8_t*)dArrayHist), sizeof(uint32_t) * kNumLevels);
+    memcpy(fineSlots.data(), span + ((const uint8_t*)dFine - (const uint8_t*)dArrayHist), sizeof(unsigned long long) * fineSlots.size());
 
     tm.uploadMs = 0.f; tm.hostSetupMs = 0.f; tm.setupMs = et.ms(e0, e1); tm.triageMs = et.ms(e1, e1b); tm.classifyMs = et.ms(e1b, e2); tm.digestMs = et.ms(e2, e3);
     tm.streamPreviewMs = pv0 >= 0 ? et.ms(pv0, pv1) : 0.f;

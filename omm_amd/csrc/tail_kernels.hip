@@ -1172,7 +1172,7 @@ size_t tail_scratch_bytes(uint32_t numItems, uint32_t numTris)
     return tail > prep ? tail : prep;
 }
 
-hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch, size_t scratchBytes, TailCounts* counts, hipStream_t stream)
+hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch, size_t scratchBytes, TailCounts* counts, hipStream_t stream, void* hostWork)
 {
     const uint32_t n = in.numItems;
     counts->numOmms = 0; counts->arrayDataSize = 0; counts->smallOmms = 0;
@@ -1225,9 +1225,11 @@ hipError_t run_tail(const TailInputs& in, const TailOutputs& out, void* scratch,
     if (in.numTris != 0)
         hipLaunchKernelGGL(tail_indices, dim3((in.numTris + 255u) / 256u), dim3(256), 0, stream, in, out.rep, out.itemValue, out.indexBuffer, out.indexHist, out.narrowIndex, out.narrowBytes);
     if (workDev) {
-        TailWork w; memset(&w, 0, sizeof w);
-        TAIL_CHECK(hipMemcpyAsync(&w, workDev, sizeof w, hipMemcpyDeviceToHost, stream));
+        TailWork local; memset(&local, 0, sizeof local);
+        TailWork* dst = hostWork ? (TailWork*)hostWork : &local;
+        TAIL_CHECK(hipMemcpyAsync(dst, workDev, sizeof local, hipMemcpyDeviceToHost, stream));
         TAIL_CHECK(hipStreamSynchronize(stream));
+        const TailWork w = *dst;
         counts->numOmms = w.numEmitted < workBound ? w.numEmitted : workBound; counts->arrayDataSize = w.arrayBytes; counts->smallOmms = (uint32_t)w.smallOmms;
         if (w.err) return hipErrorAssert;
     }

@@ -193,6 +193,23 @@ def test_per_triangle_levels_and_dynamic(product, oracle):
     both(product, oracle, [noise_u8()], uv, ix, 6, dyn_scale=0.7, addr=ot.WRAP, levels=lv)
 
 
+@pytest.mark.parametrize("count", [5000, 16300, 16500, 40000])
+@pytest.mark.parametrize("flags", [ot.FLAG_THREADS, ot.FLAG_THREADS | ot.FLAG_NO_SPECIAL, ot.FLAG_THREADS | ot.FLAG_NO_SPECIAL | ot.FLAG_NO_DEDUP | ot.FLAG_FORCE32])
+def test_descriptor_order_and_offsets_both_tail_paths(product, oracle, count, flags):
+    """The spatial sort + Serialize (bake_cpu_impl.cpp:1707-1920) on either side of the tail's threshold (tail_kernels.hip: descriptor slots by counting up
+    to 16 384 candidate OMMs, key sort + single-pass offset scan above), with mixed per-triangle levels (offsets from the level histogram), exact
+    duplicates (emitted once) and uniform items (special indices, or emitted blocks with special indices disabled)."""
+    uv, ix = ot.random_triangles(1234 + count, count, 0.004)
+    uv = uv.reshape(-1, 3, 2).copy()
+    uv[count // 2: count // 2 + count // 10] = uv[0: count // 10]          # exact UV duplicates
+    uv[count - count // 10:] = uv[0: count // 10] + np.float32(0.5)           # digest duplicates (periodic texture)
+    lv = (ot.hash_u32(np.arange(count) + 17) % 5).astype(np.uint8)          # levels 0..3 and 0xF (= the global level 4)
+    lv[lv == 4] = 0xF
+    tex = np.tile(noise_u8(256)[:128, :128], (2, 2))
+    r = both(product, oracle, [tex], uv.reshape(-1, 2), ix, 4, addr=ot.WRAP, flags=flags, levels=lv)
+    assert r.index.size == count
+
+
 @pytest.mark.parametrize("glob,n_global,n0,n1,n2,n3,n4", [
     # the parameter sets of support/tests/test_subdiv.cpp:255-350 (BakeSubDiv: Mixed, Mixed2, Lvl0Only .. Lvl4Only, LvlGlobalOnly)
     (2, 8, 4, 7, 7, 7, 7), (4, 84, 234, 0, 23, 34, 57), (2, 0, 56, 0, 0, 0, 0), (2, 0, 0, 526, 0, 0, 0), (2, 0, 0, 0, 91, 0, 0), (2, 0, 0, 0, 0, 391, 0), (2, 0, 0, 0, 0, 0, 391), (4, 430, 0, 0, 0, 0, 0)])
