@@ -187,9 +187,13 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
         }
         const MicroTri sub = micro_triangle(uv, tileInItem, level - TILE_LOG4);
         r = region_rect<ModeDynamic>(P, sub, maxAbs);
-        if (P.useCoarse) st = region_state<ModeDynamic>(P, sub, maxAbs, no_window());
+        // (a tile that IS its work item -- level 6 here, level 5 in the 1024-tile queue -- was asked both questions by triage_items, with the same arguments,
+        //  and is on the active list because the answer was no: configs[1], 10 192 such tiles, 22 -> 9 us)
+        constexpr bool kSameTests = ((OMMX_RC_LEVELS & 1) != 0) == ((OMMX_RC_LEVELS & 2) != 0);
+        const bool asked = kSameTests && level == TILE_LOG4;
+        if (P.useCoarse && !asked) st = region_state<ModeDynamic>(P, sub, maxAbs, no_window());
         // a tile in a mixed neighbourhood that the level curve does not reach (region_curve.h): settled like a uniform one
-        if ((OMMX_RC_LEVELS & 2) && st < 0 && region_curve_applies(P) && !A.degenerate[item]) {
+        if ((OMMX_RC_LEVELS & 2) && !asked && st < 0 && region_curve_applies(P) && !A.degenerate[item]) {
             const DevMip& m = P.mips[0];
             st = region_curve_state<ModeDynamic>(P, P.texIsFp32 != 0, rc_shape(uv, m.fw, m.fh, m.w, m.h, level), sub, maxAbs);
         }

@@ -1538,14 +1538,29 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
             codecHead.resize((size_t)co.L.offCodes);
             ok = ok && HIP_OK(hipMemcpyAsync(codecHead.data(), co.dComp, (size_t)co.L.offCodes, hipMemcpyDeviceToHost, stream));
         } else if (!so.used) ok = ok && HIP_OK(hipMemcpyAsync(res->arrayData, R.arrayData, (size_t)R.arrayDataSize, hipMemcpyDeviceToHost, stream));
-        ok = ok && HIP_OK(hipMemcpyAsync(res->descs, R.descs, sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, hipMemcpyDeviceToHost, stream));
     }
     res->index = (int32_t*)baker.mem.allocate(sizeof(int32_t) * (size_t)(T ? T : 1), 16);
     res->triArea = (float*)baker.mem.allocate(sizeof(float) * (size_t)(T ? T : 1), 16);
     ok = ok && res->index != nullptr && res->triArea != nullptr;
     const size_t outIdx = R.indexFormat == ommIndexFormat_UINT_8 ? 1 : (R.indexFormat == ommIndexFormat_UINT_16 ? 2 : 4);
-    if (ok && T) ok = HIP_OK(hipMemcpyAsync(res->index, R.index, outIdx * T, hipMemcpyDeviceToHost, stream));
-    if (ok && T) ok = HIP_OK(hipMemcpyAsync(res->triArea, R.triAreaScratch, sizeof(float) * (size_t)T, hipMemcpyDeviceToHost, stream));
+    // descriptors, index buffer and triangle areas (8.6 MB at the metric configuration, into the caller's pageable arrays: each copy holds its thread until it is done).
+    // With a compressed result they cross the link on the second stream WHILE the helper threads expand the array (one of the expansion's tasks issues them);
+    // otherwise here, in front of the wait.
+    auto small_copies = [&](hipStream_t s) -> bool {
+        bool k = true;
+        if (E) k = HIP_OK(hipMemcpyAsync(res->descs, R.descs, sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, hipMemcpyDeviceToHost, s));
+        if (k && T) k = HIP_OK(hipMemcpyAsync(res->index, R.index, outIdx * T, hipMemcpyDeviceToHost, s));
+        if (k && T) k = HIP_OK(hipMemcpyAsync(res->triArea, R.triAreaScratch, sizeof(float) * (size_t)T, hipMemcpyDeviceToHost, s));
+        return k;
+    };
+    hipEvent_t evResult = nullptr;   // the device result is complete (everything in front of it on the bake's stream)
+#ifndef OMMX_DEFER_SMALL
+#define OMMX_DEFER_SMALL 1
+#endif
+    bool deferSmall = OMMX_DEFER_SMALL && ok && co.on && ses.open_comm() && HIP_OK(hipEventCreateWithFlags(&evResult, hipEventDisableTiming));
+    if (deferSmall) deferSmall = HIP_OK(hipEventRecord(evResult, stream)) && HIP_OK(hipStreamWaitEvent(ses.commStream, evResult, 0));
+    struct EvGuard { hipEvent_t& e; ~EvGuard() { if (e) (void)hipEventDestroy(e); } } evGuard{ evResult };
+    if (ok && !deferSmall) ok = small_copies(stream);
     const int d1 = et.mark();
     ok = ok && HIP_OK(hipStreamSynchronize(stream));
     if (so.chunks) { ok = so.finish() && ok; if (so.used) tm.streamTailMs = (float)(so.lastByteMs - so.classifyEndMs); }   // (the last streamed bytes arrive while the small arrays above are read back)
@@ -1556,7 +1571,7 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
         uint8_t* hStream = ses.set->pinned.base;
         if (fits) memcpy(hStream, codecHead.data(), codecHead.size());
         if (!fits) {   // noise-like states (the stream would not be below half of the array): the array itself crosses the link
-            ok = HIP_OK(hipMemcpyAsync(res->arrayData, R.arrayData, (size_t)R.arrayDataSize, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipStreamSynchronize(stream));
+            ok = HIP_OK(hipMemcpyAsync(res->arrayData, R.arrayData, (size_t)R.arrayDataSize, hipMemcpyDeviceToHost, stream)) && (!deferSmall || small_copies(stream)) && HIP_OK(hipStreamSynchronize(stream));
             tm.resultTransfer = ommxResultTransfer_Plain;
         } else {
             // The rest of the stream lands in the working set's pinned block slice by slice -- the codes of a range of codec blocks and the raw units those blocks
@@ -1591,7 +1606,15 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
                 std::atomic<uint32_t> arrived{ 0 }; std::atomic<bool> failed{ false };
                 ok = HIP_OK(hipEventSynchronize(evs[0]));
                 if (ok) arrived.store(1);
-                if (ok) pool.run((uint32_t)numTasks, [&](uint32_t t) {
+                const int dev = baker.bind_device();
+                const uint32_t extra = deferSmall ? 1u : 0u;   // task 0: the small arrays, on the second stream
+                if (ok) pool.run((uint32_t)numTasks + extra, [&](uint32_t t0) {
+                    if (extra && t0 == 0u) {
+                        const DeviceScope onDev(dev);
+                        if (!small_copies(ses.commStream) || !HIP_OK(hipStreamSynchronize(ses.commStream))) failed.store(true);
+                        return;
+                    }
+                    const uint32_t t = t0 - extra;
                     const uint64_t s0 = (uint64_t)t * kTaskBlocks, s1 = s0 + kTaskBlocks < L.blocks ? s0 + kTaskBlocks : L.blocks;
                     uint32_t need = 0; while (need + 1u < kSlices && blockCut[need + 1u] < s1) ++need;   // the last slice this task reads from
                     for (uint32_t a; (a = arrived.load(std::memory_order_acquire)) <= need && !failed.load(std::memory_order_relaxed); ) {

@@ -313,6 +313,7 @@ void launch_write_descs(const uint32_t* order, const uint32_t* dstOfs, const uin
 // tiles handed out by ticket.  The state words (prep_state_words(): ticket, then count and byte states per tile) sit at the start of the scratch block
 // and are zeroed by triage_items, the launch in front of this one.
 constexpr uint32_t kPrepTile = 1024u;   // (items per tile = threads per workgroup: a look-back per 1024 items)
+static_assert(kPrepTile == 1024u, "prep_state_words() (bake_kernels.h) sizes the state block for tiles of 1024 items");
 __global__ __launch_bounds__(kPrepTile) void prep_compact(const uint32_t* __restrict__ itemIds, const uint8_t* __restrict__ active, const uint8_t* __restrict__ level,
                                                           int bits, SetupCounters* __restrict__ counters, uint32_t* __restrict__ stateWords,
                                                           uint32_t* __restrict__ activeIds, uint64_t* __restrict__ stateOfs)
