@@ -1066,11 +1066,8 @@ def test_fuzz_all_knobs(product, oracle, seed):
     both(product, oracle, mips, uv, ix, level, sat=sat, cutoff=cutoff, **kw)
 
 
-@pytest.mark.parametrize("seed", list(range(400, 496)))
-def test_fuzz_deferred_texel_walks(product, oracle, seed):
-    """The deferred generic pass (bake_kernels.hip: classify_generic / generic_dense -- owners, visit rings, votes summed in LDS) against the oracle over the fuzz
-    generator's textures, address modes, filters, promotions, formats, flags and per-triangle levels, with triangles of 4 .. 300 texels at levels 5 .. 8:
-    micro-triangles from a fraction of a texel to a dozen texels across, i.e. walks of every length in one wave."""
+def _walk_case(seed):
+    """a fuzz case of the deferred generic pass: triangles of 4 .. 300 texels at levels 5 .. 8 over _fuzz_case's textures and knobs (also tests/scripts/bigfuzz.py walks)"""
     mips, _, _, _, cutoff, sat, kw = _fuzz_case(seed)
     h = lambda k: int(ot.hash_u32(np.array([seed * 977 + k], dtype=np.int64))[0])
     level = 5 + h(1) % 4
@@ -1081,6 +1078,15 @@ def test_fuzz_deferred_texel_walks(product, oracle, seed):
     kw = dict(kw); kw.pop("levels", None); kw["dyn_scale"] = 0.0
     if h(4) % 2:
         kw["levels"] = (5 + ot.hash_u32(np.arange(n) + seed) % (level - 4)).astype(np.uint8)
+    return mips, uv, ix, level, cutoff, sat, kw
+
+
+@pytest.mark.parametrize("seed", list(range(400, 496)))
+def test_fuzz_deferred_texel_walks(product, oracle, seed):
+    """The deferred generic pass (bake_kernels.hip: classify_generic / generic_dense -- owners, visit rings, votes summed in LDS) against the oracle over the fuzz
+    generator's textures, address modes, filters, promotions, formats, flags and per-triangle levels, with triangles of 4 .. 300 texels at levels 5 .. 8:
+    micro-triangles from a fraction of a texel to a dozen texels across, i.e. walks of every length in one wave."""
+    mips, uv, ix, level, cutoff, sat, kw = _walk_case(seed)
     both(product, oracle, mips, uv, ix, level, sat=sat, cutoff=cutoff, knobs=[(ot.KNOB_GENERIC_PASS, 2)], **kw)
 
 
