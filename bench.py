@@ -197,6 +197,22 @@ def cpu_baseline(tex, uv, ix, lv, kw, sample, sat=True, grow=True, sweep=True):
     return out, res, (suv, six, slv), dt, ph
 
 
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: re-exec the same command line under torch.distributed.run (one process per GPU, rendezvous on
+    127.0.0.1 at a free port).  os.execv: no wrapper process stays between the driver's clock and the ranks."""
+    import socket
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,6 +232,10 @@ def main():
     ap.add_argument("--concurrent", type=int, default=0, help="also measure K host threads baking concurrently on ONE baker through ommCpuBake (bakes/s for 1, 4, .. K threads; "
                                                               "the reference documents caller-level parallelism as a first-class strategy, docs/integration_guide.md:434)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: this process becomes the launcher -- one rank per GPU under torch.distributed.run, same arguments,
+        # rank 0's JSON line on this process's stdout.  (The driver's own torch.distributed.run command line lands in the branch below.)
+        relaunch_under_torchrun(args.gpus)
     cfg = CONFIGS[args.config]
     tris = args.tris or cfg["tris"]
     host_steps = args.steps if args.host_api_steps < 0 else args.host_api_steps
@@ -226,7 +246,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d, or plainly as `python bench.py --gpus %d`" % (world, args.gpus, args.gpus, args.gpus)
     # self-test hooks (tests only): OMM_BENCH_ONE_GPU=1 puts every rank on GPU 0 and OMM_BENCH_BACKEND=gloo replaces RCCL, which
     # refuses two ranks on one device -- the driver's runs use neither
     torch.cuda.set_device(0 if os.environ.get("OMM_BENCH_ONE_GPU") == "1" else local)

@@ -70,8 +70,8 @@ OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings*
  * Tuning and test switches are state of ONE baker, set explicitly through this call; the library reads no environment variables.
  * A value of 0 restores the default.  Unknown knobs -> INVALID_ARGUMENT. */
 typedef enum ommxBakerKnob {
-    ommxBakerKnob_SetupKeyBits     = 0, /* TEST ONLY: work-item dedup keys are cut to this many bits (1..62), which forces 64-bit key collisions and with
-                                           them the exact host form of SetupWorkItems; 0 = full 64-bit keys */
+    ommxBakerKnob_Reserved0        = 0, /* (was ommxBakerKnob_SetupKeyBits, a test switch of rounds 1 - 5: the work-item ids are the reference's own 64-bit ids
+                                           since round 6, see omm_amd/csrc/vm_id.h; setting it has no effect) */
     ommxBakerKnob_ShardChunkBytes  = 1, /* sharded bake: bytes per rank and chunk of the block all-gather (>= 256; default 64 MiB, at most 8 chunks) */
     ommxBakerKnob_StreamChunks     = 2, /* ommCpuBake: number of ranges (of work items, in the order of the result) whose finished OMM blocks are copied to
                                            their place in the host array while the following ranges are being classified; a value (1..32) forces streaming

@@ -115,10 +115,10 @@ struct SetupParams {
     int globalLevel; float dynScale; int edgeHeuristic;
     int texW, texH; int disableDedup; int wantWorkload;
     int degenerateInvalid;   // internal flag DisableLevelLineIntersection: degenerate triangles count as invalid (bake_cpu_impl.cpp:569-572)
-    uint64_t keyMask;   // all ones; tests narrow it (ommxBakerKnob_SetupKeyBits) to force key collisions and exercise the exact host redo
+    int format;              // ommFormat of the bake: part of the work-item id (vm_id.h)
 };
 struct SetupCounters {                                         // one device-resident block, read back in a single copy
-    uint32_t numItems, numDisabled, numPending, collision;
+    uint32_t numItems, numDisabled, numPending, reserved_;
     uint64_t workload;
     uint32_t levelCount[kNumLevels];
     uint32_t levelStart[kNumLevels + 1];

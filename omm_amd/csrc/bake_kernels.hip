@@ -1530,6 +1530,10 @@ hipError_t launch_classify(const ClassifyParams& P, const ItemArrays& A, const u
 #ifdef OMMX_ONLY_HOT   // (A/B and resource-usage builds: one instantiation set -- UNORM8 texels, Wrap addressing, power-of-two size -- compiles in a sixth of the time)
     if (P.texIsFp32 || !wrapP2) return hipErrorNotSupported;
     launch_classify_md<false, ModeStatic<0, 1>>(P, A, activeIds, first, count, q, queueCtl, numCUs, chunks, stream);
+#elif defined(OMMX_ONLY_U8)   // (A/B builds for the bench configurations: UNORM8 texels, power-of-two size, Wrap or Clamp)
+    if (P.texIsFp32 || !(wrapP2 || clampP2)) return hipErrorNotSupported;
+    if (wrapP2) launch_classify_md<false, ModeStatic<0, 1>>(P, A, activeIds, first, count, q, queueCtl, numCUs, chunks, stream);
+    else launch_classify_md<false, ModeStatic<2, 1>>(P, A, activeIds, first, count, q, queueCtl, numCUs, chunks, stream);
 #else
     if (P.texIsFp32) {
         if (wrapP2) launch_classify_md<true, ModeStatic<0, 1>>(P, A, activeIds, first, count, q, queueCtl, numCUs, chunks, stream);

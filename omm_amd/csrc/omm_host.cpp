@@ -518,18 +518,6 @@ int32_t level_for_primitive(const ommCpuBakeInputDesc& d, uint32_t flags, uint32
     return (int32_t)(lvl < d.maxSubdivisionLevel ? lvl : d.maxSubdivisionLevel);
 }
 
-// UV-dedup key: the reference keys its map by a 64-bit hash chain over (p0,p1,p2,level,format) and
-// trusts it (bake_cpu_impl.cpp:626-649); modulo 2^-64 collisions that is equality of the tuple with
-// +0 == -0 (std::hash<float>).  The tuple itself is the key here.
-struct UvKey { uint32_t k[8]; bool operator==(const UvKey& o) const { return memcmp(k, o.k, sizeof k) == 0; } };
-struct UvKeyHash {
-    size_t operator()(const UvKey& a) const {
-        uint64_t h = 0x9E3779B97F4A7C15ull;
-        for (int i = 0; i < 8; ++i) { h ^= a.k[i]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
-        return (size_t)h;
-    }
-};
-
 const char* special_name(int s)
 {
     switch (s) { case -1: return "Fully Transparent"; case -2: return "Fully Opaque"; case -3: return "Fully Unknown Transparent"; case -4: return "Fully Unknown Opaque"; default: return "Unknown State"; }
@@ -703,32 +691,6 @@ struct MarkCtx { EventTimer* et; int mark, markGeneric; };
 void mark_hook(void* user) { MarkCtx& c = *(MarkCtx*)user; c.mark = c.et->mark(); }
 void mark_generic_hook(void* user) { MarkCtx& c = *(MarkCtx*)user; c.markGeneric = c.et->mark(); }
 
-// host form of SetupWorkItems, used when the device setup reports a hash collision (never observed; 2^-64 class event)
-void setup_on_host(const ommCpuBakeInputDesc& d, uint32_t flags, const Texture& tex, std::vector<HostTri>& itemUv, std::vector<uint8_t>& itemLevel,
-                   std::vector<uint8_t>& itemDegenerate, std::vector<int32_t>& triToItem, uint32_t& numDisabled)
-{
-    const uint32_t triCount = d.indexCount / 3u;
-    std::unordered_map<UvKey, uint32_t, UvKeyHash> seen;
-    seen.reserve((size_t)triCount * 2);
-    const bool noDedup = (flags & (1u << 3)) != 0;
-    numDisabled = 0;
-    for (uint32_t i = 0; i < triCount; ++i) {
-        const HostTri t = fetch_triangle(d, i);
-        const int32_t lvl = level_for_primitive(d, flags, i, t, tex.mips[0].w, tex.mips[0].h);
-        if (lvl == 0xE || tri_invalid(t) || ((flags & (1u << 8)) && tri_degenerate(t))) { numDisabled++; continue; }   // (:563-575: degenerate triangles are invalid without the level-line kernel)
-        UvKey key;
-        for (int k = 0; k < 6; ++k) { const float f = t.p[k] == 0.f ? 0.f : t.p[k]; memcpy(&key.k[k], &f, 4); }
-        key.k[6] = (uint32_t)lvl; key.k[7] = (uint32_t)d.format;
-        auto it = noDedup ? seen.end() : seen.find(key);
-        if (it == seen.end()) {
-            const uint32_t id = (uint32_t)itemUv.size();
-            if (!noDedup) seen.emplace(key, id);
-            itemUv.push_back(t); itemLevel.push_back((uint8_t)lvl); itemDegenerate.push_back(tri_degenerate(t) ? 1 : 0);
-            triToItem[i] = (int32_t)id;
-        } else triToItem[i] = (int32_t)it->second;
-    }
-}
-
 // One byte per micro-triangle of every work item on the host, for the serial reducers (host_tail.cpp): near-duplicate merge and the
 // maxArrayDataSize budget work on the reference's own data layout (bake_cpu_impl.cpp:401-411).  Synchronises the stream.
 ommResult gather_host_items(const Logger& L, hipStream_t stream, uint32_t U, uint32_t T, const SetupCounters& hc, const float* dUv, const uint8_t* dLevel,
@@ -851,8 +813,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     S.wantWorkload = 1;   // (also the input of the two shape decisions below: streamed result, deferred generic pass)
     S.degenerateInvalid = (flags & (1u << 8)) != 0;
     const bool checkWorkload = ((flags & (1u << 5)) != 0) || d.maxWorkloadSize != 0xFFFFFFFFFFFFFFFFull;
-    S.keyMask = ~0ull;
-    if (const uint64_t kb = baker.knob(ommxBakerKnob_SetupKeyBits)) S.keyMask = (1ull << kb) - 1ull;   // (tests: forced key collisions)
+    S.format = (int)d.format;   // (per-triangle formats other than the global one are refused above: one format per bake)
     bool ok = (const uint8_t*)dUniformDigest == (const uint8_t*)dCounters + 256   // (adjacent arena slots: see BakeHead)
            && HIP_OK(hipMemcpyAsync(dCounters, &bake_head(), sizeof(BakeHead), hipMemcpyHostToDevice, stream));
     ok = ok && HIP_OK(run_setup_fetch(S, dScratch, scratchBytes, dCounters, dKnown, maxItems, (uint32_t*)dFine, 2u * kFineSlots * kFineStride, dTriArea, stream));
@@ -922,56 +883,6 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     if (hostBlock) memcpy(&hc, hcDst, sizeof hc);
 
     uint32_t U = hc.numItems;
-    if (hc.collision) { // two different (UV, level) tuples shared a 64-bit hash: redo the setup serially with exact keys
-        // (a device-resident caller has no host arrays: its index / UV / level arrays are read back for this 2^-64-class event)
-        ommCpuBakeInputDesc readBack = d; std::vector<uint8_t> hIdx, hUvRaw, hLv;
-        if (!hostDesc) {
-            const size_t idxSize = d.indexFormat == ommIndexFormat_UINT_8 ? 1 : (d.indexFormat == ommIndexFormat_UINT_16 ? 2 : 4);
-            hIdx.resize(idxSize * 3ull * T + 1);
-            if (!HIP_OK(hipMemcpyAsync(hIdx.data(), din.indices, idxSize * 3ull * T, hipMemcpyDeviceToHost, stream)) || !HIP_OK(hipStreamSynchronize(stream)))
-                return L.failure("[Failure] - device to host transfer of the index buffer failed");
-            uint32_t maxIndex = 0;
-            for (size_t i = 0; i < 3ull * T; ++i) {
-                const uint32_t v = idxSize == 1 ? hIdx[i] : (idxSize == 2 ? ((const uint16_t*)hIdx.data())[i] : ((const uint32_t*)hIdx.data())[i]);
-                maxIndex = v > maxIndex ? v : maxIndex;
-            }
-            const size_t elem = d.texCoordFormat == ommTexCoordFormat_UV32_FLOAT ? 8 : 4;
-            hUvRaw.resize((size_t)S.stride * maxIndex + elem); hLv.resize(din.perTriLevels ? T : 0);
-            bool okb = HIP_OK(hipMemcpyAsync(hUvRaw.data(), din.texCoords, hUvRaw.size(), hipMemcpyDeviceToHost, stream));
-            if (okb && !hLv.empty()) okb = HIP_OK(hipMemcpyAsync(hLv.data(), din.perTriLevels, hLv.size(), hipMemcpyDeviceToHost, stream));
-            if (!okb || !HIP_OK(hipStreamSynchronize(stream))) return L.failure("[Failure] - device to host transfer of the triangle data failed");
-            readBack.indexBuffer = hIdx.data(); readBack.texCoords = hUvRaw.data(); readBack.subdivisionLevels = hLv.empty() ? nullptr : hLv.data();
-            hostDesc = &readBack;
-        }
-        std::vector<HostTri> itemUv; std::vector<uint8_t> itemLevel, itemDegenerate; std::vector<int32_t> triToItem(T ? T : 1, -1);
-        setup_on_host(*hostDesc, flags, tex, itemUv, itemLevel, itemDegenerate, triToItem, hc.numDisabled);
-        U = (uint32_t)itemUv.size();
-        memset(hc.levelCount, 0, sizeof hc.levelCount); hc.workload = 0; hc.numItems = U;
-        for (uint32_t i = 0; i < U; ++i) hc.levelCount[itemLevel[i]]++;
-        hc.levelStart[0] = 0; for (int l = 0; l < kNumLevels; ++l) hc.levelStart[l + 1] = hc.levelStart[l] + hc.levelCount[l];
-        std::vector<uint32_t> itemIds(U ? U : 1);
-        { uint32_t cur[kNumLevels]; memcpy(cur, hc.levelStart, sizeof cur); for (uint32_t i = 0; i < U; ++i) itemIds[cur[itemLevel[i]]++] = i; }
-        const float fw = (float)S.texW, fh = (float)S.texH;
-        for (uint32_t i = 0; i < U; ++i) {
-            const float* p = itemUv[i].p;
-            const float lox = std::min(std::min(p[0], p[2]), p[4]), loy = std::min(std::min(p[1], p[3]), p[5]);
-            const float hix = std::max(std::max(p[0], p[2]), p[4]), hiy = std::max(std::max(p[1], p[3]), p[5]);
-            hc.workload += (uint64_t)(int64_t)(int32_t)((uint32_t)f2i((hix - lox) * fw) * (uint32_t)f2i((hiy - loy) * fh));
-        }
-        ok = HIP_OK(hipMemcpyAsync(dCounters, &hc, sizeof hc, hipMemcpyHostToDevice, stream));
-        if (U) {
-            ok = ok && HIP_OK(hipMemcpyAsync(dUv, itemUv.data(), (size_t)U * 24, hipMemcpyHostToDevice, stream));
-            ok = ok && HIP_OK(hipMemcpyAsync(dLevel, itemLevel.data(), U, hipMemcpyHostToDevice, stream));
-            ok = ok && HIP_OK(hipMemcpyAsync(dDegen, itemDegenerate.data(), U, hipMemcpyHostToDevice, stream));
-            ok = ok && HIP_OK(hipMemcpyAsync(dItemIds, itemIds.data(), (size_t)U * 4, hipMemcpyHostToDevice, stream));
-        }
-        if (T) ok = ok && HIP_OK(hipMemcpyAsync(dTriToItem, triToItem.data(), (size_t)T * 4, hipMemcpyHostToDevice, stream));
-        launch_triage(P, dUv, dLevel, dDegen, dCounters, maxItems, dMask, dActive, dScratch, stream);
-        ok = ok && HIP_OK(run_prep(dItemIds, dActive, dLevel, storeBits, maxItems, dCounters, dActiveIds, dStateOfs, dScratch, scratchBytes, stream));
-        ok = ok && HIP_OK(hipMemcpyAsync(hcDst, dCounters, sizeof hc, hipMemcpyDeviceToHost, stream)) && HIP_OK(hipStreamSynchronize(stream));
-        if (!ok) return L.failure("[Failure] - serial work-item setup failed");
-        if (hostBlock) memcpy(&hc, hcDst, sizeof hc);
-    }
     if ((flags & (1u << 5)) && hc.numDisabled != 0) { // bake_cpu_impl.cpp:652-657
         char buf[256];
         snprintf(buf, sizeof buf, "[Info] - The workload consists of %d unclassifiable triangles, these will be classified as unresolvedTriState = %s.", hc.numDisabled, special_name(d.unresolvedTriState));
@@ -1004,7 +915,7 @@ ommResult bake_core(Baker& baker, const ommCpuBakeInputDesc& d, const DeviceInpu
     // ---- streamed result (ommCpuBake)?  Worth it when the packed states are large enough for the copy to matter ----
     uint32_t streamChunks = 0; const uint32_t numActiveAll = hc.activeStart[kNumLevels];
     uint8_t* hostArray = nullptr; unsigned long long* hCursor = nullptr; bool hostPinned = false;
-    if (so && numActiveAll && !(flags & (1u << 1)) && !hc.collision && !P.altKernel && storeBits == bits) {   // (with special indices disabled every uniform item is a block too: the plain path handles that)
+    if (so && numActiveAll && !(flags & (1u << 1)) && !P.altKernel && storeBits == bits) {   // (with special indices disabled every uniform item is a block too: the plain path handles that)
         uint32_t k = so->chunksWanted;
         if (!so->forced) {
             // >= 64 MiB of packed states: one range per 32 MiB, at most 32 (round 3, classification-bound, at 1.27 GB: 8 / 16 / 24 / 32 ranges = 38.4 / 36.7 / 36.2 / 36.2 ms)
@@ -2440,6 +2351,11 @@ ommResult bake_impl_multi(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBake
     const uint32_t E = c0.counts.numOmms, U = c0.ti.numItems;
     std::vector<uint32_t> hOrder(E ? E : 1), hDstOfs(E ? E : 1), hSizes(E ? E : 1), hMask(U ? U : 1); std::vector<uint64_t> hCofs(E ? E : 1);
     std::vector<uint8_t> hActive(U ? U : 1), hOwner(U ? U : 1), hLevel(U ? U : 1);
+    // Asynchronous copies into the vectors above (and, further down, into the result's arrays) are queued on stream0: whatever way this function is left --
+    // a failed copy half way down a chain, an exception of a host container or of the thread pool -- the stream is drained BEFORE their memory is released
+    // (destructors run in reverse order of declaration: each guard is declared right behind the memory it protects).
+    struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } };
+    const SyncOnExit drainBeforeVectors{ stream0 };
     bool ok = true;
     if (E) ok = HIP_OK(hipMemcpyAsync(hOrder.data(), c0.to.order, (size_t)E * 4, hipMemcpyDeviceToHost, stream0)) && HIP_OK(hipMemcpyAsync(hDstOfs.data(), c0.to.dstOfs, (size_t)E * 4, hipMemcpyDeviceToHost, stream0))
               && HIP_OK(hipMemcpyAsync(hSizes.data(), c0.to.sizes, (size_t)E * 4, hipMemcpyDeviceToHost, stream0)) && HIP_OK(hipMemcpyAsync(hCofs.data(), c0.dCofs, (size_t)E * 8, hipMemcpyDeviceToHost, stream0));
@@ -2456,6 +2372,7 @@ ommResult bake_impl_multi(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBake
     if (!res) return ommResult_FAILURE;
     res->mem = baker.mem;
     struct ResGuard { Baker& b; BakeResult*& r; ~ResGuard() { if (r) b.mem.destroy(r); } } resGuard{ baker, res };
+    const SyncOnExit drainBeforeResult{ stream0 };
     if (E) {
         if (baker.mem.alloc == default_alloc && (size_t)DR.arrayDataSize >= HostPool::kMinBytes) { res->arrayData = baker.hostPool->acquire((size_t)DR.arrayDataSize); if (res->arrayData) res->pool = baker.hostPool; }
         if (!res->arrayData) res->arrayData = baker.mem.allocate((size_t)DR.arrayDataSize, 64);
@@ -2488,7 +2405,7 @@ ommResult bake_impl_multi(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBake
         threadsUsed = pool->workers() + 1u;
     }
     ok = ok && HIP_OK(hipStreamSynchronize(stream0));
-    if (!ok) { (void)hipStreamSynchronize(stream0); return L.failure("[Failure] - device to host transfer of the bake result failed"); }
+    if (!ok) return L.failure("[Failure] - device to host transfer of the bake result failed");
     memcpy(res->arrayHist, dr->arrayHist, sizeof(ommCpuOpacityMicromapUsageCount) * 2 * kNumLevels);
     memcpy(res->indexHist, dr->indexHist, sizeof(ommCpuOpacityMicromapUsageCount) * 2 * kNumLevels);
     res->desc.arrayData = E ? res->arrayData : nullptr; res->desc.arrayDataSize = E ? (uint32_t)DR.arrayDataSize : 0;
@@ -2778,7 +2695,6 @@ OMM_MI355X_API ommResult ommxDestroyDeviceBakeResult(ommxDeviceBakeResult result
 OMM_MI355X_API ommResult ommxSetBakerKnob(ommBaker baker, ommxBakerKnob knob, uint64_t value)
 {
     if (baker == 0 || tag_of(baker) != kCpuBaker || (unsigned)knob >= (unsigned)ommxBakerKnob_MAX_NUM) return ommResult_INVALID_ARGUMENT;
-    if (knob == ommxBakerKnob_SetupKeyBits && value > 62) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_ShardChunkBytes && value != 0 && value < 256) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_StreamChunks && value > kMaxStreamRanges) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_GenericPass && value > 2) return ommResult_INVALID_ARGUMENT;

@@ -1,19 +1,21 @@
 // setup_kernels.hip -- SetupWorkItems (bake_cpu_impl.cpp:589-660) on the device.
 //
 // The reference walks the triangles serially: fetch UVs, pick the subdivision level, drop invalid (NaN/Inf) triangles,
-// and merge triangles with an identical (UV triangle, level, format) into one work item owned by the FIRST occurrence.
-// Device form: one lane per triangle + a hash build over a 64-bit key hash (hash_build.h):
+// and merge triangles with the same 64-bit work-item id (vm_id.h: the reference's hash chain over (UV triangle, level, format), which its map
+// trusts -- triangles whose ids collide are ONE work item there, and so they are here) into one work item owned by the FIRST occurrence.
+// Device form: one lane per triangle + a hash build over the ids (hash_build.h):
 //   * slot value = smallest triangle index with the key  = first occurrence
 //   * exclusive scan over "is first occurrence" in triangle order = work-item numbering in the reference's order
 //   * stable counting split of the items by level = the per-level launch lists
-// The reference itself keys its map by a 64-bit hash and trusts it; here every merged triangle is additionally compared
-// against its first occurrence's full key and a mismatch raises `collision` (the host then redoes the setup serially).
+// (Rounds 1 - 5 keyed the table by an own hash of the tuple, compared the tuples of merged triangles and redid the setup on the host when they
+// differed: tuple equality, which is what the reference computes only as long as its ids do not collide.  tests/golden/vmid_collisions.json holds inputs where they do.)
 // The one libm-dependent piece -- log2f in the edge heuristic for degenerate triangles under dynamic subdivision
 // (bake_cpu_impl.cpp:511-528) -- is not evaluated here: such triangles are reported in `pending` for the host.
 #include <hip/hip_runtime.h>
 #include <string.h>
 
 #include "hash_build.h"
+#include "vm_id.h"
 #include "scan_lookback.h"
 #include <stdint.h>
 #include "bake_types.h"
@@ -34,12 +36,6 @@ __device__ __forceinline__ float half_bits_to_float(uint32_t h) // glm::unpackHa
     } else if (e == 31) bits = sign | 0x7f800000u | (m << 13);
     else bits = sign | ((e + 112u) << 23) | (m << 13);
     return __uint_as_float(bits);
-}
-
-__device__ __forceinline__ uint64_t mix64(uint64_t h, uint32_t w)
-{
-    h ^= w; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ULL; h ^= h >> 29;
-    return h;
 }
 
 // x86: uint(float) goes through cvttss2si r64 and keeps the low 32 bits (bake_cpu_impl.cpp:502)
@@ -117,16 +113,8 @@ __global__ __launch_bounds__(256) void setup_fetch(SetupParams S, float* __restr
     triFlags[t] = (uint8_t)((invalid ? 1u : 0u) | (degenerate ? 2u : 0u) | (pending ? 4u : 0u));
     if (invalid) atomicAdd(&counters->numDisabled, 1u);
     if (pending) { const uint32_t slot = atomicAdd(&counters->numPending, 1u); pendingList[slot] = t; }
-    uint64_t h;
-    if (invalid || S.disableDedup) h = (invalid ? 0xFFFFFFFF00000000ULL : 0ULL) | t; // unique: never merged
-    else {
-        h = 0x9E3779B97F4A7C15ULL;
-        #pragma unroll
-        for (int k = 0; k < 6; ++k) h = mix64(h, __float_as_uint(p[k] == 0.f ? 0.f : p[k])); // +0 == -0 (std::hash<float>)
-        h = mix64(h, level);
-        h &= 0x7FFFFFFFFFFFFFFFULL & S.keyMask; // keep clear of the invalid-triangle key range
-    }
-    hashKeys[t] = h;
+    // the reference's work-item id (vm_id.h).  Invalid triangles and bakes without duplicate detection never look at the table (setup_dedup_*).
+    hashKeys[t] = (invalid || S.disableDedup) ? (uint64_t)t : vm_id(p, (int32_t)level, S.format);
     // UV-space area of the input triangle (bake_cpu_impl.cpp:1904-1915, GetArea2D util/geometry.h:141-149): the side channel of ommDebugGetStats2's
     // knownAreaMetric.  Triangles that own no work item (NaN / Inf coordinates) keep area 0 like the reference's value-initialised vector.
     if (triArea) {
@@ -148,10 +136,9 @@ __global__ __launch_bounds__(256) void setup_rehash_pending(SetupParams S, const
     if (k >= numPending) return;
     const uint32_t t = pendingList[k];
     if (S.disableDedup) return;
-    uint64_t h = 0x9E3779B97F4A7C15ULL;
-    for (int q = 0; q < 6; ++q) { const float f = triUv[6ull * t + q]; h = mix64(h, __float_as_uint(f == 0.f ? 0.f : f)); }
-    h = mix64(h, triLevel[t]);
-    hashKeys[t] = h & 0x7FFFFFFFFFFFFFFFULL & S.keyMask;
+    float p[6];
+    for (int q = 0; q < 6; ++q) p[q] = triUv[6ull * t + q];
+    hashKeys[t] = vm_id(p, (int32_t)triLevel[t], S.format);
 }
 
 // ---- UV-triangle dedup as a hash build (hash_build.h): firstTri[t] = smallest triangle index with triangle t's 64-bit key ----
@@ -164,8 +151,7 @@ __global__ __launch_bounds__(256) void setup_dedup_insert(const uint64_t* __rest
     hash_put_min_block(table, live, live ? hashKeys[t] : 0ull, t, buckets);
 }
 
-// first occurrence, item flag, and the collision check: a triangle whose key equals the first occurrence's must have the same (UV, level)
-// tuple, else the 64-bit hash collided and the host redoes the dedup exactly
+// first occurrence and item flag: a triangle whose id equals an earlier triangle's belongs to that triangle's work item (bake_cpu_impl.cpp:633-649)
 // ... and (round 5) the item numbers: the exclusive scan of the item flags in the same launch -- single pass with decoupled look-back (a tile publishes its
 // count with flag 1, collects the counts of the tiles before it until one with an inclusive prefix, flag 2; tiles handed out by ticket; state word =
 // flag << 62 | count; `scanState`: ticket word, then the states from word 64 on -- zeroed by setup_fetch).  It was a rocPRIM scan of two launches.
@@ -185,11 +171,6 @@ __global__ __launch_bounds__(1024) void setup_dedup_lookup(const uint64_t* __res
         uint32_t f = t;
         if (!invalid && !disableDedup) {
             f = hash_get(table, hashKeys[t], t);
-            if (f != t) {
-                bool same = triLevel[t] == triLevel[f];
-                for (int q = 0; q < 6; ++q) { const float x = triUv[6ull * t + q], y = triUv[6ull * f + q]; same &= (x == y); }
-                if (!same) atomicOr(&counters->collision, 1u);
-            }
         }
         firstTri[t] = f;
         item = (f == t && !invalid) ? 1u : 0u;

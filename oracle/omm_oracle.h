@@ -32,6 +32,8 @@ void     orc_micro_triangle(const float tri[6], uint32_t index, uint32_t level, 
 void     orc_get_tex_coord(int mode, int pow2, int x, int y, int w, int h, int out[2]);
 uint64_t orc_xxh64(const void* data, size_t len, uint64_t seed);
 uint64_t orc_sort_key(const float uv[6], uint32_t level);
+uint64_t oracle_std_hash_float(float f);                                     /* libstdc++ std::hash<float> */
+uint64_t oracle_vm_id(const float uv[6], int32_t level, int32_t format);     /* the work-item id of SetupWorkItems (bake_cpu_impl.cpp:626-631) */
 #ifdef __cplusplus
 }
 #endif

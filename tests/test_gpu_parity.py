@@ -1123,22 +1123,40 @@ def test_concurrent_bakes_on_one_baker(product):
     product.destroy_baker(b)
 
 
-def test_work_item_key_collisions_take_the_exact_host_path(product, oracle):
-    """the device dedup of UV triangles keys a hash table by a 64-bit hash and verifies every merge against the first occurrence's full
-    (UV, level) tuple; a mismatch makes the host redo SetupWorkItems exactly.  ommxBakerKnob_SetupKeyBits = 6 leaves 64 distinct keys for 3000
-    triangles, so nearly every triangle collides: the result must still be the oracle's (with real duplicates and per-triangle levels in the mix)"""
-    uv, ix = ot.random_triangles(77, 3000, 0.03)
-    uv[3 * 100:3 * 103] = uv[3 * 10:3 * 13]; uv[3 * 2000:3 * 2003] = uv[3 * 10:3 * 13]   # real duplicates of triangle 10..12
-    lv = (3 + ot.hash_u32(np.arange(3000) + 5) % 4).astype(np.uint8); lv[100:103] = lv[10:13]; lv[2000:2003] = lv[10:13]
+def test_work_item_ids_collide_like_the_reference(product, oracle):
+    """SetupWorkItems keys its triangle -> work item map by a 64-bit hash chain and trusts it (libraries/omm-lib/src/bake_cpu_impl.cpp:626-649): triangles
+    whose ids collide are ONE work item, whatever their coordinates.  tests/golden/vmid_collisions.json holds pairs of different UV points with the same
+    std::hash<glm::vec2>; triangles that differ only in such a point must share the first one's micro-map -- in the oracle (which restates the hash chain)
+    and in the HIP library (omm_amd/csrc/vm_id.h), through ommCpuBake and through the device-resident entry.  Real duplicates and per-triangle levels in
+    the mix; with a different level the ids differ again."""
+    import json, os
+    pairs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vmid_collisions.json")))["pairs"]
+    f = lambda h: np.array([int(h, 16)], np.uint32).view(np.float32)[0]
+    uv, ix = ot.random_triangles(77, 300, 0.03)
+    lv = (3 + ot.hash_u32(np.arange(300) + 5) % 4).astype(np.uint8)
+    k = 10
+    for pr in pairs:                       # triangle k ends in point a, triangle k + 100 is the same triangle ending in point b; k + 200: b again at another level
+        for j, pt in ((k, pr["a"]), (k + 100, pr["b"]), (k + 200, pr["b"])):
+            uv[3 * j:3 * j + 2] = uv[3 * k:3 * k + 2]
+            uv[3 * j + 2] = (f(pt[0]), f(pt[1]))
+        lv[k + 100] = lv[k]; lv[k + 200] = lv[k] + 1
+        k += 7
+    uv[3 * 50:3 * 53] = uv[3 * 40:3 * 43]; lv[50:53] = lv[40:43]                # real duplicates
     tex = ot.foliage_texture(8, 512, 512, feature=24)
-    both(product, oracle, [tex], uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv, knobs=[(ot.KNOB_SETUP_KEY_BITS, 6)])
-    both(product, oracle, [tex], uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv)
-    # the device-resident entry point has no host arrays: on a collision it reads the caller's device arrays back and takes the same exact path
+    got = both(product, oracle, [tex], uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv)
+    res = got[0] if isinstance(got, (tuple, list)) else got
+    if res is not None and hasattr(res, "index"):
+        k = 10
+        for pr in pairs:
+            assert res.index[k] == res.index[k + 100], "colliding ids must share a micro-map"
+            k += 7
+    both(product, oracle, [tex], uv, ix, 5, addr=ot.CLAMP, promo=ot.PROMO_NEAREST, fmt=ot.FMT_2STATE)
     hip = ot.Hip()
     ob = oracle.create_baker(); otx = oracle.create_texture(ob, [tex], alpha_cutoff=0.5)
     ref = oracle.bake(ob, ot.make_desc(otx, uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv))
     oracle.destroy_texture(ob, otx); oracle.destroy_baker(ob)
-    b = product.create_baker(); product.set_knob(b, ot.KNOB_SETUP_KEY_BITS, 6)
+    assert all(ref.index[10 + 7 * i] == ref.index[110 + 7 * i] for i in range(len(pairs)))
+    b = product.create_baker()
     t = product.create_texture(b, [tex], alpha_cutoff=0.5)
     dev = ot.bake_device(product, hip, b, ot.make_desc(t, uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE, levels=lv), uv, ix, levels=lv)
     product.destroy_texture(b, t); product.destroy_baker(b)
@@ -1280,16 +1298,19 @@ def test_two_process_sharded_bake_on_one_gpu():
     assert out.returncode == 0 and "two-process sharded bake ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
 
 
-@pytest.mark.parametrize("collectives", ["native", "torch"])
-def test_bench_two_ranks_on_one_gpu(collectives):
-    """bench.py's N > 1 path end to end (launch through torch.distributed.run, barrier + max-over-ranks timing, one JSON line from rank 0),
-    with both ranks on GPU 0 over gloo (self-test hooks of bench.py): the one-call entry ommxShardedBakeRccl over the process group's
-    collectives, and the caller-driven four-call path"""
+@pytest.mark.parametrize("collectives,launcher", [("native", "torchrun"), ("torch", "torchrun"), ("native", "plain")])
+def test_bench_two_ranks_on_one_gpu(collectives, launcher):
+    """bench.py's N > 1 path end to end (barrier + max-over-ranks timing, one JSON line from rank 0), with both ranks on GPU 0 over gloo
+    (self-test hooks of bench.py): the one-call entry ommxShardedBakeRccl over the process group's collectives, and the caller-driven
+    four-call path -- launched through torch.distributed.run as the driver does, and PLAINLY as `python bench.py --gpus 2`, which
+    re-executes itself under the launcher"""
     import json, subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, OMM_BENCH_ONE_GPU="1", OMM_BENCH_BACKEND="gloo", OMM_BENCH_COLLECTIVES=collectives)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--tris", "20000"]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    wrap = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517"] if launcher == "torchrun" else []
+    cmd = [sys.executable] + wrap + [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--tris", "20000"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -46,3 +46,41 @@ def test_oracle_reproduces_fixture(fx):
 @pytest.mark.parametrize("fx", FIXTURES, ids=lambda f: f["case"]["name"])
 def test_hip_library_reproduces_fixture(fx):
     check(ot.Lib("product"), fx)
+
+
+# ---- every triangle of the BASELINE configurations, slice by slice (tests/golden/slice_fixtures.json, made by tests/golden/make_slice_fixtures.py) ----
+import make_slice_fixtures as ms          # noqa: E402
+
+SLICES = ms.load()
+
+
+def test_slice_fixture_file_covers_every_triangle_of_the_metric_configuration():
+    """all 20 slices of configs[2] (1 M triangles: the configuration BASELINE's metric is quoted on), all 4 of the asset-shaped cards, and at least every
+    8th of configs[4]'s 160 (the container's 8 cores bound what the oracle can bake)"""
+    assert [(e["first"], e["end"]) for e in SLICES["c2"]["slices"]] == ms.slices_of("c2")
+    assert [(e["first"], e["end"]) for e in SLICES["cards"]["slices"]] == ms.slices_of("cards")
+    assert {(e["first"], e["end"]) for e in SLICES["c4"]["slices"]} >= set(ms.slices_of("c4", 8))
+    assert sum(e["end"] - e["first"] for e in SLICES["c2"]["slices"]) == 1000000
+
+
+def _check_slices(lib, cfg, entries):
+    s = ms.Slicer(lib, cfg)
+    bad = []
+    for e in entries:
+        got, want = ms.digest(s.bake(e["first"], e["end"])), e["expect"]
+        bad += [(cfg, e["first"], k, got[k], want[k]) for k in want if got[k] != want[k]]
+    s.close()
+    assert not bad, bad[:6]
+
+
+def test_oracle_reproduces_a_slice_of_the_cards():
+    """the generator's answers are the oracle's (cheap case on the CPU: the last 10 000 of the asset-shaped quads)"""
+    _check_slices(ot.Lib("oracle"), "cards", SLICES["cards"]["slices"][-1:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", sorted(SLICES))
+def test_hip_library_reproduces_every_slice(cfg):
+    """ommCpuBake on every committed slice of the configuration against the oracle's committed digests: for configs[2] that is every one of its 1 000 000
+    triangles (6.55e10 micro-triangles, 1.3 GB of arrayData), compared with answers computed in the build container, not with an oracle run next to it"""
+    _check_slices(ot.Lib("product"), cfg, SLICES[cfg]["slices"])

@@ -116,3 +116,31 @@ def test_communicator_bootstrap_fails_on_every_rank_or_on_none(tmp_path):
     assert got[0] == got[1], got
     if not torch.cuda.is_available():
         assert got == ["raised", "raised"], got
+
+
+def test_bench_gpus_n_relaunches_itself_under_the_launcher(monkeypatch):
+    """`python bench.py --gpus 8` as typed (no WORLD_SIZE in the environment) must not die on an assert: it re-executes the same command line
+    under torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1 (the driver's own launcher command line sets WORLD_SIZE and is untouched)"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    seen = {}
+
+    class Stop(Exception):
+        pass
+
+    def fake_execv(exe, argv):
+        seen["exe"], seen["argv"] = exe, list(argv)
+        raise Stop()
+    monkeypatch.setattr(os, "execv", fake_execv)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(Stop):
+        bench.main()
+    a = seen["argv"]
+    assert seen["exe"] == sys.executable and a[1:3] == ["-m", "torch.distributed.run"]
+    assert a[a.index("--nproc-per-node") + 1] == "8" and a[a.index("--master-addr") + 1] == "127.0.0.1" and int(a[a.index("--master-port") + 1]) > 0
+    assert os.path.samefile(a[a.index("--master-port") + 2], os.path.join(root, "bench.py"))
+    assert a[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
