@@ -469,6 +469,8 @@ def main():
                                                     "codec_and_readback_ms": havg("compressMs"), "copy_and_expand_ms": havg("expandMs"), "expand_threads": int(host_tms[-1].expandThreads),
                                                     "copy_and_expand_ms_min_max": [float(min(t.expandMs for t in host_tms)), float(max(t.expandMs for t in host_tms))],
                                                     "bake_ms_min_max": [float(min(t.totalMs for t in host_tms)), float(max(t.totalMs for t in host_tms))],
+                                                    "bake_ms_p50_p95": [float(np.percentile([t.totalMs for t in host_tms], 50)), float(np.percentile([t.totalMs for t in host_tms], 95))],
+                                                    "copy_and_expand_ms_p50_p95": [float(np.percentile([t.expandMs for t in host_tms], 50)), float(np.percentile([t.expandMs for t in host_tms], 95))],
                                                     "expand_GBps": result_info["arrayDataBytes"] / (havg("expandMs") * 1e6) if havg("expandMs") > 0 else None,
                                                     "devices": int(host_tms[-1].devices) or 1},
                                 "stream": {"ranges": int(host_tms[-1].streamChunks), "streamed_bytes": int(host_tms[-1].streamedBytes), "exposed_copy_ms": havg("streamTailMs"),

@@ -64,7 +64,13 @@ typedef struct ommxBakeTimings {
  * ommxGetLastBakeTimings is the round-3 symbol: it fills the fields up to and including contributionBytes (the struct as it was then) and never writes
  * beyond them, whatever the caller's header says -- the fields from streamPreviewMs on are only available through the sized call. */
 OMM_MI355X_API ommResult ommxGetLastBakeTimingsSized(ommBaker baker, void* out, size_t outBytes, size_t* libraryBytes);
-OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings* out);
+/* DEPRECATED (kept for binaries built against the round-3 header): fills only the round-3 prefix of the struct and leaves the rest of `out` untouched --
+ * zero the struct first, or better call ommxGetLastBakeTimingsSized(baker, &t, sizeof t, NULL). */
+OMM_MI355X_API ommResult ommxGetLastBakeTimings(ommBaker baker, ommxBakeTimings* out)
+#if defined(__GNUC__)
+    __attribute__((deprecated("use ommxGetLastBakeTimingsSized")))
+#endif
+    ;
 
 /* ---- per-baker knobs ----
  * Tuning and test switches are state of ONE baker, set explicitly through this call; the library reads no environment variables.
@@ -90,7 +96,12 @@ typedef enum ommxBakerKnob {
     ommxBakerKnob_Devices          = 7, /* ommCpuBake over N >= 2 devices of this process (at most 16): one host thread per device, rank r on HIP device (baker's + r) mod the
                                            device count; the texture is copied to the other devices by the first bake that needs it; every device classifies its share of
                                            the work items and sends its own blocks to the host as a codec stream over its own PCIe link.  Not for bakes with near-duplicate
-                                           merging / maxArrayDataSize or per-triangle formats (those keep to one device).  0 / 1: one device */
+                                           merging / maxArrayDataSize or per-triangle formats (those keep to one device).  0 / 1: one device.
+                                           HELPER THREADS: a baker starts threads of its own only with the caller's permission.  That permission is
+                                           ommCpuBakeFlags_EnableInternalThreads on the bake (the automatic choice of the compressed transfer looks at it), OR setting one of the two
+                                           knobs that cannot work without threads: ommxBakerKnob_ResultTransfer = ommxResultTransfer_Compressed (helper threads expand the
+                                           result) and ommxBakerKnob_Devices >= 2 (a host thread per device + the expansion).  Setting such a knob IS the permission, whatever
+                                           the bake's flags say; without either, ommCpuBake runs on the calling thread only, like the reference without the flag */
     ommxBakerKnob_MAX_NUM          = 8
 } ommxBakerKnob;
 typedef enum ommxResultTransfer {

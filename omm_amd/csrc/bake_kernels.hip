@@ -357,8 +357,20 @@ constexpr int WIN = 32; // largest LDS texel window edge
 #endif
 // TILE micro-triangles per workgroup: 4096 for levels >= 6, 1024 below (a level-5 item is exactly one 1024-tile)
 constexpr uint32_t kDeferredState = 0xFEu;   // s_state code of a micro-triangle that classify_generic() will classify
+// The kernel's first argument read again from the kernarg segment (scalar loads through the scalar cache) behind an empty asm the optimizer cannot look through:
+// a phase that starts with it re-loads the few fields it uses instead of the kernel holding every field any phase uses in SGPRs from its first line to its
+// last -- which do not exist: the allocator parks them in VGPR lanes (74 in the instantiation that defers the texel walks) and every use is a v_readlane.
+#ifndef OMMX_FRESH_PARAMS
+#define OMMX_FRESH_PARAMS 1
+#endif
+__device__ __forceinline__ const ClassifyParams* fresh_kernarg_params()
+{
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();   // (a pointer into the constant address space; ClassifyParams is the first argument of the kernels that call this)
+    asm volatile("" : "+s"(p));
+    return (const ClassifyParams*)p;
+}
 template <bool FP32, bool SLICED, int TILE, class MD, bool DEFER = false>
-__global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(ClassifyParams P, ItemArrays A, const uint32_t* __restrict__ itemIds,
+__global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(ClassifyParams Pk, ItemArrays A, const uint32_t* __restrict__ itemIds,
                                                         uint32_t numItems, uint32_t levelArg, uint64_t numTiles,
                                                         const uint4* __restrict__ tileQueue, uint32_t* __restrict__ queueCtl, uint32_t numSections, GenericQueue G)
 {
@@ -379,10 +391,20 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     // from it -- LDS addresses, lane masks, wave indices, a dozen of them -- out of the persistent tile loop and keeps them alive across all phases, i.e. in
     // scratch (round 4: 18 scratch stores in front of the loop, reloads in every phase).  Recomputing them costs one or two instructions each.
     uint32_t tid = threadIdx.x;
-#ifndef OMMX_NO_TID_LAUNDER
-#define OMMX_FRESH_TID() asm volatile("" : "+v"(tid))
+#if OMMX_FRESH_PARAMS
+    // (only the instantiation that defers the texel walks: there it takes the last 20 bytes of scratch away, 4.65 -> 4.34 ms on the asset-shaped bake; the
+    //  hot instantiation of the metric configuration has no scratch to lose and runs 7.41 -> 7.50 ms with the reloads)
+    const ClassifyParams* Pp = DEFER ? fresh_kernarg_params() : &Pk;
+#define P (*Pp)
+#define OMMX_FRESH_P() do { if (DEFER) Pp = fresh_kernarg_params(); } while (0)
 #else
-#define OMMX_FRESH_TID() ((void)0)
+#define P Pk
+#define OMMX_FRESH_P() ((void)0)
+#endif
+#ifndef OMMX_NO_TID_LAUNDER
+#define OMMX_FRESH_TID() do { asm volatile("" : "+v"(tid)); OMMX_FRESH_P(); } while (0)
+#else
+#define OMMX_FRESH_TID() OMMX_FRESH_P()
 #endif
     // DEFER: hand `n` queued micro-triangles (s_queue[0 .. n)) to the generic queue; false = no room, the caller walks them itself.  Block-uniform.
     auto defer_generic = [&](uint32_t n, uint32_t itemWord, uint32_t level) -> bool {
@@ -806,6 +828,8 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     }
     return;   // (!SLICED: one tile per workgroup)
   }
+#undef P
+#undef OMMX_FRESH_P
 }
 
 

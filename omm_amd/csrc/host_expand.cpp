@@ -8,31 +8,70 @@
 #include <stdlib.h>
 #include <sys/syscall.h>
 #include <unistd.h>
+#include <chrono>
+#include <mutex>
+#include <thread>
 #include <stdlib.h>
 #include <string.h>
 
 namespace ommx {
 
-unsigned effective_cpus()
+// The CPUs this process may use AT ONCE: hardware threads, cut by the affinity mask and by the cgroup CPU quota of the process's OWN cgroup
+// (/proc/self/cgroup names it; the root of the mounted hierarchy is only right inside a cgroup namespace).  Both can change while a baker lives -- a
+// scheduler re-pins the process, an orchestrator edits the quota -- so the value is read again when the cached one is older than 100 ms (a bake asks
+// three times; the files cost ~20 us).
+static double cgroup_quota()
 {
-    static const unsigned cached = [] {
-        unsigned n = std::thread::hardware_concurrency(); if (n == 0) n = 1;
-        cpu_set_t set; CPU_ZERO(&set);
-        if (sched_getaffinity(0, sizeof set, &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0 && (unsigned)a < n) n = (unsigned)a; }
-        double quota = -1.0;
-        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char rel[512] = { 0 };
+    if (FILE* f = fopen("/proc/self/cgroup", "r")) {   // v2: "0::/path"; v1: "N:cpu,cpuacct:/path"
+        char line[768];
+        while (fgets(line, sizeof line, f)) {
+            char* c1 = strchr(line, ':'); char* c2 = c1 ? strchr(c1 + 1, ':') : nullptr;
+            if (!c2) continue;
+            const bool v2 = line[0] == '0' && c1 == line + 1 && c2 == c1 + 1, v1cpu = strstr(c1, "cpu,") == c1 + 1 || strstr(c1, ":cpu:") == c1 || strstr(c1, ",cpu:") != nullptr;
+            if (!v2 && !v1cpu) continue;
+            size_t n = strlen(c2 + 1); while (n && (c2[n] == '\n' || c2[n] == '/')) c2[n--] = 0;
+            snprintf(rel, sizeof rel, "%s", c2 + 1);
+            if (v2) break;
+        }
+        fclose(f);
+    }
+    double best = -1.0;
+    auto take = [&](double q) { if (q > 0 && (best < 0 || q < best)) best = q; };
+    // the quota of the own group and of every ancestor up to the mount point applies: walk up
+    char path[768];
+    for (int depth = 0; depth < 32; ++depth) {
+        snprintf(path, sizeof path, "/sys/fs/cgroup%s/cpu.max", rel);
+        if (FILE* f = fopen(path, "r")) {
             char q[64] = { 0 }; double per = 0;
-            if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) quota = atof(q) / per;
+            if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) take(atof(q) / per);
             fclose(f);
         } else {
             double q = -1, per = 0;
-            if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lf", &q) != 1) q = -1; fclose(fq); }
-            if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lf", &per) != 1) per = 0; fclose(fp); }
-            if (q > 0 && per > 0) quota = q / per;
+            snprintf(path, sizeof path, "/sys/fs/cgroup/cpu%s/cpu.cfs_quota_us", rel);
+            if (FILE* fq = fopen(path, "r")) { if (fscanf(fq, "%lf", &q) != 1) q = -1; fclose(fq); }
+            snprintf(path, sizeof path, "/sys/fs/cgroup/cpu%s/cpu.cfs_period_us", rel);
+            if (FILE* fp = fopen(path, "r")) { if (fscanf(fp, "%lf", &per) != 1) per = 0; fclose(fp); }
+            if (q > 0 && per > 0) take(q / per);
         }
-        if (quota > 0 && quota < (double)n) n = (unsigned)(quota + 0.5);
-        return n ? n : 1u;
-    }();
+        char* slash = strrchr(rel, '/');
+        if (!slash) break;
+        *slash = 0;   // (the last round runs with rel == "": the mount point itself)
+    }
+    return best;
+}
+unsigned effective_cpus()
+{
+    static std::mutex mu; static unsigned cached = 0; static std::chrono::steady_clock::time_point stamp;
+    std::lock_guard<std::mutex> g(mu);
+    const auto now = std::chrono::steady_clock::now();
+    if (cached && now - stamp < std::chrono::milliseconds(100)) return cached;
+    unsigned n = std::thread::hardware_concurrency(); if (n == 0) n = 1;
+    cpu_set_t set; CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0 && (unsigned)a < n) n = (unsigned)a; }
+    const double quota = cgroup_quota();
+    if (quota > 0 && quota < (double)n) n = (unsigned)(quota + 0.5);
+    cached = n ? n : 1u; stamp = now;
     return cached;
 }
 
@@ -88,15 +127,18 @@ int WorkerPool::bind_near(const void* memory)
 #ifdef SYS_move_pages
     if (syscall(SYS_move_pages, 0, 1ul, &page, (const int*)nullptr, &node, 0) != 0) node = -1;
 #endif
-    if (node < 0 || node == boundNode_ || threads_.empty()) return node;
+    cpu_set_t allowedNow; CPU_ZERO(&allowedNow);
+    const bool haveMask = sched_getaffinity(0, sizeof allowedNow, &allowedNow) == 0;
+    // (bound already -- unless the process's own mask has changed since: the workers may sit on CPUs it must no longer use)
+    if (node < 0 || threads_.empty() || (node == boundNode_ && haveMask && CPU_EQUAL(&allowedNow, &boundMask_))) return node;
     char path[128]; snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
     FILE* f = fopen(path, "r");
     if (!f) return -1;
     char list[4096] = { 0 };
     const bool got = fgets(list, sizeof list, f) != nullptr; fclose(f);
     if (!got) return -1;
-    cpu_set_t allowed; CPU_ZERO(&allowed);
-    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return -1;
+    if (!haveMask) return -1;
+    const cpu_set_t allowed = allowedNow;
     // the node's cores this process may use, one entry per physical core (the first hardware thread of its sibling list), in CPU order
     std::vector<int> cores;
     for (char* p = list; *p; ) {   // "64-127,192-255"
@@ -123,7 +165,7 @@ int WorkerPool::bind_near(const void* memory)
         for (size_t c = lo; c < hi; ++c) CPU_SET(cores[c], &want);
         (void)pthread_setaffinity_np(threads_[k].native_handle(), sizeof want, &want);
     }
-    boundNode_ = node;
+    boundNode_ = node; boundMask_ = allowed;
     return node;
 }
 

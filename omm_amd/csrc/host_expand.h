@@ -2,6 +2,7 @@
 // exchange codec": one nibble per 16-byte unit = which state it repeats, or "raw") and a few host threads expand it into the caller's array.
 // Plain C++ (no HIP): compiled like host_tail.cpp.
 #pragma once
+#include <sched.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <atomic>
@@ -38,6 +39,7 @@ private:
     uint32_t tasks_ = 0; uint64_t generation_ = 0; unsigned active_ = 0; bool stop_ = false;
     std::atomic<uint32_t> next_{ 0 };
     int boundNode_ = -2;
+    cpu_set_t boundMask_;   // the process's affinity mask when the workers were bound (bind_near binds again when it has changed)
 };
 
 // Layout of a codec stream (the same arithmetic as tail_kernels.hip: codec_layout): header 16 B | first raw unit of every 256-unit block (uint32, blocks + 1) |

@@ -1528,11 +1528,14 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
                     const uint32_t t = t0 - extra;
                     const uint64_t s0 = (uint64_t)t * kTaskBlocks, s1 = s0 + kTaskBlocks < L.blocks ? s0 + kTaskBlocks : L.blocks;
                     uint32_t need = 0; while (need + 1u < kSlices && blockCut[need + 1u] < s1) ++need;   // the last slice this task reads from
+                    // (a few polls back to back -- a slice is ~0.1 ms of PCIe time --, then short sleeps: up to twelve threads spinning on hipEventQuery burn the
+                    //  process's CPU quota for nothing, and a throttled process expands slower)
+                    uint32_t polls = 0;
                     for (uint32_t a; (a = arrived.load(std::memory_order_acquire)) <= need && !failed.load(std::memory_order_relaxed); ) {
                         const hipError_t q = hipEventQuery(evs[a]);
-                        if (q == hipSuccess) { uint32_t expect = a; arrived.compare_exchange_strong(expect, a + 1u, std::memory_order_acq_rel); }
+                        if (q == hipSuccess) { uint32_t expect = a; arrived.compare_exchange_strong(expect, a + 1u, std::memory_order_acq_rel); polls = 0; }
                         else if (q != hipErrorNotReady) { (void)hipGetLastError(); failed.store(true); }
-                        else { (void)hipGetLastError(); std::this_thread::yield(); }
+                        else { (void)hipGetLastError(); if (++polls < 32u) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20)); }
                     }
                     if (!failed.load(std::memory_order_relaxed)) codec_expand_blocks(dst, dstBytes, hStream, L, s0, s1);
                 });

@@ -32,8 +32,6 @@ for it in range(2):
     lib.fn("ommCpuDestroyBakeResult")(out)
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
     import bench
-    tm = bench.BakeTimings()
-    lib.dll.ommxGetLastBakeTimings.argtypes = [C.c_void_p, C.POINTER(bench.BakeTimings)]
-    lib.dll.ommxGetLastBakeTimings(b, C.byref(tm))
+    tm = bench.get_timings(lib, b)   # (ommxGetLastBakeTimingsSized: the unsized symbol only fills the round-3 prefix)
     print("  micro-triangles %.3e, active %d / %d items, level-line %.3e; ms: setup %.1f triage %.1f classify %.1f digest %.1f tail %.1f gather %.1f d2h %.1f"
           % (tm.microTriangles, tm.activeItems, tm.uniqueItems, tm.fineMicroTriangles, tm.setupMs, tm.triageMs, tm.classifyMs, tm.digestMs, tm.tailMs, tm.gatherMs, tm.downloadMs))

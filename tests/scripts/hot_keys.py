@@ -7,7 +7,6 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, ommtest as ot, bench
 lib = ot.Lib("product"); b = lib.create_baker()
-lib.dll.ommxGetLastBakeTimings.argtypes = [C.c_void_p, C.POINTER(bench.BakeTimings)]
 period = 64
 tile = np.zeros((period, period), np.uint8); tile[:, period // 2:] = 255; tile[:, period // 2 - 2:period // 2 + 2] = np.array([40, 100, 160, 220], np.uint8)[None, :]   # a soft vertical edge
 tex = np.tile(tile, (2048 // period, 2048 // period))
@@ -19,7 +18,7 @@ def run(name, uv):
     d = ot.make_desc(t, uv, ix, 6, addr=ot.WRAP, promo=ot.PROMO_FORCE_OPAQUE)
     for it in range(2):
         t0 = time.time(); r = lib.bake(b, d, want_stats=False); dt = time.time() - t0
-    tm = bench.BakeTimings(); lib.dll.ommxGetLastBakeTimings(b, C.byref(tm))
+    tm = bench.get_timings(lib, b)
     print("%s: %d OMM blocks, %d unique items, bake %.1f ms; setup %.2f triage %.2f classify %.2f digest %.2f tail %.2f gather %.2f" %
           (name, len(r.descs), tm.uniqueItems, dt * 1e3, tm.setupMs, tm.triageMs, tm.classifyMs, tm.digestMs, tm.tailMs, tm.gatherMs))
     return r

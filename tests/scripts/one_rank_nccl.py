@@ -37,10 +37,7 @@ assert res3.same_as(ref3) and res3.array_data.size <= 300000 < ref.array_data.si
 # shrinks to a few per cent and must arrive bit for bit; blocks of noise do not shrink below half and travel as they are
 import bench
 def timings():
-    tm = bench.BakeTimings()
-    prod.dll.ommxGetLastBakeTimings.argtypes = [C.c_void_p, C.POINTER(bench.BakeTimings)]
-    prod.dll.ommxGetLastBakeTimings(b, C.byref(tm))
-    return tm
+    return bench.get_timings(prod, b)
 res2b = ot.device_result_to_host(prod, ot.Hip(), sh.sharded_bake_rccl(prod.dll, b, C.byref(dd), comm))
 tm2 = timings()
 assert res2b.same_as(ref)

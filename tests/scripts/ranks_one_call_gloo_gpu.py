@@ -18,7 +18,6 @@ def worker(rank, world, port, outdir, full):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     prod = ot.Lib("product"); b = prod.create_baker(); hip = ot.Hip()
     comm = sh.CollectivesComm(prod.dll, torch, dist, rank, world)
-    prod.dll.ommxGetLastBakeTimings.argtypes = [C.c_void_p, C.POINTER(bench.BakeTimings)]
     log = []
 
     def case(name, tex, uv, ix, level, levels=None, budget=None, flags=None, chunk=0, expect=None):
@@ -40,7 +39,7 @@ def worker(rank, world, port, outdir, full):
             if not same:
                 print("rank", rank, name, res.diff(ref), flush=True)
             ok = ok and same
-        tm = bench.BakeTimings(); prod.dll.ommxGetLastBakeTimings(b, C.byref(tm))
+        tm = bench.get_timings(prod, b)
         if expect == "codec":
             ok = ok and 0 < tm.exchangeBytes < tm.contributionBytes // 2
         elif expect == "raw":
