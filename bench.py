@@ -434,7 +434,8 @@ def main():
             "unit": "micro-triangles/s", "n_gpus": world, "steps": host_steps if headline_host else args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["what"] % tris, "name": args.config,
-                       "entry": "ommCpuBake (the SDK entry point: host arrays in, host arrays out, PCIe inclusive)" if headline_host else
+                       "entry": "ommCpuBake (the SDK entry point: host arrays in, host arrays out, PCIe inclusive) with bakeFlags = ommCpuBakeFlags_EnableInternalThreads "
+                                "(the baker's helper threads expand the compressed result; ommCpuBakeInputDescDefault has no flags: without it the result is streamed, ~2x the time)" if headline_host else
                                 (entry_n if world > 1 else "ommxBakeDevice") + " (ommCpuBake contract, UV/index inputs and result arrays resident in HBM)",
                        "sharding": ("active work items partitioned over ranks; RCCL all-reduce of item metadata + all-gather of the OMM blocks as codec streams "
                                     "(%d of %d contribution bytes per rank on the wire)" % (int(tms[-1].exchangeBytes), int(tms[-1].contributionBytes))) if world > 1 else "none",

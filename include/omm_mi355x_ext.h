@@ -102,7 +102,11 @@ typedef enum ommxBakerKnob {
                                            knobs that cannot work without threads: ommxBakerKnob_ResultTransfer = ommxResultTransfer_Compressed (helper threads expand the
                                            result) and ommxBakerKnob_Devices >= 2 (a host thread per device + the expansion).  Setting such a knob IS the permission, whatever
                                            the bake's flags say; without either, ommCpuBake runs on the calling thread only, like the reference without the flag */
-    ommxBakerKnob_MAX_NUM          = 8
+    ommxBakerKnob_HelperAffinity   = 8, /* where the baker's helper threads run while they fill a large arrayData.  0 / default: each helper thread is bound to its own slice of
+                                           the physical cores of the NUMA node that holds the array (pthread_setaffinity_np on the baker's OWN threads only -- never on the
+                                           caller's; measured on the two-socket host of the GPU box: 16.6 - 16.8 ms per bake bound, 17 - 26 ms unbound).  1: the threads are
+                                           left where the scheduler puts them (for hosts whose thread placement is managed from outside) */
+    ommxBakerKnob_MAX_NUM          = 9
 } ommxBakerKnob;
 typedef enum ommxResultTransfer {
     ommxResultTransfer_Auto        = 0,

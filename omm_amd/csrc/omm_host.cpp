@@ -1507,7 +1507,7 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
                 const std::shared_ptr<WorkerPool> poolRef = baker.worker_pool(expandThreads); WorkerPool& pool = *poolRef;
                 // the helper threads next to the memory they fill: on the two-socket host of the GPU box a process whose threads happened to run on the other socket
                 // expanded at half the rate (five process pairs on one lease: 17.0 - 25.0 ms per call without, 17.0 - 19.8 with the binding)
-                (void)pool.bind_near(res->arrayData);
+                if (baker.knob(ommxBakerKnob_HelperAffinity) == 0) (void)pool.bind_near(res->arrayData);
                 uint8_t* dst = (uint8_t*)res->arrayData; const uint64_t dstBytes = R.arrayDataSize; const HostCodecLayout L = co.L;
                 // ONE run over all tasks (2 MiB of the array each, in slice order): a task whose slice is not on the host yet polls the slices' events in order --
                 // whichever thread gets there first moves the `arrived` mark -- so the threads never meet at a barrier between slices (12 runs, one per slice,
@@ -2403,7 +2403,7 @@ ommResult bake_impl_multi(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBake
         unsigned nth = effective_cpus() * 3u / 4u; nth = nth > 12u ? 12u : (nth < 1u ? 1u : nth);
         if (const uint64_t k = baker.knob(ommxBakerKnob_ExpandThreads)) nth = (unsigned)k;
         const std::shared_ptr<WorkerPool> pool = baker.worker_pool(nth);
-        (void)pool->bind_near(res->arrayData);
+        if (baker.knob(ommxBakerKnob_HelperAffinity) == 0) (void)pool->bind_near(res->arrayData);
         pool->run((uint32_t)cut.size() - 1u, [&](uint32_t t) { codec_scatter_omms(S, cut[t], cut[t + 1]); });
         threadsUsed = pool->workers() + 1u;
     }
@@ -2704,6 +2704,7 @@ OMM_MI355X_API ommResult ommxSetBakerKnob(ommBaker baker, ommxBakerKnob knob, ui
     if (knob == ommxBakerKnob_ResultTransfer && value > (uint64_t)ommxResultTransfer_Compressed) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_ExpandThreads && value > 64) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_Devices && value > (uint64_t)kMaxRanks) return ommResult_INVALID_ARGUMENT;
+    if (knob == ommxBakerKnob_HelperAffinity && value > 1) return ommResult_INVALID_ARGUMENT;
     if (knob == ommxBakerKnob_RetainMemory) {
         if (value > 1) return ommResult_INVALID_ARGUMENT;
         Baker* bk = untag<Baker>(baker);

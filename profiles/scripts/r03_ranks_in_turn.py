@@ -119,6 +119,10 @@ def worker(rank, world, port, outdir, cfg, bakes):
 
 if __name__ == "__main__":
     import tempfile, torch.multiprocessing as mp
+    # N processes on ONE GPU: with the HIP runtime's default of up to four hardware queues per process, four or more processes oversubscribe the GPU's
+    # hardware-queue scheduler and every phase of every rank waits a scheduler quantum (10 ms at 4 processes, 33 ms at 8: profiles/r06_ranks_in_turn_c2.jsonl).
+    # One queue per TEST process removes the artefact (an environment variable of the HIP runtime; the library itself reads none).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
     world = int(sys.argv[1]); cfg = sys.argv[2] if len(sys.argv) > 2 else "c2"; bakes = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     with tempfile.TemporaryDirectory() as td:
