@@ -394,9 +394,10 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
 #if OMMX_FRESH_PARAMS
     // (only the instantiation that defers the texel walks: there it takes the last 20 bytes of scratch away, 4.65 -> 4.34 ms on the asset-shaped bake; the
     //  hot instantiation of the metric configuration has no scratch to lose and runs 7.41 -> 7.50 ms with the reloads)
-    const ClassifyParams* Pp = DEFER ? fresh_kernarg_params() : &Pk;
+    constexpr bool kFresh = DEFER || OMMX_FRESH_PARAMS == 2;   // (2: A/B builds, every instantiation)
+    const ClassifyParams* Pp = kFresh ? fresh_kernarg_params() : &Pk;
 #define P (*Pp)
-#define OMMX_FRESH_P() do { if (DEFER) Pp = fresh_kernarg_params(); } while (0)
+#define OMMX_FRESH_P() do { if (kFresh) Pp = fresh_kernarg_params(); } while (0)
 #else
 #define P Pk
 #define OMMX_FRESH_P() ((void)0)
@@ -432,6 +433,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
     __shared__ uint32_t s_sec, s_nsec, s_retired; // sliced: section of the current tile / of the next one, tiles of the current section this workgroup has finished
     __shared__ uint32_t s_gdec[SLICED ? TILE / GROUP : 1];   // sliced: bird-curve decode of each 64-group of the tile (classify_device.h: BirdGroup)
     __shared__ uint8_t  s_btab[SLICED ? 256 : 1];            // ... and the 4 x 64 table of the low decode bits, filled once per workgroup
+    __shared__ uint32_t s_shape[4];                          // sliced: rc_shape() of the chunk's work item (rhoX, rhoY, ok & fat): fine_single_texel's corner test
     __shared__ float    s_wtex[SLICED ? WIN * WIN : 1];
     __shared__ uint32_t s_wsat[SLICED ? (WIN + 1) * (WIN + 1) : 1];
     constexpr uint32_t TILE_LOG4 = TILE == 4096 ? 6u : 5u; // the tile is the level-(N - TILE_LOG4) sub-triangle of its item
@@ -534,6 +536,11 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                         s_wsat[cx + cy * (ww + 1)] = (x >= 1 && y >= 1) ? m0.sat[(size_t)(x - 1) + (size_t)(y - 1) * (size_t)m0.w] : 0u;
                 }
                 windowOk = true;
+            }
+            if (tid == 0 && uFast) {   // (read by phase 2a, behind the barriers of this phase)
+                const DevMip& m0 = P.mips[0];
+                const RcShape sh = rc_shape(uUv, m0.fw, m0.fh, m0.w, m0.h, level);
+                s_shape[0] = __float_as_uint(sh.rhoX); s_shape[1] = __float_as_uint(sh.rhoY); s_shape[2] = (uint32_t)(sh.ok & sh.fat);
             }
             // ---- phase 0c: the slot tables.  Wave w takes the chunk's member records w and w + 4 (member 0 = the head, then the records its follower mask
             //      names): lane = group of the member's tile, verdict byte from the record; the member's open groups take consecutive slots from the start
@@ -662,7 +669,7 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 if (k < ocount) i = (uint32_t)s_olist[k] * 64u + (tid & 63u);
                 else { const uint32_t q = (k - ocount) * 64u + (tid & 63u); live = q < qn; i = live ? (uint32_t)s_queue[q] : 0u; }
                 if (live) {
-                    const int st = fine_single_texel<FP32, MD>(P, tile_micro_triangle(i), W);   // state | kNeedsEdges + hints | -1
+                    const int st = fine_single_texel<FP32, MD>(P, tile_micro_triangle(i), W, (const lds_u32*)s_shape);   // state | kNeedsEdges + hints | -1
                     s_state[i] = (uint8_t)(st < 0 ? 0xFF : st);
                     pend |= st < 0 ? 1u : ((st & kNeedsEdges) ? 2u : 0u);
                 }

@@ -925,7 +925,8 @@ __device__ __attribute__((noinline)) int region_curve_state_call(RcTex T, RcShap
 // kNeedsEdges | (above >= below) << 2 | the state without a crossing, and single_texel_edges() below finishes them in a second, compacted pass.
 constexpr int kNeedsEdges = 0x80;
 template <bool FP32, class MD>
-__device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const MicroTri& t, const TexWindow& W)
+// `shape`: three words of the work item's RcShape (region_curve.h: rhoX, rhoY as floats, ok & fat as a word), in LDS.
+__device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const MicroTri& t, const TexWindow& W, const lds_u32* shape)
 {
     const DevMip& m = P.mips[0];
     const float q0x = t.p0.x * m.fw - 0.5f, q0y = t.p0.y * m.fh - 0.5f;
@@ -974,25 +975,42 @@ __device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const 
         const float pfx = sx + 0.5f, pfy = sy + 0.5f;
         const float ipx = pfx * m.rw, ipy = pfy * m.rh;
         const bool o0 = P.cutoff < g00, o1 = P.cutoff < g01, o2 = P.cutoff < g11, o3 = P.cutoff < g10;
-        // (ipx is never a zero, so the reference's "+ 0.f" on the unchanged coordinate of each corner is the identity)
-        const bool in0 = point_in_triangle_flat(t, ipx, ipy);
-        const bool in1 = point_in_triangle_flat(t, ipx, ipy + m.rh);
-        const bool in2 = point_in_triangle_flat(t, ipx + m.rw, ipy + m.rh);
-        const bool in3 = point_in_triangle_flat(t, ipx + m.rw, ipy);
-        const bool isO = (in0 && o0) || (in1 && o1) || (in2 && o2) || (in3 && o3);
-        const bool isT = (in0 && !o0) || (in1 && !o1) || (in2 && !o2) || (in3 && !o3);
+        // The four corner votes.  A micro-triangle of this pass is a small fraction of a texel: a corner of its cell lies inside it once in a thousand.  When
+        // the work item has the corner bound and all four corners are outside the micro-triangle's box fattened by rho, PointInTriangle cannot report
+        // one inside (rc_corners_far, region_curve.h: audited on every cell visit of the oracle's level-line kernel) -- the four tests, 100 of this pass's 460
+        // vector instructions, run only in waves where a lane is near a corner.
+        bool isO = false, isT = false;
+        // the vertices in the cell's coordinates, as the level-line kernel forms them (bake_kernels_cpu.h:378-379); their box is rc_corners_far()'s frame
+        const V2 r0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy);
+        const V2 r1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy);
+        const V2 r2 = mk2(m.fw * t.p2.x - pfx, m.fh * t.p2.y - pfy);
+#ifdef OMMX_EXP_SKIP_ALL_CORNERS   // (timing experiment: wrong results)
+        const bool nearCorner = false;
+#elif !defined(OMMX_NO_CORNER_SKIP)
+        bool nearCorner = true;
+        if (shape[2] != 0u) {   // (wave-uniform: the chunk's work item has the corner bound)
+            RcShape sh; sh.Kub = 0.f; sh.Klb = 0.f; sh.rhoX = __uint_as_float(shape[0]); sh.rhoY = __uint_as_float(shape[1]); sh.ok = sh.fat = 1;
+            nearCorner = !rc_corners_far(&sh, __builtin_fminf(__builtin_fminf(r0.x, r1.x), r2.x), __builtin_fmaxf(__builtin_fmaxf(r0.x, r1.x), r2.x),
+                                         __builtin_fminf(__builtin_fminf(r0.y, r1.y), r2.y), __builtin_fmaxf(__builtin_fmaxf(r0.y, r1.y), r2.y));
+        }
+#else
+        const bool nearCorner = true;   // (A/B builds: the four tests for every micro-triangle, as in rounds 1 - 5)
+#endif
+        if (__any(nearCorner)) {   // (wave-uniform branch; the tests themselves stay straight-line code)
+            // (ipx is never a zero, so the reference's "+ 0.f" on the unchanged coordinate of each corner is the identity)
+            const bool in0 = point_in_triangle_flat(t, ipx, ipy);
+            const bool in1 = point_in_triangle_flat(t, ipx, ipy + m.rh);
+            const bool in2 = point_in_triangle_flat(t, ipx + m.rw, ipy + m.rh);
+            const bool in3 = point_in_triangle_flat(t, ipx + m.rw, ipy);
+            isO = nearCorner && ((in0 && o0) || (in1 && o1) || (in2 && o2) || (in3 && o3));
+            isT = nearCorner && ((in0 && !o0) || (in1 && !o1) || (in2 && !o2) || (in3 && !o3));
+        }
         if (isO) above += 1;
         if (isT) below += 1;
         if (!(isO && isT)) {
             const float sa = g00, sb = g10 - g00, sc = g01 - g00, sd = g00 + g11 - g01 - g10;
             if (near_zero(sb, 1e-6f) && near_zero(sc, 1e-6f) && near_zero(sd, 1e-6f)) vote(P.cutoff < sa, above, below);
-            else {
-                const float ha = sa - P.cutoff;
-                const V2 r0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy);
-                const V2 r1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy);
-                const V2 r2 = mk2(m.fw * t.p2.x - pfx, m.fh * t.p2.y - pfy);
-                needsEdges = !curve_excluded(r0, r1, r2, ha, sb, sc, sd);   // (88 % of the micro-triangles are provably not touched by the level curve)
-            }
+            else needsEdges = !curve_excluded(r0, r1, r2, sa - P.cutoff, sb, sc, sd);   // (88 % of the micro-triangles are provably not touched by the level curve)
         }
     }
     const int st = state_from_coverage(P, above, below);

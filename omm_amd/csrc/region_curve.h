@@ -163,4 +163,20 @@ OMMX_RC_FN int rc_cell(const RcShape* sh, float g00, float g10, float g01, float
     return pass ? (fmn > 0.f ? 1 : -1) : 0;
 }
 
+/* Round 6: the corner statement above for ONE micro-triangle and ONE cell, on its own (rc_cell() only uses it when its other bounds hold as well).
+ * (bx0..by1): the box of the micro-triangle's vertices in the cell's coordinates, r = size x p - (cell + 0.5) as bake_kernels_cpu.h:378-379 computes them.
+ * Returns 1 when NO corner of the unit cell can be reported inside the micro-triangle by PointInTriangle (util/geometry.h:101-114): the work item has the corner
+ * bound (sh->fat: smallest angle, vertices resolved by fp32) and all four corners lie outside D = the box fattened by rho (rho = 6e-3 + 22 u + 1/64, the
+ * fattening of rc_cell(): "a corner outside D is at least g = 1/64 texel away from every micro-triangle", the distance the cross-product bound needs).
+ * A corner (cx, cy), cx, cy in {0, 1}, lies in the fattened box iff cx is in its x range and cy in its y range: none does when one of the two ranges holds
+ * neither 0 nor 1.  NaN compares false: "not far".  The four point-in-triangle tests of a cell visit (100 of the single-texel pass's 460 vector instructions)
+ * are skipped by classify_device.h: fine_single_texel() when this holds; audited by the oracle's audit build on every cell visit of the level-line kernel
+ * (tests/test_edge_prefilter_audit.py: skipped visits in which one of the four tests succeeds -- none). */
+OMMX_RC_FN int rc_corners_far(const RcShape* sh, float bx0, float bx1, float by0, float by1)
+{
+    const float rx = sh->rhoX, ry = sh->rhoY;
+    const int farX = (bx0 - rx > 0.f) & (bx1 + rx < 1.f), farY = (by0 - ry > 0.f) & (by1 + ry < 1.f);
+    return (sh->ok != 0) & (sh->fat != 0) & (farX | farY);
+}
+
 #endif

@@ -134,3 +134,50 @@ def test_cell_exclusion_on_asset_sized_triangles(audit):
     assert bad == 0, (calls, excluded, bad)                 # the shipped predicate (8x)
     assert derived_bad == 0, (derived, derived_bad)         # the bounds as derived (1x)
     assert probe >= derived >= excluded                     # (0.25x: below the derivation; it may -- and does -- exclude next to a crossing: probe_bad is not asserted)
+
+
+def _corner_counts(audit):
+    audit.dll.orc_audit_corner_counter.restype = C.c_longlong
+    audit.dll.orc_audit_corner_counter.argtypes = [C.c_int]
+    return [audit.dll.orc_audit_corner_counter(i) for i in range(3)]
+
+
+def test_corner_votes_skipped_only_where_no_corner_can_be_inside(audit):
+    """rc_corners_far() (omm_amd/csrc/region_curve.h, round 6): fine_single_texel() skips the four PointInTriangle tests of a cell visit when the work item has the
+    corner bound and every corner of the cell lies outside the micro-triangle's box fattened by rho.  The audit build evaluates the predicate on EVERY cell
+    visit of the level-line kernel, with the box formed exactly as the kernel forms it, next to the four tests of the reference: a visit the predicate calls
+    "far" must never have a corner inside.  Sweep: the BASELINE workloads' first triangles, micro-triangles from 1e-5 to 150 texels, UV offsets of +-1000 and
+    -70000 (coarse fp32 vertices), slivers and axis-aligned edges, non-power-of-two sizes, every address mode, FP32 and UNORM8 texels, alpha hugging the cutoff."""
+    import workloads as wl
+    audit.dll.orc_audit_corner_reset()
+    rng = np.random.RandomState(3)
+    yy, xx = np.mgrid[0:256, 0:256].astype(np.float32)
+    b = audit.create_baker()
+    # (1) the configurations of BASELINE.json: the first triangles of each stream, their own textures and levels
+    for cfg, n in (("c1", 300), ("c2", 100), ("c4", 100), ("cards", 16)):
+        tex, uv, ix, lv, kw = wl.workload(cfg, n)
+        kw = dict(kw); level = kw.pop("level")
+        t = audit.create_texture(b, [tex], alpha_cutoff=-1.0)
+        audit.bake(b, ot.make_desc(t, uv, ix, level, levels=lv, flags=ot.FLAG_THREADS | ot.FLAG_NO_DEDUP, **kw), want_stats=False)
+        audit.destroy_texture(b, t)
+    # (2) sizes, offsets, address modes
+    tex8 = (ot.value_noise(5, 512, 512, octaves=5, base_cell=32) * 255).astype(np.uint8)
+    texf = ot.value_noise(6, 300, 200, octaves=3, base_cell=16).astype(np.float32)
+    hug = (0.5 + 1e-3 * np.sin(xx * 0.7) * np.cos(yy * 0.9) + 2e-6 * rng.rand(256, 256)).astype(np.float32)
+    for tx in (tex8, texf, hug):
+        t = audit.create_texture(b, [tx], alpha_cutoff=-1.0)
+        for seed, (ext, level, n) in enumerate([(0.3, 0, 20), (0.1, 3, 24), (0.05, 5, 20), (0.01, 7, 8), (0.004, 8, 4), (0.004, 6, 24), (1e-5, 6, 16), (3.0, 2, 6)]):
+            for off in (0.0, 1000.0, -70000.0):
+                uv, ix = ot.random_triangles(700 + seed, n, ext)
+                tri = uv.reshape(-1, 3, 2)
+                tri[::4, 1, 0] = tri[::4, 0, 0] + np.float32(1e-7); tri[1::4, 2, 1] = tri[1::4, 0, 1]                 # nearly vertical / exactly horizontal edges
+                tri[2::4, 2] = tri[2::4, 0] + (tri[2::4, 1] - tri[2::4, 0]) * np.float32(0.5) + np.float32(ext * 1e-3)    # slivers (thin: no corner bound)
+                uvo = (tri.reshape(-1, 2) + np.float32(off)).astype(np.float32)
+                for addr in ((ot.WRAP, ot.MIRROR, ot.CLAMP, ot.BORDER, ot.MIRROR_ONCE) if off == 0.0 else (ot.WRAP, ot.CLAMP)):
+                    audit.bake(b, ot.make_desc(t, uvo, ix, level, addr=addr, promo=ot.PROMO_NEAREST, flags=ot.FLAG_THREADS | ot.FLAG_NO_DEDUP), want_stats=False)
+        audit.destroy_texture(b, t)
+    audit.destroy_baker(b)
+    visits, far, bad = _corner_counts(audit)
+    # (the long form of this sweep -- ~4x the triangles, every address mode at every offset, five minutes -- ran when the predicate went in: 0 disagreements)
+    assert visits > 1000000 and far > visits // 4, (visits, far)
+    assert bad == 0, (visits, far, bad)
