@@ -223,6 +223,17 @@ struct HostPool {
     struct Blk { void* p; size_t cap; bool used; bool pinned; };
     std::mutex mu; std::vector<Blk> blks; std::atomic<bool> retain{ true };
     static constexpr size_t kMinBytes = 8u << 20, kHuge = 2u << 20;
+    // Results between kSmallBytes and kMinBytes (a configs[1]-sized bake: 6.5 MB): a fresh malloc of that size is an mmap whose pages fault in under the
+    // device-to-host copy -- 0.46 of the call's 1.16 ms -- and an munmap at ommCpuDestroyBakeResult.  They come from this pool too, but only kSmallInUse of them
+    // at a time: an application that keeps thousands of small results alive must not find them all pinned (2 MB each at least).
+    static constexpr size_t kSmallBytes = 256u << 10; static constexpr unsigned kSmallInUse = 8;
+    bool wants(size_t bytes) {
+        if (bytes >= kMinBytes) return true;
+        if (bytes < kSmallBytes) return false;
+        std::lock_guard<std::mutex> g(mu);
+        unsigned n = 0; for (auto& b : blks) if (b.used && b.cap < kMinBytes) ++n;
+        return n < kSmallInUse;
+    }
     static void drop(const Blk& b) { if (b.pinned) (void)hipHostFree(b.p); else free(b.p); }
     ~HostPool() { for (auto& b : blks) drop(b); }
     void* acquire(size_t bytes, bool* pinned = nullptr) {
@@ -257,11 +268,15 @@ struct HostPool {
     }
     void release(void* p) {
         std::lock_guard<std::mutex> g(mu);
-        size_t freeBlocks = 0;
-        for (auto& b : blks) { if (b.p == p) b.used = false; if (!b.used) freeBlocks++; }
-        const size_t keep = retain.load() ? 2 : 0;
-        for (size_t i = 0; i < blks.size() && freeBlocks > keep; ) // keep at most two idle blocks (none: ommxBakerKnob_RetainMemory = 1)
-            if (!blks[i].used && (blks[i].p != p || keep == 0)) { drop(blks[i]); blks.erase(blks.begin() + (long)i); freeBlocks--; } else ++i;
+        // idle blocks kept: two large ones, and as many small ones as may be in use at once (<= 8 x 8 MB: concurrent callers of small bakes would otherwise
+        // free and pin a block per bake); none with ommxBakerKnob_RetainMemory = 1
+        size_t idle[2] = { 0, 0 };
+        for (auto& b : blks) { if (b.p == p) b.used = false; if (!b.used) idle[b.cap < kMinBytes ? 1 : 0]++; }
+        const size_t keep[2] = { retain.load() ? (size_t)2 : (size_t)0, retain.load() ? (size_t)kSmallInUse : (size_t)0 };
+        for (size_t i = 0; i < blks.size(); ) {
+            const int k = blks[i].cap < kMinBytes ? 1 : 0;
+            if (!blks[i].used && idle[k] > keep[k] && (blks[i].p != p || keep[k] == 0)) { drop(blks[i]); blks.erase(blks.begin() + (long)i); idle[k]--; } else ++i;
+        }
     }
     void trim() {
         std::lock_guard<std::mutex> g(mu);
@@ -354,6 +369,7 @@ struct Baker {
     }
     std::mutex timingsMu; ommxBakeTimings timings; bool haveTimings = false;
     std::atomic<uint64_t> knobs[ommxBakerKnob_MAX_NUM];   // ommxSetBakerKnob: 0 = default
+    std::atomic<uint32_t> activeBakes{ 0 };               // ommCpuBake calls inside bake_impl right now (callers may bake concurrently on one baker)
     Baker() { for (auto& k : knobs) k.store(0); }
     uint64_t knob(ommxBakerKnob k) const { return knobs[k].load(std::memory_order_relaxed); }
 };
@@ -1284,6 +1300,7 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
 {
     const Logger& L = baker.log;
     const double t0 = now_ms();
+    struct Active { std::atomic<uint32_t>& n; explicit Active(std::atomic<uint32_t>& c) : n(c) { n.fetch_add(1); } ~Active() { n.fetch_sub(1); } } activeGuard(baker.activeBakes);
     const ommResult fr = scope_fences(baker, d, true);
     if (fr != ommResult_SUCCESS) return fr;
     const uint32_t T = d.indexCount / 3u;
@@ -1368,7 +1385,9 @@ ommResult bake_impl(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBakeResult
             if (pinned) *pinned = false;
             if (a.res->arrayData && a.cap >= bytes) { if (pinned) *pinned = a.pinned; return (uint8_t*)a.res->arrayData; }
             if (a.res->arrayData) { if (a.res->pool) { a.res->pool->release(a.res->arrayData); a.res->pool.reset(); } else a.b->mem.release(a.res->arrayData); a.res->arrayData = nullptr; a.cap = 0; }
-            if (a.b->mem.alloc == default_alloc && (size_t)bytes >= HostPool::kMinBytes) {
+            // (small results are pooled -- pinned -- only while this is the baker's one bake in flight: sixteen callers copying into pinned blocks at once take
+            //  turns on the copy engines -- measured on configs[1]: 2 278 -> 1 190 bakes/s at 16 threads --, while one caller gains 0.28 ms per bake)
+            if (a.b->mem.alloc == default_alloc && ((size_t)bytes >= HostPool::kMinBytes || (a.b->activeBakes.load() <= 1u && a.b->hostPool->wants((size_t)bytes)))) {
                 a.res->arrayData = a.b->hostPool->acquire((size_t)bytes, &a.pinned);
                 if (a.res->arrayData) a.res->pool = a.b->hostPool;
             }
@@ -2377,7 +2396,7 @@ ommResult bake_impl_multi(Baker& baker, const ommCpuBakeInputDesc& d, ommCpuBake
     struct ResGuard { Baker& b; BakeResult*& r; ~ResGuard() { if (r) b.mem.destroy(r); } } resGuard{ baker, res };
     const SyncOnExit drainBeforeResult{ stream0 };
     if (E) {
-        if (baker.mem.alloc == default_alloc && (size_t)DR.arrayDataSize >= HostPool::kMinBytes) { res->arrayData = baker.hostPool->acquire((size_t)DR.arrayDataSize); if (res->arrayData) res->pool = baker.hostPool; }
+        if (baker.mem.alloc == default_alloc && baker.hostPool->wants((size_t)DR.arrayDataSize)) { res->arrayData = baker.hostPool->acquire((size_t)DR.arrayDataSize); if (res->arrayData) res->pool = baker.hostPool; }
         if (!res->arrayData) res->arrayData = baker.mem.allocate((size_t)DR.arrayDataSize, 64);
         res->descs = (ommCpuOpacityMicromapDesc*)baker.mem.allocate(sizeof(ommCpuOpacityMicromapDesc) * (size_t)E, 16);
     }
