@@ -137,6 +137,7 @@ static_assert(kTileRecordWords * 16u == kTileRecordBytes, "tile record size");
 // verdict byte of a 64-group: 0..3 = every micro-triangle of the group has that state; kGvUnknown = test them one by one; kGvAllOpen = none of them is resolved by
 // the coarse pass; kGvEdgeFree | code = region_curve_state()'s edge-free verdict -(kRegionEdgeFreeBase + code), code = 16 above + mask of the wrong-side corners
 constexpr uint32_t kGvUnknown = 0xFFu, kGvAllOpen = 0xFEu, kGvEdgeFree = 0x80u;
+constexpr uint32_t kTileFat = 1u << 22;    // word [0].y of a record: the work item has the corner bound (RcShape::ok & fat, region_curve.h): fine_single_texel may skip corner votes (rc_corners_far)
 constexpr uint32_t kTileDead = 1u << 23;   // word [0].y of a record: every group of the tile was settled by triage_groups (the tile index needs 12 of the 24 low bits)
 __device__ __forceinline__ uint32_t group_verdict_byte(int gs)
 {
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
     if (t < S.n) queueCtl[kSecBases + stride * t] = S.cut[t];   // (the persistent launch walks the sections by these; the odd ones: early_tiles_bases)
     const uint32_t lane = threadIdx.x & 63u;
     const bool live = t < L.tileStart[L.n];
-    uint32_t sec = 0; bool isEarly = false, bigMicro = false;
+    uint32_t sec = 0; bool isEarly = false, bigMicro = false, fatItem = false;
     int st = -1; uint32_t item = 0, tileInItem = 0, level = TILE_LOG4; TexRect r; r.sx = r.sy = r.ex = r.ey = 0; r.ok = false;
     float uvv[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
     const uint32_t bits = (uint32_t)P.format, tileBytes = (uint32_t)TILE * bits / 8u;
@@ -193,9 +194,11 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
         const bool asked = kSameTests && level == TILE_LOG4;
         if (P.useCoarse && !asked) st = region_state<ModeDynamic>(P, sub, maxAbs, no_window());
         // a tile in a mixed neighbourhood that the level curve does not reach (region_curve.h): settled like a uniform one
-        if ((OMMX_RC_LEVELS & 2) && !asked && st < 0 && region_curve_applies(P) && !A.degenerate[item]) {
+        if (st < 0 && region_curve_applies(P) && !A.degenerate[item]) {
             const DevMip& m = P.mips[0];
-            st = region_curve_state<ModeDynamic>(P, P.texIsFp32 != 0, rc_shape(uv, m.fw, m.fh, m.w, m.h, level), sub, maxAbs);
+            const RcShape shape = rc_shape(uv, m.fw, m.fh, m.w, m.h, level);
+            fatItem = shape.ok != 0 && shape.fat != 0;   // (into the record of an open tile: the persistent launch's single-texel pass asks per micro-triangle)
+            if ((OMMX_RC_LEVELS & 2) && !asked) st = region_curve_state<ModeDynamic>(P, P.texIsFp32 != 0, shape, sub, maxAbs);
         }
     }
     // ---- open tiles: wave-compacted append, section by section (a wave sees one section, two at a range boundary, early items apart) ----
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(256) void triage_tiles(ClassifyParams P, ItemArrays
         if (open && key == k0) {
             uint4* rec = ((k0 & 1u) ? earlyStage : queue) + (size_t)kTileRecordWords * (wbase + __popcll(ob & ((1ull << lane) - 1ull)));
             const unsigned long long dst = (unsigned long long)(A.states + A.stateOfs[item] + (size_t)tileInItem * tileBytes);
-            rec[0] = make_uint4(item | (A.degenerate[item] ? 0x40000000u : 0u) | (r.ok ? 0x80000000u : 0u), tileInItem | (level << 24) | (bigMicro ? 0x80000000u : 0u) | ((k0 & 1u) ? (k0 >> 1) << 16 : 0u),
+            rec[0] = make_uint4(item | (A.degenerate[item] ? 0x40000000u : 0u) | (r.ok ? 0x80000000u : 0u), tileInItem | (level << 24) | (bigMicro ? 0x80000000u : 0u) | (fatItem ? kTileFat : 0u) | ((k0 & 1u) ? (k0 >> 1) << 16 : 0u),
                                 (uint32_t)r.sx | ((uint32_t)r.sy << 16), (uint32_t)r.ex | ((uint32_t)r.ey << 16));
             rec[1] = make_uint4(__float_as_uint(uvv[0]), __float_as_uint(uvv[1]), __float_as_uint(uvv[2]), __float_as_uint(uvv[3]));
             rec[2] = make_uint4(__float_as_uint(uvv[4]), __float_as_uint(uvv[5]), (uint32_t)dst, (uint32_t)(dst >> 32));
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256, OMMX_TRIAGE_WAVES) void triage_groups(Classify
             uint4* rec = queue + (size_t)kTileRecordWords * (base + r);
             const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
             float uv[6] = { __uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x), __uint_as_float(r2.y) };
-            const uint32_t level = (r0.y >> 24) & 0x7Fu, first = (r0.y & 0xFFFFFFu) * (GROUPS);   // first group of the tile in the item's level-(N - 3) enumeration
+            const uint32_t level = (r0.y >> 24) & 0x7Fu, first = (r0.y & 0xFFFu) * (GROUPS);   // first group of the tile in the item's level-(N - 3) enumeration
             const float maxAbs = item_max_abs(uv);
             const bool degenerate = ((r0.x >> 30) & 1u) != 0u;
             const bool fast = fastFine && !degenerate && maxAbs <= 16384.f && (r0.y >> 31) == 0u;   // (= classify_tiles' uFast: only then can it use the edge-free verdict)
@@ -537,10 +540,11 @@ __global__ __launch_bounds__(BLOCK, OMMX_CLASSIFY_WAVES) void classify_tiles(Cla
                 }
                 windowOk = true;
             }
-            if (tid == 0 && uFast) {   // (read by phase 2a, behind the barriers of this phase)
+            if (tid == 0 && uFast) {   // (read by phase 2a, behind the barriers of this phase; the corner bound itself was decided by triage_tiles: kTileFat)
                 const DevMip& m0 = P.mips[0];
-                const RcShape sh = rc_shape(uUv, m0.fw, m0.fh, m0.w, m0.h, level);
-                s_shape[0] = __float_as_uint(sh.rhoX); s_shape[1] = __float_as_uint(sh.rhoY); s_shape[2] = (uint32_t)(sh.ok & sh.fat);
+                float ux, uy, rhoX, rhoY;
+                rc_rho(uUv, m0.fw, m0.fh, &ux, &uy, &rhoX, &rhoY);
+                s_shape[0] = __float_as_uint(rhoX); s_shape[1] = __float_as_uint(rhoY); s_shape[2] = (rec.y & kTileFat) ? 1u : 0u;
             }
             // ---- phase 0c: the slot tables.  Wave w takes the chunk's member records w and w + 4 (member 0 = the head, then the records its follower mask
             //      names): lane = group of the member's tile, verdict byte from the record; the member's open groups take consecutive slots from the start

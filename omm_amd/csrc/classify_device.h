@@ -980,18 +980,16 @@ __device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const 
         // one inside (rc_corners_far, region_curve.h: audited on every cell visit of the oracle's level-line kernel) -- the four tests, 100 of this pass's 460
         // vector instructions, run only in waves where a lane is near a corner.
         bool isO = false, isT = false;
-        // the vertices in the cell's coordinates, as the level-line kernel forms them (bake_kernels_cpu.h:378-379); their box is rc_corners_far()'s frame
-        const V2 r0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy);
-        const V2 r1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy);
-        const V2 r2 = mk2(m.fw * t.p2.x - pfx, m.fh * t.p2.y - pfy);
 #ifdef OMMX_EXP_SKIP_ALL_CORNERS   // (timing experiment: wrong results)
         const bool nearCorner = false;
 #elif !defined(OMMX_NO_CORNER_SKIP)
         bool nearCorner = true;
         if (shape[2] != 0u) {   // (wave-uniform: the chunk's work item has the corner bound)
+            // the vertices in the cell's coordinates, as the level-line kernel forms them (bake_kernels_cpu.h:378-379): their box is rc_corners_far()'s frame
+            const float r0x = m.fw * t.p0.x - pfx, r0y = m.fh * t.p0.y - pfy, r1x = m.fw * t.p1.x - pfx, r1y = m.fh * t.p1.y - pfy, r2x = m.fw * t.p2.x - pfx, r2y = m.fh * t.p2.y - pfy;
             RcShape sh; sh.Kub = 0.f; sh.Klb = 0.f; sh.rhoX = __uint_as_float(shape[0]); sh.rhoY = __uint_as_float(shape[1]); sh.ok = sh.fat = 1;
-            nearCorner = !rc_corners_far(&sh, __builtin_fminf(__builtin_fminf(r0.x, r1.x), r2.x), __builtin_fmaxf(__builtin_fmaxf(r0.x, r1.x), r2.x),
-                                         __builtin_fminf(__builtin_fminf(r0.y, r1.y), r2.y), __builtin_fmaxf(__builtin_fmaxf(r0.y, r1.y), r2.y));
+            nearCorner = !rc_corners_far(&sh, __builtin_fminf(__builtin_fminf(r0x, r1x), r2x), __builtin_fmaxf(__builtin_fmaxf(r0x, r1x), r2x),
+                                         __builtin_fminf(__builtin_fminf(r0y, r1y), r2y), __builtin_fmaxf(__builtin_fmaxf(r0y, r1y), r2y));
         }
 #else
         const bool nearCorner = true;   // (A/B builds: the four tests for every micro-triangle, as in rounds 1 - 5)
@@ -1010,7 +1008,12 @@ __device__ __forceinline__ int fine_single_texel(const ClassifyParams& P, const 
         if (!(isO && isT)) {
             const float sa = g00, sb = g10 - g00, sc = g01 - g00, sd = g00 + g11 - g01 - g10;
             if (near_zero(sb, 1e-6f) && near_zero(sc, 1e-6f) && near_zero(sd, 1e-6f)) vote(P.cutoff < sa, above, below);
-            else needsEdges = !curve_excluded(r0, r1, r2, sa - P.cutoff, sb, sc, sd);   // (88 % of the micro-triangles are provably not touched by the level curve)
+            else {
+                const V2 r0 = mk2(m.fw * t.p0.x - pfx, m.fh * t.p0.y - pfy);
+                const V2 r1 = mk2(m.fw * t.p1.x - pfx, m.fh * t.p1.y - pfy);
+                const V2 r2 = mk2(m.fw * t.p2.x - pfx, m.fh * t.p2.y - pfy);
+                needsEdges = !curve_excluded(r0, r1, r2, sa - P.cutoff, sb, sc, sd);   // (88 % of the micro-triangles are provably not touched by the level curve)
+            }
         }
     }
     const int st = state_from_coverage(P, above, below);

@@ -54,13 +54,22 @@ OMMX_RC_FN float rc_floor(float f) { return __builtin_floorf(f); }
 
 #define OMMX_RC_MAX_CELLS 4   /* cells per axis a sub-triangle may touch (5 x 5 texels) */
 
+/* The fattening rho of a work item, per axis (rc_shape() below stores it; classify_tiles recomputes it per chunk from the record's coordinates): 6e-3 of
+ * curve_excluded()'s ellipse argument + 22 u of vertex rounding + g = 1/64 texel of the corner bound, u = size x maxAbs x 2^-24. */
+OMMX_RC_FN void rc_rho(const float* uv, float fw, float fh, float* ux, float* uy, float* rhoX, float* rhoY)
+{
+    const float mx = rc_max(rc_max(rc_abs(uv[0]), rc_abs(uv[2])), rc_abs(uv[4])), my = rc_max(rc_max(rc_abs(uv[1]), rc_abs(uv[3])), rc_abs(uv[5]));
+    *ux = fw * mx * 5.9604645e-8f; *uy = fh * my * 5.9604645e-8f;
+    *rhoX = 6e-3f + 22.f * *ux + 0.015625f; *rhoY = 6e-3f + 22.f * *uy + 0.015625f;
+}
+
 /* Slope and shape bounds shared by every micro-triangle of a work item (uv: its six floats; level: its subdivision level; w, h: texture size). */
 OMMX_RC_FN RcShape rc_shape(const float* uv, float fw, float fh, int w, int h, uint32_t level)
 {
     RcShape s; s.Kub = 0.f; s.Klb = 0.f; s.rhoX = 0.f; s.rhoY = 0.f; s.ok = 0; s.fat = 0;
     /* u: bound of ONE rounding of a raster-space coordinate of this item (2^-24 relative), per axis */
-    const float mx = rc_max(rc_max(rc_abs(uv[0]), rc_abs(uv[2])), rc_abs(uv[4])), my = rc_max(rc_max(rc_abs(uv[1]), rc_abs(uv[3])), rc_abs(uv[5]));
-    const float ux = fw * mx * 5.9604645e-8f, uy = fh * my * 5.9604645e-8f;
+    float ux, uy, rhoX, rhoY;
+    rc_rho(uv, fw, fh, &ux, &uy, &rhoX, &rhoY);
     if (!(ux <= 1e-3f && uy <= 1e-3f)) return s;
     const float sc = 1.f / (float)(1u << (level > 12u ? 12u : level));
     const float ex0 = fw * (uv[2] - uv[0]) * sc, ey0 = fh * (uv[3] - uv[1]) * sc;
@@ -91,7 +100,7 @@ OMMX_RC_FN RcShape rc_shape(const float* uv, float fw, float fh, int w, int h, u
      * PointInTriangle puts a cell corner of the OTHER side inside the micro-triangle", which the caller then evaluates per micro-triangle. */
     s.fat = twoAlb >= 0.005f * L2ub;
     s.Kub = (dymax / rc_max(dxmin, 1e-6f)) * 1.00001f; s.Klb = (dymin / dxmax) * 0.99999f;
-    s.rhoX = 6e-3f + 22.f * ux + 0.015625f; s.rhoY = 6e-3f + 22.f * uy + 0.015625f;
+    s.rhoX = rhoX; s.rhoY = rhoY;
     s.ok = 1;
     return s;
 }
