@@ -54,7 +54,8 @@ class BakeTimings(C.Structure):
                 ("openTiles", C.c_uint32), ("openTileMicroTriangles", C.c_uint64), ("streamEarlyItems", C.c_uint32), ("persistentMs", C.c_float),
                 ("genericMs", C.c_float), ("genericMicroTriangles", C.c_uint64), ("exchangeBytes", C.c_uint64), ("contributionBytes", C.c_uint64),
                 ("streamPreviewMs", C.c_float), ("streamFirstCopyMs", C.c_float), ("streamLastCopyMs", C.c_float), ("streamRangeReadyMs", C.c_float * 32),
-                ("resultTransfer", C.c_uint32), ("expandThreads", C.c_uint32), ("compressedBytes", C.c_uint64), ("compressMs", C.c_float), ("expandMs", C.c_float), ("devices", C.c_uint32)]
+                ("resultTransfer", C.c_uint32), ("expandThreads", C.c_uint32), ("compressedBytes", C.c_uint64), ("compressMs", C.c_float), ("expandMs", C.c_float), ("devices", C.c_uint32),
+                ("prefilledBytes", C.c_uint64), ("expandSkippedBytes", C.c_uint64)]
 
 
 def get_timings(lib, baker):
@@ -229,6 +230,7 @@ def main():
     ap.add_argument("--result-transfer", type=int, default=0, help="ommxBakerKnob_ResultTransfer for the ommCpuBake measurement (0 = library default, 1 = plain copy, 2 = streamed placement, 3 = compressed)")
     ap.add_argument("--devices", type=int, default=0, help="ommxBakerKnob_Devices for the ommCpuBake measurement: the bake spread over N devices of THIS process (on a one-GPU box the ranks share the device)")
     ap.add_argument("--expand-threads", type=int, default=0, help="ommxBakerKnob_ExpandThreads (0 = library default)")
+    ap.add_argument("--zero-ahead", type=int, default=0, help="ommxBakerKnob_ZeroAhead (0 = library default: on, 1 = off)")
     ap.add_argument("--concurrent", type=int, default=0, help="also measure K host threads baking concurrently on ONE baker through ommCpuBake (bakes/s for 1, 4, .. K threads; "
                                                               "the reference documents caller-level parallelism as a first-class strategy, docs/integration_guide.md:434)")
     args = ap.parse_args()
@@ -270,6 +272,8 @@ def main():
         prod.set_knob(baker, ot.KNOB_RESULT_TRANSFER, args.result_transfer)
     if args.expand_threads:
         prod.set_knob(baker, ot.KNOB_EXPAND_THREADS, args.expand_threads)
+    if args.zero_ahead:
+        prod.set_knob(baker, ot.KNOB_ZERO_AHEAD, args.zero_ahead)
     th = prod.create_texture(baker, [tex], alpha_cutoff=0.5)
     host_desc = desc_for(th, uv, ix, lv, kw)
     # inputs resident in HBM before the timed region: torch owns the device buffers, the library gets raw pointers
@@ -468,6 +472,7 @@ def main():
                                                              "compressed (codec stream over PCIe, expanded by the baker's helper threads)"][int(host_tms[-1].resultTransfer) & 3],
                                                     "array_data_bytes": result_info["arrayDataBytes"], "bytes_over_pcie": int(host_tms[-1].compressedBytes) or int(host_tms[-1].streamedBytes) or result_info["arrayDataBytes"],
                                                     "codec_and_readback_ms": havg("compressMs"), "copy_and_expand_ms": havg("expandMs"), "expand_threads": int(host_tms[-1].expandThreads),
+                                                    "zeroed_ahead_bytes": int(host_tms[-1].prefilledBytes), "expansion_skipped_bytes": int(host_tms[-1].expandSkippedBytes),
                                                     "copy_and_expand_ms_min_max": [float(min(t.expandMs for t in host_tms)), float(max(t.expandMs for t in host_tms))],
                                                     "bake_ms_min_max": [float(min(t.totalMs for t in host_tms)), float(max(t.totalMs for t in host_tms))],
                                                     "bake_ms_p50_p95": [float(np.percentile([t.totalMs for t in host_tms], 50)), float(np.percentile([t.totalMs for t in host_tms], 95))],

@@ -57,6 +57,9 @@ typedef struct ommxBakeTimings {
     float    compressMs;           /* wall clock from the end of the bake proper to the stream's size on the host (codec kernels + the small read-backs) */
     float    expandMs;             /* wall clock of the stream's copy and its expansion into arrayData (overlapped slice by slice) */
     uint32_t devices;              /* devices a multi-device ommCpuBake ran on (ommxBakerKnob_Devices); 0 / 1: one */
+    /* (round 6) compressed transfer: the helper threads zero an idle result block of the baker WHILE the device bakes; codec blocks that repeat state 0 are then not written again */
+    uint64_t prefilledBytes;       /* bytes of the result array that were zeroed ahead (0: no idle block, first bake, another transfer) */
+    uint64_t expandSkippedBytes;   /* bytes of arrayData the expansion did not have to write because of that */
 } ommxBakeTimings;
 
 /* ommxBakeTimings only ever grows at its END.  ommxGetLastBakeTimingsSized copies min(outBytes, the library's size) bytes and zeros the rest of `out`, so a
@@ -106,7 +109,10 @@ typedef enum ommxBakerKnob {
                                            the physical cores of the NUMA node that holds the array (pthread_setaffinity_np on the baker's OWN threads only -- never on the
                                            caller's; measured on the two-socket host of the GPU box: 16.6 - 16.8 ms per bake bound, 17 - 26 ms unbound).  1: the threads are
                                            left where the scheduler puts them (for hosts whose thread placement is managed from outside) */
-    ommxBakerKnob_MAX_NUM          = 9
+    ommxBakerKnob_ZeroAhead        = 9, /* compressed transfer: 0 / default: while the device bakes, the helper threads zero the idle result block the previous bake of this
+                                           baker left (default allocator only), and the expansion does not write codec blocks of zeros again (ommxBakeTimings::prefilledBytes,
+                                           expandSkippedBytes); 1: off -- the helper threads only run during the expansion */
+    ommxBakerKnob_MAX_NUM          = 10
 } ommxBakerKnob;
 typedef enum ommxResultTransfer {
     ommxResultTransfer_Auto        = 0,

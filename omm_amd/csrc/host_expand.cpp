@@ -106,7 +106,7 @@ void WorkerPool::loop()
 void WorkerPool::run(uint32_t tasks, const std::function<void(uint32_t)>& fn)
 {
     if (tasks == 0) return;
-    std::lock_guard<std::mutex> one(runMu_);
+    const TurnGuard one(turn_);
     if (threads_.empty() || tasks == 1) { for (uint32_t t = 0; t < tasks; ++t) fn(t); return; }
     {
         std::lock_guard<std::mutex> g(mu_);
@@ -119,9 +119,33 @@ void WorkerPool::run(uint32_t tasks, const std::function<void(uint32_t)>& fn)
     fn_ = nullptr;
 }
 
+bool WorkerPool::start(uint32_t tasks, std::function<void(uint32_t)> fn)
+{
+    if (threads_.empty() || tasks == 0) return false;
+    turn_.take();   // (kept until wait(): one run at a time)
+    background_ = std::move(fn); backgroundActive_ = true;
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        fn_ = &background_; tasks_ = tasks; next_.store(0, std::memory_order_relaxed); active_ = (unsigned)threads_.size(); ++generation_;
+    }
+    wake_.notify_all();
+    return true;
+}
+void WorkerPool::wait()
+{
+    if (!backgroundActive_) return;
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return active_ == 0; });
+        fn_ = nullptr;
+    }
+    backgroundActive_ = false; background_ = nullptr;
+    turn_.give();
+}
+
 int WorkerPool::bind_near(const void* memory)
 {
-    std::lock_guard<std::mutex> one(runMu_);
+    const TurnGuard one(turn_);
     // the node of the page (move_pages with a null target list only reports): raw syscall, no libnuma in the image
     void* page = (void*)((uintptr_t)memory & ~(uintptr_t)4095); int node = -1;
 #ifdef SYS_move_pages
@@ -194,8 +218,9 @@ typedef void (*Fill4k)(uint8_t*, uint32_t);
 const Fill4k g_fill4k = __builtin_cpu_supports("avx2") ? fill4k_avx2 : fill4k_sse2;
 template <bool NT> inline void put16(uint8_t* d, __m128i v) { if (NT) _mm_stream_si128((__m128i*)d, v); else _mm_storeu_si128((__m128i*)d, v); }
 template <bool NT>
-void expand(uint8_t* dst, uint64_t dstBytes, const uint8_t* stream, const HostCodecLayout& L, uint64_t b0, uint64_t b1)
+void expand(uint8_t* dst, uint64_t dstBytes, const uint8_t* stream, const HostCodecLayout& L, uint64_t b0, uint64_t b1, const ZeroedPieces* zeroed, uint64_t* skipped)
 {
+    uint64_t skippedHere = 0;
     const uint32_t* ofs = (const uint32_t*)(stream + L.offOfs);
     for (uint64_t b = b0; b < b1; ++b) {
         const uint64_t u0 = b * 256u, u1 = u0 + 256u < L.units ? u0 + 256u : L.units;
@@ -209,6 +234,11 @@ void expand(uint8_t* dst, uint64_t dstBytes, const uint8_t* stream, const HostCo
             bool same = (w0 & 0xCCCCCCCCCCCCCCCCull) == 0 && ((w0 >> 4) & 0x0F0F0F0F0F0F0F0Full) == (w0 & 0x0F0F0F0F0F0F0F0Full) && w0 == (w0 & 0xFF) * 0x0101010101010101ull;
             for (int k = 1; same && k < 16; ++k) { uint64_t w; memcpy(&w, codes + 8 * k, 8); same = w == w0; }
             if (same) {
+                // (a block of zeros in a piece of the array that was zeroed while the device was baking: nothing to write)
+                if (zeroed && (w0 & 3u) == 0u) {
+                    const size_t piece = (size_t)((u0 * 16u) >> 21);
+                    if (piece < zeroed->pieces && zeroed->done[piece].load(std::memory_order_acquire)) { skippedHere += 4096u; continue; }
+                }
                 if (NT && ((uintptr_t)d & 31u) == 0u) { g_fill4k(d, kPattern[w0 & 3u]); continue; }
                 const __m128i v = _mm_set1_epi32((int)kPattern[w0 & 3u]);
                 for (int k = 0; k < 256; ++k) put16<NT>(d + 16 * k, v);
@@ -234,12 +264,21 @@ void expand(uint8_t* dst, uint64_t dstBytes, const uint8_t* stream, const HostCo
         }
     }
     if (NT) _mm_sfence();
+    if (skipped) *skipped += skippedHere;
 }
 } // namespace
 
-void codec_expand_blocks(uint8_t* dst, uint64_t dstBytes, const uint8_t* stream, const HostCodecLayout& L, uint64_t b0, uint64_t b1)
+void codec_expand_blocks(uint8_t* dst, uint64_t dstBytes, const uint8_t* stream, const HostCodecLayout& L, uint64_t b0, uint64_t b1, const ZeroedPieces* zeroed, uint64_t* skipped)
 {
-    if (((uintptr_t)dst & 15u) == 0) expand<true>(dst, dstBytes, stream, L, b0, b1); else expand<false>(dst, dstBytes, stream, L, b0, b1);
+    if (((uintptr_t)dst & 15u) == 0) expand<true>(dst, dstBytes, stream, L, b0, b1, zeroed, skipped); else expand<false>(dst, dstBytes, stream, L, b0, b1, zeroed, skipped);
+}
+
+void fill_zero_nt(uint8_t* dst, size_t lo, size_t hi)
+{
+    size_t o = lo;
+    if (((uintptr_t)dst & 31u) == 0u) for (; o + 4096u <= hi; o += 4096u) g_fill4k(dst + o, 0u);
+    if (o < hi) memset(dst + o, 0, hi - o);
+    _mm_sfence();
 }
 
 void codec_scatter_omms(const HostScatter& S, uint32_t j0, uint32_t j1)

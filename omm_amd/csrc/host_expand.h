@@ -27,15 +27,27 @@ public:
     WorkerPool(const WorkerPool&) = delete; WorkerPool& operator=(const WorkerPool&) = delete;
     unsigned workers() const { return (unsigned)threads_.size(); }
     void run(uint32_t tasks, const std::function<void(uint32_t)>& fn);
+    // The same tasks on the WORKERS only, in the background: start() returns at once (false: no workers -- nothing was started), wait() returns when every
+    // task is done.  Between the two the pool is taken (run() and bind_near() of any thread wait for wait()); whoever owns the started run calls wait() exactly once (any
+    // thread) and must not call run() / bind_near() before that.
+    bool start(uint32_t tasks, std::function<void(uint32_t)> fn);
+    void wait();
     // Moves the workers onto the NUMA node that holds `memory` (the array they are about to fill), each onto its own slice of the node's cores; the calling
     // thread's affinity is not touched.  Best effort: returns the node, or -1 when it could not be found / nothing was changed.
     int bind_near(const void* memory);
 private:
     void loop();
     std::vector<std::thread> threads_;
-    std::mutex runMu_;                         // one run() at a time
+    // one run() / start()..wait() / bind_near() at a time.  Not a plain mutex: wait() may be called by another thread than start() was
+    struct Turn {
+        std::mutex m; std::condition_variable cv; bool taken = false;
+        void take() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !taken; }); taken = true; }
+        void give() { { std::lock_guard<std::mutex> l(m); taken = false; } cv.notify_one(); }
+    } turn_;
+    struct TurnGuard { Turn& t; explicit TurnGuard(Turn& x) : t(x) { t.take(); } ~TurnGuard() { t.give(); } };
     std::mutex mu_; std::condition_variable wake_, done_;
     const std::function<void(uint32_t)>* fn_ = nullptr;
+    std::function<void(uint32_t)> background_; bool backgroundActive_ = false;   // start() / wait()
     uint32_t tasks_ = 0; uint64_t generation_ = 0; unsigned active_ = 0; bool stop_ = false;
     std::atomic<uint32_t> next_{ 0 };
     int boundNode_ = -2;
@@ -49,7 +61,14 @@ HostCodecLayout host_codec_layout(uint64_t paddedBytes);
 
 // Expands codec blocks [b0, b1) of `stream` (layout L) into dst[0 .. dstBytes): block b covers dst bytes [4096 b, 4096 (b + 1)); bytes beyond dstBytes are not
 // written (the device pads the array to a multiple of 256 bytes).  Write-only on dst (non-temporal stores when dst is 16-byte aligned).
-void codec_expand_blocks(uint8_t* dst, uint64_t dstBytes, const uint8_t* stream, const HostCodecLayout& L, uint64_t b0, uint64_t b1);
+// `zeroed` (optional): the destination was filled with zeros in pieces of 2 MiB while the device was baking -- piece j (bytes [j << 21, (j + 1) << 21) of dst)
+// is complete when zeroed->done[j] is set; a codec block of 4 KiB that repeats state 0 and lies in a complete piece is not written again (a quarter of the
+// blocks of the metric configuration).  *skipped (optional) += the bytes left as they were.
+struct ZeroedPieces { const std::atomic<uint8_t>* done; size_t pieces; };
+void codec_expand_blocks(uint8_t* dst, uint64_t dstBytes, const uint8_t* stream, const HostCodecLayout& L, uint64_t b0, uint64_t b1,
+                         const ZeroedPieces* zeroed = nullptr, uint64_t* skipped = nullptr);
+// zero bytes [lo, hi) of a 4 KiB-aligned block with non-temporal stores (the pre-fill itself)
+void fill_zero_nt(uint8_t* dst, size_t lo, size_t hi);
 
 // Multi-device ommCpuBake: every device hands its own surviving blocks to the host as ONE codec stream of its contribution (the blocks it owns, back to
 // back in the order of the result; all contributions padded to the same size, hence one layout); the host writes every block of the result from its owner's

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <vector>
 using namespace ommx;
 static uint64_t s = 0x9E3779B97F4A7C15ull;
@@ -48,6 +49,55 @@ int main()
             for (int k = 0; k < 16; ++k) if (base[bytes + k] != 0xCD) { printf("OVERRUN bytes=%zu variant=%d at +%d\n", bytes, variant, k); return 1; }
             ++cases;
         }
+    }
+    // ---- zeroing ahead (round 6): the destination holds STALE bytes (the previous bake's result); helper threads zero it in pieces of 2 MiB in the background
+    //      (WorkerPool::start / wait), some pieces are cancelled; the expansion may leave a block of zeros alone only inside a piece that was completed ----
+    int zeroCases = 0;
+    for (int variant = 1; variant <= 2; ++variant) for (unsigned workers : { 1u, 3u, 7u }) for (int cancelAt : { -1, 0, 2 }) {
+        const size_t bytes = (9u << 20) + 4096 * 3 + 48, padded = (bytes + 255) & ~(size_t)255;
+        std::vector<uint8_t> src(padded, 0);
+        static const uint8_t pat[4] = { 0x00, 0x55, 0xAA, 0xFF };
+        for (size_t o = 0; o < padded; ) {   // long runs (whole 4 KiB blocks of one state, many of them zeros) with noise in between
+            size_t len = 16 * (1 + rnd() % (variant == 1 ? 4000 : 600));
+            if (o + len > padded) len = padded - o;
+            if (rnd() % 10 == 0) for (size_t k = 0; k < len; ++k) src[o + k] = (uint8_t)rnd(); else memset(&src[o], pat[rnd() % 2 ? 0 : rnd() % 4], len);
+            o += len;
+        }
+        const HostCodecLayout L = host_codec_layout(padded);
+        std::vector<uint8_t> stream(L.offRaw + 16 * L.units + 64, 0xEE);
+        uint32_t* ofs = (uint32_t*)(stream.data() + L.offOfs); uint32_t nraw = 0;
+        for (uint64_t u = 0; u < L.units; ++u) {
+            if (u % 256 == 0) ofs[u / 256] = nraw;
+            uint32_t w[4]; memcpy(w, &src[u * 16], 16);
+            const bool same = w[0] == w[1] && w[0] == w[2] && w[0] == w[3];
+            const uint32_t code = !same ? 4u : (w[0] == 0u ? 0u : (w[0] == 0x55555555u ? 1u : (w[0] == 0xAAAAAAAAu ? 2u : (w[0] == 0xFFFFFFFFu ? 3u : 4u))));
+            uint8_t& c = stream[L.offCodes + u / 2];
+            c = (uint8_t)((u & 1) ? ((c & 0x0F) | (code << 4)) : code);
+            if (code == 4u) { memcpy(&stream[L.offRaw + 16ull * nraw], w, 16); ++nraw; }
+        }
+        ofs[L.blocks] = nraw;
+        std::vector<uint8_t> out(bytes + 8192, 0x77);   // stale content everywhere
+        uint8_t* base = out.data(); while (((uintptr_t)base & 4095u) != 0u) ++base;
+        const size_t pieces = (bytes + (2u << 20) - 1) >> 21;
+        std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[pieces]);
+        for (size_t j = 0; j < pieces; ++j) done[j].store(0);
+        WorkerPool pool(workers);
+        std::atomic<bool> cancel{ false };
+        const bool started = pool.start((uint32_t)pieces, [&](uint32_t j) {
+            if (cancel.load() || (int)j == cancelAt) return;   // (a cancelled / skipped piece keeps its stale bytes and stays unmarked)
+            const size_t lo = (size_t)j << 21, hi = lo + (2u << 20) < bytes ? lo + (2u << 20) : bytes;
+            fill_zero_nt(base, lo, hi);
+            done[j].store(1, std::memory_order_release);
+        });
+        if (!started) { printf("START FAILED workers=%u\n", workers); return 1; }
+        pool.wait();
+        const ZeroedPieces z{ done.get(), pieces };
+        std::atomic<uint64_t> skipped{ 0 };
+        const uint32_t tasks = (uint32_t)((L.blocks + 63) / 64);
+        pool.run(tasks, [&](uint32_t t) { const uint64_t b0 = (uint64_t)t * 64, b1 = b0 + 64 < L.blocks ? b0 + 64 : L.blocks; uint64_t sk = 0; codec_expand_blocks(base, bytes, stream.data(), L, b0, b1, &z, &sk); skipped += sk; });
+        if (memcmp(base, src.data(), bytes) != 0) { printf("ZERO-AHEAD MISMATCH variant=%d workers=%u cancelAt=%d\n", variant, workers, cancelAt); return 1; }
+        if (skipped.load() == 0) { printf("ZERO-AHEAD skipped nothing variant=%d\n", variant); return 1; }
+        ++zeroCases;
     }
     // ---- codec_scatter_omms: blocks of a result from the codec streams of their owners' contributions (multi-device ommCpuBake) ----
     int scatterCases = 0;
@@ -109,6 +159,6 @@ int main()
         for (int k = 0; k < 64; ++k) if (got[total + k] != 0xCD) { printf("SCATTER OVERRUN world=%u\n", world); return 1; }
         ++scatterCases;
     }
-    printf("ok %d scatter %d effective_cpus %u\n", cases, scatterCases, effective_cpus());
+    printf("ok %d scatter %d zero-ahead %d effective_cpus %u\n", cases, scatterCases, zeroCases, effective_cpus());
     return 0;
 }

@@ -25,7 +25,7 @@ TEX_UNORM8, TEX_FP32 = 0, 1
 FLAG_THREADS, FLAG_NO_SPECIAL, FLAG_FORCE32, FLAG_NO_DEDUP, FLAG_NEAR_DUP, FLAG_VALIDATION, FLAG_ALLOW8 = (1 << i for i in range(7))
 TEXFLAG_DISABLE_ZORDER = 1
 SPECIAL_FT, SPECIAL_FO, SPECIAL_FUT, SPECIAL_FUO = -1, -2, -3, -4
-KNOB_RESERVED0, KNOB_SHARD_CHUNK_BYTES, KNOB_STREAM_CHUNKS, KNOB_GENERIC_PASS, KNOB_RETAIN_MEMORY, KNOB_RESULT_TRANSFER, KNOB_EXPAND_THREADS, KNOB_DEVICES, KNOB_HELPER_AFFINITY = range(9)   # ommxBakerKnob
+KNOB_RESERVED0, KNOB_SHARD_CHUNK_BYTES, KNOB_STREAM_CHUNKS, KNOB_GENERIC_PASS, KNOB_RETAIN_MEMORY, KNOB_RESULT_TRANSFER, KNOB_EXPAND_THREADS, KNOB_DEVICES, KNOB_HELPER_AFFINITY, KNOB_ZERO_AHEAD = range(10)   # ommxBakerKnob
 TRANSFER_AUTO, TRANSFER_PLAIN, TRANSFER_STREAMED, TRANSFER_COMPRESSED = range(4)   # ommxResultTransfer
 
 

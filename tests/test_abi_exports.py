@@ -262,6 +262,7 @@ def test_baker_knobs_are_per_baker_state_not_environment():
     b = lib.create_baker()          # (no GPU needed: a baker is host state until its first texture)
     assert dll.ommxSetBakerKnob(b, ot.KNOB_RESERVED0, 6) == ot.SUCCESS            # (the retired test switch of rounds 1 - 5: accepted, no effect)
     assert dll.ommxSetBakerKnob(b, ot.KNOB_HELPER_AFFINITY, 1) == ot.SUCCESS and dll.ommxSetBakerKnob(b, ot.KNOB_HELPER_AFFINITY, 2) == ot.INVALID_ARGUMENT
+    assert dll.ommxSetBakerKnob(b, ot.KNOB_ZERO_AHEAD, 1) == ot.SUCCESS and dll.ommxSetBakerKnob(b, ot.KNOB_ZERO_AHEAD, 2) == ot.INVALID_ARGUMENT
     assert dll.ommxSetBakerKnob(b, ot.KNOB_SHARD_CHUNK_BYTES, 100) == ot.INVALID_ARGUMENT
     assert dll.ommxSetBakerKnob(b, ot.KNOB_SHARD_CHUNK_BYTES, 4352) == ot.SUCCESS
     assert dll.ommxSetBakerKnob(b, ot.KNOB_STREAM_CHUNKS, 3) == ot.SUCCESS

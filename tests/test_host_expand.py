@@ -11,4 +11,4 @@ def test_codec_expansion_and_worker_pool(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "native", "expand_check.cpp"),
                            os.path.join(ROOT, "omm_amd", "csrc", "host_expand.cpp")])
     out = subprocess.check_output([exe], text=True, timeout=300)
-    assert out.startswith("ok 288 scatter 24"), out
+    assert out.startswith("ok 288 scatter 24 zero-ahead 18"), out
