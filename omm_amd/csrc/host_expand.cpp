@@ -244,7 +244,11 @@ void expand(uint8_t* dst, uint64_t dstBytes, const uint8_t* stream, const HostCo
                 for (int k = 0; k < 256; ++k) put16<NT>(d + 16 * k, v);
                 continue;
             }
+            // (in a zeroed piece, a 64-byte line of four zero units is left alone too: states come in long runs, so most lines of a mixed block are one state)
+            const bool zeroedPiece = zeroed && (size_t)((u0 * 16u) >> 21) < zeroed->pieces && zeroed->done[(size_t)((u0 * 16u) >> 21)].load(std::memory_order_acquire)
+                                     && ((uintptr_t)d & 63u) == 0u;
             for (int k = 0; k < 128; ++k) {
+                if (zeroedPiece && (k & 1) == 0) { uint16_t four; memcpy(&four, codes + k, 2); if (four == 0u) { skippedHere += 64u; ++k; continue; } }
                 const uint32_t two = codes[k], c0 = two & 15u, c1 = two >> 4;
                 __m128i v0, v1;
                 if (c0 < 4u) v0 = _mm_set1_epi32((int)kPattern[c0]); else { v0 = _mm_loadu_si128((const __m128i*)raw); raw += 16; }

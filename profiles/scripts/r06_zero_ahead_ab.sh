@@ -1,7 +1,7 @@
 #!/bin/bash
 # ommCpuBake at the metric configuration with and without the zeroing ahead of the result block, N bakes each, alternating processes
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; n=${1:-100}
-for z in 0 1 0 1 0 1 0 1 0 1; do
+for z in 0 1 0 1 0 1; do
   timeout 600 python bench.py --config c2 --cpu-sample 0 --sat-off-sample 0 --create-texture 0 --steps 3 --host-api-steps $n --zero-ahead $z 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1]); h=j['host_api']; r=h['result_transfer']
